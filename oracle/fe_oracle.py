@@ -1,0 +1,494 @@
+"""ORACLE (test infrastructure, not product code) - CPU restatement of the finite-element side of nuPGCM's hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+
+What it restates (reference file:line, all under /root/reference/):
+  * spaces / DoF numbering ............ src/spaces.jl:31-72, src/dofs.jl:51-63 (Gridap 0.20.3 + GridapGmsh 0.7.4
+                                        conventions, un-vendored: SURVEY.md section 8c lists them)
+  * inversion system A, B, b .......... src/inversion.jl:133-249
+  * evolution pieces M, Kh, Kv, lifts . src/evolution.jl:209-296
+  * advection linear form ............. src/model.jl:292-300
+  * preconditioner length scale ....... src/inversion.jl:42-54 + src/meshes.jl:94-108
+  * CFL cell sizes .................... src/meshes.jl:127-134
+
+The algorithm lives in third-party packages that are absent from /root/reference (Gridap 0.20.3, GridapGmsh 0.7.4);
+their published behaviour is restated here and PINNED by the reference's own data fixtures (tests/golden/*.npz, made by
+tests/golden/make_fixtures.py): tests/test_oracle_fixtures.py checks K1 (2-D A_inversion values + pattern), K2 (3-D
+inversion identity on bowl_surface_flux), K3 (50-step state of bowl_surface_flux) and K4 (three older fixtures at the
+reference's own 1e-3 bar).
+
+Everything is dense-per-cell numpy (einsum over cells); no attempt at speed beyond vectorisation.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import scipy.sparse as sp
+from scipy.special import roots_jacobi, roots_legendre
+
+# ----------------------------------------------------------------------------------------------------------------------
+# reference elements and quadrature
+# ----------------------------------------------------------------------------------------------------------------------
+
+TET_EDGES = [(0, 1), (0, 2), (1, 2), (0, 3), (1, 3), (2, 3)]   # Gridap local edge order on a TET
+TRI_EDGES = [(0, 1), (0, 2), (1, 2)]
+
+
+def keast11():
+    """Degree-4, 11-point rule on the unit tetrahedron (volume 1/6) with a negative centroid weight - what
+    `Measure(Omega, 4)` (src/meshes.jl:33) resolves to for TET in Gridap 0.20.3 (pinned by fixture K3)."""
+    pts, wts = [[0.25, 0.25, 0.25, 0.25]], [-74.0 / 5625.0]
+    a, b = 1.0 / 14.0, 11.0 / 14.0
+    for k in range(4):
+        lam = [a] * 4
+        lam[k] = b
+        pts.append(lam)
+        wts.append(343.0 / 45000.0)
+    c, d = 0.399403576166799, 0.100596423833201
+    for (i, j) in [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]:
+        lam = [d] * 4
+        lam[i] = lam[j] = c
+        pts.append(lam)
+        wts.append(56.0 / 2250.0)
+    return np.array(pts), np.array(wts)      # barycentric (nq,4), weights summing to 1/6
+
+
+def duffy3x3():
+    """Degree-4 rule Gridap uses on TRI (boundary faces, `Measure(Gamma, 4)`): 3x3 collapsed tensor rule, Gauss-Jacobi
+    (1,0) in xi and Gauss-Legendre in eta on [0,1]; point (x, y) = (xi, eta (1 - xi)).  Not symmetric (pinned by K3)."""
+    tj, wj = roots_jacobi(3, 1, 0)
+    tl, wl = roots_legendre(3)
+    xi, wxi = (tj + 1) / 2, wj / 4
+    eta, weta = (tl + 1) / 2, wl / 2
+    pts, wts = [], []
+    for i in range(3):
+        for j in range(3):
+            x, y = xi[i], eta[j] * (1 - xi[i])
+            pts.append([1 - x - y, x, y])
+            wts.append(wxi[i] * weta[j])
+    return np.array(pts), np.array(wts)      # barycentric (9,3), weights summing to 1/2
+
+
+def p1_basis(lam):
+    """P1 values (nq, d+1) and barycentric-derivative table (d+1, d+1): dN_i/dlam_k."""
+    return lam.copy(), np.eye(lam.shape[1])
+
+
+def p2_basis(lam, edges):
+    """Nodal P2 Lagrange basis in Gridap's local order (vertices, then edges): values (nq, nloc) and derivatives with
+    respect to the barycentric coordinates (nq, nloc, d+1)."""
+    nq, nv = lam.shape
+    nloc = nv + len(edges)
+    N = np.zeros((nq, nloc))
+    dN = np.zeros((nq, nloc, nv))
+    for k in range(nv):
+        N[:, k] = lam[:, k] * (2 * lam[:, k] - 1)
+        dN[:, k, k] = 4 * lam[:, k] - 1
+    for e, (a, b) in enumerate(edges):
+        N[:, nv + e] = 4 * lam[:, a] * lam[:, b]
+        dN[:, nv + e, a] = 4 * lam[:, b]
+        dN[:, nv + e, b] = 4 * lam[:, a]
+    return N, dN
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# mesh topology with GridapGmsh's conventions
+# ----------------------------------------------------------------------------------------------------------------------
+
+@dataclass
+class Topo:
+    dim: int
+    coords: np.ndarray        # (nv, 3)
+    cells: np.ndarray         # (nc, dim+1) oriented the way Gridap sees them
+    edges: np.ndarray         # (ne, 2) first-encounter numbering
+    cell_edges: np.ndarray    # (nc, 3 or 6)
+    vert_mask: np.ndarray     # (nv,) bitmask of physical names
+    edge_mask: np.ndarray     # (ne,)
+    surf_faces: dict          # name -> (nf, dim) boundary facets carrying that name, node ids sorted ascending
+    phys_names: list
+
+    @property
+    def nv(self):
+        return len(self.coords)
+
+    @property
+    def ne(self):
+        return len(self.edges)
+
+    def p2_coords(self):
+        return np.vstack([self.coords, 0.5 * (self.coords[self.edges[:, 0]] + self.coords[self.edges[:, 1]])])
+
+    def cell_p2_nodes(self):
+        return np.hstack([self.cells, self.nv + self.cell_edges])
+
+    def node_mask(self):
+        return np.concatenate([self.vert_mask, self.edge_mask])
+
+    def mask_of(self, names):
+        m = 0
+        for nm in names:
+            m |= 1 << self.phys_names.index(nm)
+        return m
+
+
+def build_topo(model) -> Topo:
+    """model: anything with the attributes of nupgcm_amd.gmsh_io.GmshModel (the fixtures are stored in that form)."""
+    dim = int(model.dim)
+    cells = np.array(model.cells, dtype=np.int64)
+    if dim == 3:
+        cells = np.sort(cells, axis=1)          # GridapGmsh orients simplices by sorting node ids (3-D in 3-D only)
+    local = TET_EDGES if dim == 3 else TRI_EDGES
+    edge_id: dict = {}
+    edges = []
+    cell_edges = np.zeros((len(cells), len(local)), dtype=np.int64)
+    for c, cell in enumerate(cells):
+        for k, (a, b) in enumerate(local):
+            key = (min(cell[a], cell[b]), max(cell[a], cell[b]))
+            if key not in edge_id:
+                edge_id[key] = len(edges)
+                edges.append(key)
+            cell_edges[c, k] = edge_id[key]
+    edges = np.array(edges, dtype=np.int64)
+
+    # edge labels: a matching 1-D element wins, else a boundary 2-D element containing the edge, else interior (0 here:
+    # "interior" never appears in a Dirichlet tag list)
+    edge_mask = np.zeros(len(edges), dtype=np.uint32)
+    if dim == 3:
+        for tri, m in zip(model.facets, model.facets_phys):
+            t = sorted(tri)
+            for (a, b) in [(0, 1), (0, 2), (1, 2)]:
+                e = edge_id.get((t[a], t[b]))
+                if e is not None:
+                    edge_mask[e] |= np.uint32(m)
+        for ln, m in zip(model.ridges, model.ridges_phys):
+            e = edge_id.get((min(ln), max(ln)))
+            if e is not None:
+                edge_mask[e] = np.uint32(m)
+    else:
+        for ln, m in zip(model.facets, model.facets_phys):
+            e = edge_id.get((min(ln), max(ln)))
+            if e is not None:
+                edge_mask[e] = np.uint32(m)
+
+    surf = {}
+    for i, nm in enumerate(model.phys_names):
+        sel = (np.asarray(model.facets_phys) >> i) & 1 == 1
+        if sel.any():
+            surf[nm] = np.sort(np.asarray(model.facets)[sel], axis=1)
+    return Topo(dim, np.array(model.coords, dtype=float), cells, edges, cell_edges,
+                np.array(model.node_phys, dtype=np.uint32), edge_mask, surf, list(model.phys_names))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# spaces: free / Dirichlet numbering
+# ----------------------------------------------------------------------------------------------------------------------
+
+@dataclass
+class Spaces:
+    topo: Topo
+    u_dof: np.ndarray      # (nn, 3): free id >= 0, or -1 if Dirichlet (value 0: every reference config uses zeros)
+    p_dof: np.ndarray      # (nv,): free id, -1 for the fixed last vertex
+    b_dof: np.ndarray      # (nn,): free id or -1
+    b_diri: np.ndarray     # (nn,): Dirichlet value on Dirichlet nodes, 0 elsewhere
+    nu: int
+    np_: int
+    nb: int
+
+
+def build_spaces(topo: Topo, u_diri_tags, u_diri_masks, b_diri_tags=(), b_diri_fn=None) -> Spaces:
+    """src/spaces.jl:31-72.  DoFs: vertices first then edges, vector components interleaved per node; a DoF is
+    Dirichlet iff its face carries a listed tag and that tag's component mask is true; pressure: zero-mean space =
+    last vertex fixed (src/dofs.jl:57)."""
+    nmask = topo.node_mask()
+    nn = len(nmask)
+    diri_u = np.zeros((nn, 3), dtype=bool)
+    for tag, cm in zip(u_diri_tags, u_diri_masks):
+        has = (nmask >> topo.phys_names.index(tag)) & 1 == 1
+        for c in range(3):
+            if cm[c]:
+                diri_u[:, c] |= has
+    u_dof = np.full((nn, 3), -1, dtype=np.int64)
+    free = ~diri_u
+    u_dof[free] = np.arange(free.sum())          # C order = node-major, component-minor
+    p_dof = np.arange(topo.nv, dtype=np.int64)
+    p_dof[-1] = -1
+    diri_b = np.zeros(nn, dtype=bool)
+    for tag in b_diri_tags:
+        diri_b |= (nmask >> topo.phys_names.index(tag)) & 1 == 1
+    b_dof = np.full(nn, -1, dtype=np.int64)
+    b_dof[~diri_b] = np.arange((~diri_b).sum())
+    b_diri = np.zeros(nn)
+    if b_diri_fn is not None and diri_b.any():
+        b_diri[diri_b] = b_diri_fn(topo.p2_coords()[diri_b])
+    return Spaces(topo, u_dof, p_dof, b_dof, b_diri, int(free.sum()), topo.nv - 1, int((~diri_b).sum()))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# cell geometry
+# ----------------------------------------------------------------------------------------------------------------------
+
+@dataclass
+class CellGeom:
+    G: np.ndarray      # (nc, dim+1, 3): physical gradient of each barycentric coordinate
+    detJ: np.ndarray   # (nc,) |det J| (sqrt(det J^T J) for embedded 2-D)
+    xq: np.ndarray     # (nc, nq, 3) physical quadrature points
+    lam: np.ndarray    # (nq, dim+1)
+    w: np.ndarray      # (nq,)
+
+
+def cell_geometry(topo: Topo, quad=None) -> CellGeom:
+    X = topo.coords[topo.cells]                          # (nc, dim+1, 3)
+    J = np.transpose(X[:, 1:, :] - X[:, :1, :], (0, 2, 1))   # (nc, 3, dim): columns = edge vectors
+    if topo.dim == 3:
+        detJ = np.abs(np.linalg.det(J))
+        Jinv = np.linalg.inv(J)                          # rows = grad of reference coords
+        gref = Jinv                                      # (nc, 3(ref), 3(phys))
+        lam, w = quad if quad is not None else keast11()
+    else:
+        JtJ = np.einsum("cik,cil->ckl", J, J)
+        detJ = np.sqrt(np.linalg.det(JtJ))
+        gref = np.einsum("ckl,cil->cki", np.linalg.inv(JtJ), J)    # pseudo-inverse rows: tangential gradients
+        lam, w = quad if quad is not None else duffy3x3()
+    G = np.concatenate([-gref.sum(axis=1, keepdims=True), gref], axis=1)
+    xq = np.einsum("qk,cki->cqi", lam, X)
+    return CellGeom(G, detJ, xq, lam, w)
+
+
+def _const_or_fn(v, x):
+    return v(x) if callable(v) else np.full(x.shape[:-1], float(v))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# assembly helpers
+# ----------------------------------------------------------------------------------------------------------------------
+
+def _scatter_matrix(rows, cols, vals, shape):
+    keep = (rows >= 0) & (cols >= 0)
+    return sp.coo_matrix((vals[keep], (rows[keep], cols[keep])), shape=shape).tocsr()   # explicit zeros are kept
+
+
+class Oracle:
+    """All operators of one configuration, in NATIVE (Gridap) free-DoF order."""
+
+    def __init__(self, topo: Topo, spaces: Spaces, *, eps, alpha, mu_rho, N2, f, nu=1.0, kappa_h=1.0, kappa_v=1.0,
+                 tau_x=0.0, tau_y=0.0, surface_flux=None, quad=None):
+        self.topo, self.sp = topo, spaces
+        self.eps, self.alpha, self.mu_rho, self.N2 = float(eps), float(alpha), float(mu_rho), float(N2)
+        self.f, self.nu, self.kappa_h, self.kappa_v = f, nu, kappa_h, kappa_v
+        self.tau_x, self.tau_y, self.surface_flux = tau_x, tau_y, surface_flux
+        self.geo = cell_geometry(topo, quad)
+        edges = TET_EDGES if topo.dim == 3 else TRI_EDGES
+        self.N2q, dN = p2_basis(self.geo.lam, edges)                   # (nq, n2), (nq, n2, dim+1)
+        self.N1q = self.geo.lam                                         # P1 values
+        self.gradN2 = np.einsum("qnk,cki->cqni", dN, self.geo.G)        # (nc, nq, n2, 3)
+        self.gradN1 = self.geo.G                                        # (nc, dim+1, 3) constant per cell
+        self.wdet = self.geo.detJ[:, None] * self.geo.w[None, :]        # (nc, nq)
+        self.cn2 = topo.cell_p2_nodes()                                 # (nc, n2)
+        self.n2 = self.cn2.shape[1]
+
+    # -- inversion ------------------------------------------------------------------------------------------------
+    def A_inversion(self):
+        """src/inversion.jl:133-147,183-192 (constant nu: Laplacian form).  N x N CSR, structural zeros stored."""
+        s, t = self.sp, self.topo
+        nc, n2, n1 = len(t.cells), self.n2, t.dim + 1
+        a2e2nu = self.alpha ** 2 * self.eps ** 2 * float(self.nu)
+        fq = _const_or_fn(self.f, self.geo.xq)                                          # (nc, nq)
+        Kloc = a2e2nu * np.einsum("cq,cqia,cqja->cij", self.wdet, self.gradN2, self.gradN2)
+        Cloc = np.einsum("cq,cq,qi,qj->cij", self.wdet, fq, self.N2q, self.N2q)        # int f phi_i phi_j
+        Dloc = np.einsum("cq,cqia,qj->caij", self.wdet, self.gradN2, self.N1q)         # int d_a phi_i psi_j
+        udof = s.u_dof[self.cn2]                                                        # (nc, n2, 3)
+        pdof = np.where(s.p_dof[t.cells] >= 0, s.nu + s.p_dof[t.cells], -1)            # (nc, n1)
+        rows, cols, vals = [], [], []
+        zero = np.zeros_like(Kloc)
+        for a in range(3):
+            for c in range(3):
+                if a == c:
+                    v = Kloc
+                elif (a, c) == (0, 1):
+                    v = -Cloc
+                elif (a, c) == (1, 0):
+                    v = Cloc
+                else:
+                    v = zero
+                rows.append(np.broadcast_to(udof[:, :, None, a], (nc, n2, n2)).ravel())
+                cols.append(np.broadcast_to(udof[:, None, :, c], (nc, n2, n2)).ravel())
+                vals.append(v.ravel())
+            rows.append(np.broadcast_to(udof[:, :, None, a], (nc, n2, n1)).ravel())     # (v_a, p): -int d_a phi psi
+            cols.append(np.broadcast_to(pdof[:, None, :], (nc, n2, n1)).ravel())
+            vals.append((-Dloc[:, a]).ravel())
+            rows.append(np.broadcast_to(pdof[:, :, None], (nc, n1, n2)).ravel())        # (q, u_a): +int psi d_a phi
+            cols.append(np.broadcast_to(udof[:, None, :, a], (nc, n1, n2)).ravel())
+            vals.append(np.transpose(Dloc[:, a], (0, 2, 1)).ravel())
+        N = s.nu + s.np_
+        return _scatter_matrix(np.concatenate(rows), np.concatenate(cols), np.concatenate(vals), (N, N))
+
+    def _B_full(self):
+        """(1/alpha) int phi_i phi_j per cell, to be scattered onto (u_z rows) x (b nodes)."""
+        return np.einsum("cq,qi,qj->cij", self.wdet, self.N2q, self.N2q) / self.alpha
+
+    def B_inversion(self):
+        """src/inversion.jl:199-219.  N x nb, columns in native b order; x/y rows stored as structural zeros."""
+        s = self.sp
+        nc, n2 = len(self.topo.cells), self.n2
+        Bl = self._B_full()
+        udof = s.u_dof[self.cn2]
+        bdof = s.b_dof[self.cn2]
+        rows, cols, vals = [], [], []
+        for a in range(3):
+            rows.append(np.broadcast_to(udof[:, :, None, a], (nc, n2, n2)).ravel())
+            cols.append(np.broadcast_to(bdof[:, None, :], (nc, n2, n2)).ravel())
+            vals.append((Bl if a == 2 else np.zeros_like(Bl)).ravel())
+        return _scatter_matrix(np.concatenate(rows), np.concatenate(cols), np.concatenate(vals),
+                               (s.nu + s.np_, s.nb))
+
+    def b_inversion(self):
+        """src/inversion.jl:226-249: wind stress on the surface + Dirichlet-b lift, rows 1:nu."""
+        s = self.sp
+        out = np.zeros(s.nu + s.np_)
+        Bl = self._B_full()
+        lift = np.einsum("cij,cj->ci", Bl, s.b_diri[self.cn2])
+        dz = s.u_dof[self.cn2][:, :, 2]
+        np.add.at(out, dz[dz >= 0], lift[dz >= 0])
+        for comp, tau in ((0, self.tau_x), (1, self.tau_y)):
+            if callable(tau) or float(tau) != 0.0:
+                vec = self.surface_integral(lambda x: self.alpha * _const_or_fn(tau, x))
+                d = s.u_dof[:, comp]
+                out[d[d >= 0]] += vec[d >= 0]
+        return out
+
+    def surface_integral(self, g, name="surface"):
+        """int_Gamma g phi_i dGamma for every P2 node i (length nn) over the boundary facets named `name`."""
+        t = self.topo
+        out = np.zeros(len(t.node_mask()))
+        if name not in t.surf_faces:
+            return out
+        faces = t.surf_faces[name]                              # sorted node ids per face
+        if t.dim == 3:
+            lam, w = duffy3x3()
+            X = t.coords[faces]
+            area2 = np.linalg.norm(np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), axis=1)
+            N, _ = p2_basis(lam, TRI_EDGES)
+            emap = {tuple(e): i for i, e in enumerate(map(tuple, t.edges))}
+            en = np.array([[emap[(f[a], f[b])] for (a, b) in TRI_EDGES] for f in faces]) + t.nv
+            nodes = np.hstack([faces, en])
+            xq = np.einsum("qk,fki->fqi", lam, X)
+            vals = np.einsum("f,q,fq,qi->fi", area2, w, g(xq), N)
+            np.add.at(out, nodes, vals)
+        else:
+            raise NotImplementedError("surface integrals are only needed for the 3-D configurations")
+        return out
+
+    # -- evolution ------------------------------------------------------------------------------------------------
+    def _b_matrix_and_lift(self, loc):
+        s = self.sp
+        nc, n2 = len(self.topo.cells), self.n2
+        bdof = s.b_dof[self.cn2]
+        rows = np.broadcast_to(bdof[:, :, None], (nc, n2, n2)).ravel()
+        cols = np.broadcast_to(bdof[:, None, :], (nc, n2, n2)).ravel()
+        A = _scatter_matrix(rows, cols, loc.ravel(), (s.nb, s.nb))
+        lift = np.zeros(s.nb)
+        lv = np.einsum("cij,cj->ci", loc, s.b_diri[self.cn2])
+        np.add.at(lift, bdof[bdof >= 0], lv[bdof >= 0])
+        return A, lift
+
+    def M(self):
+        """src/evolution.jl:209-212."""
+        return self._b_matrix_and_lift(np.einsum("cq,qi,qj->cij", self.wdet, self.N2q, self.N2q))
+
+    def K_h(self, kappa=None):
+        """src/evolution.jl:225-228."""
+        kq = _const_or_fn(self.kappa_h if kappa is None else kappa, self.geo.xq)
+        g = self.gradN2[..., :2]
+        return self._b_matrix_and_lift(np.einsum("cq,cq,cqia,cqja->cij", self.wdet, kq, g, g))
+
+    def K_v(self, kappa=None):
+        """src/evolution.jl:243-246."""
+        kq = _const_or_fn(self.kappa_v if kappa is None else kappa, self.geo.xq)
+        g = self.gradN2[..., 2]
+        return self._b_matrix_and_lift(np.einsum("cq,cq,cqi,cqj->cij", self.wdet, kq, g, g))
+
+    def rhs_diff(self, kappa=None):
+        """src/evolution.jl:269-278: -N2 int kappa_v d_z(d)."""
+        kq = _const_or_fn(self.kappa_v if kappa is None else kappa, self.geo.xq)
+        loc = -self.N2 * np.einsum("cq,cq,cqi->ci", self.wdet, kq, self.gradN2[..., 2])
+        return self._to_b(loc)
+
+    def rhs_flux(self):
+        """src/evolution.jl:280-296."""
+        if self.surface_flux is None:
+            return np.zeros(self.sp.nb)
+        full = self.surface_integral(lambda x: self.alpha * _const_or_fn(self.surface_flux, x))
+        d = self.sp.b_dof
+        out = np.zeros(self.sp.nb)
+        out[d[d >= 0]] = full[d >= 0]
+        return out
+
+    def _to_b(self, loc):
+        bdof = self.sp.b_dof[self.cn2]
+        out = np.zeros(self.sp.nb)
+        np.add.at(out, bdof[bdof >= 0], loc[bdof >= 0])
+        return out
+
+    # -- state helpers --------------------------------------------------------------------------------------------
+    def b_nodal(self, b_free):
+        s = self.sp
+        full = s.b_diri.copy()
+        full[s.b_dof >= 0] = b_free[s.b_dof[s.b_dof >= 0]]
+        return full
+
+    def u_nodal(self, u_free):
+        s = self.sp
+        full = np.zeros((len(s.b_dof), 3))
+        m = s.u_dof >= 0
+        full[m] = u_free[s.u_dof[m]]
+        return full
+
+    def interpolate_b(self, fn):
+        x = self.topo.p2_coords()
+        return fn(x)[self.sp.b_dof >= 0]
+
+    def advection_rhs(self, b, b_prev, u, u_prev, dt, scheme="BDF2"):
+        """src/model.jl:292-300 assembled over B_test (src/model.jl:271-273).  b, u: free-value vectors (native)."""
+        bn, bp = self.b_nodal(b)[self.cn2], self.b_nodal(b_prev)[self.cn2]            # (nc, n2)
+        un, up = self.u_nodal(u)[self.cn2], self.u_nodal(u_prev)[self.cn2]            # (nc, n2, 3)
+        if scheme == "BDF1":
+            bq = np.einsum("qi,ci->cq", self.N2q, bn)
+            gb = np.einsum("cqia,ci->cqa", self.gradN2, bn)
+            uq = np.einsum("qi,cia->cqa", self.N2q, un)
+            integrand = bq - dt * (np.einsum("cqa,cqa->cq", uq, gb) + uq[..., 2] * self.N2)
+        else:
+            bt, ut = 2 * bn - bp, 2 * un - up
+            bq = np.einsum("qi,ci->cq", self.N2q, 4.0 / 3.0 * bn - 1.0 / 3.0 * bp)
+            gb = np.einsum("cqia,ci->cqa", self.gradN2, bt)
+            uq = np.einsum("qi,cia->cqa", self.N2q, ut)
+            integrand = bq - 2.0 / 3.0 * dt * (np.einsum("cqa,cqa->cq", uq, gb) + uq[..., 2] * self.N2)
+        loc = np.einsum("cq,cq,qi->ci", self.wdet, integrand, self.N2q)
+        return self._to_b(loc)
+
+    # -- norms used by the reference's tests ----------------------------------------------------------------------
+    def l2_sq_b(self, b_free_a, b_free_b=None):
+        d = self.b_nodal(b_free_a) - (0 if b_free_b is None else self.b_nodal(b_free_b))
+        dq = np.einsum("qi,ci->cq", self.N2q, d[self.cn2])
+        return float(np.einsum("cq,cq->", self.wdet, dq * dq))
+
+    def l2_sq_u(self, u_free_a, u_free_b=None):
+        d = self.u_nodal(u_free_a) - (0 if u_free_b is None else self.u_nodal(u_free_b))
+        dq = np.einsum("qi,cia->cqa", self.N2q, d[self.cn2])
+        return float(np.einsum("cq,cqa->", self.wdet, dq * dq))
+
+    # -- scalars ---------------------------------------------------------------------------------------------------
+    def precond_h(self):
+        """src/inversion.jl:44-49 with src/meshes.jl:94-108: median length over the unique edges enumerated from the
+        local pairs (1,2),(2,3),(3,1) only (vertex-4 edges are skipped - a quirk that only moves the scalar)."""
+        t = self.topo.cells
+        e = np.vstack([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]])
+        e = np.unique(np.sort(e, axis=1), axis=0)
+        hs = np.sort(np.linalg.norm(self.topo.coords[e[:, 0]] - self.topo.coords[e[:, 1]], axis=1))
+        return hs[len(hs) // 2 - 1], len(hs)
+
+    def h_cells(self):
+        """src/meshes.jl:127-134: longest edge per cell."""
+        X = self.topo.coords[self.topo.cells]
+        d = np.linalg.norm(X[:, :, None, :] - X[:, None, :, :], axis=-1)
+        return d.max(axis=(1, 2))

@@ -1,0 +1,199 @@
+"""ORACLE (test infrastructure) - the timestep recipe of /root/reference/src/model.jl:90-317 on top of fe_oracle.
+
+`CONFIGS` holds the parameter sets of the reference's four regression scripts (test/bowl_*_tests.jl) plus the example's
+(examples/bowl_mixing.jl:35-52,171); `setup()` builds every operator; `run()` does n steps of
+
+    evolve!  (src/model.jl:213-285)   y = rhs_adv + theta rhs_diff + dt rhs_flux - (rhs_M + theta (rhs_h + rhs_v))
+    invert!  (src/model.jl:302-317)   A [u;p] = B b + b0
+
+with either the reference CPU() path's direct solves (src/iterative_solvers.jl:42-55; scipy SuperLU stands in for
+UMFPACK) or the GPU() path's Krylov solves (krylov_oracle).  Quirks reproduced: the first step of a
+BDF2 run uses the BDF1 left-hand side while the right-hand side already uses BDF2's theta; flux scaled by dt; u = 0
+during step 1 unless the caller inverted first.  `first_step_lhs="bdf2"` is the compatibility switch that the exact
+fixture bowl_surface_flux.jld2 (older revision) needs.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+from scipy.sparse.csgraph import reverse_cuthill_mckee
+
+from . import fe_oracle as fo
+from . import krylov_oracle as ko
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+class _Model:
+    pass
+
+
+def load_mesh(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = _Model()
+    import json
+    m.dim = int(z["dim"])
+    for k in ("coords", "node_phys", "cells", "facets", "facets_phys", "ridges", "ridges_phys"):
+        setattr(m, k, z[k])
+    m.phys_names = json.loads(bytes(z["phys_names"]).decode())
+    return m
+
+
+def _H(x, alpha):
+    return alpha * (1 - x[..., 0] ** 2 - x[..., 1] ** 2)
+
+
+def _kappa_bottom(alpha):
+    return lambda x: 1e-2 + np.exp(-(x[..., 2] + _H(x, alpha)) / (0.1 * alpha))
+
+
+U_TAGS = ["bottom", "coastline", "surface"]
+U_MASKS = [(True, True, True), (True, True, True), (False, False, True)]
+
+# parameter sets: test/bowl_mixing_tests.jl:16-32,67-68 ; test/bowl_dirichlet_tests.jl ; test/bowl_wind_tests.jl ;
+# test/bowl_surface_flux_tests.jl ; examples/bowl_mixing.jl:35-52,171
+CONFIGS = {
+    "bowl_mixing": dict(eps=2e-1, alpha=0.5, mu_rho=10.0, N2=2.0, f=lambda x: 1 + 0.5 * x[..., 1], nu=1.0,
+                        kappa="bottom", b_diri_tags=["coastline", "surface"], b_diri_fn=lambda x: 0 * x[..., 0],
+                        dt=1e-4 * 10.0 / (0.5 * 0.2) ** 2, b0=None),
+    "bowl_diri": dict(eps=np.sqrt(1e-1), alpha=0.5, mu_rho=1.0, N2=0.0, f=lambda x: 0.5 * x[..., 1], nu=1.0,
+                      kappa=1.0, b_diri_tags=["coastline", "surface"], b_diri_fn=lambda x: x[..., 1],
+                      dt=1e-1, b0=lambda x: x[..., 1]),
+    "bowl_wind": dict(eps=np.sqrt(1e-1), alpha=0.5, mu_rho=1.0, N2=0.0, f=lambda x: 0.5 * x[..., 1], nu=1.0,
+                      kappa="bottom", b_diri_tags=["coastline", "surface"], b_diri_fn=lambda x: 0 * x[..., 0],
+                      tau_x=lambda x: -1e-1 * np.cos(np.pi * x[..., 1] / 2), dt=1e-1, b0=lambda x: x[..., 2] / 0.5),
+    "bowl_surface_flux": dict(eps=np.sqrt(1e-1), alpha=0.5, mu_rho=1.0, N2=0.0, f=lambda x: 1 + 0 * x[..., 1], nu=1.0,
+                              kappa=1e-2, b_diri_tags=[], b_diri_fn=None,
+                              surface_flux=lambda x: 1e-3 * np.sin(np.pi * x[..., 0]), dt=1e-1,
+                              b0=lambda x: x[..., 2] / 0.5),
+    "example": dict(eps=2e-1, alpha=0.5, mu_rho=1.0, N2=2.0, f=lambda x: 1 + 0.5 * x[..., 1], nu=1.0,
+                    kappa="bottom", b_diri_tags=["coastline", "surface"], b_diri_fn=lambda x: 0 * x[..., 0],
+                    dt=1e-3, b0=None),
+}
+
+
+@dataclass
+class System:
+    name: str
+    orc: fo.Oracle
+    cfg: dict
+    A: sp.csr_matrix
+    B: sp.csr_matrix
+    b0: np.ndarray
+    M: sp.csr_matrix
+    Kh: sp.csr_matrix
+    Kv: sp.csr_matrix
+    rhs_M: np.ndarray
+    rhs_h: np.ndarray
+    rhs_v: np.ndarray
+    rhs_diff: np.ndarray
+    rhs_flux: np.ndarray
+    dt: float
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def c(self):
+        return self.orc.alpha ** 2 * self.orc.eps ** 2 / self.orc.mu_rho
+
+    def theta(self, scheme):
+        """src/evolution.jl:187-193."""
+        return self.dt * self.c * (1.0 if scheme == "BDF1" else 2.0 / 3.0)
+
+
+def setup(name, mesh="mesh_bowl3D_h0.1", **override) -> System:
+    cfg = dict(CONFIGS[name])
+    cfg.update(override)
+    topo = fo.build_topo(load_mesh(mesh))
+    spc = fo.build_spaces(topo, U_TAGS, U_MASKS, cfg["b_diri_tags"], cfg["b_diri_fn"])
+    kap = _kappa_bottom(cfg["alpha"]) if cfg["kappa"] == "bottom" else cfg["kappa"]
+    orc = fo.Oracle(topo, spc, eps=cfg["eps"], alpha=cfg["alpha"], mu_rho=cfg["mu_rho"], N2=cfg["N2"], f=cfg["f"],
+                    nu=cfg["nu"], kappa_h=kap, kappa_v=kap, tau_x=cfg.get("tau_x", 0.0), tau_y=cfg.get("tau_y", 0.0),
+                    surface_flux=cfg.get("surface_flux"))
+    M, rM = orc.M()
+    Kh, rh = orc.K_h()
+    Kv, rv = orc.K_v()
+    return System(name, orc, cfg, orc.A_inversion(), orc.B_inversion(), orc.b_inversion(), M, Kh, Kv, rM, rh, rv,
+                  orc.rhs_diff(), orc.rhs_flux(), float(cfg["dt"]))
+
+
+def rcm_perms(sysm: System):
+    """src/dofs.jl:70-100: per-field RCM of the mass-matrix graphs; p_inversion = [p_u; nu + p_p].  Any valid RCM is
+    acceptable to the reference (test/bowl_mixing_tests.jl:60 comment); scipy's is used."""
+    s = sysm.orc.sp
+    A = sysm.A
+    Auu = A[:s.nu, :s.nu]
+    p_u = np.asarray(reverse_cuthill_mckee(sp.csr_matrix(Auu), symmetric_mode=False))
+    App = (A[s.nu:, :s.nu] @ A[:s.nu, s.nu:])
+    p_p = np.asarray(reverse_cuthill_mckee(sp.csr_matrix(App), symmetric_mode=False))
+    p_b = np.asarray(reverse_cuthill_mckee(sp.csr_matrix(sysm.M), symmetric_mode=True))
+    return np.concatenate([p_u, s.nu + p_p]), p_b
+
+
+def run(sysm: System, nsteps, solver="direct", first_step_lhs="bdf1", invert_first=False, scheme="BDF2",
+        krylov_kw=None, record=None):
+    """Returns (u, p, b) free values in native order after `nsteps` steps from the configuration's initial condition."""
+    orc, s = sysm.orc, sysm.orc.sp
+    b0fn = sysm.cfg["b0"]
+    b = np.zeros(s.nb) if b0fn is None else orc.interpolate_b(b0fn)
+    u = np.zeros(s.nu)
+    p = np.zeros(s.np_)
+    krylov_kw = dict(krylov_kw or {})
+    nu = s.nu
+    if solver == "direct":
+        luA = spla.splu(sp.csc_matrix(sysm.A))
+    else:
+        h, _ = orc.precond_h()
+        Pinv = 1.0 / h ** orc.topo.dim
+        xinv = np.zeros(s.nu + s.np_)
+        xb = np.zeros(s.nb)
+
+    def invert(bv):
+        nonlocal xinv
+        y = sysm.B @ bv + sysm.b0
+        if solver == "direct":
+            x = luA.solve(y)
+        else:
+            x, st = ko.gmres(sysm.A, y, x0=xinv, M=Pinv, **krylov_kw)
+            xinv = x
+            if record is not None:
+                record.append(("gmres", st["niter"], st["solved"]))
+        return x[:nu], x[nu:]
+
+    if invert_first:
+        u, p = invert(b)
+    u_prev, b_prev = u.copy(), b.copy()
+    lhs_cache = {}
+
+    def lhs(theta):
+        if theta not in lhs_cache:
+            Amat = (sysm.M + theta * (sysm.Kh + sysm.Kv)).tocsr()
+            lhs_cache[theta] = (Amat, spla.splu(sp.csc_matrix(Amat)) if solver == "direct" else 1.0 / Amat.diagonal())
+        return lhs_cache[theta]
+
+    for i in range(1, nsteps + 1):
+        theta_rhs = sysm.theta(scheme)
+        if scheme == "BDF2" and i == 1 and first_step_lhs == "bdf1":
+            theta_lhs = sysm.theta("BDF1")          # src/evolution.jl:110-111 + src/model.jl:134-137
+        else:
+            theta_lhs = theta_rhs
+        u_curr, b_curr = u.copy(), b.copy()
+        radv = orc.advection_rhs(b, b_prev, u, u_prev, sysm.dt, scheme)
+        y = radv + theta_rhs * sysm.rhs_diff + sysm.dt * sysm.rhs_flux \
+            - (sysm.rhs_M + theta_rhs * (sysm.rhs_h + sysm.rhs_v))                      # src/model.jl:278
+        Amat, fac = lhs(theta_lhs)
+        if solver == "direct":
+            b = fac.solve(y)
+        else:
+            b, st = ko.cg(Amat, y, x0=xb, M=fac, **{k: v for k, v in krylov_kw.items() if k in ("atol", "rtol")})
+            xb = b
+            if record is not None:
+                record.append(("cg", st["niter"], st["solved"]))
+        u, p = invert(b)
+        if max(np.abs(u).max(), np.abs(b).max()) > 1e3 or not np.isfinite(u).all():
+            raise RuntimeError("Blow-up detected, stopping simulation")                  # src/model.jl:149-153
+        u_prev, b_prev = u_curr, b_curr
+    return u, p, b
