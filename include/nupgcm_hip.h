@@ -1,0 +1,231 @@
+/* nupgcm_hip.h - C ABI of libnupgcm_hip.so: the MI355X (gfx950) device layer behind nuPGCM's
+ * Architecture / IterativeSolverToolkit / InversionToolkit / EvolutionToolkit surface.
+ *
+ * Each entry point names the reference interface it replaces (file:line under /root/reference/).  The reference reaches
+ * its device through Julia dispatch on CuArray / CuSparseMatrixCSR (ext/nuPGCMCUDAExt.jl:24-33) and through Krylov.jl
+ * (src/iterative_solvers.jl:58); a Julia package extension binds these symbols with `ccall`, and the
+ * Python package `nupgcm_amd` binds the same symbols with ctypes.
+ *
+ * Conventions: plain C, opaque handles, every call returns NPG_OK (0) or a negative NPG_E* code and leaves a message in
+ * npg_last_error().  All indices crossing the boundary are 0-based.  All floating point is fp64; device column indices
+ * are int32.  Calls enqueue on the context's HIP stream and are host-synchronous only where they return host data.
+ * A context is thread-compatible, not thread-safe.
+ */
+#ifndef NUPGCM_HIP_H
+#define NUPGCM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPG_OK 0
+#define NPG_EINVAL (-1)   /* bad argument / shape mismatch                                    */
+#define NPG_EHIP (-2)     /* a HIP runtime call failed                                        */
+#define NPG_ENOMEM (-3)   /* device or host allocation failed                                 */
+#define NPG_ENODEV (-4)   /* no usable gfx950 device                                          */
+#define NPG_ECOMM (-5)    /* RCCL failure                                                     */
+#define NPG_EBLOWUP (-6)  /* blow-up guard tripped (src/model.jl:149-153)                     */
+
+typedef struct npg_ctx npg_ctx;
+typedef struct npg_vec npg_vec;
+typedef struct npg_csr npg_csr;
+typedef struct npg_gmres npg_gmres;
+typedef struct npg_cg npg_cg;
+typedef struct npg_fe npg_fe;
+typedef struct npg_halo npg_halo;
+
+/* ---- context: replaces the implicit CUDA.jl device/stream (ext/nuPGCMCUDAExt.jl:8-16) ------------------------- */
+int npg_ctx_create(int device, npg_ctx **out);
+int npg_ctx_destroy(npg_ctx *ctx);
+const char *npg_last_error(void);
+int npg_ctx_sync(npg_ctx *ctx);
+/* print_memory_status(::GPU)  (src/architectures.jl:20, ext/nuPGCMCUDAExt.jl:33) */
+int npg_mem_status(npg_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
+int npg_device_name(npg_ctx *ctx, char *buf, size_t cap);
+/* the hipStream_t all work is enqueued on (so a caller can bracket it with HIP events) */
+void *npg_ctx_stream(npg_ctx *ctx);
+/* HIP-event timer on the context's stream: start ... stop -> elapsed milliseconds (host-synchronous at stop) */
+int npg_timer_start(npg_ctx *ctx);
+int npg_timer_stop(npg_ctx *ctx, double *ms);
+
+/* ---- dense vectors: on_architecture(::GPU, ::Array) / (::CPU, ::CuArray), vector_type(::GPU, T)
+ *      (ext/nuPGCMCUDAExt.jl:24-26,31) and the BLAS-1 / broadcast calls of SURVEY.md section 2a ------------------ */
+int npg_vec_create(npg_ctx *ctx, int64_t n, npg_vec **out);              /* zero-filled */
+int npg_vec_destroy(npg_vec *v);
+/* non-owning window [offset, offset+n) of v (e.g. the velocity part x[1:nu] of [u; p], src/model.jl:314); the parent must
+ * outlive the view */
+int npg_vec_view(npg_vec *v, int64_t offset, int64_t n, npg_vec **out);
+int64_t npg_vec_len(const npg_vec *v);
+int npg_vec_upload(npg_vec *v, const double *host);
+int npg_vec_download(const npg_vec *v, double *host);
+/* v[i] = host[perm[i]]   -- `rhs[perm]` then H2D   (src/model.jl:274-275, src/evolution.jl:91-106) */
+int npg_vec_upload_perm(npg_vec *v, const double *host, const int64_t *perm);
+/* host[i] = v[perm[i]]   -- `solver.x[inv_perm]` then D2H   (src/model.jl:282,312) */
+int npg_vec_download_perm(const npg_vec *v, double *host, const int64_t *perm);
+int npg_vec_fill(npg_vec *v, double a);
+int npg_vec_copy(npg_vec *dst, const npg_vec *src);
+int npg_vec_axpby(npg_vec *y, double a, const npg_vec *x, double b);    /* y = a x + b y */
+int npg_vec_dot(const npg_vec *x, const npg_vec *y, double *out);
+int npg_vec_nrm2(const npg_vec *x, double *out);
+/* max |x_i| and whether any entry is NaN: the blow-up guard's reductions (src/model.jl:149-153) */
+int npg_vec_maxabs(const npg_vec *x, double *out, int *has_nan);
+/* y = sum_k coef[k] * xs[k]   (k < nterms <= 8): the fused broadcasts at src/inversion.jl:104, src/model.jl:278 */
+int npg_vec_lincomb(npg_vec *y, int nterms, const double *coef, const npg_vec *const *xs);
+/* y = d .* x   -- mul!(y, ::Diagonal, x) */
+int npg_vec_mul(npg_vec *y, const npg_vec *d, const npg_vec *x);
+
+/* ---- CSR matrices: on_architecture(::GPU, ::SparseMatrixCSC) = CuSparseMatrixCSR(a) and its inverse
+ *      (ext/nuPGCMCUDAExt.jl:27-29) ------------------------------------------------------------------------------- */
+/* CSC (Julia SparseMatrixCSC, made 0-based by the binding) -> device CSR.  drop_zeros != 0 removes entries that are
+ * exactly 0.0 (Gridap stores structural zeros; a correct SpMV need not stream them). */
+int npg_csr_create_from_csc(npg_ctx *ctx, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval,
+                            const double *nzval, int drop_zeros, npg_csr **out);
+int npg_csr_create(npg_ctx *ctx, int64_t m, int64_t n, const int64_t *rowptr, const int32_t *colind,
+                   const double *val, npg_csr **out);
+int npg_csr_destroy(npg_csr *A);
+int npg_csr_shape(const npg_csr *A, int64_t *m, int64_t *n, int64_t *nnz);
+/* device CSR -> host CSC arrays (caller allocates n+1 / nnz / nnz) : on_architecture(::CPU, ::CuSparseMatrixCSR) */
+int npg_csr_to_csc(const npg_csr *A, int64_t *colptr, int64_t *rowval, double *nzval);
+/* host CSR copy (rowptr m+1 int64, colind nnz int32, val nnz) */
+int npg_csr_download(const npg_csr *A, int64_t *rowptr, int32_t *colind, double *val);
+/* new matrix with the pattern of A and values copied from it */
+int npg_csr_clone(const npg_csr *A, npg_csr **out);
+int npg_csr_zero_values(npg_csr *A);
+/* out = a*X + b*(Y + Z) on identical patterns: `A = M + theta*(Kh + Kv)` (src/evolution.jl:144,162; src/model.jl:254)
+ * done on the device instead of a host SparseMatrixCSC add + re-upload */
+int npg_csr_combine(npg_csr *out, double a, const npg_csr *X, double b, const npg_csr *Y, const npg_csr *Z);
+/* d[i] = 1 / A[i,i]   -- `Diagonal(1 ./ diag(A))` (src/evolution.jl:149,167; src/model.jl:256) */
+int npg_csr_inv_diag(const npg_csr *A, npg_vec *d);
+/* y = alpha * A x + beta * y   -- mul!(y, A, x) / A*x  (cuSPARSE SpMV in the reference) */
+int npg_spmv(const npg_csr *A, const npg_vec *x, npg_vec *y, double alpha, double beta);
+
+/* ---- Krylov solvers: Krylov.krylov_solve!(workspace, A, y, x; M=P, kwargs...) (src/iterative_solvers.jl:58) ---- */
+#define NPG_PRECOND_NONE 0
+#define NPG_PRECOND_SCALAR 1   /* P = Diagonal(s * ones(n))   (src/inversion.jl:54)          */
+#define NPG_PRECOND_DIAG 2     /* P = Diagonal(d)             (src/evolution.jl:149,167)     */
+
+typedef struct npg_solve_stats {
+    int32_t solved;       /* workspace.stats.solved                                             */
+    int32_t niter;        /* workspace.stats.niter (cumulative inner iterations)                */
+    int32_t npass;        /* GMRES restart cycles started                                       */
+    int32_t status;       /* 1 solved, 2 itmax reached, 3 breakdown, 4 zero residual at start   */
+    int32_t nreorth;      /* GMRES: second Gram-Schmidt passes taken                            */
+    int32_t reserved;
+    double rnorm0;        /* || M r0 ||                                                         */
+    double rnorm;         /* last residual estimate                                             */
+    double seconds;       /* host wall time of the call                                         */
+} npg_solve_stats;
+
+/* GmresWorkspace(n, n, VT; memory)  (src/inversion.jl:84) */
+int npg_gmres_create(npg_ctx *ctx, int64_t n, int memory, npg_gmres **out);
+int npg_gmres_destroy(npg_gmres *ws);
+/* Left-preconditioned restarted GMRES(memory).  x is in/out: the incoming x is the warm start (x aliases workspace.x in
+ * the reference, src/iterative_solvers.jl:26-29).  itmax == 0 means 2 n.  Orthogonalisation is classical Gram-Schmidt
+ * with a selective second pass (reorth_eta: take it when ||w'|| < eta ||w||; eta <= 0 never, eta >= 1 always) instead
+ * of Krylov.jl's sequential modified Gram-Schmidt: one reduction per pass instead of j. */
+int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, double precond_scalar,
+                    const npg_vec *precond_diag, const npg_vec *y, npg_vec *x, double atol, double rtol,
+                    int64_t itmax, double reorth_eta, npg_solve_stats *stats);
+/* residual history of the last solve (workspace.stats.residuals with history=true): returns entries written */
+int64_t npg_gmres_history(npg_gmres *ws, double *buf, int64_t cap);
+
+/* CgWorkspace(n, n, VT)  (src/evolution.jl:120) */
+int npg_cg_create(npg_ctx *ctx, int64_t n, npg_cg **out);
+int npg_cg_destroy(npg_cg *ws);
+int npg_cg_solve(npg_cg *ws, const npg_csr *A, int precond_kind, double precond_scalar, const npg_vec *precond_diag,
+                 const npg_vec *y, npg_vec *x, double atol, double rtol, int64_t itmax, npg_solve_stats *stats);
+int64_t npg_cg_history(npg_cg *ws, double *buf, int64_t cap);
+
+/* ---- element-local finite-element kernels: Gridap.assemble_vector / assemble_matrix call sites ------------------
+ * The host supplies what Gridap holds: cell geometry, per-cell DoF tables and the quadrature / shape tables, so the
+ * device uses the same rule as `Measure(Omega, 4)` (src/meshes.jl:33).  A DoF table entry >= 0 is an index into the
+ * *device vector the field lives in* (i.e. already composed with the RCM permutation the solvers use,
+ * src/dofs.jl:27-41); an entry < 0 is Dirichlet value number (-1 - entry) of the `diri` array. */
+typedef struct npg_fe_desc {
+    int64_t ncell;
+    int32_t nq;               /* quadrature points per cell                                                    */
+    int32_t nloc_b;           /* buoyancy nodes per cell: 10 (P2) or 4 (P1)                                    */
+    const double *grad_lambda;/* [ncell][4][3] physical gradients of the barycentric coordinates              */
+    const double *wdet;       /* [ncell] |det J|                                                               */
+    const double *qw;         /* [nq] quadrature weights on the reference cell                                 */
+    const double *N2;         /* [nq][10] P2 shape values                                                      */
+    const double *dN2;        /* [nq][10][4] P2 shape derivatives w.r.t. barycentric coordinates               */
+    const double *Nb;         /* [nq][nloc_b] buoyancy shape values (== N2 when nloc_b == 10)                  */
+    const double *dNb;        /* [nq][nloc_b][4]                                                               */
+    const double *N1;         /* [nq][4] P1 shape values (pressure)                                            */
+    const int32_t *cell_u;    /* [ncell][10][3] velocity DoF table (into the inversion solution vector)        */
+    const int32_t *cell_p;    /* [ncell][4] pressure DoF table (into the inversion solution vector)            */
+    const int32_t *cell_b;    /* [ncell][nloc_b] buoyancy DoF table (into the evolution solution vector)       */
+    const double *u_diri;     /* Dirichlet values referenced by cell_u                                          */
+    int64_t n_u_diri;
+    const double *b_diri;     /* Dirichlet values referenced by cell_b                                          */
+    int64_t n_b_diri;
+    int64_t n_inv;            /* length of the inversion vector [u; p]                                          */
+    int64_t n_b;              /* length of the buoyancy vector                                                  */
+} npg_fe_desc;
+
+int npg_fe_create(npg_ctx *ctx, const npg_fe_desc *desc, npg_fe **out);
+int npg_fe_destroy(npg_fe *fe);
+/* per-cell, per-quadrature-point coefficient tables [ncell][nq], pre-evaluated by the host from the user's closures
+ * (nu, kappa_h, kappa_v, f): the device never runs user code.  name in {"nu","kappa_h","kappa_v","f"} */
+int npg_fe_set_coeff(npg_fe *fe, const char *name, const double *values);
+
+#define NPG_BDF1 1
+#define NPG_BDF2 2
+/* y = assemble_vector(d -> advection_lform(d, b, b_prev, u, u_prev, ...), B_test)[perm]
+ *       + theta*rhs_diff + dt*rhs_flux - (rhs_M + theta*(rhs_h + rhs_v))
+ * i.e. src/model.jl:269-278 in one call, entirely on the device.  x_inv / x_inv_prev are the inversion solution vectors
+ * [u; p] (current and previous step), b / b_prev the evolution solution vectors.  Any of the five rhs_* may be NULL. */
+int npg_fe_evolution_rhs(npg_fe *fe, int scheme, double dt, double N2, double theta, const npg_vec *b,
+                         const npg_vec *b_prev, const npg_vec *x_inv, const npg_vec *x_inv_prev,
+                         const npg_vec *rhs_diff, const npg_vec *rhs_flux, const npg_vec *rhs_M, const npg_vec *rhs_h,
+                         const npg_vec *rhs_v, npg_vec *y);
+/* advection part alone (for parity tests of src/model.jl:292-300) */
+int npg_fe_advection_rhs(npg_fe *fe, int scheme, double dt, double N2, const npg_vec *b, const npg_vec *b_prev,
+                         const npg_vec *x_inv, const npg_vec *x_inv_prev, npg_vec *out);
+
+/* Matrix (re)assembly into an existing CSR pattern (values are overwritten).
+ * which: */
+#define NPG_MAT_M 1        /* build_M        src/evolution.jl:209-212 ; lift = rhs_M                         */
+#define NPG_MAT_KH 2       /* build_Kh       src/evolution.jl:225-228 ; coefficient "kappa_h" ; lift = rhs_h */
+#define NPG_MAT_KV 3       /* build_Kv       src/evolution.jl:240-246 ; coefficient "kappa_v" ; lift = rhs_v */
+#define NPG_MAT_A 4        /* build_A_inversion(!) src/inversion.jl:133-192, coefficients "nu", "f"          */
+#define NPG_MAT_B 5        /* build_B_inversion    src/inversion.jl:199-219 ; lift = Dirichlet part of b0    */
+/* a2e2 = alpha^2 eps^2 (A), scale = 1/alpha (B); full_stress != 0 selects the sigma(u):sigma(v) form used when nu is
+ * a function (src/inversion.jl:172-181).  lift (may be NULL) receives sum_j a(phi_j^D, phi_i) b_D,j, the Dirichlet
+ * correction vector of build_matrix_vector (src/evolution.jl:256-260) / build_b_inversion (src/inversion.jl:241). */
+int npg_fe_assemble_matrix(npg_fe *fe, int which, double scale, int full_stress, npg_csr *A, npg_vec *lift);
+/* rhs_diff = -N2 int kappa_v d_z(d)   (src/evolution.jl:269-278) */
+int npg_fe_assemble_rhs_diff(npg_fe *fe, double N2, npg_vec *out);
+/* kappa_v <- kappa_v0 + kappa_c (1 + tanh(-alpha (N2 + d_z b) / N2min)) / 2 at every quadrature point
+ * (kappa_v_convection, src/inputs.jl:87-91, called at src/model.jl:229-232) */
+int npg_fe_update_kappa_convection(npg_fe *fe, const double *kappa_v0_host_or_null, double kappa_c, double N2min,
+                                   double alpha, double N2, const npg_vec *b);
+/* nu <- LogSumExp(nu_min, f^2 / sqrt(N2min^2 + (alpha (N2 + d_z b))^2)) (nu_eddy, src/inputs.jl:130-137) */
+int npg_fe_update_nu_eddy(npg_fe *fe, double N2min, double alpha, double N2, double smoothing, double nu_min,
+                          const npg_vec *b);
+/* CFL:  min_K h_K / max(max_q |u|, u_min)   (update_dt!, src/timesteppers.jl:108-119) */
+int npg_fe_cfl_ratio(npg_fe *fe, const double *h_cells_host, double u_min, const npg_vec *x_inv, double *out);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI (new work: the reference is single-device) ----------------- */
+#define NPG_UNIQUE_ID_BYTES 128
+int npg_comm_unique_id(void *id128);                                  /* rank 0 makes it, the launcher broadcasts it */
+int npg_comm_init(npg_ctx *ctx, const void *id128, int rank, int nranks);
+int npg_comm_allreduce_sum(npg_ctx *ctx, double *host_inout, int n);  /* tiny host-side helper for tests/bench */
+/* Halo plan for a row-block distributed CSR: this rank owns n_owned rows; columns >= n_owned of the local matrix are
+ * ghosts filled from neighbours.  send_idx lists owned entries to ship to each peer, recv goes to consecutive ghost
+ * slots. */
+int npg_halo_create(npg_ctx *ctx, int64_t n_owned, int64_t n_ghost, int npeers, const int32_t *peer_rank,
+                    const int64_t *send_ptr, const int32_t *send_idx, const int64_t *recv_ptr, npg_halo **out);
+int npg_halo_destroy(npg_halo *h);
+int npg_halo_exchange(npg_halo *h, npg_vec *x_with_ghosts);
+int npg_gmres_set_halo(npg_gmres *ws, npg_halo *h);
+int npg_cg_set_halo(npg_cg *ws, npg_halo *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NUPGCM_HIP_H */

@@ -1,0 +1,15 @@
+"""nupgcm_amd - MI355X-native hot path of nuPGCM (assembly -> Krylov inversion -> buoyancy evolution) behind the
+reference's Architecture / InversionToolkit / EvolutionToolkit / invert! / evolve! surface.  GPU() only: the device layer
+is libnupgcm_hip.so (hand-written HIP for gfx950) and there is no CPU fallback."""
+from .architectures import (CPU, GPU, AbstractArchitecture, DeviceCSR, DeviceVector, architecture, on_architecture,
+                            print_memory_status, vector_type)
+from .evolution import EvolutionToolkit, collect_evolution_LHS, evolution_parameter
+from .fe import DoFHandler, FEData, Mesh, Spaces, get_n_dofs
+from .inputs import (ConvectionParameterization, EddyParameterization, Forcings, Parameters, SurfaceDirichletBC,
+                     SurfaceFluxBC)
+from .inversion import InversionToolkit, build_A_inversion, build_B_inversion, build_b_inversion
+from .iterative_solvers import CgWorkspace, Diagonal, GmresWorkspace, IterativeSolverToolkit, iterative_solve
+from .model import BlowUp, Model, State, evolve, invert, run, set_b, sync_flow
+from .timesteppers import BDF1, BDF2, update_dt, update_t
+
+__all__ = [n for n in dir() if not n.startswith("_")]

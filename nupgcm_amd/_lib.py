@@ -1,0 +1,136 @@
+"""ctypes binding of libnupgcm_hip.so (include/nupgcm_hip.h) - the same symbols ext/nuPGCMHIPExt.jl `ccall`s.
+
+There is no CPU fallback: if the shared library is missing this module raises, and creating a context without a gfx950
+device raises `DeviceError` (NPG_ENODEV)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnupgcm_hip.so")
+HEADER_PATH = os.path.join(_HERE, "..", "include", "nupgcm_hip.h")
+
+
+class DeviceError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libnupgcm_hip error {code}: {msg}")
+        self.code = code
+
+
+class SolveStats(C.Structure):
+    _fields_ = [("solved", C.c_int32), ("niter", C.c_int32), ("npass", C.c_int32), ("status", C.c_int32),
+                ("nreorth", C.c_int32), ("reserved", C.c_int32), ("rnorm0", C.c_double), ("rnorm", C.c_double),
+                ("seconds", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class FeDesc(C.Structure):
+    _fields_ = [("ncell", C.c_int64), ("nq", C.c_int32), ("nloc_b", C.c_int32),
+                ("grad_lambda", C.c_void_p), ("wdet", C.c_void_p), ("qw", C.c_void_p), ("N2", C.c_void_p),
+                ("dN2", C.c_void_p), ("Nb", C.c_void_p), ("dNb", C.c_void_p), ("N1", C.c_void_p),
+                ("cell_u", C.c_void_p), ("cell_p", C.c_void_p), ("cell_b", C.c_void_p),
+                ("u_diri", C.c_void_p), ("n_u_diri", C.c_int64), ("b_diri", C.c_void_p), ("n_b_diri", C.c_int64),
+                ("n_inv", C.c_int64), ("n_b", C.c_int64)]
+
+
+def declared_symbols(header=HEADER_PATH):
+    """Every function name declared in include/nupgcm_hip.h (used by the CPU test that the library exports them all)."""
+    txt = open(header).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(npg_[a-z0-9_]+)\s*\(", txt)))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(make -C nupgcm_amd/csrc). nupgcm_amd has no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    P, I64, I32, D, VP = C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p
+    PP = C.POINTER(C.c_void_p)
+    sig = {
+        "npg_ctx_create": [C.c_int, PP], "npg_ctx_destroy": [P], "npg_ctx_sync": [P],
+        "npg_mem_status": [P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
+        "npg_device_name": [P, C.c_char_p, C.c_size_t],
+        "npg_timer_start": [P], "npg_timer_stop": [P, C.POINTER(D)],
+        "npg_vec_create": [P, I64, PP], "npg_vec_view": [P, I64, I64, PP], "npg_vec_destroy": [P], "npg_vec_upload": [P, VP], "npg_vec_download": [P, VP],
+        "npg_vec_upload_perm": [P, VP, VP], "npg_vec_download_perm": [P, VP, VP], "npg_vec_fill": [P, D],
+        "npg_vec_copy": [P, P], "npg_vec_axpby": [P, D, P, D], "npg_vec_dot": [P, P, C.POINTER(D)],
+        "npg_vec_nrm2": [P, C.POINTER(D)], "npg_vec_maxabs": [P, C.POINTER(D), C.POINTER(C.c_int)],
+        "npg_vec_lincomb": [P, C.c_int, C.POINTER(D), PP], "npg_vec_mul": [P, P, P],
+        "npg_csr_create_from_csc": [P, I64, I64, VP, VP, VP, C.c_int, PP],
+        "npg_csr_create": [P, I64, I64, VP, VP, VP, PP], "npg_csr_destroy": [P],
+        "npg_csr_shape": [P, C.POINTER(I64), C.POINTER(I64), C.POINTER(I64)],
+        "npg_csr_to_csc": [P, VP, VP, VP], "npg_csr_download": [P, VP, VP, VP], "npg_csr_clone": [P, PP],
+        "npg_csr_zero_values": [P], "npg_csr_combine": [P, D, P, D, P, P], "npg_csr_inv_diag": [P, P],
+        "npg_spmv": [P, P, P, D, D],
+        "npg_gmres_create": [P, I64, C.c_int, PP], "npg_gmres_destroy": [P],
+        "npg_gmres_solve": [P, P, C.c_int, D, P, P, P, D, D, I64, D, C.POINTER(SolveStats)],
+        "npg_cg_create": [P, I64, PP], "npg_cg_destroy": [P],
+        "npg_cg_solve": [P, P, C.c_int, D, P, P, P, D, D, I64, C.POINTER(SolveStats)],
+        "npg_fe_create": [P, C.POINTER(FeDesc), PP], "npg_fe_destroy": [P], "npg_fe_set_coeff": [P, C.c_char_p, VP],
+        "npg_fe_evolution_rhs": [P, C.c_int, D, D, D, P, P, P, P, P, P, P, P, P, P],
+        "npg_fe_advection_rhs": [P, C.c_int, D, D, P, P, P, P, P],
+        "npg_fe_assemble_matrix": [P, C.c_int, D, C.c_int, P, P], "npg_fe_assemble_rhs_diff": [P, D, P],
+        "npg_fe_update_kappa_convection": [P, VP, D, D, D, D, P],
+        "npg_fe_update_nu_eddy": [P, D, D, D, D, D, P], "npg_fe_cfl_ratio": [P, VP, D, P, C.POINTER(D)],
+        "npg_comm_unique_id": [VP], "npg_comm_init": [P, VP, C.c_int, C.c_int],
+        "npg_comm_allreduce_sum": [P, C.POINTER(D), C.c_int],
+        "npg_halo_create": [P, I64, I64, C.c_int, VP, VP, VP, VP, PP], "npg_halo_destroy": [P],
+        "npg_halo_exchange": [P, P], "npg_gmres_set_halo": [P, P], "npg_cg_set_halo": [P, P],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    L.npg_last_error.restype = C.c_char_p
+    L.npg_last_error.argtypes = []
+    L.npg_ctx_stream.restype = C.c_void_p
+    L.npg_ctx_stream.argtypes = [P]
+    L.npg_vec_len.restype = I64
+    L.npg_vec_len.argtypes = [P]
+    L.npg_gmres_history.restype = I64
+    L.npg_gmres_history.argtypes = [P, VP, I64]
+    L.npg_cg_history.restype = I64
+    L.npg_cg_history.argtypes = [P, VP, I64]
+
+
+def check(rc):
+    if rc != 0:
+        raise DeviceError(rc, lib().npg_last_error().decode(errors="replace"))
+
+
+def ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def as_i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def as_i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+NPG_PRECOND_NONE, NPG_PRECOND_SCALAR, NPG_PRECOND_DIAG = 0, 1, 2
+NPG_BDF1, NPG_BDF2 = 1, 2
+NPG_MAT_M, NPG_MAT_KH, NPG_MAT_KV, NPG_MAT_A, NPG_MAT_B = 1, 2, 3, 4, 5

@@ -1,0 +1,102 @@
+"""DeviceFE: the element-local assembly engine of one (FEData, GPU) pair - wraps the npg_fe_* entry points.
+
+Replaces the Gridap `assemble_vector` / `assemble_matrix` call sites of the hot path (src/model.jl:271-273,
+src/evolution.jl:257-258,277, src/inversion.jl:145,163-166,210) with HIP kernels; user closures (nu, kappa, f) are
+evaluated by the host at the quadrature points once and shipped as tables, so the device never runs user code."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .architectures import DeviceCSR, DeviceVector
+
+
+def eval_at_quad_points(mesh, v):
+    """table (ncell, nq) of a coefficient given as a number or as a function of x (arrays (..., 3) -> (...))"""
+    xq = mesh.quad_points()
+    if callable(v):
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(v(xq), dtype=float), xq.shape[:2]))
+    return np.full(xq.shape[:2], float(v))
+
+
+class DeviceFE:
+    def __init__(self, ctx, fe_data):
+        self.ctx, self.fe_data = ctx, fe_data
+        m, s, t = fe_data.mesh, fe_data.spaces, fe_data.tables
+        nloc_b = 10 if s.b_order == 2 else 4
+        Nb, dNb = (m.N2, m.dN2) if s.b_order == 2 else (m.N1, m.dN1)
+        self._keep = dict(
+            G=L.as_f64(m.grad_lambda), wdet=L.as_f64(m.detJ), qw=L.as_f64(m.q_w), N2=L.as_f64(m.N2), dN2=L.as_f64(m.dN2),
+            Nb=L.as_f64(Nb), dNb=L.as_f64(dNb), N1=L.as_f64(m.N1), cu=L.as_i32(t.cell_u), cp=L.as_i32(t.cell_p),
+            cb=L.as_i32(t.cell_b), ud=L.as_f64(t.u_diri), bd=L.as_f64(t.b_diri))
+        k = self._keep
+        d = L.FeDesc(ncell=m.ncell, nq=len(m.q_w), nloc_b=nloc_b, grad_lambda=k["G"].ctypes.data,
+                     wdet=k["wdet"].ctypes.data, qw=k["qw"].ctypes.data, N2=k["N2"].ctypes.data, dN2=k["dN2"].ctypes.data,
+                     Nb=k["Nb"].ctypes.data, dNb=k["dNb"].ctypes.data, N1=k["N1"].ctypes.data, cell_u=k["cu"].ctypes.data,
+                     cell_p=k["cp"].ctypes.data, cell_b=k["cb"].ctypes.data, u_diri=k["ud"].ctypes.data,
+                     n_u_diri=k["ud"].size, b_diri=k["bd"].ctypes.data, n_b_diri=k["bd"].size,
+                     n_inv=fe_data.dofs.nu + fe_data.dofs.np, n_b=fe_data.dofs.nb)
+        h = C.c_void_p()
+        L.check(L.lib().npg_fe_create(ctx.h, C.byref(d), C.byref(h)))
+        self.h = h
+        self._patterns = {}
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.lib().npg_fe_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_coeff(self, name, v):
+        tab = L.as_f64(eval_at_quad_points(self.fe_data.mesh, v))
+        L.check(L.lib().npg_fe_set_coeff(self.h, name.encode(), L.ptr(tab)))
+
+    def new_matrix(self, kind, structural=False):
+        """zero-valued DeviceCSR with the pattern of 'A', 'B' or 'b' (buoyancy-buoyancy)"""
+        key = (kind, structural)
+        if key not in self._patterns:
+            fd = self.fe_data
+            rp, ci, shape = {"A": fd.pattern_A, "B": fd.pattern_B}[kind](structural) if kind != "b" else fd.pattern_b()
+            self._patterns[key] = DeviceCSR.from_pattern(self.ctx, shape[0], shape[1], rp, ci)
+            return self._patterns[key]
+        return self._patterns[key].clone()
+
+    def assemble(self, which, A: DeviceCSR, scale=1.0, full_stress=False, lift: DeviceVector = None):
+        L.check(L.lib().npg_fe_assemble_matrix(self.h, which, float(scale), int(bool(full_stress)), A.h,
+                                               None if lift is None else lift.h))
+        return A
+
+    def rhs_diff(self, N2, out: DeviceVector):
+        L.check(L.lib().npg_fe_assemble_rhs_diff(self.h, float(N2), out.h))
+        return out
+
+    def advection_rhs(self, scheme, dt, N2, b, b_prev, x_inv, x_inv_prev, out):
+        L.check(L.lib().npg_fe_advection_rhs(self.h, scheme, float(dt), float(N2), b.h, b_prev.h, x_inv.h, x_inv_prev.h,
+                                             out.h))
+        return out
+
+    def evolution_rhs(self, scheme, dt, N2, theta, b, b_prev, x_inv, x_inv_prev, rhs_diff, rhs_flux, rhs_M, rhs_h, rhs_v,
+                      y):
+        hh = [None if v is None else v.h for v in (rhs_diff, rhs_flux, rhs_M, rhs_h, rhs_v)]
+        L.check(L.lib().npg_fe_evolution_rhs(self.h, scheme, float(dt), float(N2), float(theta), b.h, b_prev.h, x_inv.h,
+                                             x_inv_prev.h, *hh, y.h))
+        return y
+
+    def update_kappa_convection(self, kappa_c, N2min, alpha, N2, b):
+        L.check(L.lib().npg_fe_update_kappa_convection(self.h, None, float(kappa_c), float(N2min), float(alpha),
+                                                       float(N2), b.h))
+
+    def update_nu_eddy(self, N2min, alpha, N2, b, smoothing=10.0, nu_min=1.0):
+        L.check(L.lib().npg_fe_update_nu_eddy(self.h, float(N2min), float(alpha), float(N2), float(smoothing),
+                                              float(nu_min), b.h))
+
+    def cfl_ratio(self, x_inv, u_min=0.01, h_cells=None):
+        out = C.c_double()
+        hc = None if h_cells is None else L.as_f64(h_cells)
+        L.check(L.lib().npg_fe_cfl_ratio(self.h, None if hc is None else L.ptr(hc), float(u_min), x_inv.h,
+                                         C.byref(out)))
+        return out.value

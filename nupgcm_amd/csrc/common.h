@@ -1,0 +1,89 @@
+// Internal definitions shared by the translation units of libnupgcm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nupgcm_hip.h"
+
+#define NPG_API extern "C" __attribute__((visibility("default")))
+
+namespace npg {
+
+void set_error(const char *fmt, ...);
+
+#define NPG_HIP(call)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            npg::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_ == hipErrorOutOfMemory ? NPG_ENOMEM : NPG_EHIP;                             \
+        }                                                                                         \
+    } while (0)
+
+#define NPG_REQUIRE(cond, ...)              \
+    do {                                    \
+        if (!(cond)) {                      \
+            npg::set_error(__VA_ARGS__);    \
+            return NPG_EINVAL;              \
+        }                                   \
+    } while (0)
+
+constexpr int kWave = 64;          // CDNA4 wavefront
+constexpr int kBlock = 256;        // 4 waves per workgroup everywhere
+constexpr int kNumCU = 256;        // MI355X
+constexpr int kPartStride = 32;    // doubles per block in a partial-sum row (256 B)
+constexpr int kMaxMem = 30;        // largest GMRES memory supported (partial rows hold mem + 2 values)
+
+}  // namespace npg
+
+struct npg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int num_cu = npg::kNumCU;
+    // scratch for reductions (device) and their results (pinned host)
+    double *d_scratch = nullptr;
+    double *h_scratch = nullptr;
+    size_t scratch_doubles = 0;
+    // pinned staging buffer for perm uploads/downloads
+    double *h_stage = nullptr;
+    size_t stage_doubles = 0;
+    // communicator (RCCL), opaque here
+    void *comm = nullptr;
+    int rank = 0, nranks = 1;
+};
+
+struct npg_vec {
+    npg_ctx *ctx = nullptr;
+    int64_t n = 0;
+    double *d = nullptr;
+    bool owns = true;
+};
+
+struct npg_csr {
+    npg_ctx *ctx = nullptr;
+    int64_t m = 0, n = 0, nnz = 0;
+    int64_t *rowptr = nullptr;   // device, m+1
+    int32_t *col = nullptr;      // device, nnz
+    double *val = nullptr;       // device, nnz
+    bool owns_pattern = true;
+    // nnz-balanced row tiles for the tiled SpMV kernels (device + host copy)
+    int32_t *tile_ptr = nullptr; // device, ntiles+1 row boundaries
+    int32_t ntiles = 0;
+    int32_t lanes = 16;          // lanes per row chosen from the mean row length
+    std::vector<int64_t> h_rowptr;
+};
+
+namespace npg {
+int ensure_stage(npg_ctx *ctx, size_t doubles);
+int build_tiles(npg_csr *A);
+// reductions that return a scalar to the host (synchronous)
+int reduce_dot(npg_ctx *ctx, const double *x, const double *y, int64_t n, double *out);
+int reduce_maxabs(npg_ctx *ctx, const double *x, int64_t n, double *out, int *has_nan);
+}  // namespace npg

@@ -1,0 +1,253 @@
+// CSR matrices on the device: construction from Julia's CSC, round trip, same-pattern combination, SpMV.
+#include <algorithm>
+
+#include "common.h"
+#include "spmv_device.h"
+
+namespace npg {
+
+// nnz-balanced tiles of at most 256 rows
+int build_tiles(npg_csr *A) {
+    const int64_t m = A->m, nnz = A->nnz;
+    const int64_t *rp = A->h_rowptr.data();
+    int64_t target = nnz / (2 * (int64_t)A->ctx->num_cu);
+    target = std::max<int64_t>(1024, std::min<int64_t>(16384, target));
+    std::vector<int32_t> tp;
+    tp.push_back(0);
+    int64_t r = 0;
+    while (r < m) {
+        int64_t r1 = r + 1;
+        while (r1 < m && r1 - r < 256 && rp[r1] - rp[r] < target) ++r1;
+        tp.push_back((int32_t)r1);
+        r = r1;
+    }
+    A->ntiles = (int32_t)tp.size() - 1;
+    const double mean = m > 0 ? (double)nnz / (double)m : 0.0;
+    A->lanes = mean <= 6 ? 4 : mean <= 24 ? 8 : mean <= 96 ? 16 : 32;
+    if (A->tile_ptr) NPG_HIP(hipFree(A->tile_ptr));
+    NPG_HIP(hipMalloc((void **)&A->tile_ptr, tp.size() * sizeof(int32_t)));
+    NPG_HIP(hipMemcpy(A->tile_ptr, tp.data(), tp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return NPG_OK;
+}
+
+template <int L>
+__global__ void __launch_bounds__(kBlock) k_spmv(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                 const double *__restrict__ val, const int32_t *__restrict__ tile_ptr,
+                                                 int ntiles, const double *__restrict__ x, double *__restrict__ y,
+                                                 double alpha, double beta) {
+    const int g = threadIdx.x / L, l = threadIdx.x % L;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int r0 = tile_ptr[t], r1 = tile_ptr[t + 1];
+        for (int row = r0 + g; row < r1; row += kBlock / L) {
+            const double s = csr_row_dot<L>(rowptr, col, val, x, row, l);
+            if (l == 0) y[row] = (beta == 0.0) ? alpha * s : alpha * s + beta * y[row];
+        }
+    }
+}
+
+__global__ void k_combine(double *out, double a, const double *X, double b, const double *Y, const double *Z,
+                          int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = a * X[i] + b * (Y[i] + Z[i]);
+}
+
+__global__ void k_inv_diag(const int64_t *rowptr, const int32_t *col, const double *val, double *d, int64_t m) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < m; r += (int64_t)gridDim.x * blockDim.x) {
+        double a = 0.0;
+        for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k)
+            if (col[k] == r) a += val[k];
+        d[r] = 1.0 / a;
+    }
+}
+
+static int upload_csr(npg_ctx *ctx, int64_t m, int64_t n, std::vector<int64_t> &&rowptr, const std::vector<int32_t> &col,
+                      const std::vector<double> &val, npg_csr **out) {
+    npg_csr *A = new npg_csr();
+    A->ctx = ctx;
+    A->m = m;
+    A->n = n;
+    A->nnz = (int64_t)col.size();
+    NPG_HIP(hipSetDevice(ctx->device));
+    NPG_HIP(hipMalloc((void **)&A->rowptr, (size_t)(m + 1) * sizeof(int64_t)));
+    NPG_HIP(hipMalloc((void **)&A->col, std::max<size_t>(1, col.size()) * sizeof(int32_t)));
+    NPG_HIP(hipMalloc((void **)&A->val, std::max<size_t>(1, val.size()) * sizeof(double)));
+    NPG_HIP(hipMemcpy(A->rowptr, rowptr.data(), (size_t)(m + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (!col.empty()) {
+        NPG_HIP(hipMemcpy(A->col, col.data(), col.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        NPG_HIP(hipMemcpy(A->val, val.data(), val.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    A->h_rowptr = std::move(rowptr);
+    int rc = build_tiles(A);
+    if (rc) return rc;
+    *out = A;
+    return NPG_OK;
+}
+
+template <int L>
+static void launch_spmv(const npg_csr *A, const double *x, double *y, double alpha, double beta) {
+    const int grid = std::min<int>(A->ntiles, 8 * A->ctx->num_cu);
+    hipLaunchKernelGGL(k_spmv<L>, dim3(std::max(grid, 1)), dim3(kBlock), 0, A->ctx->stream, A->rowptr, A->col, A->val,
+                       A->tile_ptr, A->ntiles, x, y, alpha, beta);
+}
+
+}  // namespace npg
+
+using namespace npg;
+
+NPG_API int npg_csr_create_from_csc(npg_ctx *ctx, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval,
+                                    const double *nzval, int drop_zeros, npg_csr **out) {
+    NPG_REQUIRE(ctx && colptr && out && m >= 0 && n >= 0, "npg_csr_create_from_csc: bad argument");
+    NPG_REQUIRE(m < INT32_MAX && n < INT32_MAX, "npg_csr_create_from_csc: dimensions exceed int32 indices");
+    const int64_t nnz_in = colptr[n];
+    NPG_REQUIRE(nnz_in == 0 || (rowval && nzval), "npg_csr_create_from_csc: NULL arrays");
+    std::vector<int64_t> rowptr((size_t)m + 1, 0);
+    for (int64_t j = 0; j < n; ++j) {
+        NPG_REQUIRE(colptr[j + 1] >= colptr[j], "npg_csr_create_from_csc: colptr not monotone at %lld", (long long)j);
+        for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
+            NPG_REQUIRE(rowval[k] >= 0 && rowval[k] < m, "npg_csr_create_from_csc: row index out of range");
+            if (drop_zeros && nzval[k] == 0.0) continue;
+            ++rowptr[(size_t)rowval[k] + 1];
+        }
+    }
+    for (int64_t i = 0; i < m; ++i) rowptr[i + 1] += rowptr[i];
+    const int64_t nnz = rowptr[m];
+    std::vector<int32_t> col((size_t)nnz);
+    std::vector<double> val((size_t)nnz);
+    std::vector<int64_t> next(rowptr.begin(), rowptr.end() - 1);
+    for (int64_t j = 0; j < n; ++j)        // columns ascending => each CSR row ends up sorted by column
+        for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
+            if (drop_zeros && nzval[k] == 0.0) continue;
+            const int64_t p = next[rowval[k]]++;
+            col[p] = (int32_t)j;
+            val[p] = nzval[k];
+        }
+    return upload_csr(ctx, m, n, std::move(rowptr), col, val, out);
+}
+
+NPG_API int npg_csr_create(npg_ctx *ctx, int64_t m, int64_t n, const int64_t *rowptr, const int32_t *colind,
+                           const double *val, npg_csr **out) {
+    NPG_REQUIRE(ctx && rowptr && out && m >= 0 && n >= 0, "npg_csr_create: bad argument");
+    NPG_REQUIRE(m < INT32_MAX && n < INT32_MAX, "npg_csr_create: dimensions exceed int32 indices");
+    NPG_REQUIRE(rowptr[0] == 0, "npg_csr_create: rowptr must be 0-based");
+    const int64_t nnz = rowptr[m];
+    for (int64_t i = 0; i < m; ++i)
+        NPG_REQUIRE(rowptr[i + 1] >= rowptr[i], "npg_csr_create: rowptr not monotone at %lld", (long long)i);
+    for (int64_t k = 0; k < nnz; ++k)
+        NPG_REQUIRE(colind[k] >= 0 && colind[k] < n, "npg_csr_create: column index out of range at %lld", (long long)k);
+    std::vector<int64_t> rp(rowptr, rowptr + m + 1);
+    std::vector<int32_t> col(colind, colind + nnz);
+    std::vector<double> v((size_t)nnz, 0.0);
+    if (val) std::copy(val, val + nnz, v.begin());
+    return upload_csr(ctx, m, n, std::move(rp), col, v, out);
+}
+
+NPG_API int npg_csr_destroy(npg_csr *A) {
+    if (!A) return NPG_OK;
+    hipStreamSynchronize(A->ctx->stream);
+    if (A->owns_pattern) {
+        if (A->rowptr) hipFree(A->rowptr);
+        if (A->col) hipFree(A->col);
+        if (A->tile_ptr) hipFree(A->tile_ptr);
+    }
+    if (A->val) hipFree(A->val);
+    delete A;
+    return NPG_OK;
+}
+
+NPG_API int npg_csr_shape(const npg_csr *A, int64_t *m, int64_t *n, int64_t *nnz) {
+    NPG_REQUIRE(A, "npg_csr_shape: NULL matrix");
+    if (m) *m = A->m;
+    if (n) *n = A->n;
+    if (nnz) *nnz = A->nnz;
+    return NPG_OK;
+}
+
+NPG_API int npg_csr_download(const npg_csr *A, int64_t *rowptr, int32_t *colind, double *val) {
+    NPG_REQUIRE(A, "npg_csr_download: NULL matrix");
+    NPG_HIP(hipStreamSynchronize(A->ctx->stream));
+    if (rowptr) std::copy(A->h_rowptr.begin(), A->h_rowptr.end(), rowptr);
+    if (colind && A->nnz) NPG_HIP(hipMemcpy(colind, A->col, (size_t)A->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (val && A->nnz) NPG_HIP(hipMemcpy(val, A->val, (size_t)A->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    return NPG_OK;
+}
+
+NPG_API int npg_csr_to_csc(const npg_csr *A, int64_t *colptr, int64_t *rowval, double *nzval) {
+    NPG_REQUIRE(A && colptr && rowval && nzval, "npg_csr_to_csc: NULL argument");
+    std::vector<int32_t> col((size_t)A->nnz);
+    std::vector<double> val((size_t)A->nnz);
+    int rc = npg_csr_download(A, nullptr, col.data(), val.data());
+    if (rc) return rc;
+    std::fill(colptr, colptr + A->n + 1, 0);
+    for (int64_t k = 0; k < A->nnz; ++k) ++colptr[col[k] + 1];
+    for (int64_t j = 0; j < A->n; ++j) colptr[j + 1] += colptr[j];
+    std::vector<int64_t> next(colptr, colptr + A->n);
+    for (int64_t i = 0; i < A->m; ++i)
+        for (int64_t k = A->h_rowptr[i]; k < A->h_rowptr[i + 1]; ++k) {
+            const int64_t p = next[col[k]]++;
+            rowval[p] = i;
+            nzval[p] = val[k];
+        }
+    return NPG_OK;
+}
+
+NPG_API int npg_csr_clone(const npg_csr *A, npg_csr **out) {
+    NPG_REQUIRE(A && out, "npg_csr_clone: NULL argument");
+    npg_csr *B = new npg_csr();
+    B->ctx = A->ctx;
+    B->m = A->m;
+    B->n = A->n;
+    B->nnz = A->nnz;
+    B->rowptr = A->rowptr;        // pattern is shared; the original must outlive the clone
+    B->col = A->col;
+    B->tile_ptr = A->tile_ptr;
+    B->ntiles = A->ntiles;
+    B->lanes = A->lanes;
+    B->owns_pattern = false;
+    B->h_rowptr = A->h_rowptr;
+    NPG_HIP(hipMalloc((void **)&B->val, std::max<size_t>(1, (size_t)A->nnz) * sizeof(double)));
+    NPG_HIP(hipMemcpyAsync(B->val, A->val, (size_t)A->nnz * sizeof(double), hipMemcpyDeviceToDevice, A->ctx->stream));
+    *out = B;
+    return NPG_OK;
+}
+
+NPG_API int npg_csr_zero_values(npg_csr *A) {
+    NPG_REQUIRE(A, "npg_csr_zero_values: NULL matrix");
+    NPG_HIP(hipMemsetAsync(A->val, 0, (size_t)A->nnz * sizeof(double), A->ctx->stream));
+    return NPG_OK;
+}
+
+NPG_API int npg_csr_combine(npg_csr *out, double a, const npg_csr *X, double b, const npg_csr *Y, const npg_csr *Z) {
+    NPG_REQUIRE(out && X && Y && Z, "npg_csr_combine: NULL argument");
+    NPG_REQUIRE(out->nnz == X->nnz && X->nnz == Y->nnz && Y->nnz == Z->nnz && out->m == X->m && X->m == Y->m &&
+                    Y->m == Z->m,
+                "npg_csr_combine: operands must share one sparsity pattern");
+    const int grid = (int)std::min<int64_t>(2048, (out->nnz + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_combine, dim3(std::max(grid, 1)), dim3(kBlock), 0, out->ctx->stream, out->val, a, X->val, b,
+                       Y->val, Z->val, out->nnz);
+    NPG_HIP(hipGetLastError());
+    return NPG_OK;
+}
+
+NPG_API int npg_csr_inv_diag(const npg_csr *A, npg_vec *d) {
+    NPG_REQUIRE(A && d && A->m == A->n && d->n == A->m, "npg_csr_inv_diag: shape mismatch");
+    const int grid = (int)std::min<int64_t>(2048, (A->m + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_inv_diag, dim3(std::max(grid, 1)), dim3(kBlock), 0, A->ctx->stream, A->rowptr, A->col, A->val,
+                       d->d, A->m);
+    NPG_HIP(hipGetLastError());
+    return NPG_OK;
+}
+
+NPG_API int npg_spmv(const npg_csr *A, const npg_vec *x, npg_vec *y, double alpha, double beta) {
+    NPG_REQUIRE(A && x && y, "npg_spmv: NULL argument");
+    NPG_REQUIRE(x->n == A->n && y->n == A->m, "npg_spmv: A is %lld x %lld but x has %lld and y has %lld entries",
+                (long long)A->m, (long long)A->n, (long long)x->n, (long long)y->n);
+    NPG_REQUIRE(x->d != y->d, "npg_spmv: x and y must not alias");
+    switch (A->lanes) {
+        case 4: launch_spmv<4>(A, x->d, y->d, alpha, beta); break;
+        case 8: launch_spmv<8>(A, x->d, y->d, alpha, beta); break;
+        case 16: launch_spmv<16>(A, x->d, y->d, alpha, beta); break;
+        default: launch_spmv<32>(A, x->d, y->d, alpha, beta); break;
+    }
+    NPG_HIP(hipGetLastError());
+    return NPG_OK;
+}

@@ -1,0 +1,125 @@
+"""IterativeSolverToolkit / iterative_solve! - mirrors /root/reference/src/iterative_solvers.jl:1-68.
+
+On GPU() the Krylov workspaces are the device-resident solvers of libnupgcm_hip.so (one C call per solve, x warm-started
+because `x` aliases `workspace.x` exactly as in the reference, src/iterative_solvers.jl:26-29)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .architectures import DeviceCSR, DeviceVector
+
+
+class Diagonal:
+    """Diagonal(v): the preconditioner type of src/inversion.jl:54 and src/evolution.jl:149,167 (`M` is applied with
+    mul!, so it holds the INVERSE action).  `scalar` is set when every entry is the same number - the device then folds
+    it into the SpMV epilogue without streaming a vector."""
+
+    def __init__(self, diag=None, scalar=None, n=None):
+        self.diag, self.scalar = diag, scalar
+        self.n = n if n is not None else (len(diag) if diag is not None else None)
+
+    def kind(self):
+        if self.scalar is not None:
+            return L.NPG_PRECOND_SCALAR, float(self.scalar), None
+        return L.NPG_PRECOND_DIAG, 0.0, self.diag.h
+
+    def __repr__(self):
+        return f"Diagonal(scalar={self.scalar})" if self.scalar is not None else f"Diagonal({self.diag!r})"
+
+
+class _Workspace:
+    def __init__(self):
+        self.stats = None
+
+    def history(self):
+        raise NotImplementedError
+
+
+class GmresWorkspace(_Workspace):
+    """Krylov.GmresWorkspace(n, n, VT; memory) at src/inversion.jl:84"""
+
+    def __init__(self, ctx, n, memory=20):
+        super().__init__()
+        h = C.c_void_p()
+        L.check(L.lib().npg_gmres_create(ctx.h, int(n), int(memory), C.byref(h)))
+        self.h, self.ctx, self.n, self.memory = h, ctx, n, memory
+        self.x = DeviceVector(ctx, n)          # workspace.x .= 0 (src/inversion.jl:85)
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.lib().npg_gmres_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def solve(self, A: DeviceCSR, y: DeviceVector, x: DeviceVector, P, atol=1e-6, rtol=1e-6, itmax=0,
+              reorth_eta=0.7071067811865476, **_ignored):
+        kind, s, dh = (L.NPG_PRECOND_NONE, 0.0, None) if P is None else P.kind()
+        st = L.SolveStats()
+        L.check(L.lib().npg_gmres_solve(self.h, A.h, kind, s, dh, y.h, x.h, float(atol), float(rtol), int(itmax),
+                                        float(reorth_eta), C.byref(st)))
+        self.stats = st.as_dict()
+        return self.stats
+
+    def history(self):
+        buf = np.empty(int(self.stats["niter"]) + 1 if self.stats else 1)
+        k = L.lib().npg_gmres_history(self.h, L.ptr(buf), buf.size)
+        return buf[:max(k, 0)]
+
+
+class CgWorkspace(_Workspace):
+    """Krylov.CgWorkspace(n, n, VT) at src/evolution.jl:120"""
+
+    def __init__(self, ctx, n):
+        super().__init__()
+        h = C.c_void_p()
+        L.check(L.lib().npg_cg_create(ctx.h, int(n), C.byref(h)))
+        self.h, self.ctx, self.n = h, ctx, n
+        self.x = DeviceVector(ctx, n)
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.lib().npg_cg_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def solve(self, A: DeviceCSR, y: DeviceVector, x: DeviceVector, P, atol=1e-6, rtol=1e-6, itmax=0, **_ignored):
+        kind, s, dh = (L.NPG_PRECOND_NONE, 0.0, None) if P is None else P.kind()
+        st = L.SolveStats()
+        L.check(L.lib().npg_cg_solve(self.h, A.h, kind, s, dh, y.h, x.h, float(atol), float(rtol), int(itmax),
+                                     C.byref(st)))
+        self.stats = st.as_dict()
+        return self.stats
+
+    def history(self):
+        buf = np.empty(int(self.stats["niter"]) + 1 if self.stats else 1)
+        k = L.lib().npg_cg_history(self.h, L.ptr(buf), buf.size)
+        return buf[:max(k, 0)]
+
+
+class IterativeSolverToolkit:
+    """src/iterative_solvers.jl:1-9,26-29: {A, P, x, y, workspace, kwargs, label}; x just points to workspace.x."""
+
+    def __init__(self, A, P, y, workspace, kwargs, label):
+        self.A, self.P, self.y, self.workspace = A, P, y, workspace
+        self.x = workspace.x
+        self.kwargs, self.label = dict(kwargs), label
+
+    def __repr__(self):
+        return (f"IterativeSolverToolkit:\n├── A: {self.A!r}\n├── P: {self.P!r}\n├── x: {self.x!r}\n├── y: {self.y!r}\n"
+                f"├── workspace: {type(self.workspace).__name__}\n├── kwargs: {self.kwargs}\n└── label: \"{self.label}\"")
+
+
+def iterative_solve(solver: IterativeSolverToolkit):
+    """iterative_solve!(solver) - src/iterative_solvers.jl:31-68.  The reference's CPU() branches (`ldiv!` with an LU,
+    `A\\y`) belong to its CPU architecture and are not reproduced: this package is the GPU() architecture."""
+    if not isinstance(solver.A, DeviceCSR):
+        raise TypeError("iterative_solve: nupgcm_amd only implements the GPU() architecture; A must be a DeviceCSR")
+    solver.workspace.solve(solver.A, solver.y, solver.x, solver.P, **solver.kwargs)
+    return solver

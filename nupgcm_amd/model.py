@@ -1,0 +1,165 @@
+"""State, Model, run!, evolve!, invert!, sync_flow!, set_b! - mirrors /root/reference/src/model.jl:1-317 for GPU().
+
+Residency: the reference keeps the state in host FEFunctions and crosses the device boundary 4-6 times per step
+(src/model.jl:243-244,275,282,312).  Here the state IS the two solver vectors in HBM (x_inv = [u; p] in p_inversion
+order, x_b in p_b order) plus their previous-step copies; a timestep is device-only.  `state.u / p / b` download and
+un-permute on access (what sync_flow! / src/model.jl:282 do every step in the reference)."""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from . import _lib as L
+from .architectures import GPU, DeviceVector
+from .evolution import EvolutionToolkit, collect_evolution_LHS, collect_evolution_LHS_into, evolution_parameter
+from .inversion import InversionToolkit, build_A_inversion, invert as invert_toolkit
+from .iterative_solvers import iterative_solve
+from .timesteppers import BDF1, BDF2, update_dt, update_t
+
+
+class BlowUp(RuntimeError):
+    pass
+
+
+class State:
+    """src/model.jl:1-5.  u, p, b are host copies of the free values in the native (Gridap) DoF order."""
+
+    def __init__(self, model):
+        self._m = model
+
+    @property
+    def u(self):
+        d = self._m.fe_data.dofs
+        return self._m.inversion.solver.x.to_host(d.inv_p_inversion)[:d.nu]
+
+    @property
+    def p(self):
+        d = self._m.fe_data.dofs
+        return self._m.inversion.solver.x.to_host(d.inv_p_inversion)[d.nu:]
+
+    @property
+    def b(self):
+        return self._m.b_vec.to_host(self._m.fe_data.dofs.inv_p_b)
+
+    def __repr__(self):
+        d = self._m.fe_data.dofs
+        return f"State:\n├── u: {d.nu} DOFs\n├── p: {d.np} DOFs\n└── b: {d.nb} DOFs"
+
+
+class Model:
+    """Model(arch, params, forcings, fe_data, inversion[, evolution, timestepper]) - src/model.jl:18-62; starts from
+    rest."""
+
+    def __init__(self, arch, params, forcings, fe_data, inversion: InversionToolkit, evolution: EvolutionToolkit = None,
+                 timestepper=None):
+        if not isinstance(arch, GPU):
+            raise TypeError("nupgcm_amd implements the GPU() architecture only (no CPU fallback)")
+        self.arch, self.params, self.forcings, self.fe_data = arch, params, forcings, fe_data
+        self.inversion, self.evolution, self.timestepper = inversion, evolution, timestepper
+        ctx = arch.ctx
+        # buoyancy lives in the evolution solver's x when there is one
+        self.b_vec = evolution.solver.x if evolution is not None else DeviceVector(ctx, fe_data.dofs.nb)
+        self.state = State(self)
+        self.step_index = 1
+        self.stats = []
+        self._prev = None
+        self._u_view = inversion.solver.x.view(0, fe_data.dofs.nu)     # x[1:nu] = u (p_inversion = [p_u; nu + p_p])
+
+    def __repr__(self):
+        return f"Model:\n├── arch: {self.arch}\n├── fe_data: {self.fe_data!r}\n└── timestepper: {self.timestepper!r}"
+
+
+def set_b(model: Model, b):
+    """set_b!(model, b::Function | b::AbstractArray) - src/model.jl:77-88 (array in native free-DoF order)"""
+    s, d = model.fe_data.spaces, model.fe_data.dofs
+    vals = s.interpolate_b(b) if callable(b) else np.asarray(b, dtype=float)
+    if vals.shape != (d.nb,):
+        raise ValueError(f"set_b: expected {d.nb} free values, got {vals.shape}")
+    model.b_vec.upload(vals, d.p_b)
+    return model
+
+
+def invert(model: Model, b: DeviceVector = None):
+    """invert!(model[, b]) - src/model.jl:302-309 (sync_flow! is implicit: the flow lives in solver.x)"""
+    invert_toolkit(model.inversion, model.b_vec if b is None else b)
+    return model
+
+
+def sync_flow(model: Model):
+    """sync_flow! - src/model.jl:311-317: returns (u, p) on the host in native order"""
+    return model.state.u, model.state.p
+
+
+def _scheme(ts):
+    return L.NPG_BDF1 if isinstance(ts, BDF1) else L.NPG_BDF2
+
+
+def evolve(model: Model, x_inv_prev: DeviceVector, b_prev: DeviceVector):
+    """evolve!(model, u_prev, b_prev) - src/model.jl:213-285, device-only:
+       [convection: kappa_v closure -> Kv, rhs_v, rhs_diff reassembly]  ->  [LHS + Jacobi rebuild]  ->
+       advection assembly + RHS combination (one call)  ->  CG."""
+    ev, ts, prm, frc = model.evolution, model.timestepper, model.params, model.forcings
+    solver, fe = ev.solver, ev.fe
+    theta = evolution_parameter(prm, ts)
+    if frc.conv_param.is_on:
+        cp = frc.conv_param
+        fe.update_kappa_convection(cp.kappa_c, cp.N2min, prm.alpha, prm.N2, model.b_vec)       # src/model.jl:229-232
+        fe.assemble(L.NPG_MAT_KV, ev.Kv, lift=ev.rhs_v)                                        # src/model.jl:235
+        fe.rhs_diff(prm.N2, ev.rhs_diff)                                                       # src/model.jl:237
+    if frc.conv_param.is_on or ts.adaptive:
+        collect_evolution_LHS_into(solver.A, solver.P, prm, ts, ev.M, ev.Kh, ev.Kv)            # src/model.jl:251-261
+    x_inv = model.inversion.solver.x
+    fe.evolution_rhs(_scheme(ts), ts.dt, prm.N2, theta, model.b_vec, b_prev, x_inv, x_inv_prev, ev.rhs_diff,
+                     ev.rhs_flux, ev.rhs_M, ev.rhs_h, ev.rhs_v, solver.y)                      # src/model.jl:269-278
+    iterative_solve(solver)                                                                    # src/model.jl:279
+    return model
+
+
+def run(model: Model, n_info=10, n_save=float("inf"), n_plot=float("inf"), advection=True, n_steps=None, log=None):
+    """run!(model; n_info, n_save, n_plot, advection) - src/model.jl:90-211.  `n_steps` (extension) bounds the number of
+    steps taken by this call so that a caller can time a fixed number of steps; state carries over between calls."""
+    ts, prm, frc = model.timestepper, model.params, model.forcings
+    inv_x, b = model.inversion.solver.x, model.b_vec
+    fe = model.evolution.fe
+    ctx = model.arch.ctx
+    if model._prev is None:
+        # copies of previous and current u, b (src/model.jl:119-123)
+        model._prev = dict(x_prev=inv_x.copy(), b_prev=b.copy(), x_curr=inv_x.copy(), b_curr=b.copy())
+        if isinstance(ts, BDF1):
+            model._h_cells = model.fe_data.mesh.h_cells()                                       # src/model.jl:100
+    pv = model._prev
+    t0 = t_last = time.time()
+    taken = 0
+    while ts.t < ts.t_stop and (n_steps is None or taken < n_steps):
+        i = model.step_index
+        if isinstance(ts, BDF1):
+            update_dt(ts, fe, inv_x, h_cells=model.__dict__.pop("_h_cells", None))              # src/model.jl:131
+        if i == 2 and isinstance(ts, BDF2):
+            collect_evolution_LHS(model.evolution, prm, frc, ts)                                # src/model.jl:134-137
+        pv["x_curr"].copy_from(inv_x)                                                           # src/model.jl:140-141
+        pv["b_curr"].copy_from(b)
+        evolve(model, pv["x_prev"], pv["b_prev"])                                               # src/model.jl:144
+        invert(model)                                                                           # src/model.jl:145
+        update_t(ts)
+        # blow-up guard (src/model.jl:149-153): device reductions over [u; p] and b
+        xm, xnan = model._u_view.maxabs()
+        bm, bnan = b.maxabs()
+        if max(xm, bm) > 1e3 or xnan or bnan:
+            raise BlowUp("Blow-up detected, stopping simulation")
+        pv["x_prev"], pv["x_curr"] = pv["x_curr"], pv["x_prev"]                                 # src/model.jl:156-157
+        pv["b_prev"], pv["b_curr"] = pv["b_curr"], pv["b_prev"]
+        if frc.eddy_param.is_on and advection and i % 10 == 0:                                  # src/model.jl:160-170
+            ep = frc.eddy_param
+            fe.update_nu_eddy(ep.N2min, prm.alpha, prm.N2, b)
+            build_A_inversion(model.arch, model.fe_data, prm, None, A=model.inversion.solver.A)
+        model.stats.append((model.evolution.solver.workspace.stats, model.inversion.solver.workspace.stats))
+        if i % n_info == 0 and log is not None:
+            t1 = time.time()
+            log(f"t = {ts.t:.3e}/{ts.t_stop:.3e} (i = {i}, Δt = {ts.dt:.3e}); step ~ {(t1 - t_last) / n_info:.3e} s; "
+                f"|u|max = {xm:.3e}; GMRES it = {model.stats[-1][1]['niter']}, CG it = {model.stats[-1][0]['niter']}")
+            t_last = t1
+        model.step_index += 1
+        taken += 1
+    ctx.sync()
+    return model
