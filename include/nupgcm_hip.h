@@ -129,6 +129,11 @@ int npg_gmres_destroy(npg_gmres *ws);
 int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, double precond_scalar,
                     const npg_vec *precond_diag, const npg_vec *y, npg_vec *x, double atol, double rtol,
                     int64_t itmax, double reorth_eta, npg_solve_stats *stats);
+/* Profile mode: the next solves launch eagerly (no hipGraph) with HIP events on the context's stream around every
+ * Arnoldi kernel - the fused SpMV + Gram-Schmidt-dots kernel that dominates the solve - and accumulate their durations
+ * over complete restart cycles.  npg_gmres_get_profile returns the accumulated milliseconds and launch count. */
+int npg_gmres_set_profile(npg_gmres *ws, int on);
+int npg_gmres_get_profile(npg_gmres *ws, double *ms_total, int64_t *launches);
 /* residual history of the last solve (workspace.stats.residuals with history=true): returns entries written */
 int64_t npg_gmres_history(npg_gmres *ws, double *buf, int64_t cap);
 

@@ -81,6 +81,7 @@ def _declare(L):
         "npg_spmv": [P, P, P, D, D],
         "npg_gmres_create": [P, I64, C.c_int, PP], "npg_gmres_destroy": [P],
         "npg_gmres_solve": [P, P, C.c_int, D, P, P, P, D, D, I64, D, C.POINTER(SolveStats)],
+        "npg_gmres_set_profile": [P, C.c_int], "npg_gmres_get_profile": [P, C.POINTER(D), C.POINTER(I64)],
         "npg_cg_create": [P, I64, PP], "npg_cg_destroy": [P],
         "npg_cg_solve": [P, P, C.c_int, D, P, P, P, D, D, I64, C.POINTER(SolveStats)],
         "npg_fe_create": [P, C.POINTER(FeDesc), PP], "npg_fe_destroy": [P], "npg_fe_set_coeff": [P, C.c_char_p, VP],

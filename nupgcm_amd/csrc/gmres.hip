@@ -375,14 +375,21 @@ struct npg_gmres {
     double *hist = nullptr;
     int hist_cap = 0;
     GParams *prm = nullptr;
-    Snap *h_C = nullptr;          // pinned
+    Snap *h_C = nullptr;          // pinned, two slots (one per graph of the ping-pong pair)
     GParams *h_prm = nullptr;     // pinned
     int64_t hist_len = 0;
-    // graph cache
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
+    // graph cache: two instances of the cycle graph that differ only in where the carried state is copied for the host,
+    // so that cycle c+1 can be enqueued before the host has looked at the outcome of cycle c
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t exec[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
     GDev key;
     bool have_graph = false;
+    // profile mode: eager launches with HIP events around every Arnoldi (SpMV) kernel
+    bool profile = false;
+    std::vector<hipEvent_t> pev;
+    double prof_ms = 0.0;
+    int64_t prof_launches = 0;
     npg_halo *halo = nullptr;
     static constexpr int kMaxG = 512;
 };
@@ -393,31 +400,38 @@ static void launch_arnoldi(const GDev &d, int j, hipStream_t st) {
 }
 
 template <int L>
-static void launch_cycle_L(const GDev &d, hipStream_t st) {
+static void launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev) {
     for (int j = 0; j < d.mem; ++j) {
         const int nb = j + 1;
+        if (pev) hipEventRecord(pev[2 * j], st);
         if (nb <= 4) {
             launch_arnoldi<L, 4>(d, j, st);
+            if (pev) hipEventRecord(pev[2 * j + 1], st);
             hipLaunchKernelGGL(k_gmres_orth1<4>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
             hipLaunchKernelGGL(k_gmres_orth2<4>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
         } else if (nb <= 8) {
             launch_arnoldi<L, 8>(d, j, st);
+            if (pev) hipEventRecord(pev[2 * j + 1], st);
             hipLaunchKernelGGL(k_gmres_orth1<8>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
             hipLaunchKernelGGL(k_gmres_orth2<8>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
         } else if (nb <= 12) {
             launch_arnoldi<L, 12>(d, j, st);
+            if (pev) hipEventRecord(pev[2 * j + 1], st);
             hipLaunchKernelGGL(k_gmres_orth1<12>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
             hipLaunchKernelGGL(k_gmres_orth2<12>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
         } else if (nb <= 16) {
             launch_arnoldi<L, 16>(d, j, st);
+            if (pev) hipEventRecord(pev[2 * j + 1], st);
             hipLaunchKernelGGL(k_gmres_orth1<16>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
             hipLaunchKernelGGL(k_gmres_orth2<16>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
         } else if (nb <= 20) {
             launch_arnoldi<L, 20>(d, j, st);
+            if (pev) hipEventRecord(pev[2 * j + 1], st);
             hipLaunchKernelGGL(k_gmres_orth1<20>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
             hipLaunchKernelGGL(k_gmres_orth2<20>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
         } else {
             launch_arnoldi<L, 30>(d, j, st);
+            if (pev) hipEventRecord(pev[2 * j + 1], st);
             hipLaunchKernelGGL(k_gmres_orth1<30>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
             hipLaunchKernelGGL(k_gmres_orth2<30>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
         }
@@ -435,12 +449,12 @@ static void launch_residual(const GDev &d, int lanes, hipStream_t st) {
     }
 }
 
-static void launch_cycle(const GDev &d, int lanes, hipStream_t st) {
+static void launch_cycle(const GDev &d, int lanes, hipStream_t st, hipEvent_t *pev) {
     switch (lanes) {
-        case 4: launch_cycle_L<4>(d, st); break;
-        case 8: launch_cycle_L<8>(d, st); break;
-        case 16: launch_cycle_L<16>(d, st); break;
-        default: launch_cycle_L<32>(d, st); break;
+        case 4: launch_cycle_L<4>(d, st, pev); break;
+        case 8: launch_cycle_L<8>(d, st, pev); break;
+        case 16: launch_cycle_L<16>(d, st, pev); break;
+        default: launch_cycle_L<32>(d, st, pev); break;
     }
 }
 
@@ -475,7 +489,9 @@ NPG_API int npg_gmres_create(npg_ctx *ctx, int64_t n, int memory, npg_gmres **ou
     ws->hist_cap = (int)std::min<int64_t>(2 * n + 2, 1 << 22);
     NPG_HIP(hipMalloc((void **)&ws->hist, sizeof(double) * ws->hist_cap));
     NPG_HIP(hipMalloc((void **)&ws->prm, sizeof(GParams)));
-    NPG_HIP(hipHostMalloc((void **)&ws->h_C, sizeof(Snap), hipHostMallocDefault));
+    NPG_HIP(hipHostMalloc((void **)&ws->h_C, 2 * sizeof(Snap), hipHostMallocDefault));
+    NPG_HIP(hipEventCreateWithFlags(&ws->ev[0], hipEventDisableTiming));
+    NPG_HIP(hipEventCreateWithFlags(&ws->ev[1], hipEventDisableTiming));
     NPG_HIP(hipHostMalloc((void **)&ws->h_prm, sizeof(GParams), hipHostMallocDefault));
     NPG_HIP(hipMemsetAsync(ws->V, 0, vb * memory, ctx->stream));
     NPG_HIP(hipMemsetAsync(ws->w, 0, vb, ctx->stream));
@@ -494,8 +510,12 @@ NPG_API int npg_gmres_create(npg_ctx *ctx, int64_t n, int memory, npg_gmres **ou
 NPG_API int npg_gmres_destroy(npg_gmres *ws) {
     if (!ws) return NPG_OK;
     hipStreamSynchronize(ws->ctx->stream);
-    if (ws->exec) hipGraphExecDestroy(ws->exec);
-    if (ws->graph) hipGraphDestroy(ws->graph);
+    for (int k = 0; k < 2; ++k) {
+        if (ws->exec[k]) hipGraphExecDestroy(ws->exec[k]);
+        if (ws->graph[k]) hipGraphDestroy(ws->graph[k]);
+        if (ws->ev[k]) hipEventDestroy(ws->ev[k]);
+    }
+    for (hipEvent_t e : ws->pev) hipEventDestroy(e);
     void *ptrs[] = {ws->V, ws->w, ws->wt, ws->P1, ws->P2, ws->P3, ws->PR, ws->C, ws->T, ws->c, ws->s,
                     ws->z, ws->R, ws->hcol1, ws->hcol2, ws->ci, ws->hist, ws->prm};
     for (void *p : ptrs)
@@ -580,15 +600,17 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     // (re)capture the per-cycle graph when any baked-in argument changed
     if (!ws->have_graph || memcmp(&ws->key, &d, sizeof(GDev)) != 0) {
         NPG_HIP(hipStreamSynchronize(st));
-        if (ws->exec) hipGraphExecDestroy(ws->exec);
-        if (ws->graph) hipGraphDestroy(ws->graph);
-        ws->exec = nullptr;
-        ws->graph = nullptr;
-        NPG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        launch_cycle(d, A->lanes, st);
-        NPG_HIP(hipMemcpyAsync(ws->h_C, ws->C, sizeof(Snap), hipMemcpyDeviceToHost, st));
-        NPG_HIP(hipStreamEndCapture(st, &ws->graph));
-        NPG_HIP(hipGraphInstantiate(&ws->exec, ws->graph, nullptr, nullptr, 0));
+        for (int k = 0; k < 2; ++k) {
+            if (ws->exec[k]) hipGraphExecDestroy(ws->exec[k]);
+            if (ws->graph[k]) hipGraphDestroy(ws->graph[k]);
+            ws->exec[k] = nullptr;
+            ws->graph[k] = nullptr;
+            NPG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            launch_cycle(d, A->lanes, st, nullptr);
+            NPG_HIP(hipMemcpyAsync(ws->h_C + k, ws->C, sizeof(Snap), hipMemcpyDeviceToHost, st));
+            NPG_HIP(hipStreamEndCapture(st, &ws->graph[k]));
+            NPG_HIP(hipGraphInstantiate(&ws->exec[k], ws->graph[k], nullptr, nullptr, 0));
+        }
         memcpy(&ws->key, &d, sizeof d);
         ws->have_graph = true;
     }
@@ -598,12 +620,41 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     NPG_HIP(hipGetLastError());
     const int64_t max_cycles = (itmax + ws->mem - 1) / ws->mem + 1;
     Snap last{};
-    int64_t cyc = 0;
-    for (; cyc < max_cycles; ++cyc) {
-        NPG_HIP(hipGraphLaunch(ws->exec, st));
+    if (!ws->profile) {
+        // cycle c+1 is enqueued before the host reads the outcome of cycle c: the device never idles waiting for the
+        // host, and a cycle launched after convergence costs only its early-exit kernels
+        NPG_HIP(hipGraphLaunch(ws->exec[0], st));
+        NPG_HIP(hipEventRecord(ws->ev[0], st));
+        for (int64_t cyc = 0;; ++cyc) {
+            const int cur = (int)(cyc & 1), nxt = cur ^ 1;
+            const bool more = cyc + 1 < max_cycles;
+            if (more) {
+                NPG_HIP(hipGraphLaunch(ws->exec[nxt], st));
+                NPG_HIP(hipEventRecord(ws->ev[nxt], st));
+            }
+            NPG_HIP(hipEventSynchronize(ws->ev[cur]));
+            last = ws->h_C[cur];
+            if (last.done != 0 || !more) break;
+        }
         NPG_HIP(hipStreamSynchronize(st));
-        last = *ws->h_C;
-        if (last.done != 0) break;
+    } else {
+        if (ws->pev.empty()) {
+            ws->pev.resize(2 * ws->mem);
+            for (auto &e : ws->pev) NPG_HIP(hipEventCreate(&e));
+        }
+        for (int64_t cyc = 0; cyc < max_cycles; ++cyc) {
+            launch_cycle(d, A->lanes, st, ws->pev.data());
+            NPG_HIP(hipMemcpyAsync(ws->h_C, ws->C, sizeof(Snap), hipMemcpyDeviceToHost, st));
+            NPG_HIP(hipStreamSynchronize(st));
+            last = ws->h_C[0];
+            if (last.done != 0) break;      // the last (partial) cycle is not counted: some of its kernels exit early
+            for (int j = 0; j < ws->mem; ++j) {
+                float ms = 0.f;
+                NPG_HIP(hipEventElapsedTime(&ms, ws->pev[2 * j], ws->pev[2 * j + 1]));
+                ws->prof_ms += ms;
+                ws->prof_launches += 1;
+            }
+        }
     }
     ws->hist_len = std::min<int64_t>((int64_t)last.iter + 1, ws->hist_cap);
     if (stats) {
@@ -617,6 +668,21 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
         stats->rnorm = last.rnorm;
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
+    return NPG_OK;
+}
+
+NPG_API int npg_gmres_set_profile(npg_gmres *ws, int on) {
+    NPG_REQUIRE(ws, "npg_gmres_set_profile: NULL workspace");
+    ws->profile = on != 0;
+    ws->prof_ms = 0.0;
+    ws->prof_launches = 0;
+    return NPG_OK;
+}
+
+NPG_API int npg_gmres_get_profile(npg_gmres *ws, double *ms_total, int64_t *launches) {
+    NPG_REQUIRE(ws && ms_total && launches, "npg_gmres_get_profile: NULL argument");
+    *ms_total = ws->prof_ms;
+    *launches = ws->prof_launches;
     return NPG_OK;
 }
 

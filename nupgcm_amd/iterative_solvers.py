@@ -70,6 +70,16 @@ class GmresWorkspace(_Workspace):
         k = L.lib().npg_gmres_history(self.h, L.ptr(buf), buf.size)
         return buf[:max(k, 0)]
 
+    def set_profile(self, on=True):
+        """eager launches with HIP events around every Arnoldi (SpMV) kernel; see npg_gmres_set_profile"""
+        L.check(L.lib().npg_gmres_set_profile(self.h, int(bool(on))))
+
+    def get_profile(self):
+        """(total milliseconds, launches) of the Arnoldi kernel since set_profile(True)"""
+        ms, n = C.c_double(), C.c_int64()
+        L.check(L.lib().npg_gmres_get_profile(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
 
 class CgWorkspace(_Workspace):
     """Krylov.CgWorkspace(n, n, VT) at src/evolution.jl:120"""

@@ -1,0 +1,97 @@
+"""Uniform red refinement of a tagged tetrahedral Gmsh model (each tet -> 8, each boundary triangle -> 4, each tagged line
+-> 2), with optional projection of the new boundary nodes onto the analytic geometry.
+
+Why it exists: the benchmark configuration "bowl3D refined h ~ 0.02" (BASELINE.json configs[3]) has no committed mesh
+and Gmsh (/root/reference/meshes/mesh_bowl3D.jl drives it) is not available offline, so the refined meshes are derived
+from the reference's committed h = 0.08 / h = 0.1 bowl meshes.  Physical tags are inherited the way a Gmsh refinement would
+classify the new nodes: on a tagged curve -> the curve's tag, else on a boundary surface -> the surface's tag, else the
+volume's tag."""
+from __future__ import annotations
+
+import numpy as np
+
+from .gmsh_io import GmshModel
+
+_E = np.array([[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]])
+
+
+def _mid_ids(nv, a, b):
+    """ids of midpoint nodes for node pairs (a, b): returns (unique_keys, lookup(a, b) -> nv + index)"""
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    return lo * nv + hi
+
+
+def refine_once(model: GmshModel, project=None) -> GmshModel:
+    if model.dim != 3:
+        raise NotImplementedError("refine_once: tetrahedral meshes only")
+    nv = len(model.coords)
+    cells = np.asarray(model.cells, dtype=np.int64)
+    keys = _mid_ids(nv, cells[:, _E[:, 0]], cells[:, _E[:, 1]])               # (nc, 6)
+    uniq, inv = np.unique(keys.ravel(), return_inverse=True)
+    mid = (nv + inv).reshape(-1, 6)                                            # m01 m02 m03 m12 m13 m23
+    coords = np.vstack([model.coords, 0.5 * (model.coords[uniq // nv] + model.coords[uniq % nv])])
+    v0, v1, v2, v3 = cells.T
+    m01, m02, m03, m12, m13, m23 = mid.T
+    kids = [(v0, m01, m02, m03), (m01, v1, m12, m13), (m02, m12, v2, m23), (m03, m13, m23, v3),
+            (m01, m02, m03, m13), (m01, m02, m12, m13), (m02, m03, m13, m23), (m02, m12, m13, m23)]
+    new_cells = np.stack([np.stack(k, axis=1) for k in kids], axis=1).reshape(-1, 4)
+
+    def lookup(a, b):
+        pos = np.searchsorted(uniq, _mid_ids(nv, a, b))
+        return nv + pos
+
+    # every new node starts with the volume's tag, then surface, then curve tags override
+    interior = 0
+    if "interior" in model.phys_names:
+        interior = 1 << model.phys_names.index("interior")
+    node_phys = np.concatenate([np.asarray(model.node_phys, dtype=np.uint32),
+                                np.full(len(uniq), interior, dtype=np.uint32)])
+    fac = np.asarray(model.facets, dtype=np.int64).reshape(-1, 3)
+    fph = np.asarray(model.facets_phys, dtype=np.uint32)
+    a, b, c = fac.T
+    mab, mbc, mca = lookup(a, b), lookup(b, c), lookup(c, a)
+    for m in (mab, mbc, mca):
+        node_phys[m] = fph
+    new_fac = np.stack([np.stack(t, axis=1) for t in ((a, mab, mca), (mab, b, mbc), (mca, mbc, c), (mab, mbc, mca))],
+                       axis=1).reshape(-1, 3)
+    new_fph = np.repeat(fph, 4)
+    rid = np.asarray(model.ridges, dtype=np.int64).reshape(-1, 2)
+    rph = np.asarray(model.ridges_phys, dtype=np.uint32)
+    if len(rid):
+        mr = lookup(rid[:, 0], rid[:, 1])
+        node_phys[mr] = rph
+        new_rid = np.stack([np.stack((rid[:, 0], mr), axis=1), np.stack((mr, rid[:, 1]), axis=1)], axis=1).reshape(-1, 2)
+        new_rph = np.repeat(rph, 2)
+    else:
+        new_rid, new_rph = rid, rph
+    out = GmshModel(3, coords, node_phys, new_cells, new_fac, new_fph, new_rid, new_rph, list(model.phys_names))
+    if project is not None:
+        out.coords = project(out)
+    return out
+
+
+def refine(model: GmshModel, levels: int, project=None) -> GmshModel:
+    for _ in range(levels):
+        model = refine_once(model, project)
+    return model
+
+
+def bowl_projector(alpha):
+    """Put boundary nodes back on the bowl of /root/reference/meshes/mesh_bowl3D.jl:12-28: bottom z = -alpha (1 - x^2 - y^2)
+    (the Bezier generator revolved about z is exactly this paraboloid), coastline = unit circle at z = 0, surface z = 0."""
+
+    def project(m: GmshModel):
+        x = m.coords.copy()
+        bit = {n: 1 << i for i, n in enumerate(m.phys_names)}
+        ph = np.asarray(m.node_phys)
+        coast = (ph & bit.get("coastline", 0)) != 0
+        surf = ((ph & bit.get("surface", 0)) != 0) & ~coast
+        bot = ((ph & bit.get("bottom", 0)) != 0) & ~coast
+        r = np.linalg.norm(x[coast, :2], axis=1)
+        x[coast, :2] /= r[:, None]
+        x[coast, 2] = 0.0
+        x[surf, 2] = 0.0
+        x[bot, 2] = -alpha * (1.0 - x[bot, 0] ** 2 - x[bot, 1] ** 2)
+        return x
+
+    return project

@@ -104,10 +104,11 @@ class System:
         return self.dt * self.c * (1.0 if scheme == "BDF1" else 2.0 / 3.0)
 
 
-def setup(name, mesh="mesh_bowl3D_h0.1", **override) -> System:
+def setup(name, mesh="mesh_bowl3D_h0.1", model=None, **override) -> System:
+    """model: an already loaded / refined mesh model (anything with GmshModel's attributes) instead of a fixture name"""
     cfg = dict(CONFIGS[name])
     cfg.update(override)
-    topo = fo.build_topo(load_mesh(mesh))
+    topo = fo.build_topo(load_mesh(mesh) if model is None else model)
     spc = fo.build_spaces(topo, U_TAGS, U_MASKS, cfg["b_diri_tags"], cfg["b_diri_fn"])
     kap = _kappa_bottom(cfg["alpha"]) if cfg["kappa"] == "bottom" else cfg["kappa"]
     orc = fo.Oracle(topo, spc, eps=cfg["eps"], alpha=cfg["alpha"], mu_rho=cfg["mu_rho"], N2=cfg["N2"], f=cfg["f"],
@@ -134,8 +135,11 @@ def rcm_perms(sysm: System):
 
 
 def run(sysm: System, nsteps, solver="direct", first_step_lhs="bdf1", invert_first=False, scheme="BDF2",
-        krylov_kw=None, record=None):
-    """Returns (u, p, b) free values in native order after `nsteps` steps from the configuration's initial condition."""
+        krylov_kw=None, record=None, timer=None):
+    """Returns (u, p, b) free values in native order after `nsteps` steps from the configuration's initial condition.
+    timer: optional dict; receives 'loop_seconds' = wall time of the step loop only (factorisations excluded, as the
+    reference's CPU() path factorises at set-up time, src/inversion.jl:58, src/evolution.jl:152)."""
+    import time as _time
     orc, s = sysm.orc, sysm.orc.sp
     b0fn = sysm.cfg["b0"]
     b = np.zeros(s.nb) if b0fn is None else orc.interpolate_b(b0fn)
@@ -174,6 +178,10 @@ def run(sysm: System, nsteps, solver="direct", first_step_lhs="bdf1", invert_fir
             lhs_cache[theta] = (Amat, spla.splu(sp.csc_matrix(Amat)) if solver == "direct" else 1.0 / Amat.diagonal())
         return lhs_cache[theta]
 
+    if solver == "direct":
+        lhs(sysm.theta("BDF1" if (scheme == "BDF2" and first_step_lhs == "bdf1") else scheme))
+        lhs(sysm.theta(scheme))
+    _t0 = _time.perf_counter()
     for i in range(1, nsteps + 1):
         theta_rhs = sysm.theta(scheme)
         if scheme == "BDF2" and i == 1 and first_step_lhs == "bdf1":
@@ -196,4 +204,6 @@ def run(sysm: System, nsteps, solver="direct", first_step_lhs="bdf1", invert_fir
         if max(np.abs(u).max(), np.abs(b).max()) > 1e3 or not np.isfinite(u).all():
             raise RuntimeError("Blow-up detected, stopping simulation")                  # src/model.jl:149-153
         u_prev, b_prev = u_curr, b_curr
+    if timer is not None:
+        timer["loop_seconds"] = _time.perf_counter() - _t0
     return u, p, b
