@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("NPG_BENCH_WORKLOAD", "bowl3D_h0.02"))
     ap.add_argument("--dt", type=float, default=1e-3)
+    ap.add_argument("--reorth-eta", type=float, default=None, help="override the GMRES second-pass threshold")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU budget of the cpu_baseline sample")
     return ap.parse_args()
@@ -100,7 +101,8 @@ def main():
         from nupgcm_amd import distributed
         model = distributed.example_model(arch, mesh_model, dist, dt=a.dt)
     else:
-        model = workloads.example_model(arch, mesh_model, dt=a.dt)
+        kw = {} if a.reorth_eta is None else {"reorth_eta": a.reorth_eta}
+        model = workloads.example_model(arch, mesh_model, dt=a.dt, **kw)
     d = model.fe_data.dofs
     npg.invert(model)                                     # examples/bowl_mixing.jl:194
     ctx.sync()
@@ -165,7 +167,8 @@ def main():
                                f"mu_rho=1, N2=2, BDF2 dt={a.dt:g}), full evolve!+invert! timestep loop",
                    "tets": int(model.fe_data.mesh.ncell), "nu": int(d.nu), "np": int(d.np), "nb": int(d.nb),
                    "N_inversion": int(N), "nnz_A": int(nnz), "gmres_iterations_per_step": gm_its,
-                   "cg_iterations_per_step": cg_its, "gmres_memory": 20, "atol": 1e-6, "rtol": 1e-6,
+                   "cg_iterations_per_step": cg_its, "gmres_second_gs_passes_per_step": [s[1]["nreorth"] for s in stats],
+                   "gmres_memory": 20, "atol": 1e-6, "rtol": 1e-6,
                    "setup_seconds": round(t_setup, 1), "parallelism": f"row-partitioned x{world}" if world > 1 else "1 GPU"},
         "roofline": roofline,
         "spmv_standalone": {"avg_launch_us": spmv_ms * 1e3, "GBps": alg_bytes / (spmv_ms * 1e-3) / 1e9},

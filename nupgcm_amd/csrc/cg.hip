@@ -46,10 +46,16 @@ struct CDev {
     const CParams *prm;
 };
 
+constexpr int kKB = 1024;                 // threads per Krylov workgroup (see gmres.hip)
+constexpr int kKW = kKB / 64;
+constexpr int kNS = kKB / kPartStride;
+constexpr int kMaxG = 256;
+constexpr int kMaxI = kMaxG / kNS;
+
 struct CShared {
-    double tmp[8 * kPartStride];
+    double tmp[kNS * kPartStride];
     double red[kPartStride];
-    double wsum[4 * kPartStride];
+    double wsum[kKW * kPartStride];
     CSnap S;
 };
 
@@ -59,31 +65,31 @@ __device__ __forceinline__ double cg_precond(const CDev &d, int64_t row) {
 
 // r = b - A x ; z = P r ; partial r'z
 template <int L>
-__global__ void __launch_bounds__(kBlock) k_cg_init(CDev d) {
-    __shared__ double sh[4 * kPartStride];
+__global__ void __launch_bounds__(kKB) k_cg_init(CDev d) {
+    __shared__ double sh[kKW * kPartStride];
+    __shared__ TileLds tl;
+    __shared__ double sw[kTileRows];
     double acc[1] = {0.0};
-    const int g = threadIdx.x / L, l = threadIdx.x % L;
     for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
         const int r0 = d.tile_ptr[t], r1 = d.tile_ptr[t + 1];
-        for (int row = r0 + g; row < r1; row += kBlock / L) {
-            const double ax = csr_row_dot<L>(d.rowptr, d.col, d.val, d.x, row, l);
-            if (l == 0) {
-                const double r = d.b[row] - ax;
-                const double z = cg_precond(d, row) * r;
-                d.r[row] = r;
-                d.z[row] = z;
-                acc[0] += r * z;
-            }
+        spmv_tile<kKB, L>(d.rowptr, d.col, d.val, PlainX{d.x}, r0, r1, tl, sw);
+        if ((int)threadIdx.x < r1 - r0) {
+            const int row = r0 + threadIdx.x;
+            const double r = d.b[row] - sw[threadIdx.x];
+            const double z = cg_precond(d, row) * r;
+            d.r[row] = r;
+            d.z[row] = z;
+            acc[0] += r * z;
         }
     }
-    block_store_partials<1>(acc, 1, sh, d.Pg);
+    block_store_partials<1, kKW>(acc, 1, sh, d.Pg);
 }
 
 // CP: reads slot `src`, writes slot `dst`.  ng = number of partial rows in Pg.
-__global__ void __launch_bounds__(kBlock) k_cg_direction(CDev d, int src, int dst, int ng) {
+__global__ void __launch_bounds__(kKB) k_cg_direction(CDev d, int src, int dst, int ng) {
     __shared__ CShared sh;
     const CSnap prev = d.S[src];
-    if (prev.done == 0) reduce_partials(d.Pg, ng, 1, sh.tmp, sh.red);
+    reduce_partials<kNS, kMaxI>(d.Pg, ng, 1, sh.tmp, sh.red);
     if (threadIdx.x == 0) {
         CSnap s = prev;
         if (s.done == 0) {
@@ -114,40 +120,41 @@ __global__ void __launch_bounds__(kBlock) k_cg_direction(CDev d, int src, int ds
     __syncthreads();
     if (sh.S.done != 0) return;
     const double beta = sh.red[1];
-    for (int64_t row = blockIdx.x * (int64_t)kBlock + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kBlock)
+    for (int64_t row = blockIdx.x * (int64_t)kKB + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kKB)
         d.p[row] = d.z[row] + beta * d.p[row];
 }
 
 // CS
 template <int L>
-__global__ void __launch_bounds__(kBlock) k_cg_spmv(CDev d, int slot) {
-    __shared__ double sh[4 * kPartStride];
+__global__ void __launch_bounds__(kKB) k_cg_spmv(CDev d, int slot) {
+    __shared__ double sh[kKW * kPartStride];
+    __shared__ TileLds tl;
+    __shared__ double sw[kTileRows];
     if (d.S[slot].done != 0) return;
     double acc[1] = {0.0};
-    const int g = threadIdx.x / L, l = threadIdx.x % L;
     for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
         const int r0 = d.tile_ptr[t], r1 = d.tile_ptr[t + 1];
-        for (int row = r0 + g; row < r1; row += kBlock / L) {
-            const double ap = csr_row_dot<L>(d.rowptr, d.col, d.val, d.p, row, l);
-            if (l == 0) {
-                d.Ap[row] = ap;
-                acc[0] += d.p[row] * ap;
-            }
+        spmv_tile<kKB, L>(d.rowptr, d.col, d.val, PlainX{d.p}, r0, r1, tl, sw);
+        if ((int)threadIdx.x < r1 - r0) {
+            const int row = r0 + threadIdx.x;
+            const double ap = sw[threadIdx.x];
+            d.Ap[row] = ap;
+            acc[0] += d.p[row] * ap;
         }
     }
-    block_store_partials<1>(acc, 1, sh, d.Pp);
+    block_store_partials<1, kKW>(acc, 1, sh, d.Pp);
 }
 
 // CU
-__global__ void __launch_bounds__(kBlock) k_cg_update(CDev d, int slot) {
+__global__ void __launch_bounds__(kKB) k_cg_update(CDev d, int slot) {
     __shared__ CShared sh;
     const CSnap s = d.S[slot];
+    reduce_partials<kNS, kMaxI>(d.Pp, d.G1, 1, sh.tmp, sh.red);
     if (s.done != 0) return;
-    reduce_partials(d.Pp, d.G1, 1, sh.tmp, sh.red);
     const double pAp = sh.red[0];
     const double alpha = (pAp > 0.0) ? s.gamma / pAp : 0.0;
     double acc[1] = {0.0};
-    for (int64_t row = blockIdx.x * (int64_t)kBlock + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kBlock) {
+    for (int64_t row = blockIdx.x * (int64_t)kKB + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kKB) {
         const double pv = d.p[row];
         d.x[row] += alpha * pv;
         const double r = d.r[row] - alpha * d.Ap[row];
@@ -156,7 +163,7 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CDev d, int slot) {
         d.z[row] = z;
         acc[0] += r * z;
     }
-    block_store_partials<1>(acc, 1, sh.wsum, d.Pg);
+    block_store_partials<1, kKW>(acc, 1, sh.wsum, d.Pg);
 }
 
 }  // namespace npg
@@ -175,7 +182,7 @@ struct npg_cg {
     CParams *h_prm = nullptr;
     int64_t hist_len = 0;
     npg_halo *halo = nullptr;
-    static constexpr int kMaxG = 512;
+    static constexpr int kMaxG = npg::kMaxG;
 };
 
 NPG_API int npg_cg_create(npg_ctx *ctx, int64_t n, npg_cg **out) {
@@ -225,8 +232,8 @@ NPG_API int npg_cg_set_halo(npg_cg *ws, npg_halo *h) {
 template <int L>
 static int cg_run(npg_cg *ws, const CDev &d, int64_t itmax, CSnap *last) {
     hipStream_t st = ws->ctx->stream;
-    hipLaunchKernelGGL(k_cg_init<L>, dim3(d.G1), dim3(kBlock), 0, st, d);
-    hipLaunchKernelGGL(k_cg_direction, dim3(d.G2), dim3(kBlock), 0, st, d, 0, 1, d.G1);   // slot 0 = initial state
+    hipLaunchKernelGGL(k_cg_init<L>, dim3(d.G1), dim3(kKB), 0, st, d);
+    hipLaunchKernelGGL(k_cg_direction, dim3(d.G2), dim3(kKB), 0, st, d, 0, 1, d.G1);   // slot 0 = initial state
     int cur = 1;
     const int chunk = 4;
     int64_t it = 0;
@@ -236,9 +243,9 @@ static int cg_run(npg_cg *ws, const CDev &d, int64_t itmax, CSnap *last) {
         *last = ws->h_S[0];
         if (last->done != 0 || it >= itmax) break;
         for (int k = 0; k < chunk; ++k, ++it) {
-            hipLaunchKernelGGL(k_cg_spmv<L>, dim3(d.G1), dim3(kBlock), 0, st, d, cur);
-            hipLaunchKernelGGL(k_cg_update, dim3(d.G2), dim3(kBlock), 0, st, d, cur);
-            hipLaunchKernelGGL(k_cg_direction, dim3(d.G2), dim3(kBlock), 0, st, d, cur, cur ^ 1, d.G2);
+            hipLaunchKernelGGL(k_cg_spmv<L>, dim3(d.G1), dim3(kKB), 0, st, d, cur);
+            hipLaunchKernelGGL(k_cg_update, dim3(d.G2), dim3(kKB), 0, st, d, cur);
+            hipLaunchKernelGGL(k_cg_direction, dim3(d.G2), dim3(kKB), 0, st, d, cur, cur ^ 1, d.G2);
             cur ^= 1;
         }
         NPG_HIP(hipGetLastError());
@@ -278,8 +285,8 @@ NPG_API int npg_cg_solve(npg_cg *ws, const npg_csr *A, int precond_kind, double 
     d.Ap = ws->Ap;
     d.Pg = ws->Pg;
     d.Pp = ws->Pp;
-    d.G1 = std::max(1, std::min<int>(A->ntiles, std::min(npg_cg::kMaxG, 2 * ctx->num_cu)));
-    d.G2 = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kBlock - 1) / kBlock, d.G1));
+    d.G1 = std::max(1, std::min<int>(A->ntiles, std::min(npg_cg::kMaxG, ctx->num_cu)));
+    d.G2 = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kKB - 1) / kKB, d.G1));
     d.S = ws->S;
     d.hist = ws->hist;
     d.hist_cap = ws->hist_cap;

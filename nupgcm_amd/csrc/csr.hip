@@ -6,18 +6,19 @@
 
 namespace npg {
 
-// nnz-balanced tiles of at most 256 rows
+// Row tiles for the CSR-stream kernels: consecutive whole rows, at most kTileNnz stored entries and kTileRows rows per
+// tile; small matrices get about one tile per CU.  A row longer than kTileNnz becomes a tile of its own.
 int build_tiles(npg_csr *A) {
     const int64_t m = A->m, nnz = A->nnz;
     const int64_t *rp = A->h_rowptr.data();
-    int64_t target = nnz / (2 * (int64_t)A->ctx->num_cu);
-    target = std::max<int64_t>(1024, std::min<int64_t>(16384, target));
+    int64_t target = nnz / (int64_t)A->ctx->num_cu;
+    target = std::max<int64_t>(1024, std::min<int64_t>(kTileNnz, target));   // >= 1 tile per CU on small matrices
     std::vector<int32_t> tp;
     tp.push_back(0);
     int64_t r = 0;
     while (r < m) {
         int64_t r1 = r + 1;
-        while (r1 < m && r1 - r < 256 && rp[r1] - rp[r] < target) ++r1;
+        while (r1 < m && r1 - r < kTileRows && rp[r1 + 1] - rp[r] <= target) ++r1;
         tp.push_back((int32_t)r1);
         r = r1;
     }
@@ -30,17 +31,22 @@ int build_tiles(npg_csr *A) {
     return NPG_OK;
 }
 
+constexpr int kSpmvThreads = 512;
+
 template <int L>
-__global__ void __launch_bounds__(kBlock) k_spmv(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                 const double *__restrict__ val, const int32_t *__restrict__ tile_ptr,
-                                                 int ntiles, const double *__restrict__ x, double *__restrict__ y,
-                                                 double alpha, double beta) {
-    const int g = threadIdx.x / L, l = threadIdx.x % L;
+__global__ void __launch_bounds__(kSpmvThreads) k_spmv(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                        const double *__restrict__ val,
+                                                        const int32_t *__restrict__ tile_ptr, int ntiles,
+                                                        const double *__restrict__ x, double *__restrict__ y,
+                                                        double alpha, double beta) {
+    __shared__ TileLds tl;
+    __shared__ double sw[kTileRows];
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int r0 = tile_ptr[t], r1 = tile_ptr[t + 1];
-        for (int row = r0 + g; row < r1; row += kBlock / L) {
-            const double s = csr_row_dot<L>(rowptr, col, val, x, row, l);
-            if (l == 0) y[row] = (beta == 0.0) ? alpha * s : alpha * s + beta * y[row];
+        spmv_tile<kSpmvThreads, L>(rowptr, col, val, PlainX{x}, r0, r1, tl, sw);
+        for (int r = threadIdx.x; r < r1 - r0; r += kSpmvThreads) {
+            const int row = r0 + r;
+            y[row] = (beta == 0.0) ? alpha * sw[r] : alpha * sw[r] + beta * y[row];
         }
     }
 }
@@ -85,9 +91,9 @@ static int upload_csr(npg_ctx *ctx, int64_t m, int64_t n, std::vector<int64_t> &
 
 template <int L>
 static void launch_spmv(const npg_csr *A, const double *x, double *y, double alpha, double beta) {
-    const int grid = std::min<int>(A->ntiles, 8 * A->ctx->num_cu);
-    hipLaunchKernelGGL(k_spmv<L>, dim3(std::max(grid, 1)), dim3(kBlock), 0, A->ctx->stream, A->rowptr, A->col, A->val,
-                       A->tile_ptr, A->ntiles, x, y, alpha, beta);
+    const int grid = std::min<int>(A->ntiles, 2 * A->ctx->num_cu);      // 2 x 72 KiB of LDS per CU
+    hipLaunchKernelGGL(k_spmv<L>, dim3(std::max(grid, 1)), dim3(kSpmvThreads), 0, A->ctx->stream, A->rowptr, A->col,
+                       A->val, A->tile_ptr, A->ntiles, x, y, alpha, beta);
 }
 
 }  // namespace npg

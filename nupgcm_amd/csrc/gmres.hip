@@ -2,21 +2,28 @@
 // /root/reference/src/inversion.jl:74-94 and driven from /root/reference/src/iterative_solvers.jl:58.
 //
 // MI355X design.  On the reference's GPU path one inner iteration is ~23 library calls and ~11 host-blocking scalar
-// reductions (modified Gram-Schmidt: j dependent dot->axpy pairs).  Here a restart cycle is ONE hipGraph of 3 kernels per
-// inner iteration, no scalar ever visits the host inside a cycle, and the kernel boundary (the cheapest grid-wide
-// synchronisation on this chip, ~1.5 us) is the only global barrier:
+// reductions (modified Gram-Schmidt: j dependent dot->axpy pairs).  Measured on MI355X, a dependent kernel boundary that
+// carries a small reduction costs ~4.5 us, so the iteration is organised to need exactly TWO of them, and no scalar ever
+// visits the host inside a restart cycle (one hipGraph = 2 m + 2 kernels):
 //
-//   K1(j)  finalise column j-1 (Givens, residual estimate, stopping test - redundantly in every workgroup, from
-//          fixed-order partial sums), v_j = wt/beta, w = P A v_j (tiled CSR SpMV, rows staged in LDS),
-//          partial h1 = V_{0..j}' w and ||w||^2                                    -> P1
-//   K2(j)  h1 = sum P1 ; wt = w - V h1 ; partial h2 = V' wt and ||wt||^2            -> P2
-//   K3(j)  h2 = sum P2 ; if ||wt|| < eta ||w|| (DGKS test): wt -= V h2, ||wt||^2    -> P3   (else: returns at once)
+//   K1(j)  finalise Hessenberg column j-1 from the previous kernel's partial sums (Givens, residual estimate, stopping
+//          test - redundantly in every workgroup, fixed summation order), v_j = wt/beta, w = P A v_j with the CSR-stream
+//          SpMV of spmv_device.h, partial h1 = V_{0..j}' w and ||w||^2                                        -> P1
+//   K2(j)  h1 = sum P1 ; wt = w - V h1 ; partial h2 = V' wt and ||wt||^2                                      -> P2
 //   XU     finalise the last column, back-substitute R y = z, x += V y
-//   R1     wt = P (b - A x), ||wt||^2                                              -> PR   (true residual for next cycle)
+//   R1     wt = P (b - A x), ||wt||^2   (true residual that starts the next cycle)                            -> PR
 //
-// i.e. classical Gram-Schmidt with a selective second pass: one reduction per pass instead of MGS's j sequential ones;
-// the Hessenberg column is h1 (+ h2 when the second pass ran).  Results agree with MGS to rounding, not bitwise.
-// All partial sums are reduced in a fixed order, so a solve is bit-reproducible run to run.
+// Orthogonalisation = classical Gram-Schmidt (one reduction for all j+1 coefficients instead of MGS's j sequential
+// ones) with a SELECTIVE second pass folded into the next K1: h2 = V' wt is always available from K2's reduction; when
+// ||wt|| < eta ||w|| (cancellation, DGKS test) K1 uses wt - V h2 instead of wt - correcting its SpMV gather on the fly -
+// the Hessenberg column becomes h1 + h2 and ||wt - V h2||^2 = ||wt||^2 - ||h2||^2.  No third kernel, no extra reduction.
+// Results agree with Krylov.jl's MGS to rounding, not bitwise; partial sums are combined in a fixed order, so a solve is
+// bit-reproducible run to run.
+//
+// Basis layout: V is stored INTERLEAVED, Vi[row][32] (256 B per row).  Every kernel that needs "all basis vectors at one
+// row" maps 32 consecutive lanes to one row (lane = basis index): one coalesced segment per row, ONE accumulator per
+// thread (its basis index, summed over the rows the thread visits), and the block reduction is a 32 x 32 LDS transpose
+// instead of 22 shuffle trees.  The SpMV never reads Vi: its input is the contiguous vector wt.
 //
 // State hand-off between kernels goes through write-once snapshot slots T[j] ("state after j finalised columns"): a slot
 // is written by workgroup 0 of one kernel and only read by LATER kernels, so no workgroup ever reads a location another
@@ -24,20 +31,24 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 #include "spmv_device.h"
 
 namespace npg {
 
+constexpr int kKB = 1024;                 // threads per Krylov workgroup: 16 waves, at most one workgroup per CU
+constexpr int kKW = kKB / 64;
+constexpr int kKP = kPartStride;          // 32: lanes per row group = padded basis size = doubles per partial row
+constexpr int kNS = kKB / kKP;            // 32 row slots per workgroup pass / slices of the partial reduction
+constexpr int kMaxG = 512;                // max workgroups (= partial rows): two per CU
+constexpr int kMaxI = kMaxG / kNS;        // loads per thread in the partial reduction (8)
+constexpr int kNormSlot = kKP - 1;        // partial rows carry the squared norm in their last entry
+
 struct Snap {
     double eps, rnorm0, rnorm, beta, zeta;
     int iter, inner, done, npass, first, nreorth, pad0, pad1;
-};
-
-struct ColInfo {
-    double wnorm2, n2p;
-    int reorth, pad;
 };
 
 struct GParams {
@@ -50,17 +61,16 @@ struct GDev {
     const int32_t *col;
     const double *val;
     const int32_t *tile_ptr;
-    int ntiles, n, ld, mem;
+    int ntiles, n, mem;
     int pkind;
     double pscalar;
     const double *pdiag;
     const double *b;
-    double *x, *V, *w, *wt;
-    double *P1, *P2, *P3, *PR;
+    double *x, *Vi, *w, *wt;
+    double *P1, *P2, *PR;
     int G1, G2;
     Snap *C, *T;
-    double *c, *s, *z, *R, *hcol1, *hcol2;
-    ColInfo *ci;
+    double *c, *s, *z, *R, *hcol1, *wnorm2;
     double *hist;
     int hist_cap;
     const GParams *prm;
@@ -88,31 +98,62 @@ __device__ __forceinline__ void sym_givens(double a, double b, double &c, double
     }
 }
 
-// Shared scratch of the Krylov kernels
 struct KShared {
-    double tmp[8 * kPartStride];
-    double red[kPartStride];
-    double wsum[4 * kPartStride];
-    double h[kPartStride], cc[kPartStride], ss[kPartStride];
+    double tmp[kNS * kKP];
+    double red[kKP];
+    double h[kKP], h2[kKP], cc[kKP], ss[kKP], y[kKP];
     Snap T;
-    double y[kPartStride];
+    double rho, zcol;     // diagonal entry of R and rotated z of the column finalised in THIS launch
+    int fin;              // 1 if finalize_column really finalised a column in this launch
+    int reorth;           // 1 if that column took the second Gram-Schmidt pass (the new vector is wt - V h2)
 };
 
-// Finalise Hessenberg column `colj` (all threads call; thread 0 does the serial part).  Leaves the new snapshot in sh.T.
+// All threads: acc holds this thread's accumulator for (slot = tid / 32, k = tid % 32).  Sums the 32 slots in a fixed
+// order and stores the block's partial row.
+__device__ __forceinline__ void store_partial_row(double acc, double *tmp, double *part) {
+    __syncthreads();
+    tmp[threadIdx.x] = acc;                   // [slot][k]
+    __syncthreads();
+    if (threadIdx.x < kKP) {
+        double s = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < kNS; ++sl) s += tmp[sl * kKP + threadIdx.x];
+        part[(size_t)blockIdx.x * kKP + threadIdx.x] = s;
+    }
+}
+
+// Finalise Hessenberg column `colj` from K2(colj)'s partial sums (all threads call; thread 0 does the serial part).
+// Every global load is issued before the first barrier: one memory round trip.  Leaves the new snapshot in sh.T.
 __device__ void finalize_column(const GDev &d, int colj, KShared &sh) {
+    const int t32 = threadIdx.x & (kKP - 1);
+    const double h1 = d.hcol1[colj * kKP + t32];
+    const double cv = d.c[t32], sv = d.s[t32];
     const Snap prev = d.T[colj];
-    const ColInfo ci = d.ci[colj];
-    if (prev.done == 0 && ci.reorth) reduce_partials(d.P3, d.G2, 1, sh.tmp, sh.red);
-    if (threadIdx.x <= colj && threadIdx.x < kPartStride) {
-        sh.h[threadIdx.x] = d.hcol1[colj * kPartStride + threadIdx.x] + d.hcol2[colj * kPartStride + threadIdx.x];
-        sh.cc[threadIdx.x] = d.c[threadIdx.x];
-        sh.ss[threadIdx.x] = d.s[threadIdx.x];
+    const double wnorm2 = d.wnorm2[colj];
+    reduce_partials<kNS, kMaxI>(d.P2, d.G2, kKP, sh.tmp, sh.red);       // [0..colj] = h2, [31] = ||wt||^2
+    if (threadIdx.x < kKP) {
+        sh.h[threadIdx.x] = h1;
+        sh.h2[threadIdx.x] = ((int)threadIdx.x <= colj) ? sh.red[threadIdx.x] : 0.0;
+        sh.cc[threadIdx.x] = cv;
+        sh.ss[threadIdx.x] = sv;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         Snap t = prev;
+        sh.fin = (t.done == 0) ? 1 : 0;
+        sh.reorth = 0;
         if (t.done == 0) {
-            const double n2 = ci.reorth ? sh.red[0] : ci.n2p;
+            double n2 = sh.red[kNormSlot];
+            const bool reorth = n2 < d.prm->eta2 * wnorm2;
+            if (reorth) {
+                double q = 0.0;
+                for (int i = 0; i <= colj; ++i) {
+                    q += sh.h2[i] * sh.h2[i];
+                    sh.h[i] += sh.h2[i];
+                }
+                n2 = fmax(n2 - q, 0.0);
+                sh.reorth = 1;
+            }
             const double hbis = sqrt(n2);
             for (int i = 0; i < colj; ++i) {
                 const double tmp = sh.cc[i] * sh.h[i] + sh.ss[i] * sh.h[i + 1];
@@ -126,11 +167,13 @@ __device__ void finalize_column(const GDev &d, int colj, KShared &sh) {
             t.rnorm = fabs(zeta_next);
             t.iter += 1;
             t.inner += 1;
-            t.nreorth += ci.reorth;
+            t.nreorth += reorth ? 1 : 0;
             const bool solved = (t.rnorm <= t.eps) || (t.rnorm + 1.0 <= 1.0);
             t.done = solved ? 1 : ((long long)t.iter >= d.prm->itmax ? 2 : (hbis <= d.prm->btol ? 3 : 0));
             t.beta = hbis;
             t.zeta = zeta_next;
+            sh.rho = rho;
+            sh.zcol = zcol;
             if (blockIdx.x == 0) {
                 d.c[colj] = cj;
                 d.s[colj] = sj;
@@ -151,37 +194,53 @@ __device__ __forceinline__ double precond_row(const GDev &d, int row) {
     return d.pkind == NPG_PRECOND_SCALAR ? d.pscalar : (d.pkind == NPG_PRECOND_DIAG ? d.pdiag[row] : 1.0);
 }
 
+// second Gram-Schmidt pass applied on the fly to the SpMV input: (wt - V h2)[c]  (rare path, see the header comment)
+struct CorrectedX {
+    const double *wt, *Vi, *h2;
+    int nb;
+    __device__ __forceinline__ double operator()(int c) const {
+        double v = wt[c];
+        const double *row = Vi + (size_t)c * kKP;
+        for (int k = 0; k < nb; ++k) v -= h2[k] * row[k];
+        return v;
+    }
+};
+
 // ---- R1: wt = P (b - A x), partial ||wt||^2 ---------------------------------------------------------------------------
 template <int L>
-__global__ void __launch_bounds__(kBlock) k_gmres_residual(GDev d) {
-    __shared__ double sh[4 * kPartStride];
+__global__ void __launch_bounds__(kKB, 8) k_gmres_residual(GDev d) {
+    __shared__ TileLds tl;
+    __shared__ double sw[kTileRows];
+    __shared__ double tmp[kNS * kKP];
     const Snap c = *d.C;
-    double acc[1] = {0.0};
+    double acc = 0.0;
     if (c.done == 0) {
-        const int g = threadIdx.x / L, l = threadIdx.x % L;
         for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
             const int r0 = d.tile_ptr[t], r1 = d.tile_ptr[t + 1];
-            for (int row = r0 + g; row < r1; row += kBlock / L) {
-                const double ax = csr_row_dot<L>(d.rowptr, d.col, d.val, d.x, row, l);
-                if (l == 0) {
-                    const double r = precond_row(d, row) * (d.b[row] - ax);
-                    d.wt[row] = r;
-                    acc[0] += r * r;
-                }
+            spmv_tile<kKB, L>(d.rowptr, d.col, d.val, PlainX{d.x}, r0, r1, tl, sw);
+            const int r = threadIdx.x;
+            if (r < r1 - r0) {
+                const int row = r0 + r;
+                const double res = precond_row(d, row) * (d.b[row] - sw[r]);
+                d.wt[row] = res;
+                acc += res * res;
             }
         }
     }
-    block_store_partials<1>(acc, 1, sh, d.PR);
+    // every thread contributes to entry 0 of the partial row: fold the 32 lanes of a slot first
+    acc = group_sum_dpp<kKP>(acc);
+    store_partial_row((threadIdx.x & (kKP - 1)) == 0 ? acc : 0.0, tmp, d.PR);
 }
 
 // ---- K1 ---------------------------------------------------------------------------------------------------------------
-template <int L, int JB>
-__global__ void __launch_bounds__(kBlock) k_gmres_arnoldi(GDev d, int j) {
+template <int L>
+__global__ void __launch_bounds__(kKB, 8) k_gmres_arnoldi(GDev d, int j) {
     __shared__ KShared sh;
-    __shared__ double sw[kBlock];
+    __shared__ TileLds tl;
+    __shared__ double sw[kTileRows];
     if (j == 0) {
         const Snap c = *d.C;
-        if (c.done == 0) reduce_partials(d.PR, d.G1, 1, sh.tmp, sh.red);
+        reduce_partials<kNS, kMaxI>(d.PR, d.G1, 1, sh.tmp, sh.red);
         if (threadIdx.x == 0) {
             Snap t = c;
             if (t.done == 0) {
@@ -196,12 +255,11 @@ __global__ void __launch_bounds__(kBlock) k_gmres_arnoldi(GDev d, int j) {
                 }
                 t.beta = beta;
                 t.zeta = beta;
-                t.inner = 0;
                 t.npass += 1;
-            } else {
-                t.inner = 0;
             }
+            t.inner = 0;
             sh.T = t;
+            sh.reorth = 0;
             if (blockIdx.x == 0) d.T[0] = t;
         }
         __syncthreads();
@@ -211,137 +269,81 @@ __global__ void __launch_bounds__(kBlock) k_gmres_arnoldi(GDev d, int j) {
     const Snap T = sh.T;
     if (T.done != 0) return;
 
+    const int k = threadIdx.x & (kKP - 1), slot = threadIdx.x >> 5;
     const double inv_beta = 1.0 / T.beta;
-    double acc[JB + 1];
-#pragma unroll
-    for (int k = 0; k <= JB; ++k) acc[k] = 0.0;
-    const int g = threadIdx.x / L, l = threadIdx.x % L;
-    double *Vj = d.V + (size_t)j * d.ld;
+    const bool ro = sh.reorth != 0;
+    const double h2k = (ro && k < j) ? sh.h2[k] : 0.0;
+    double acc = 0.0;
     for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
         const int r0 = d.tile_ptr[t], r1 = d.tile_ptr[t + 1];
-        __syncthreads();
-        // phase A: SpMV rows of the tile -> LDS
-        for (int row = r0 + g; row < r1; row += kBlock / L) {
-            const double s = csr_row_dot<L>(d.rowptr, d.col, d.val, d.wt, row, l);
-            if (l == 0) sw[row - r0] = s * inv_beta * precond_row(d, row);
-        }
-        __syncthreads();
-        // phase B: one thread per row: normalised basis vector, w, partial dot products
-        const int row = r0 + threadIdx.x;
-        if (row < r1) {
-            const double wv = sw[threadIdx.x];
-            const double vj = d.wt[row] * inv_beta;
-            Vj[row] = vj;
-            d.w[row] = wv;
-#pragma unroll
-            for (int k = 0; k < JB; ++k)
-                if (k < j) acc[k] += d.V[(size_t)k * d.ld + row] * wv;
-            acc[JB] += wv * wv;
-            // the k == j term uses the value just computed
-            double vjw = vj * wv;
-#pragma unroll
-            for (int k = 0; k < JB; ++k)
-                if (k == j) acc[k] += vjw;
+        if (!ro)
+            spmv_tile<kKB, L>(d.rowptr, d.col, d.val, PlainX{d.wt}, r0, r1, tl, sw);
+        else
+            spmv_tile<kKB, L>(d.rowptr, d.col, d.val, CorrectedX{d.wt, d.Vi, sh.h2, j}, r0, r1, tl, sw);
+        // 32 lanes per row (lane = basis index): new basis entry, w, and the partial dot products
+        for (int r = slot; r < r1 - r0; r += kNS) {
+            const int row = r0 + r;
+            const double wv = sw[r] * inv_beta * precond_row(d, row);
+            double *vrow = d.Vi + (size_t)row * kKP;
+            double vk = (k < j) ? vrow[k] : 0.0;
+            double wtr = d.wt[row];
+            if (ro) wtr -= group_sum_dpp<kKP>(h2k * vk);
+            if (k == j) {
+                vk = wtr * inv_beta;
+                vrow[j] = vk;
+            }
+            if (k == 0) d.w[row] = wv;
+            acc += (k == kNormSlot) ? wv * wv : vk * wv;
         }
     }
-    // partial row layout: [0..j] = h1, [j+1] = ||w||^2
-    double out[JB + 1];
-#pragma unroll
-    for (int k = 0; k < JB; ++k) out[k] = acc[k];
-    out[JB] = 0.0;
-#pragma unroll
-    for (int k = 0; k <= JB; ++k)
-        if (k == j + 1) out[k] = acc[JB];
-    block_store_partials<JB + 1>(out, j + 2, sh.wsum, d.P1);
+    store_partial_row(acc, sh.tmp, d.P1);
 }
 
 // ---- K2 ---------------------------------------------------------------------------------------------------------------
-template <int JB>
-__global__ void __launch_bounds__(kBlock) k_gmres_orth1(GDev d, int j) {
+__global__ void __launch_bounds__(kKB, 8) k_gmres_orth(GDev d, int j) {
     __shared__ KShared sh;
     const Snap T = d.T[j];
+    reduce_partials<kNS, kMaxI>(d.P1, d.G1, kKP, sh.tmp, sh.red);       // [0..j] = h1, [31] = ||w||^2
     if (T.done != 0) return;
-    reduce_partials(d.P1, d.G1, j + 2, sh.tmp, sh.red);
-    if (blockIdx.x == 0 && threadIdx.x < kPartStride) {
-        d.hcol1[j * kPartStride + threadIdx.x] = (threadIdx.x <= j) ? sh.red[threadIdx.x] : 0.0;
-        if (threadIdx.x == 0) d.ci[j].wnorm2 = sh.red[j + 1];
+    const int k = threadIdx.x & (kKP - 1), slot = threadIdx.x >> 5;
+    if (blockIdx.x == 0 && threadIdx.x < kKP) {
+        d.hcol1[j * kKP + threadIdx.x] = ((int)threadIdx.x <= j) ? sh.red[threadIdx.x] : 0.0;
+        if (threadIdx.x == 0) d.wnorm2[j] = sh.red[kNormSlot];
     }
-    double h[JB], acc[JB + 1];
-#pragma unroll
-    for (int k = 0; k < JB; ++k) {
-        h[k] = (k <= j) ? sh.red[k] : 0.0;
-        acc[k] = 0.0;
+    const double hk = (k <= j) ? sh.red[k] : 0.0;
+    double acc = 0.0;
+    for (int64_t row = (int64_t)blockIdx.x * kNS + slot; row < d.n; row += (int64_t)gridDim.x * kNS) {
+        const double vk = (k <= j) ? d.Vi[(size_t)row * kKP + k] : 0.0;
+        const double wp = d.w[row] - group_sum_dpp<kKP>(hk * vk);
+        if (k == 0) d.wt[row] = wp;
+        acc += (k == kNormSlot) ? wp * wp : vk * wp;
     }
-    acc[JB] = 0.0;
-    for (int64_t row = blockIdx.x * (int64_t)kBlock + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kBlock) {
-        double v[JB];
-#pragma unroll
-        for (int k = 0; k < JB; ++k) v[k] = (k <= j) ? d.V[(size_t)k * d.ld + row] : 0.0;
-        double wv = d.w[row];
-#pragma unroll
-        for (int k = 0; k < JB; ++k) wv -= h[k] * v[k];
-        d.wt[row] = wv;
-#pragma unroll
-        for (int k = 0; k < JB; ++k) acc[k] += v[k] * wv;
-        acc[JB] += wv * wv;
-    }
-    double out[JB + 1];
-#pragma unroll
-    for (int k = 0; k < JB; ++k) out[k] = acc[k];
-    out[JB] = 0.0;
-#pragma unroll
-    for (int k = 0; k <= JB; ++k)
-        if (k == j + 1) out[k] = acc[JB];
-    block_store_partials<JB + 1>(out, j + 2, sh.wsum, d.P2);
-}
-
-// ---- K3 ---------------------------------------------------------------------------------------------------------------
-template <int JB>
-__global__ void __launch_bounds__(kBlock) k_gmres_orth2(GDev d, int j) {
-    __shared__ KShared sh;
-    const Snap T = d.T[j];
-    if (T.done != 0) return;
-    const double wnorm2 = d.ci[j].wnorm2;
-    reduce_partials(d.P2, d.G2, j + 2, sh.tmp, sh.red);
-    const double n2p = sh.red[j + 1];
-    const bool reorth = n2p < d.prm->eta2 * wnorm2;
-    if (blockIdx.x == 0 && threadIdx.x < kPartStride) {
-        d.hcol2[j * kPartStride + threadIdx.x] = (reorth && threadIdx.x <= j) ? sh.red[threadIdx.x] : 0.0;
-        if (threadIdx.x == 0) {
-            d.ci[j].n2p = n2p;
-            d.ci[j].reorth = reorth ? 1 : 0;
-        }
-    }
-    if (!reorth) return;
-    double h[JB];
-#pragma unroll
-    for (int k = 0; k < JB; ++k) h[k] = (k <= j) ? sh.red[k] : 0.0;
-    double acc[1] = {0.0};
-    for (int64_t row = blockIdx.x * (int64_t)kBlock + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kBlock) {
-        double wv = d.wt[row];
-#pragma unroll
-        for (int k = 0; k < JB; ++k)
-            if (k <= j) wv -= h[k] * d.V[(size_t)k * d.ld + row];
-        d.wt[row] = wv;
-        acc[0] += wv * wv;
-    }
-    block_store_partials<1>(acc, 1, sh.wsum, d.P3);
+    store_partial_row(acc, sh.tmp, d.P2);
 }
 
 // ---- XU ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_gmres_update(GDev d) {
+__global__ void __launch_bounds__(kKB, 8) k_gmres_update(GDev d) {
     __shared__ KShared sh;
+    const double zv = d.z[threadIdx.x & (kKP - 1)];
     finalize_column(d, d.mem - 1, sh);     // no-op copy if the pass already ended
     const Snap T = sh.T;
-    const int k = T.inner;
-    if (threadIdx.x < kPartStride) sh.y[threadIdx.x] = (threadIdx.x < k) ? d.z[threadIdx.x] : 0.0;
+    const int kk = T.inner;
+    // The last column (R entries, rotated z) was finalised inside THIS launch by every workgroup redundantly: take it
+    // from shared memory, never from the global copies workgroup 0 is writing concurrently.
+    const bool fin = sh.fin != 0;
+    const int last = d.mem - 1;
+    if (threadIdx.x < kKP)
+        sh.y[threadIdx.x] = ((int)threadIdx.x < kk) ? ((fin && (int)threadIdx.x == last) ? sh.zcol : zv) : 0.0;
     __syncthreads();
     if (threadIdx.x == 0) {
-        // back substitution on the packed upper-triangular R (column-major packed, column c starts at c(c+1)/2)
-        for (int i = k - 1; i >= 0; --i) {
+        // back substitution on the packed upper-triangular R (column c starts at c(c+1)/2)
+        for (int i = kk - 1; i >= 0; --i) {
             double yi = sh.y[i];
-            for (int c = k - 1; c > i; --c) yi -= d.R[c * (c + 1) / 2 + i] * sh.y[c];
-            const double rii = d.R[i * (i + 1) / 2 + i];
+            for (int c = kk - 1; c > i; --c) {
+                const double ric = (fin && c == last) ? sh.h[i] : d.R[c * (c + 1) / 2 + i];
+                yi -= ric * sh.y[c];
+            }
+            const double rii = (fin && i == last) ? sh.rho : d.R[i * (i + 1) / 2 + i];
             sh.y[i] = (fabs(rii) <= d.prm->btol) ? 0.0 : yi / rii;
         }
         if (blockIdx.x == 0) {
@@ -351,11 +353,13 @@ __global__ void __launch_bounds__(kBlock) k_gmres_update(GDev d) {
         }
     }
     __syncthreads();
-    if (k == 0) return;
-    for (int64_t row = blockIdx.x * (int64_t)kBlock + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kBlock) {
-        double xv = d.x[row];
-        for (int i = 0; i < k; ++i) xv += sh.y[i] * d.V[(size_t)i * d.ld + row];
-        d.x[row] = xv;
+    if (kk == 0) return;
+    const int k = threadIdx.x & (kKP - 1), slot = threadIdx.x >> 5;
+    const double yk = sh.y[k];             // zero for k >= kk
+    for (int64_t row = (int64_t)blockIdx.x * kNS + slot; row < d.n; row += (int64_t)gridDim.x * kNS) {
+        const double vk = (k < kk) ? d.Vi[(size_t)row * kKP + k] : 0.0;
+        const double s = group_sum_dpp<kKP>(yk * vk);
+        if (k == 0) d.x[row] += s;
     }
 }
 
@@ -366,12 +370,11 @@ using namespace npg;
 struct npg_gmres {
     npg_ctx *ctx = nullptr;
     int64_t n = 0;
-    int mem = 20, ld = 0;
-    double *V = nullptr, *w = nullptr, *wt = nullptr;
-    double *P1 = nullptr, *P2 = nullptr, *P3 = nullptr, *PR = nullptr;
+    int mem = 20;
+    double *Vi = nullptr, *w = nullptr, *wt = nullptr;
+    double *P1 = nullptr, *P2 = nullptr, *PR = nullptr;
     Snap *C = nullptr, *T = nullptr;
-    double *c = nullptr, *s = nullptr, *z = nullptr, *R = nullptr, *hcol1 = nullptr, *hcol2 = nullptr;
-    ColInfo *ci = nullptr;
+    double *c = nullptr, *s = nullptr, *z = nullptr, *R = nullptr, *hcol1 = nullptr, *wnorm2 = nullptr;
     double *hist = nullptr;
     int hist_cap = 0;
     GParams *prm = nullptr;
@@ -391,61 +394,26 @@ struct npg_gmres {
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
     npg_halo *halo = nullptr;
-    static constexpr int kMaxG = 512;
 };
-
-template <int L, int JB>
-static void launch_arnoldi(const GDev &d, int j, hipStream_t st) {
-    hipLaunchKernelGGL((k_gmres_arnoldi<L, JB>), dim3(d.G1), dim3(kBlock), 0, st, d, j);
-}
 
 template <int L>
 static void launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev) {
     for (int j = 0; j < d.mem; ++j) {
-        const int nb = j + 1;
         if (pev) hipEventRecord(pev[2 * j], st);
-        if (nb <= 4) {
-            launch_arnoldi<L, 4>(d, j, st);
-            if (pev) hipEventRecord(pev[2 * j + 1], st);
-            hipLaunchKernelGGL(k_gmres_orth1<4>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
-            hipLaunchKernelGGL(k_gmres_orth2<4>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
-        } else if (nb <= 8) {
-            launch_arnoldi<L, 8>(d, j, st);
-            if (pev) hipEventRecord(pev[2 * j + 1], st);
-            hipLaunchKernelGGL(k_gmres_orth1<8>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
-            hipLaunchKernelGGL(k_gmres_orth2<8>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
-        } else if (nb <= 12) {
-            launch_arnoldi<L, 12>(d, j, st);
-            if (pev) hipEventRecord(pev[2 * j + 1], st);
-            hipLaunchKernelGGL(k_gmres_orth1<12>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
-            hipLaunchKernelGGL(k_gmres_orth2<12>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
-        } else if (nb <= 16) {
-            launch_arnoldi<L, 16>(d, j, st);
-            if (pev) hipEventRecord(pev[2 * j + 1], st);
-            hipLaunchKernelGGL(k_gmres_orth1<16>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
-            hipLaunchKernelGGL(k_gmres_orth2<16>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
-        } else if (nb <= 20) {
-            launch_arnoldi<L, 20>(d, j, st);
-            if (pev) hipEventRecord(pev[2 * j + 1], st);
-            hipLaunchKernelGGL(k_gmres_orth1<20>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
-            hipLaunchKernelGGL(k_gmres_orth2<20>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
-        } else {
-            launch_arnoldi<L, 30>(d, j, st);
-            if (pev) hipEventRecord(pev[2 * j + 1], st);
-            hipLaunchKernelGGL(k_gmres_orth1<30>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
-            hipLaunchKernelGGL(k_gmres_orth2<30>, dim3(d.G2), dim3(kBlock), 0, st, d, j);
-        }
+        hipLaunchKernelGGL(k_gmres_arnoldi<L>, dim3(d.G1), dim3(kKB), 0, st, d, j);
+        if (pev) hipEventRecord(pev[2 * j + 1], st);
+        hipLaunchKernelGGL(k_gmres_orth, dim3(d.G2), dim3(kKB), 0, st, d, j);
     }
-    hipLaunchKernelGGL(k_gmres_update, dim3(d.G2), dim3(kBlock), 0, st, d);
-    hipLaunchKernelGGL(k_gmres_residual<L>, dim3(d.G1), dim3(kBlock), 0, st, d);
+    hipLaunchKernelGGL(k_gmres_update, dim3(d.G2), dim3(kKB), 0, st, d);
+    hipLaunchKernelGGL(k_gmres_residual<L>, dim3(d.G1), dim3(kKB), 0, st, d);
 }
 
 static void launch_residual(const GDev &d, int lanes, hipStream_t st) {
     switch (lanes) {
-        case 4: hipLaunchKernelGGL(k_gmres_residual<4>, dim3(d.G1), dim3(kBlock), 0, st, d); break;
-        case 8: hipLaunchKernelGGL(k_gmres_residual<8>, dim3(d.G1), dim3(kBlock), 0, st, d); break;
-        case 16: hipLaunchKernelGGL(k_gmres_residual<16>, dim3(d.G1), dim3(kBlock), 0, st, d); break;
-        default: hipLaunchKernelGGL(k_gmres_residual<32>, dim3(d.G1), dim3(kBlock), 0, st, d); break;
+        case 4: hipLaunchKernelGGL(k_gmres_residual<4>, dim3(d.G1), dim3(kKB), 0, st, d); break;
+        case 8: hipLaunchKernelGGL(k_gmres_residual<8>, dim3(d.G1), dim3(kKB), 0, st, d); break;
+        case 16: hipLaunchKernelGGL(k_gmres_residual<16>, dim3(d.G1), dim3(kKB), 0, st, d); break;
+        default: hipLaunchKernelGGL(k_gmres_residual<32>, dim3(d.G1), dim3(kKB), 0, st, d); break;
     }
 }
 
@@ -461,31 +429,28 @@ static void launch_cycle(const GDev &d, int lanes, hipStream_t st, hipEvent_t *p
 NPG_API int npg_gmres_create(npg_ctx *ctx, int64_t n, int memory, npg_gmres **out) {
     NPG_REQUIRE(ctx && out && n > 0, "npg_gmres_create: bad argument");
     NPG_REQUIRE(memory >= 1 && memory <= kMaxMem, "npg_gmres_create: memory must be in [1,%d]", kMaxMem);
-    NPG_REQUIRE(n < INT32_MAX, "npg_gmres_create: n exceeds int32 row indices");
+    NPG_REQUIRE(n < INT32_MAX / kKP, "npg_gmres_create: n exceeds the int32 indexing of the interleaved basis");
     npg_gmres *ws = new npg_gmres();
     ws->ctx = ctx;
     ws->n = n;
     ws->mem = memory;
-    ws->ld = (int)((n + 31) / 32 * 32);
     NPG_HIP(hipSetDevice(ctx->device));
-    const size_t vb = (size_t)ws->ld * sizeof(double);
-    NPG_HIP(hipMalloc((void **)&ws->V, vb * memory));
+    const size_t vb = (size_t)n * sizeof(double);
+    NPG_HIP(hipMalloc((void **)&ws->Vi, vb * kKP));
     NPG_HIP(hipMalloc((void **)&ws->w, vb));
     NPG_HIP(hipMalloc((void **)&ws->wt, vb));
-    const size_t pb = (size_t)npg_gmres::kMaxG * kPartStride * sizeof(double);
+    const size_t pb = (size_t)kMaxG * kKP * sizeof(double);
     NPG_HIP(hipMalloc((void **)&ws->P1, pb));
     NPG_HIP(hipMalloc((void **)&ws->P2, pb));
-    NPG_HIP(hipMalloc((void **)&ws->P3, pb));
     NPG_HIP(hipMalloc((void **)&ws->PR, pb));
     NPG_HIP(hipMalloc((void **)&ws->C, sizeof(Snap)));
     NPG_HIP(hipMalloc((void **)&ws->T, sizeof(Snap) * (memory + 1)));
-    NPG_HIP(hipMalloc((void **)&ws->c, sizeof(double) * kPartStride));
-    NPG_HIP(hipMalloc((void **)&ws->s, sizeof(double) * kPartStride));
-    NPG_HIP(hipMalloc((void **)&ws->z, sizeof(double) * kPartStride));
-    NPG_HIP(hipMalloc((void **)&ws->R, sizeof(double) * kPartStride * (kPartStride + 1) / 2));
-    NPG_HIP(hipMalloc((void **)&ws->hcol1, sizeof(double) * kPartStride * kPartStride));
-    NPG_HIP(hipMalloc((void **)&ws->hcol2, sizeof(double) * kPartStride * kPartStride));
-    NPG_HIP(hipMalloc((void **)&ws->ci, sizeof(ColInfo) * kPartStride));
+    NPG_HIP(hipMalloc((void **)&ws->c, sizeof(double) * kKP));
+    NPG_HIP(hipMalloc((void **)&ws->s, sizeof(double) * kKP));
+    NPG_HIP(hipMalloc((void **)&ws->z, sizeof(double) * kKP));
+    NPG_HIP(hipMalloc((void **)&ws->R, sizeof(double) * kKP * (kKP + 1) / 2));
+    NPG_HIP(hipMalloc((void **)&ws->hcol1, sizeof(double) * kKP * kKP));
+    NPG_HIP(hipMalloc((void **)&ws->wnorm2, sizeof(double) * kKP));
     ws->hist_cap = (int)std::min<int64_t>(2 * n + 2, 1 << 22);
     NPG_HIP(hipMalloc((void **)&ws->hist, sizeof(double) * ws->hist_cap));
     NPG_HIP(hipMalloc((void **)&ws->prm, sizeof(GParams)));
@@ -493,15 +458,17 @@ NPG_API int npg_gmres_create(npg_ctx *ctx, int64_t n, int memory, npg_gmres **ou
     NPG_HIP(hipEventCreateWithFlags(&ws->ev[0], hipEventDisableTiming));
     NPG_HIP(hipEventCreateWithFlags(&ws->ev[1], hipEventDisableTiming));
     NPG_HIP(hipHostMalloc((void **)&ws->h_prm, sizeof(GParams), hipHostMallocDefault));
-    NPG_HIP(hipMemsetAsync(ws->V, 0, vb * memory, ctx->stream));
+    NPG_HIP(hipMemsetAsync(ws->Vi, 0, vb * kKP, ctx->stream));
     NPG_HIP(hipMemsetAsync(ws->w, 0, vb, ctx->stream));
     NPG_HIP(hipMemsetAsync(ws->wt, 0, vb, ctx->stream));
-    NPG_HIP(hipMemsetAsync(ws->c, 0, sizeof(double) * kPartStride, ctx->stream));
-    NPG_HIP(hipMemsetAsync(ws->s, 0, sizeof(double) * kPartStride, ctx->stream));
-    NPG_HIP(hipMemsetAsync(ws->z, 0, sizeof(double) * kPartStride, ctx->stream));
-    NPG_HIP(hipMemsetAsync(ws->hcol1, 0, sizeof(double) * kPartStride * kPartStride, ctx->stream));
-    NPG_HIP(hipMemsetAsync(ws->hcol2, 0, sizeof(double) * kPartStride * kPartStride, ctx->stream));
-    NPG_HIP(hipMemsetAsync(ws->ci, 0, sizeof(ColInfo) * kPartStride, ctx->stream));
+    NPG_HIP(hipMemsetAsync(ws->P1, 0, pb, ctx->stream));
+    NPG_HIP(hipMemsetAsync(ws->P2, 0, pb, ctx->stream));
+    NPG_HIP(hipMemsetAsync(ws->PR, 0, pb, ctx->stream));
+    NPG_HIP(hipMemsetAsync(ws->c, 0, sizeof(double) * kKP, ctx->stream));
+    NPG_HIP(hipMemsetAsync(ws->s, 0, sizeof(double) * kKP, ctx->stream));
+    NPG_HIP(hipMemsetAsync(ws->z, 0, sizeof(double) * kKP, ctx->stream));
+    NPG_HIP(hipMemsetAsync(ws->hcol1, 0, sizeof(double) * kKP * kKP, ctx->stream));
+    NPG_HIP(hipMemsetAsync(ws->wnorm2, 0, sizeof(double) * kKP, ctx->stream));
     NPG_HIP(hipStreamSynchronize(ctx->stream));
     *out = ws;
     return NPG_OK;
@@ -516,8 +483,8 @@ NPG_API int npg_gmres_destroy(npg_gmres *ws) {
         if (ws->ev[k]) hipEventDestroy(ws->ev[k]);
     }
     for (hipEvent_t e : ws->pev) hipEventDestroy(e);
-    void *ptrs[] = {ws->V, ws->w, ws->wt, ws->P1, ws->P2, ws->P3, ws->PR, ws->C, ws->T, ws->c, ws->s,
-                    ws->z, ws->R, ws->hcol1, ws->hcol2, ws->ci, ws->hist, ws->prm};
+    void *ptrs[] = {ws->Vi, ws->w, ws->wt, ws->P1, ws->P2, ws->PR, ws->C, ws->T, ws->c, ws->s,
+                    ws->z, ws->R, ws->hcol1, ws->wnorm2, ws->hist, ws->prm};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (ws->h_C) hipHostFree(ws->h_C);
@@ -556,22 +523,20 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     d.tile_ptr = A->tile_ptr;
     d.ntiles = A->ntiles;
     d.n = (int)ws->n;
-    d.ld = ws->ld;
     d.mem = ws->mem;
     d.pkind = precond_kind;
     d.pscalar = precond_scalar;
     d.pdiag = precond_kind == NPG_PRECOND_DIAG ? precond_diag->d : nullptr;
     d.b = y->d;
     d.x = x->d;
-    d.V = ws->V;
+    d.Vi = ws->Vi;
     d.w = ws->w;
     d.wt = ws->wt;
     d.P1 = ws->P1;
     d.P2 = ws->P2;
-    d.P3 = ws->P3;
     d.PR = ws->PR;
-    d.G1 = std::max(1, std::min<int>(A->ntiles, std::min(npg_gmres::kMaxG, 2 * ctx->num_cu)));
-    d.G2 = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kBlock - 1) / kBlock, d.G1));
+    d.G1 = std::max(1, std::min<int>(A->ntiles, std::min(kMaxG, 2 * ctx->num_cu)));
+    d.G2 = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kNS - 1) / kNS, std::min(kMaxG, 2 * ctx->num_cu)));
     d.C = ws->C;
     d.T = ws->T;
     d.c = ws->c;
@@ -579,8 +544,7 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     d.z = ws->z;
     d.R = ws->R;
     d.hcol1 = ws->hcol1;
-    d.hcol2 = ws->hcol2;
-    d.ci = ws->ci;
+    d.wnorm2 = ws->wnorm2;
     d.hist = ws->hist;
     d.hist_cap = ws->hist_cap;
     d.prm = ws->prm;
@@ -594,12 +558,15 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     NPG_HIP(hipMemcpyAsync(ws->prm, ws->h_prm, sizeof(GParams), hipMemcpyHostToDevice, st));
     Snap c0{};
     c0.first = 1;
-    *ws->h_C = c0;
+    ws->h_C[0] = c0;
     NPG_HIP(hipMemcpyAsync(ws->C, ws->h_C, sizeof(Snap), hipMemcpyHostToDevice, st));
+    NPG_HIP(hipStreamSynchronize(st));      // h_C[0] is reused below as a result slot
 
-    // (re)capture the per-cycle graph when any baked-in argument changed
-    if (!ws->have_graph || memcmp(&ws->key, &d, sizeof(GDev)) != 0) {
-        NPG_HIP(hipStreamSynchronize(st));
+    static const int eager = getenv("NPG_GMRES_EAGER") ? atoi(getenv("NPG_GMRES_EAGER")) : 0;
+    static const int trace = getenv("NPG_GMRES_TRACE") ? atoi(getenv("NPG_GMRES_TRACE")) : 0;
+
+    // (re)capture the per-cycle graphs when any baked-in argument changed
+    if (!eager && !ws->profile && (!ws->have_graph || memcmp(&ws->key, &d, sizeof(GDev)) != 0)) {
         for (int k = 0; k < 2; ++k) {
             if (ws->exec[k]) hipGraphExecDestroy(ws->exec[k]);
             if (ws->graph[k]) hipGraphDestroy(ws->graph[k]);
@@ -620,23 +587,46 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     NPG_HIP(hipGetLastError());
     const int64_t max_cycles = (itmax + ws->mem - 1) / ws->mem + 1;
     Snap last{};
+    double t_launch = 0.0;
+    int64_t n_launch = 0;
+    auto enqueue_cycle = [&](int slot) -> int {
+        const auto l0 = std::chrono::steady_clock::now();
+        if (eager) {
+            launch_cycle(d, A->lanes, st, nullptr);
+            NPG_HIP(hipMemcpyAsync(ws->h_C + slot, ws->C, sizeof(Snap), hipMemcpyDeviceToHost, st));
+        } else {
+            NPG_HIP(hipGraphLaunch(ws->exec[slot], st));
+        }
+        NPG_HIP(hipEventRecord(ws->ev[slot], st));
+        t_launch += std::chrono::duration<double>(std::chrono::steady_clock::now() - l0).count();
+        ++n_launch;
+        return NPG_OK;
+    };
     if (!ws->profile) {
         // cycle c+1 is enqueued before the host reads the outcome of cycle c: the device never idles waiting for the
         // host, and a cycle launched after convergence costs only its early-exit kernels
-        NPG_HIP(hipGraphLaunch(ws->exec[0], st));
-        NPG_HIP(hipEventRecord(ws->ev[0], st));
+        int rc0 = enqueue_cycle(0);
+        if (rc0) return rc0;
         for (int64_t cyc = 0;; ++cyc) {
             const int cur = (int)(cyc & 1), nxt = cur ^ 1;
             const bool more = cyc + 1 < max_cycles;
             if (more) {
-                NPG_HIP(hipGraphLaunch(ws->exec[nxt], st));
-                NPG_HIP(hipEventRecord(ws->ev[nxt], st));
+                rc0 = enqueue_cycle(nxt);
+                if (rc0) return rc0;
             }
             NPG_HIP(hipEventSynchronize(ws->ev[cur]));
             last = ws->h_C[cur];
             if (last.done != 0 || !more) break;
         }
         NPG_HIP(hipStreamSynchronize(st));
+        if (trace)
+            fprintf(stderr,
+                    "[npg gmres] %s: %lld cycle launches, %.1f us host time per launch, %d iterations, %.1f us wall per "
+                    "iteration, %d second GS passes\n",
+                    eager ? "eager" : "graph", (long long)n_launch, 1e6 * t_launch / (double)n_launch, last.iter,
+                    1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() /
+                        std::max(1, last.iter),
+                    last.nreorth);
     } else {
         if (ws->pev.empty()) {
             ws->pev.resize(2 * ws->mem);

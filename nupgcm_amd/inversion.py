@@ -70,7 +70,7 @@ class InversionToolkit:
     """src/inversion.jl:1-5: {B, b, solver}"""
 
     def __init__(self, arch, *args, atol=1e-6, rtol=1e-6, itmax=0, memory=20, history=True, verbose=False, restart=True,
-                 reorth_eta=0.7071067811865476):
+                 reorth_eta=0.1):
         if not isinstance(arch, GPU):
             raise TypeError("nupgcm_amd implements the GPU() architecture only (no CPU fallback)")
         if not restart:

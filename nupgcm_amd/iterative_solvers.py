@@ -57,7 +57,10 @@ class GmresWorkspace(_Workspace):
             pass
 
     def solve(self, A: DeviceCSR, y: DeviceVector, x: DeviceVector, P, atol=1e-6, rtol=1e-6, itmax=0,
-              reorth_eta=0.7071067811865476, **_ignored):
+              reorth_eta=0.1, **_ignored):
+        """reorth_eta: take the second Gram-Schmidt pass when ||w - V h|| < eta ||w||.  Measured on the bowl meshes, GMRES
+        iteration counts are identical for eta in {0, 0.05, 0.3, 0.707}: the DGKS value 0.707 keeps the basis orthogonal to
+        machine precision, which restarted GMRES(20) at rtol 1e-6 does not need; 0.1 keeps the safety net."""
         kind, s, dh = (L.NPG_PRECOND_NONE, 0.0, None) if P is None else P.kind()
         st = L.SolveStats()
         L.check(L.lib().npg_gmres_solve(self.h, A.h, kind, s, dh, y.h, x.h, float(atol), float(rtol), int(itmax),
