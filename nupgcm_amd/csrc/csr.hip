@@ -36,14 +36,14 @@ constexpr int kSpmvThreads = 512;
 template <int L>
 __global__ void __launch_bounds__(kSpmvThreads) k_spmv(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                         const double *__restrict__ val,
-                                                        const int32_t *__restrict__ tile_ptr, int ntiles,
+                                                        const int32_t *__restrict__ tile_ptr, int ntiles, int64_t nnz,
                                                         const double *__restrict__ x, double *__restrict__ y,
                                                         double alpha, double beta) {
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int r0 = tile_ptr[t], r1 = tile_ptr[t + 1];
-        spmv_tile<kSpmvThreads, L>(rowptr, col, val, PlainX{x}, r0, r1, tl, sw);
+        spmv_tile<kSpmvThreads, L>(rowptr, col, val, nnz, PlainX{x}, r0, r1, tl, sw);
         for (int r = threadIdx.x; r < r1 - r0; r += kSpmvThreads) {
             const int row = r0 + r;
             y[row] = (beta == 0.0) ? alpha * sw[r] : alpha * sw[r] + beta * y[row];
@@ -91,9 +91,9 @@ static int upload_csr(npg_ctx *ctx, int64_t m, int64_t n, std::vector<int64_t> &
 
 template <int L>
 static void launch_spmv(const npg_csr *A, const double *x, double *y, double alpha, double beta) {
-    const int grid = std::min<int>(A->ntiles, 2 * A->ctx->num_cu);      // 2 x 72 KiB of LDS per CU
+    const int grid = std::min<int>(A->ntiles, 3 * A->ctx->num_cu);      // 3 x 38 KiB of LDS per CU
     hipLaunchKernelGGL(k_spmv<L>, dim3(std::max(grid, 1)), dim3(kSpmvThreads), 0, A->ctx->stream, A->rowptr, A->col,
-                       A->val, A->tile_ptr, A->ntiles, x, y, alpha, beta);
+                       A->val, A->tile_ptr, A->ntiles, A->nnz, x, y, alpha, beta);
 }
 
 }  // namespace npg

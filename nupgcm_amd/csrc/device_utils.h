@@ -89,15 +89,20 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
                                                 double *sh_out) {
     const int k = threadIdx.x & (kPartStride - 1);
     const int slice = threadIdx.x >> 5;
-    double v[MAXI];
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) {
-        const int b = slice + NS * i;
-        v[i] = (k < nvals && b < nblocks) ? part[(size_t)b * kPartStride + k] : 0.0;
-    }
+    constexpr int CH = MAXI < 8 ? MAXI : 8;      // loads in flight per thread
+    static_assert(MAXI % CH == 0, "MAXI must be a multiple of the chunk");
     double s = 0.0;
+    for (int i0 = 0; i0 < MAXI; i0 += CH) {
+        if (slice + NS * i0 >= nblocks) break;   // uniform per 32-lane slice
+        double v[CH];
 #pragma unroll
-    for (int i = 0; i < MAXI; ++i) s += v[i];
+        for (int i = 0; i < CH; ++i) {
+            const int b = slice + NS * (i0 + i);
+            v[i] = (k < nvals && b < nblocks) ? part[(size_t)b * kPartStride + k] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) s += v[i];
+    }
     sh_tmp[slice * kPartStride + k] = s;
     __syncthreads();
     if (threadIdx.x < kPartStride) {

@@ -20,8 +20,9 @@
 // Results agree with Krylov.jl's MGS to rounding, not bitwise; partial sums are combined in a fixed order, so a solve is
 // bit-reproducible run to run.
 //
-// Basis layout: V is stored INTERLEAVED, Vi[row][32] (256 B per row).  Every kernel that needs "all basis vectors at one
-// row" maps 32 consecutive lanes to one row (lane = basis index): one coalesced segment per row, ONE accumulator per
+// Basis layout: V is stored GROUP-INTERLEAVED, Vi[k/8][row][k%8] (64 B per row and group of 8 basis vectors).  Every kernel
+// that needs "all basis vectors at one row" maps 32 consecutive lanes to one row (lane = basis index): the first j+1
+// entries of consecutive rows are ceil((j+1)/8) contiguous, fully used streams, there is ONE accumulator per
 // thread (its basis index, summed over the rows the thread visits), and the block reduction is a 32 x 32 LDS transpose
 // instead of 22 shuffle trees.  The SpMV never reads Vi: its input is the contiguous vector wt.
 //
@@ -38,11 +39,11 @@
 
 namespace npg {
 
-constexpr int kKB = 1024;                 // threads per Krylov workgroup: 16 waves, at most one workgroup per CU
+constexpr int kKB = 512;                  // threads per Krylov workgroup: 8 waves, three workgroups per CU (<= 80 VGPRs)
 constexpr int kKW = kKB / 64;
 constexpr int kKP = kPartStride;          // 32: lanes per row group = padded basis size = doubles per partial row
 constexpr int kNS = kKB / kKP;            // 32 row slots per workgroup pass / slices of the partial reduction
-constexpr int kMaxG = 512;                // max workgroups (= partial rows): two per CU
+constexpr int kMaxG = 768;                // max workgroups (= partial rows): three per CU
 constexpr int kMaxI = kMaxG / kNS;        // loads per thread in the partial reduction (8)
 constexpr int kNormSlot = kKP - 1;        // partial rows carry the squared norm in their last entry
 
@@ -61,6 +62,7 @@ struct GDev {
     const int32_t *col;
     const double *val;
     const int32_t *tile_ptr;
+    int64_t nnz;
     int ntiles, n, mem;
     int pkind;
     double pscalar;
@@ -68,7 +70,8 @@ struct GDev {
     const double *b;
     double *x, *Vi, *w, *wt;
     double *P1, *P2, *PR;
-    int G1, G2;
+    int G1, G2, GP1;      // GP1 = partial rows in P1: G1 when the dots are fused into K1, G2 in split mode
+    int split;
     Snap *C, *T;
     double *c, *s, *z, *R, *hcol1, *wnorm2;
     double *hist;
@@ -99,7 +102,6 @@ __device__ __forceinline__ void sym_givens(double a, double b, double &c, double
 }
 
 struct KShared {
-    double tmp[kNS * kKP];
     double red[kKP];
     double h[kKP], h2[kKP], cc[kKP], ss[kKP], y[kKP];
     Snap T;
@@ -124,13 +126,13 @@ __device__ __forceinline__ void store_partial_row(double acc, double *tmp, doubl
 
 // Finalise Hessenberg column `colj` from K2(colj)'s partial sums (all threads call; thread 0 does the serial part).
 // Every global load is issued before the first barrier: one memory round trip.  Leaves the new snapshot in sh.T.
-__device__ void finalize_column(const GDev &d, int colj, KShared &sh) {
+__device__ void finalize_column(const GDev &d, int colj, KShared &sh, double *tmp) {
     const int t32 = threadIdx.x & (kKP - 1);
     const double h1 = d.hcol1[colj * kKP + t32];
     const double cv = d.c[t32], sv = d.s[t32];
     const Snap prev = d.T[colj];
     const double wnorm2 = d.wnorm2[colj];
-    reduce_partials<kNS, kMaxI>(d.P2, d.G2, kKP, sh.tmp, sh.red);       // [0..colj] = h2, [31] = ||wt||^2
+    reduce_partials<kNS, kMaxI>(d.P2, d.G2, kKP, tmp, sh.red);          // [0..colj] = h2, [31] = ||wt||^2
     if (threadIdx.x < kKP) {
         sh.h[threadIdx.x] = h1;
         sh.h2[threadIdx.x] = ((int)threadIdx.x <= colj) ? sh.red[threadIdx.x] : 0.0;
@@ -155,13 +157,18 @@ __device__ void finalize_column(const GDev &d, int colj, KShared &sh) {
                 sh.reorth = 1;
             }
             const double hbis = sqrt(n2);
+            // apply the previous rotations; the running entry is carried in a register so that the LDS reads of step
+            // i+1 do not depend on the arithmetic of step i
+            double hi = sh.h[0];
+#pragma unroll 4
             for (int i = 0; i < colj; ++i) {
-                const double tmp = sh.cc[i] * sh.h[i] + sh.ss[i] * sh.h[i + 1];
-                sh.h[i + 1] = sh.ss[i] * sh.h[i] - sh.cc[i] * sh.h[i + 1];
-                sh.h[i] = tmp;
+                const double ci = sh.cc[i], si = sh.ss[i], hn = sh.h[i + 1];
+                sh.h[i] = ci * hi + si * hn;
+                hi = si * hi - ci * hn;
             }
+            sh.h[colj] = hi;
             double cj, sj, rho;
-            sym_givens(sh.h[colj], hbis, cj, sj, rho);
+            sym_givens(hi, hbis, cj, sj, rho);
             const double zeta_next = sj * t.zeta;
             const double zcol = cj * t.zeta;
             t.rnorm = fabs(zeta_next);
@@ -190,6 +197,12 @@ __device__ void finalize_column(const GDev &d, int colj, KShared &sh) {
     __syncthreads();
 }
 
+// Basis storage: four groups of eight basis vectors, each group a dense [row][8] array (64 B per row and group), so that
+// reading the first j+1 entries of consecutive rows touches ceil((j+1)/8) fully used, fully contiguous streams.
+__device__ __forceinline__ size_t vidx(int64_t row, int k, int64_t n) {
+    return ((size_t)(k >> 3) * (size_t)n + (size_t)row) * 8 + (size_t)(k & 7);
+}
+
 __device__ __forceinline__ double precond_row(const GDev &d, int row) {
     return d.pkind == NPG_PRECOND_SCALAR ? d.pscalar : (d.pkind == NPG_PRECOND_DIAG ? d.pdiag[row] : 1.0);
 }
@@ -198,26 +211,26 @@ __device__ __forceinline__ double precond_row(const GDev &d, int row) {
 struct CorrectedX {
     const double *wt, *Vi, *h2;
     int nb;
+    int64_t n;
     __device__ __forceinline__ double operator()(int c) const {
         double v = wt[c];
-        const double *row = Vi + (size_t)c * kKP;
-        for (int k = 0; k < nb; ++k) v -= h2[k] * row[k];
+        for (int k = 0; k < nb; ++k) v -= h2[k] * Vi[vidx(c, k, n)];
         return v;
     }
 };
 
 // ---- R1: wt = P (b - A x), partial ||wt||^2 ---------------------------------------------------------------------------
 template <int L>
-__global__ void __launch_bounds__(kKB, 8) k_gmres_residual(GDev d) {
+__global__ void __launch_bounds__(kKB, 6) k_gmres_residual(GDev d) {
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
-    __shared__ double tmp[kNS * kKP];
+    double *tmp = tl.prod;                // scratch for the final block reduction (the tile loop is over by then)
     const Snap c = *d.C;
     double acc = 0.0;
     if (c.done == 0) {
         for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
             const int r0 = d.tile_ptr[t], r1 = d.tile_ptr[t + 1];
-            spmv_tile<kKB, L>(d.rowptr, d.col, d.val, PlainX{d.x}, r0, r1, tl, sw);
+            spmv_tile<kKB, L>(d.rowptr, d.col, d.val, d.nnz, PlainX{d.x}, r0, r1, tl, sw);
             const int r = threadIdx.x;
             if (r < r1 - r0) {
                 const int row = r0 + r;
@@ -233,14 +246,15 @@ __global__ void __launch_bounds__(kKB, 8) k_gmres_residual(GDev d) {
 }
 
 // ---- K1 ---------------------------------------------------------------------------------------------------------------
-template <int L>
-__global__ void __launch_bounds__(kKB, 8) k_gmres_arnoldi(GDev d, int j) {
+template <int L, bool FUSED>
+__global__ void __launch_bounds__(kKB, 6) k_gmres_arnoldi(GDev d, int j) {
     __shared__ KShared sh;
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
+    double *tmp = tl.prod;                // scratch of the prologue / final block reduction, outside the tile loop
     if (j == 0) {
         const Snap c = *d.C;
-        reduce_partials<kNS, kMaxI>(d.PR, d.G1, 1, sh.tmp, sh.red);
+        reduce_partials<kNS, kMaxI>(d.PR, d.G1, 1, tmp, sh.red);
         if (threadIdx.x == 0) {
             Snap t = c;
             if (t.done == 0) {
@@ -264,7 +278,7 @@ __global__ void __launch_bounds__(kKB, 8) k_gmres_arnoldi(GDev d, int j) {
         }
         __syncthreads();
     } else {
-        finalize_column(d, j - 1, sh);
+        finalize_column(d, j - 1, sh, tmp);
     }
     const Snap T = sh.T;
     if (T.done != 0) return;
@@ -277,33 +291,80 @@ __global__ void __launch_bounds__(kKB, 8) k_gmres_arnoldi(GDev d, int j) {
     for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
         const int r0 = d.tile_ptr[t], r1 = d.tile_ptr[t + 1];
         if (!ro)
-            spmv_tile<kKB, L>(d.rowptr, d.col, d.val, PlainX{d.wt}, r0, r1, tl, sw);
+            spmv_tile<kKB, L>(d.rowptr, d.col, d.val, d.nnz, PlainX{d.wt}, r0, r1, tl, sw);
         else
-            spmv_tile<kKB, L>(d.rowptr, d.col, d.val, CorrectedX{d.wt, d.Vi, sh.h2, j}, r0, r1, tl, sw);
-        // 32 lanes per row (lane = basis index): new basis entry, w, and the partial dot products
-        for (int r = slot; r < r1 - r0; r += kNS) {
-            const int row = r0 + r;
-            const double wv = sw[r] * inv_beta * precond_row(d, row);
-            double *vrow = d.Vi + (size_t)row * kKP;
-            double vk = (k < j) ? vrow[k] : 0.0;
-            double wtr = d.wt[row];
-            if (ro) wtr -= group_sum_dpp<kKP>(h2k * vk);
-            if (k == j) {
-                vk = wtr * inv_beta;
-                vrow[j] = vk;
+            spmv_tile<kKB, L>(d.rowptr, d.col, d.val, d.nnz, CorrectedX{d.wt, d.Vi, sh.h2, j, d.n}, r0, r1, tl, sw);
+        const int nr = r1 - r0;
+        if (!FUSED) {
+            // split mode (large systems): only what depends on the SpMV result; the dots stream in k_gmres_dots
+            for (int r = threadIdx.x; r < nr; r += kKB) {
+                const int row = r0 + r;
+                d.w[row] = sw[r] * inv_beta * precond_row(d, row);
+                double tv = d.wt[row];
+                if (ro)
+                    for (int q = 0; q < j; ++q) tv -= sh.h2[q] * d.Vi[vidx(row, q, d.n)];
+                d.Vi[vidx(row, j, d.n)] = tv * inv_beta;
             }
-            if (k == 0) d.w[row] = wv;
-            acc += (k == kNormSlot) ? wv * wv : vk * wv;
+            continue;
+        }
+        // 32 lanes per row (lane = basis index): new basis entry, w, and the partial dot products
+        // (two rows per trip so that their independent loads overlap)
+        for (int r = slot; r < nr; r += 2 * kNS) {
+            const int rb = r + kNS;
+            const bool hb = rb < nr;
+            const int rowa = r0 + r, rowb = r0 + (hb ? rb : r);
+            double va = (k < j) ? d.Vi[vidx(rowa, k, d.n)] : 0.0;
+            double vb = (hb && k < j) ? d.Vi[vidx(rowb, k, d.n)] : 0.0;
+            double ta = d.wt[rowa], tb = d.wt[rowb];
+            const double wa = sw[r] * inv_beta * precond_row(d, rowa);
+            const double wb = hb ? sw[rb] * inv_beta * precond_row(d, rowb) : 0.0;
+            if (ro) {
+                ta -= group_sum_dpp<kKP>(h2k * va);
+                tb -= group_sum_dpp<kKP>(h2k * vb);
+            }
+            if (k == j) {
+                va = ta * inv_beta;
+                d.Vi[vidx(rowa, j, d.n)] = va;
+                if (hb) {
+                    vb = tb * inv_beta;
+                    d.Vi[vidx(rowb, j, d.n)] = vb;
+                }
+            }
+            if (k == 0) {
+                d.w[rowa] = wa;
+                if (hb) d.w[rowb] = wb;
+            }
+            acc += (k == kNormSlot) ? wa * wa + wb * wb : va * wa + vb * wb;
         }
     }
-    store_partial_row(acc, sh.tmp, d.P1);
+    if (FUSED) store_partial_row(acc, tmp, d.P1);
+}
+
+// ---- Kd (split mode): partial h1 = V_{0..j}' w and ||w||^2 as a pure stream over the rows -------------------------
+__global__ void __launch_bounds__(kKB, 6) k_gmres_dots(GDev d, int j) {
+    __shared__ double tmp[kNS * kKP];
+    if (d.T[j].done != 0) return;
+    const int k = threadIdx.x & (kKP - 1), slot = threadIdx.x >> 5;
+    double acc = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kNS;
+    for (int64_t row = (int64_t)blockIdx.x * kNS + slot; row < d.n; row += 2 * stride) {
+        const int64_t rowb = row + stride;
+        const bool hb = rowb < d.n;
+        const double va = (k <= j) ? d.Vi[vidx(row, k, d.n)] : 0.0;
+        const double vb = (hb && k <= j) ? d.Vi[vidx(rowb, k, d.n)] : 0.0;
+        const double wa = d.w[row];
+        const double wb = hb ? d.w[rowb] : 0.0;
+        acc += (k == kNormSlot) ? wa * wa + wb * wb : va * wa + vb * wb;
+    }
+    store_partial_row(acc, tmp, d.P1);
 }
 
 // ---- K2 ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kKB, 8) k_gmres_orth(GDev d, int j) {
+__global__ void __launch_bounds__(kKB, 6) k_gmres_orth(GDev d, int j) {
     __shared__ KShared sh;
+    __shared__ double tmp[kNS * kKP];
     const Snap T = d.T[j];
-    reduce_partials<kNS, kMaxI>(d.P1, d.G1, kKP, sh.tmp, sh.red);       // [0..j] = h1, [31] = ||w||^2
+    reduce_partials<kNS, kMaxI>(d.P1, d.GP1, kKP, tmp, sh.red);      // [0..j] = h1, [31] = ||w||^2
     if (T.done != 0) return;
     const int k = threadIdx.x & (kKP - 1), slot = threadIdx.x >> 5;
     if (blockIdx.x == 0 && threadIdx.x < kKP) {
@@ -312,41 +373,59 @@ __global__ void __launch_bounds__(kKB, 8) k_gmres_orth(GDev d, int j) {
     }
     const double hk = (k <= j) ? sh.red[k] : 0.0;
     double acc = 0.0;
-    for (int64_t row = (int64_t)blockIdx.x * kNS + slot; row < d.n; row += (int64_t)gridDim.x * kNS) {
-        const double vk = (k <= j) ? d.Vi[(size_t)row * kKP + k] : 0.0;
-        const double wp = d.w[row] - group_sum_dpp<kKP>(hk * vk);
-        if (k == 0) d.wt[row] = wp;
-        acc += (k == kNormSlot) ? wp * wp : vk * wp;
+    // two rows per trip: their loads are independent, so both are in flight before the first DPP sum
+    const int64_t stride = (int64_t)gridDim.x * kNS;
+    for (int64_t row = (int64_t)blockIdx.x * kNS + slot; row < d.n; row += 2 * stride) {
+        const int64_t rowb = row + stride;
+        const bool hb = rowb < d.n;
+        const double va = (k <= j) ? d.Vi[vidx(row, k, d.n)] : 0.0;
+        const double vb = (hb && k <= j) ? d.Vi[vidx(rowb, k, d.n)] : 0.0;
+        const double wa = d.w[row];
+        const double wb = hb ? d.w[rowb] : 0.0;
+        const double pa = wa - group_sum_dpp<kKP>(hk * va);
+        const double pb = wb - group_sum_dpp<kKP>(hk * vb);
+        if (k == 0) {
+            d.wt[row] = pa;
+            if (hb) d.wt[rowb] = pb;
+        }
+        acc += (k == kNormSlot) ? pa * pa + pb * pb : va * pa + vb * pb;
     }
-    store_partial_row(acc, sh.tmp, d.P2);
+    store_partial_row(acc, tmp, d.P2);
 }
 
 // ---- XU ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kKB, 8) k_gmres_update(GDev d) {
+__global__ void __launch_bounds__(kKB, 6) k_gmres_update(GDev d) {
     __shared__ KShared sh;
+    __shared__ double tmp[kNS * kKP];
+    __shared__ double Rl[kKP * (kKP + 1) / 2];
     const double zv = d.z[threadIdx.x & (kKP - 1)];
-    finalize_column(d, d.mem - 1, sh);     // no-op copy if the pass already ended
+    finalize_column(d, d.mem - 1, sh, tmp);     // no-op copy if the pass already ended
     const Snap T = sh.T;
     const int kk = T.inner;
     // The last column (R entries, rotated z) was finalised inside THIS launch by every workgroup redundantly: take it
     // from shared memory, never from the global copies workgroup 0 is writing concurrently.
     const bool fin = sh.fin != 0;
     const int last = d.mem - 1;
-    if (threadIdx.x < kKP)
-        sh.y[threadIdx.x] = ((int)threadIdx.x < kk) ? ((fin && (int)threadIdx.x == last) ? sh.zcol : zv) : 0.0;
+    // stage the packed upper-triangular R (column c starts at c(c+1)/2) in LDS with one parallel load
+    for (int t = threadIdx.x; t < kk * (kk + 1) / 2; t += kKB) Rl[t] = d.R[t];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        // back substitution on the packed upper-triangular R (column c starts at c(c+1)/2)
-        for (int i = kk - 1; i >= 0; --i) {
-            double yi = sh.y[i];
-            for (int c = kk - 1; c > i; --c) {
-                const double ric = (fin && c == last) ? sh.h[i] : d.R[c * (c + 1) / 2 + i];
-                yi -= ric * sh.y[c];
-            }
-            const double rii = (fin && i == last) ? sh.rho : d.R[i * (i + 1) / 2 + i];
-            sh.y[i] = (fabs(rii) <= d.prm->btol) ? 0.0 : yi / rii;
+    if (fin && threadIdx.x <= (unsigned)last && kk == d.mem)
+        Rl[last * (last + 1) / 2 + threadIdx.x] = ((int)threadIdx.x == last) ? sh.rho : sh.h[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        // column-oriented back substitution in wave 0: lane r owns y_r; step c broadcasts y_c and updates the rows above
+        const int lane = threadIdx.x;
+        double y = (lane < kk) ? ((fin && lane == last) ? sh.zcol : zv) : 0.0;
+        const double btol = d.prm->btol;
+        for (int c = kk - 1; c >= 0; --c) {
+            const double rcc = Rl[c * (c + 1) / 2 + c];
+            double yc = __shfl(y, c, 64);
+            yc = (fabs(rcc) <= btol) ? 0.0 : yc / rcc;
+            if (lane == c) y = yc;
+            if (lane < c) y -= Rl[c * (c + 1) / 2 + lane] * yc;
         }
-        if (blockIdx.x == 0) {
+        if (lane < kKP) sh.y[lane] = (lane < kk) ? y : 0.0;
+        if (blockIdx.x == 0 && lane == 0) {
             Snap c = T;
             c.inner = 0;
             *d.C = c;
@@ -357,7 +436,7 @@ __global__ void __launch_bounds__(kKB, 8) k_gmres_update(GDev d) {
     const int k = threadIdx.x & (kKP - 1), slot = threadIdx.x >> 5;
     const double yk = sh.y[k];             // zero for k >= kk
     for (int64_t row = (int64_t)blockIdx.x * kNS + slot; row < d.n; row += (int64_t)gridDim.x * kNS) {
-        const double vk = (k < kk) ? d.Vi[(size_t)row * kKP + k] : 0.0;
+        const double vk = (k < kk) ? d.Vi[vidx(row, k, d.n)] : 0.0;
         const double s = group_sum_dpp<kKP>(yk * vk);
         if (k == 0) d.x[row] += s;
     }
@@ -400,8 +479,14 @@ template <int L>
 static void launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev) {
     for (int j = 0; j < d.mem; ++j) {
         if (pev) hipEventRecord(pev[2 * j], st);
-        hipLaunchKernelGGL(k_gmres_arnoldi<L>, dim3(d.G1), dim3(kKB), 0, st, d, j);
-        if (pev) hipEventRecord(pev[2 * j + 1], st);
+        if (d.split) {
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(d.G1), dim3(kKB), 0, st, d, j);
+            if (pev) hipEventRecord(pev[2 * j + 1], st);
+            hipLaunchKernelGGL(k_gmres_dots, dim3(d.G2), dim3(kKB), 0, st, d, j);
+        } else {
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, true>), dim3(d.G1), dim3(kKB), 0, st, d, j);
+            if (pev) hipEventRecord(pev[2 * j + 1], st);
+        }
         hipLaunchKernelGGL(k_gmres_orth, dim3(d.G2), dim3(kKB), 0, st, d, j);
     }
     hipLaunchKernelGGL(k_gmres_update, dim3(d.G2), dim3(kKB), 0, st, d);
@@ -521,6 +606,7 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     d.col = A->col;
     d.val = A->val;
     d.tile_ptr = A->tile_ptr;
+    d.nnz = A->nnz;
     d.ntiles = A->ntiles;
     d.n = (int)ws->n;
     d.mem = ws->mem;
@@ -535,8 +621,11 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     d.P1 = ws->P1;
     d.P2 = ws->P2;
     d.PR = ws->PR;
-    d.G1 = std::max(1, std::min<int>(A->ntiles, std::min(kMaxG, 2 * ctx->num_cu)));
-    d.G2 = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kNS - 1) / kNS, std::min(kMaxG, 2 * ctx->num_cu)));
+    d.G1 = std::max(1, std::min<int>(A->ntiles, std::min(kMaxG, 3 * ctx->num_cu)));
+    d.G2 = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kNS - 1) / kNS, std::min(kMaxG, 3 * ctx->num_cu)));
+    static const int split_env = getenv("NPG_GMRES_SPLIT") ? atoi(getenv("NPG_GMRES_SPLIT")) : -1;
+    d.split = split_env >= 0 ? split_env : (ws->n >= 150000 ? 1 : 0);   // large systems: dots as a separate stream
+    d.GP1 = d.split ? d.G2 : d.G1;
     d.C = ws->C;
     d.T = ws->T;
     d.c = ws->c;

@@ -1,0 +1,197 @@
+// Tuning harness (not part of the public ABI): times stand-alone CSR-stream SpMV kernels with different workgroup sizes,
+// tile sizes and load widths on an existing device matrix, so that the configuration used by the product kernels is
+// chosen from measurements on the target matrix (see profiles/ and DESIGN.md).
+#include <algorithm>
+#include <map>
+
+#include "common.h"
+#include "spmv_device.h"
+
+namespace npg {
+
+template <int NT, int L, int TNNZ, int U>
+__global__ void __launch_bounds__(NT) k_spmv_var(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                 const double *__restrict__ val, const int32_t *__restrict__ tile_ptr,
+                                                 int ntiles, int64_t nnz, const double *__restrict__ x,
+                                                 double *__restrict__ y) {
+    __shared__ TileLdsT<TNNZ> tl;
+    __shared__ double sw[kTileRows];
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int r0 = tile_ptr[t], r1 = tile_ptr[t + 1];
+        spmv_tile<NT, L, PlainX, TNNZ, U>(rowptr, col, val, nnz, PlainX{x}, r0, r1, tl, sw);
+        for (int r = threadIdx.x; r < r1 - r0; r += NT) y[r0 + r] = sw[r];
+    }
+}
+
+// wide loads: every lane reads two adjacent entries with one 16-byte val load and one 8-byte col load
+template <int NT, int L, int TNNZ, int U2, bool NTL = false>
+__global__ void __launch_bounds__(NT) k_spmv_wide(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                  const double *__restrict__ val, const int32_t *__restrict__ tile_ptr,
+                                                  int ntiles, int64_t nnz, const double *__restrict__ x,
+                                                  double *__restrict__ y) {
+    __shared__ TileLdsT<TNNZ + 2> tl;
+    __shared__ double sw[kTileRows];
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int r0 = tile_ptr[t], r1 = tile_ptr[t + 1];
+        const int64_t base = rowptr[r0];
+        const int n = (int)(rowptr[r1] - base);
+        const int nrows = r1 - r0;
+        const int64_t abase = base & ~1LL;
+        const int off = (int)(base - abase);
+        const int total = n + off;
+        for (int r = threadIdx.x; r <= nrows; r += NT) tl.rp[r] = (int32_t)(rowptr[r0 + r] - base) + off;
+        for (int k0 = 2 * threadIdx.x; k0 < total; k0 += 2 * NT * U2) {
+            int2 c[U2];
+            double2 v[U2];
+            double xa[U2], xb[U2];
+#pragma unroll
+            for (int u = 0; u < U2; ++u) {
+                const int k = k0 + u * 2 * NT;
+                const bool ok = k < total && abase + k + 1 < nnz + (nnz & 1);
+                if (ok && abase + k + 1 < nnz) {
+                    if (NTL) {
+                        const long long cc = __builtin_nontemporal_load(reinterpret_cast<const long long *>(col + abase + k));
+                        c[u] = make_int2((int)(cc & 0xffffffffLL), (int)(cc >> 32));
+                        v[u].x = __builtin_nontemporal_load(val + abase + k);
+                        v[u].y = __builtin_nontemporal_load(val + abase + k + 1);
+                    } else {
+                        c[u] = *reinterpret_cast<const int2 *>(col + abase + k);
+                        v[u] = *reinterpret_cast<const double2 *>(val + abase + k);
+                    }
+                } else if (k < total && abase + k < nnz) {
+                    c[u] = make_int2(col[abase + k], 0);
+                    v[u] = make_double2(val[abase + k], 0.0);
+                } else {
+                    c[u] = make_int2(0, 0);
+                    v[u] = make_double2(0.0, 0.0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U2; ++u) {
+                xa[u] = x[c[u].x];
+                xb[u] = x[c[u].y];
+            }
+#pragma unroll
+            for (int u = 0; u < U2; ++u) {
+                const int k = k0 + u * 2 * NT;
+                if (k < total) tl.prod[k] = (k >= off) ? v[u].x * xa[u] : 0.0;
+                if (k + 1 < total) tl.prod[k + 1] = v[u].y * xb[u];
+            }
+        }
+        __syncthreads();
+        const int g = threadIdx.x / L, l = threadIdx.x % L;
+        for (int r = g; r < nrows; r += NT / L) {
+            double s = 0.0;
+            const int e = tl.rp[r + 1];
+            for (int k = tl.rp[r] + l; k < e; k += L) s += tl.prod[k];
+            s = group_sum_dpp<L>(s);
+            if (l == 0) sw[r] = s;
+        }
+        __syncthreads();
+        for (int r = threadIdx.x; r < nrows; r += NT) y[r0 + r] = sw[r];
+    }
+}
+
+struct VarTiles {
+    int32_t *d = nullptr;
+    int n = 0;
+};
+
+static std::map<std::pair<const void *, int>, VarTiles> g_tiles;
+
+static int tiles_for(const npg_csr *A, int tnnz, VarTiles *out) {
+    auto key = std::make_pair((const void *)A, tnnz);
+    auto it = g_tiles.find(key);
+    if (it != g_tiles.end()) {
+        *out = it->second;
+        return NPG_OK;
+    }
+    const int64_t *rp = A->h_rowptr.data();
+    std::vector<int32_t> tp{0};
+    int64_t r = 0;
+    while (r < A->m) {
+        int64_t r1 = r + 1;
+        while (r1 < A->m && r1 - r < kTileRows && rp[r1 + 1] - rp[r] <= tnnz) ++r1;
+        tp.push_back((int32_t)r1);
+        r = r1;
+    }
+    VarTiles v;
+    v.n = (int)tp.size() - 1;
+    NPG_HIP(hipMalloc((void **)&v.d, tp.size() * sizeof(int32_t)));
+    NPG_HIP(hipMemcpy(v.d, tp.data(), tp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    g_tiles[key] = v;
+    *out = v;
+    return NPG_OK;
+}
+
+template <int NT, int TNNZ, int U>
+static int run_var(const npg_csr *A, const double *x, double *y, int bpc, int reps, double *ms) {
+    VarTiles t;
+    int rc = tiles_for(A, TNNZ, &t);
+    if (rc) return rc;
+    npg_ctx *ctx = A->ctx;
+    const int grid = std::max(1, std::min(t.n, bpc * ctx->num_cu));
+    for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL((k_spmv_var<NT, 16, TNNZ, U>), dim3(grid), dim3(NT), 0, ctx->stream, A->rowptr, A->col, A->val,
+                           t.d, t.n, A->nnz, x, y);
+    NPG_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL((k_spmv_var<NT, 16, TNNZ, U>), dim3(grid), dim3(NT), 0, ctx->stream, A->rowptr, A->col, A->val,
+                           t.d, t.n, A->nnz, x, y);
+    NPG_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    NPG_HIP(hipEventSynchronize(ctx->ev1));
+    float f = 0.f;
+    NPG_HIP(hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    *ms = f / reps;
+    return NPG_OK;
+}
+
+template <int NT, int TNNZ, int U2, bool NTL = false>
+static int run_wide(const npg_csr *A, const double *x, double *y, int bpc, int reps, double *ms) {
+    VarTiles t;
+    int rc = tiles_for(A, TNNZ, &t);
+    if (rc) return rc;
+    npg_ctx *ctx = A->ctx;
+    const int grid = std::max(1, std::min(t.n, bpc * ctx->num_cu));
+    for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL((k_spmv_wide<NT, 16, TNNZ, U2, NTL>), dim3(grid), dim3(NT), 0, ctx->stream, A->rowptr, A->col,
+                           A->val, t.d, t.n, A->nnz, x, y);
+    NPG_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL((k_spmv_wide<NT, 16, TNNZ, U2, NTL>), dim3(grid), dim3(NT), 0, ctx->stream, A->rowptr, A->col,
+                           A->val, t.d, t.n, A->nnz, x, y);
+    NPG_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    NPG_HIP(hipEventSynchronize(ctx->ev1));
+    float f = 0.f;
+    NPG_HIP(hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    *ms = f / reps;
+    return NPG_OK;
+}
+
+}  // namespace npg
+
+using namespace npg;
+
+NPG_API int npg_spmv_variant(const npg_csr *A, const npg_vec *x, npg_vec *y, int variant, int blocks_per_cu, int reps,
+                             double *ms) {
+    NPG_REQUIRE(A && x && y && ms && x->n == A->n && y->n == A->m && reps > 0, "npg_spmv_variant: bad argument");
+    switch (variant) {
+        case 0: return run_var<512, 4096, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 1: return run_var<512, 4096, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 2: return run_var<1024, 8192, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 3: return run_var<256, 2048, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 4: return run_var<512, 8192, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 5: return run_var<256, 4096, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 6: return run_var<1024, 4096, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 7: return run_wide<512, 4096, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 8: return run_wide<256, 4096, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 9: return run_wide<1024, 8192, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 10: return run_wide<256, 2048, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 11: return run_wide<1024, 4096, 2>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 12: return run_wide<1024, 8192, 4, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 13: return run_wide<512, 4096, 4, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 14: return run_wide<1024, 8192, 2>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 15: return run_wide<512, 8192, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        default: NPG_REQUIRE(false, "npg_spmv_variant: unknown variant %d", variant);
+    }
+}

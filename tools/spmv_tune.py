@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Times the stand-alone CSR-stream SpMV variants of csrc/spmv_variants.hip on the assembled A_inversion of a bowl mesh.
+Usage: python tools/spmv_tune.py [workload] [reps]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import nupgcm_amd as npg  # noqa: E402
+from nupgcm_amd import _lib as L  # noqa: E402
+from nupgcm_amd import workloads  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "bowl3D_h0.02"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+arch = npg.GPU(0)
+fed = workloads.example_fe_data(workloads.bowl_mesh_model(wl))
+prm, frc = workloads.example_parameters()
+A = npg.build_A_inversion(arch, fed, prm, frc.nu)
+N, nnz = A.shape[0], A.nnz
+alg = 12 * nnz + 4 * (N + 1) + 16 * N
+x = npg.DeviceVector.from_host(arch.ctx, np.sin(np.arange(N, dtype=float)))
+yref = A.mul(x).to_host()
+y = npg.DeviceVector(arch.ctx, N)
+fn = L.lib().npg_spmv_variant
+fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+fn.restype = C.c_int
+names = {0: "NT512 T4096 U4", 1: "NT512 T4096 U8", 2: "NT1024 T8192 U8", 3: "NT256 T2048 U8", 4: "NT512 T8192 U8",
+         5: "NT256 T4096 U8", 6: "NT1024 T4096 U4", 7: "wide NT512 T4096 U2x4", 8: "wide NT256 T4096 U2x8",
+         9: "wide NT1024 T8192 U2x4", 10: "wide NT256 T2048 U2x4",
+         11: "wide NT1024 T4096 U2x2", 12: "wide+nt NT1024 T8192", 13: "wide+nt NT512 T4096", 14: "wide NT1024 T8192 U2x2",
+         15: "wide NT512 T8192 U2x4"}
+print(f"{wl}: N={N} nnz={nnz} algorithmic bytes={alg / 1e6:.1f} MB")
+vs = [int(a) for a in sys.argv[3].split(',')] if len(sys.argv) > 3 else range(16)
+for v in vs:
+    for bpc in (2, 3, 4):
+        ms = C.c_double()
+        y.fill(0.0)
+        rc = fn(A.h, x.h, y.h, v, bpc, reps, C.byref(ms))
+        if rc != 0:
+            print(v, bpc, "error", L.lib().npg_last_error().decode())
+            continue
+        err = np.linalg.norm(y.to_host() - yref) / np.linalg.norm(yref)
+        print(f"variant {v:2d} [{names[v]:24s}] blocks/CU<={bpc}: {ms.value * 1e3:8.1f} us  {alg / ms.value / 1e6:7.0f} GB/s  "
+              f"relerr {err:.1e}")
