@@ -85,15 +85,16 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dev = int(os.environ.get("NPG_FORCE_DEVICE", local))
+        torch.cuda.set_device(dev)
+        dist.init_process_group(os.environ.get("NPG_TORCH_BACKEND", "nccl"))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
 
     import nupgcm_amd as npg
     from nupgcm_amd import workloads
 
-    arch = npg.GPU(local)
+    arch = npg.GPU(int(os.environ.get("NPG_FORCE_DEVICE", local)))     # NPG_FORCE_DEVICE: rehearse N ranks on one GPU
     ctx = arch.ctx
     t_setup = time.time()
     mesh_model = workloads.bowl_mesh_model(a.workload)
@@ -123,7 +124,8 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cpu" if dist.get_backend() == "gloo" else f"cuda:{torch.cuda.current_device()}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stats = model.stats[-a.steps:]
@@ -148,7 +150,7 @@ def main():
                         avg_launch_us=avg_ms * 1e3, launches=launches, algorithmic_bytes_per_launch=alg_bytes,
                         cache_resident=bool(alg_bytes < 256 * 2 ** 20))
     # stand-alone SpMV kernel (same tiles, no Krylov epilogue) for reference
-    x = npg.DeviceVector.from_host(ctx, np.sin(np.arange(N, dtype=float)))
+    x = npg.DeviceVector.from_host(ctx, np.sin(np.arange(A.shape[1], dtype=float)))
     y = npg.DeviceVector(ctx, N)
     for _ in range(3):
         A.mul(x, y)

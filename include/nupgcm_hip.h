@@ -220,6 +220,11 @@ int npg_fe_cfl_ratio(npg_fe *fe, const double *h_cells_host, double u_min, const
 int npg_comm_unique_id(void *id128);                                  /* rank 0 makes it, the launcher broadcasts it */
 int npg_comm_init(npg_ctx *ctx, const void *id128, int rank, int nranks);
 int npg_comm_allreduce_sum(npg_ctx *ctx, double *host_inout, int n);  /* tiny host-side helper for tests/bench */
+/* Replicate a row-block distributed vector on every rank: segment s of `full` ([global_off, global_off + len)) is owned
+ * by rank seg_rank[s], who holds it at local[local_off ..].  One grouped ncclBroadcast per segment over xGMI. */
+int npg_comm_allgather_segments(npg_ctx *ctx, const npg_vec *local, int nseg, const int32_t *seg_rank,
+                                const int64_t *seg_local_off, const int64_t *seg_global_off, const int64_t *seg_len,
+                                npg_vec *full);
 /* Halo plan for a row-block distributed CSR: this rank owns n_owned rows; columns >= n_owned of the local matrix are
  * ghosts filled from neighbours.  send_idx lists owned entries to ship to each peer, recv goes to consecutive ghost
  * slots. */
@@ -227,6 +232,9 @@ int npg_halo_create(npg_ctx *ctx, int64_t n_owned, int64_t n_ghost, int npeers, 
                     const int64_t *send_ptr, const int32_t *send_idx, const int64_t *recv_ptr, npg_halo **out);
 int npg_halo_destroy(npg_halo *h);
 int npg_halo_exchange(npg_halo *h, npg_vec *x_with_ghosts);
+/* Attach a plan to a workspace created for n = n_owned: npg_gmres_solve / npg_cg_solve then take A as the rank's
+ * n_owned x (n_owned + n_ghost) row block, y with n_owned and x with n_owned + n_ghost entries, exchange the interface
+ * before every SpMV and all-reduce the inner products (two 32-double messages per GMRES iteration). */
 int npg_gmres_set_halo(npg_gmres *ws, npg_halo *h);
 int npg_cg_set_halo(npg_cg *ws, npg_halo *h);
 

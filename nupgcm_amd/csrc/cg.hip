@@ -41,6 +41,8 @@ struct CDev {
     double *x, *r, *z, *p, *Ap;
     double *Pg, *Pp;
     int G1, G2;
+    const double *Qp;     // what k_cg_update reduces: Pp on one GPU, the all-reduced row when distributed
+    int nQp;
     CSnap *S;   // two slots
     double *hist;
     int hist_cap;
@@ -87,10 +89,10 @@ __global__ void __launch_bounds__(kKB) k_cg_init(CDev d) {
 }
 
 // CP: reads slot `src`, writes slot `dst`.  ng = number of partial rows in Pg.
-__global__ void __launch_bounds__(kKB) k_cg_direction(CDev d, int src, int dst, int ng) {
+__global__ void __launch_bounds__(kKB) k_cg_direction(CDev d, int src, int dst, const double *qg, int ng) {
     __shared__ CShared sh;
     const CSnap prev = d.S[src];
-    reduce_partials<kNS, kMaxI>(d.Pg, ng, 1, sh.tmp, sh.red);
+    reduce_partials<kNS, kMaxI>(qg, ng, 1, sh.tmp, sh.red);
     if (threadIdx.x == 0) {
         CSnap s = prev;
         if (s.done == 0) {
@@ -150,7 +152,7 @@ __global__ void __launch_bounds__(kKB) k_cg_spmv(CDev d, int slot) {
 __global__ void __launch_bounds__(kKB) k_cg_update(CDev d, int slot) {
     __shared__ CShared sh;
     const CSnap s = d.S[slot];
-    reduce_partials<kNS, kMaxI>(d.Pp, d.G1, 1, sh.tmp, sh.red);
+    reduce_partials<kNS, kMaxI>(d.Qp, d.nQp, 1, sh.tmp, sh.red);
     if (s.done != 0) return;
     const double pAp = sh.red[0];
     const double alpha = (pAp > 0.0) ? s.gamma / pAp : 0.0;
@@ -165,6 +167,13 @@ __global__ void __launch_bounds__(kKB) k_cg_update(CDev d, int slot) {
         acc[0] += r * z;
     }
     block_store_partials<1, kKW>(acc, 1, sh.wsum, d.Pg);
+}
+
+__global__ void __launch_bounds__(kKB) k_cg_reduce_rows(const double *part, int nrows, double *out) {
+    __shared__ double tmp[kNS * kPartStride];
+    __shared__ double red[kPartStride];
+    reduce_partials<kNS, kMaxI>(part, nrows, 1, tmp, red);
+    if (threadIdx.x == 0) out[0] = red[0];
 }
 
 }  // namespace npg
@@ -183,6 +192,8 @@ struct npg_cg {
     CParams *h_prm = nullptr;
     int64_t hist_len = 0;
     npg_halo *halo = nullptr;
+    double *Rg = nullptr;          // 2 doubles: all-reduced p'Ap and r'z (distributed mode)
+    int64_t n_ghost = 0;
     static constexpr int kMaxG = npg::kMaxG;
 };
 
@@ -215,7 +226,7 @@ NPG_API int npg_cg_create(npg_ctx *ctx, int64_t n, npg_cg **out) {
 NPG_API int npg_cg_destroy(npg_cg *ws) {
     if (!ws) return NPG_OK;
     hipStreamSynchronize(ws->ctx->stream);
-    void *ptrs[] = {ws->r, ws->z, ws->p, ws->Ap, ws->Pg, ws->Pp, ws->S, ws->prm, ws->hist};
+    void *ptrs[] = {ws->r, ws->z, ws->p, ws->Ap, ws->Pg, ws->Pp, ws->S, ws->prm, ws->hist, ws->Rg};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (ws->h_S) hipHostFree(ws->h_S);
@@ -226,15 +237,37 @@ NPG_API int npg_cg_destroy(npg_cg *ws) {
 
 NPG_API int npg_cg_set_halo(npg_cg *ws, npg_halo *h) {
     NPG_REQUIRE(ws, "npg_cg_set_halo: NULL workspace");
+    NPG_REQUIRE(!h || h->n_owned == ws->n, "npg_cg_set_halo: the plan owns %lld rows, the workspace %lld",
+                h ? (long long)h->n_owned : 0LL, (long long)ws->n);
+    NPG_HIP(hipStreamSynchronize(ws->ctx->stream));
     ws->halo = h;
+    ws->n_ghost = h ? h->n_ghost : 0;
+    NPG_HIP(hipFree(ws->p));          // the SpMV input p needs room for the ghost entries
+    const size_t nb = (size_t)(ws->n + ws->n_ghost) * sizeof(double);
+    NPG_HIP(hipMalloc((void **)&ws->p, nb));
+    NPG_HIP(hipMemset(ws->p, 0, nb));
+    if (h && !ws->Rg) {
+        NPG_HIP(hipMalloc((void **)&ws->Rg, 2 * sizeof(double)));
+        NPG_HIP(hipMemset(ws->Rg, 0, 2 * sizeof(double)));
+    }
     return NPG_OK;
+}
+
+static int cg_dist_reduce(npg_cg *ws, const double *part, int nrows, int slot, hipStream_t st) {
+    hipLaunchKernelGGL(k_cg_reduce_rows, dim3(1), dim3(kKB), 0, st, part, nrows, ws->Rg + slot);
+    return allreduce_sum_device(ws->ctx, ws->Rg + slot, 1);
 }
 
 template <int L>
 static int cg_run(npg_cg *ws, const CDev &d, int64_t itmax, CSnap *last) {
     hipStream_t st = ws->ctx->stream;
+    npg_cg *dist = ws->halo ? ws : nullptr;
+    int rc = NPG_OK;
+    if (dist && (rc = halo_exchange_raw(ws->halo, d.x))) return rc;
     hipLaunchKernelGGL(k_cg_init<L>, dim3(d.G1), dim3(kKB), 0, st, d);
-    hipLaunchKernelGGL(k_cg_direction, dim3(d.G2), dim3(kKB), 0, st, d, 0, 1, d.G1);   // slot 0 = initial state
+    if (dist && (rc = cg_dist_reduce(ws, d.Pg, d.G1, 1, st))) return rc;
+    // slot 0 = initial state; r'z comes from the init kernel's G1 partial rows (or from the all-reduced scalar)
+    hipLaunchKernelGGL(k_cg_direction, dim3(d.G2), dim3(kKB), 0, st, d, 0, 1, dist ? ws->Rg + 1 : d.Pg, dist ? 1 : d.G1);
     int cur = 1;
     const int chunk = 4;
     int64_t it = 0;
@@ -244,9 +277,13 @@ static int cg_run(npg_cg *ws, const CDev &d, int64_t itmax, CSnap *last) {
         *last = ws->h_S[0];
         if (last->done != 0 || it >= itmax) break;
         for (int k = 0; k < chunk; ++k, ++it) {
+            if (dist && (rc = halo_exchange_raw(ws->halo, d.p))) return rc;
             hipLaunchKernelGGL(k_cg_spmv<L>, dim3(d.G1), dim3(kKB), 0, st, d, cur);
+            if (dist && (rc = cg_dist_reduce(ws, d.Pp, d.G1, 0, st))) return rc;
             hipLaunchKernelGGL(k_cg_update, dim3(d.G2), dim3(kKB), 0, st, d, cur);
-            hipLaunchKernelGGL(k_cg_direction, dim3(d.G2), dim3(kKB), 0, st, d, cur, cur ^ 1, d.G2);
+            if (dist && (rc = cg_dist_reduce(ws, d.Pg, d.G2, 1, st))) return rc;
+            hipLaunchKernelGGL(k_cg_direction, dim3(d.G2), dim3(kKB), 0, st, d, cur, cur ^ 1, dist ? ws->Rg + 1 : d.Pg,
+                               dist ? 1 : d.G2);
             cur ^= 1;
         }
         NPG_HIP(hipGetLastError());
@@ -258,13 +295,14 @@ NPG_API int npg_cg_solve(npg_cg *ws, const npg_csr *A, int precond_kind, double 
                          const npg_vec *precond_diag, const npg_vec *y, npg_vec *x, double atol, double rtol,
                          int64_t itmax, npg_solve_stats *stats) {
     NPG_REQUIRE(ws && A && y && x, "npg_cg_solve: NULL argument");
-    NPG_REQUIRE(A->m == ws->n && A->n == ws->n && y->n == ws->n && x->n == ws->n,
-                "npg_cg_solve: workspace is for n=%lld but A is %lldx%lld, y has %lld, x has %lld", (long long)ws->n,
-                (long long)A->m, (long long)A->n, (long long)y->n, (long long)x->n);
+    const int64_t nloc = ws->n + ws->n_ghost;     // distributed: vectors the SpMV reads hold [owned | ghosts]
+    NPG_REQUIRE(A->m == ws->n && A->n == nloc && y->n == ws->n && x->n == nloc,
+                "npg_cg_solve: workspace is for n=%lld (+%lld ghosts) but A is %lldx%lld, y has %lld, x has %lld",
+                (long long)ws->n, (long long)ws->n_ghost, (long long)A->m, (long long)A->n, (long long)y->n,
+                (long long)x->n);
     NPG_REQUIRE(precond_kind == NPG_PRECOND_NONE || precond_kind == NPG_PRECOND_SCALAR ||
                     (precond_kind == NPG_PRECOND_DIAG && precond_diag && precond_diag->n == ws->n),
                 "npg_cg_solve: bad preconditioner");
-    NPG_REQUIRE(ws->halo == nullptr, "npg_cg_solve: distributed solves go through npg_dist_* (halo set)");
     const auto t0 = std::chrono::steady_clock::now();
     npg_ctx *ctx = ws->ctx;
     CDev d;
@@ -289,6 +327,8 @@ NPG_API int npg_cg_solve(npg_cg *ws, const npg_csr *A, int precond_kind, double 
     d.Pp = ws->Pp;
     d.G1 = std::max(1, std::min<int>(A->ntiles, std::min(npg_cg::kMaxG, ctx->num_cu)));
     d.G2 = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kKB - 1) / kKB, d.G1));
+    d.Qp = ws->halo ? ws->Rg : d.Pp;
+    d.nQp = ws->halo ? 1 : d.G1;
     d.S = ws->S;
     d.hist = ws->hist;
     d.hist_cap = ws->hist_cap;

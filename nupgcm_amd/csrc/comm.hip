@@ -28,16 +28,6 @@ __global__ void k_pack(const double *x, const int32_t *idx, int64_t n, double *b
 
 using namespace npg;
 
-struct npg_halo {
-    npg_ctx *ctx = nullptr;
-    int64_t n_owned = 0, n_ghost = 0;
-    int npeers = 0;
-    std::vector<int> peer;
-    std::vector<int64_t> send_ptr, recv_ptr;
-    int32_t *send_idx = nullptr;   // device
-    double *send_buf = nullptr;    // device
-};
-
 static_assert(sizeof(ncclUniqueId) <= NPG_UNIQUE_ID_BYTES, "unique id does not fit the ABI buffer");
 
 NPG_API int npg_comm_unique_id(void *id128) {
@@ -70,6 +60,37 @@ NPG_API int npg_comm_allreduce_sum(npg_ctx *ctx, double *host_inout, int n) {
     NPG_NCCL(ncclAllReduce(ctx->d_scratch, ctx->d_scratch, n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
     NPG_HIP(hipMemcpyAsync(host_inout, ctx->d_scratch, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     NPG_HIP(hipStreamSynchronize(ctx->stream));
+    return NPG_OK;
+}
+
+NPG_API int npg_comm_allgather_segments(npg_ctx *ctx, const npg_vec *local, int nseg, const int32_t *seg_rank,
+                                        const int64_t *seg_local_off, const int64_t *seg_global_off,
+                                        const int64_t *seg_len, npg_vec *full) {
+    NPG_REQUIRE(ctx && local && full && nseg >= 0 && (nseg == 0 || (seg_rank && seg_local_off && seg_global_off && seg_len)),
+                "npg_comm_allgather_segments: bad argument");
+    for (int s = 0; s < nseg; ++s) {
+        NPG_REQUIRE(seg_rank[s] >= 0 && seg_rank[s] < ctx->nranks && seg_len[s] >= 0 && seg_global_off[s] >= 0 &&
+                        seg_global_off[s] + seg_len[s] <= full->n,
+                    "npg_comm_allgather_segments: segment %d out of range", s);
+        if (seg_rank[s] == ctx->rank)
+            NPG_REQUIRE(seg_local_off[s] >= 0 && seg_local_off[s] + seg_len[s] <= local->n,
+                        "npg_comm_allgather_segments: local segment %d out of range", s);
+    }
+    if (ctx->nranks == 1 || !ctx->comm) {
+        for (int s = 0; s < nseg; ++s)
+            NPG_HIP(hipMemcpyAsync(full->d + seg_global_off[s], local->d + seg_local_off[s],
+                                   (size_t)seg_len[s] * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        return NPG_OK;
+    }
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    NPG_NCCL(ncclGroupStart());
+    for (int s = 0; s < nseg; ++s) {
+        if (seg_len[s] == 0) continue;
+        const double *src = seg_rank[s] == ctx->rank ? local->d + seg_local_off[s] : full->d + seg_global_off[s];
+        NPG_NCCL(ncclBroadcast(src, full->d + seg_global_off[s], (size_t)seg_len[s], ncclDouble, seg_rank[s], comm,
+                               ctx->stream));
+    }
+    NPG_NCCL(ncclGroupEnd());
     return NPG_OK;
 }
 
@@ -111,24 +132,33 @@ NPG_API int npg_halo_destroy(npg_halo *h) {
     return NPG_OK;
 }
 
-NPG_API int npg_halo_exchange(npg_halo *h, npg_vec *x) {
-    NPG_REQUIRE(h && x && x->n == h->n_owned + h->n_ghost, "npg_halo_exchange: vector must hold owned + ghost entries");
+int npg::halo_exchange_raw(npg_halo *h, double *x) {
     if (h->npeers == 0) return NPG_OK;
     npg_ctx *ctx = h->ctx;
-    NPG_REQUIRE(ctx->comm, "npg_halo_exchange: communicator not initialised");
+    NPG_REQUIRE(ctx->comm, "halo exchange: communicator not initialised");
     const int64_t ns = h->send_ptr[h->npeers];
     if (ns > 0) {
         const int grid = (int)std::min<int64_t>(1024, (ns + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(k_pack, dim3(grid), dim3(kBlock), 0, ctx->stream, x->d, h->send_idx, ns, h->send_buf);
+        hipLaunchKernelGGL(k_pack, dim3(grid), dim3(kBlock), 0, ctx->stream, x, h->send_idx, ns, h->send_buf);
     }
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     NPG_NCCL(ncclGroupStart());
     for (int p = 0; p < h->npeers; ++p) {
         const int64_t s0 = h->send_ptr[p], s1 = h->send_ptr[p + 1], r0 = h->recv_ptr[p], r1 = h->recv_ptr[p + 1];
         if (s1 > s0) NPG_NCCL(ncclSend(h->send_buf + s0, (size_t)(s1 - s0), ncclDouble, h->peer[p], comm, ctx->stream));
-        if (r1 > r0)
-            NPG_NCCL(ncclRecv(x->d + h->n_owned + r0, (size_t)(r1 - r0), ncclDouble, h->peer[p], comm, ctx->stream));
+        if (r1 > r0) NPG_NCCL(ncclRecv(x + h->n_owned + r0, (size_t)(r1 - r0), ncclDouble, h->peer[p], comm, ctx->stream));
     }
     NPG_NCCL(ncclGroupEnd());
     return NPG_OK;
+}
+
+int npg::allreduce_sum_device(npg_ctx *ctx, double *buf, int n) {
+    if (ctx->nranks == 1 || !ctx->comm) return NPG_OK;
+    NPG_NCCL(ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+    return NPG_OK;
+}
+
+NPG_API int npg_halo_exchange(npg_halo *h, npg_vec *x) {
+    NPG_REQUIRE(h && x && x->n == h->n_owned + h->n_ghost, "npg_halo_exchange: vector must hold owned + ghost entries");
+    return halo_exchange_raw(h, x->d);
 }

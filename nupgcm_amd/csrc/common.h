@@ -81,7 +81,21 @@ struct npg_csr {
     std::vector<int64_t> h_rowptr;
 };
 
+// interface exchange plan of a row-block distributed vector [owned | ghosts] (comm.hip)
+struct npg_halo {
+    npg_ctx *ctx = nullptr;
+    int64_t n_owned = 0, n_ghost = 0;
+    int npeers = 0;
+    std::vector<int> peer;
+    std::vector<int64_t> send_ptr, recv_ptr;
+    int32_t *send_idx = nullptr;   // device
+    double *send_buf = nullptr;    // device
+};
+
 namespace npg {
+// enqueue the exchange of x's ghost segment / an in-place sum over ranks of n doubles on the context's stream
+int halo_exchange_raw(npg_halo *h, double *x);
+int allreduce_sum_device(npg_ctx *ctx, double *buf, int n);
 int ensure_stage(npg_ctx *ctx, size_t doubles);
 int build_tiles(npg_csr *A);
 // reductions that return a scalar to the host (synchronous)

@@ -235,7 +235,7 @@ NPG_API int npg_csr_combine(npg_csr *out, double a, const npg_csr *X, double b, 
 }
 
 NPG_API int npg_csr_inv_diag(const npg_csr *A, npg_vec *d) {
-    NPG_REQUIRE(A && d && A->m == A->n && d->n == A->m, "npg_csr_inv_diag: shape mismatch");
+    NPG_REQUIRE(A && d && A->m <= A->n && d->n == A->m, "npg_csr_inv_diag: shape mismatch");   // m < n: a rank's row block
     const int grid = (int)std::min<int64_t>(2048, (A->m + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_inv_diag, dim3(std::max(grid, 1)), dim3(kBlock), 0, A->ctx->stream, A->rowptr, A->col, A->val,
                        d->d, A->m);

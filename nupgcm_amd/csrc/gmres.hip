@@ -72,6 +72,10 @@ struct GDev {
     double *P1, *P2, *PR;
     int G1, G2, GP1;      // GP1 = partial rows in P1: G1 when the dots are fused into K1, G2 in split mode
     int split;
+    // what the CONSUMER prologues reduce: the producers' partial rows on one GPU, or the single all-reduced row when
+    // the system is distributed over several GPUs
+    const double *Q1, *Q2, *QR;
+    int nQ1, nQ2, nQR;
     Snap *C, *T;
     double *c, *s, *z, *R, *hcol1, *wnorm2;
     double *hist;
@@ -132,7 +136,7 @@ __device__ void finalize_column(const GDev &d, int colj, KShared &sh, double *tm
     const double cv = d.c[t32], sv = d.s[t32];
     const Snap prev = d.T[colj];
     const double wnorm2 = d.wnorm2[colj];
-    reduce_partials<kNS, kMaxI>(d.P2, d.G2, kKP, tmp, sh.red);          // [0..colj] = h2, [31] = ||wt||^2
+    reduce_partials<kNS, kMaxI>(d.Q2, d.nQ2, kKP, tmp, sh.red);         // [0..colj] = h2, [31] = ||wt||^2
     if (threadIdx.x < kKP) {
         sh.h[threadIdx.x] = h1;
         sh.h2[threadIdx.x] = ((int)threadIdx.x <= colj) ? sh.red[threadIdx.x] : 0.0;
@@ -254,7 +258,7 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_arnoldi(GDev d, int j) {
     double *tmp = tl.prod;                // scratch of the prologue / final block reduction, outside the tile loop
     if (j == 0) {
         const Snap c = *d.C;
-        reduce_partials<kNS, kMaxI>(d.PR, d.G1, 1, tmp, sh.red);
+        reduce_partials<kNS, kMaxI>(d.QR, d.nQR, 1, tmp, sh.red);
         if (threadIdx.x == 0) {
             Snap t = c;
             if (t.done == 0) {
@@ -364,7 +368,7 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_orth(GDev d, int j) {
     __shared__ KShared sh;
     __shared__ double tmp[kNS * kKP];
     const Snap T = d.T[j];
-    reduce_partials<kNS, kMaxI>(d.P1, d.GP1, kKP, tmp, sh.red);      // [0..j] = h1, [31] = ||w||^2
+    reduce_partials<kNS, kMaxI>(d.Q1, d.nQ1, kKP, tmp, sh.red);      // [0..j] = h1, [31] = ||w||^2
     if (T.done != 0) return;
     const int k = threadIdx.x & (kKP - 1), slot = threadIdx.x >> 5;
     if (blockIdx.x == 0 && threadIdx.x < kKP) {
@@ -442,6 +446,14 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_update(GDev d) {
     }
 }
 
+// distributed mode: fold this rank's partial rows into one row, which RCCL then sums over the ranks
+__global__ void __launch_bounds__(kKB) k_reduce_rows(const double *part, int nrows, double *out) {
+    __shared__ double tmp[kNS * kKP];
+    __shared__ double red[kKP];
+    reduce_partials<kNS, kMaxI>(part, nrows, kKP, tmp, red);
+    if (threadIdx.x < kKP) out[threadIdx.x] = red[threadIdx.x];
+}
+
 }  // namespace npg
 
 using namespace npg;
@@ -473,11 +485,22 @@ struct npg_gmres {
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
     npg_halo *halo = nullptr;
+    double *Rg = nullptr;         // 3 x 32 doubles: all-reduced rows (distributed mode)
+    int64_t n_ghost = 0;
 };
 
+// fold + all-reduce one set of partial rows (distributed mode only)
+static int dist_reduce(npg_gmres *ws, const double *part, int nrows, int slot, hipStream_t st) {
+    double *out = ws->Rg + slot * kKP;
+    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(kKB), 0, st, part, nrows, out);
+    return allreduce_sum_device(ws->ctx, out, kKP);
+}
+
 template <int L>
-static void launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev) {
+static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gmres *dist) {
+    int rc = NPG_OK;
     for (int j = 0; j < d.mem; ++j) {
+        if (dist && (rc = halo_exchange_raw(dist->halo, d.wt))) return rc;
         if (pev) hipEventRecord(pev[2 * j], st);
         if (d.split) {
             hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(d.G1), dim3(kKB), 0, st, d, j);
@@ -487,10 +510,15 @@ static void launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev) {
             hipLaunchKernelGGL((k_gmres_arnoldi<L, true>), dim3(d.G1), dim3(kKB), 0, st, d, j);
             if (pev) hipEventRecord(pev[2 * j + 1], st);
         }
+        if (dist && (rc = dist_reduce(dist, d.P1, d.GP1, 0, st))) return rc;
         hipLaunchKernelGGL(k_gmres_orth, dim3(d.G2), dim3(kKB), 0, st, d, j);
+        if (dist && (rc = dist_reduce(dist, d.P2, d.G2, 1, st))) return rc;
     }
     hipLaunchKernelGGL(k_gmres_update, dim3(d.G2), dim3(kKB), 0, st, d);
+    if (dist && (rc = halo_exchange_raw(dist->halo, d.x))) return rc;
     hipLaunchKernelGGL(k_gmres_residual<L>, dim3(d.G1), dim3(kKB), 0, st, d);
+    if (dist && (rc = dist_reduce(dist, d.PR, d.G1, 2, st))) return rc;
+    return rc;
 }
 
 static void launch_residual(const GDev &d, int lanes, hipStream_t st) {
@@ -502,12 +530,12 @@ static void launch_residual(const GDev &d, int lanes, hipStream_t st) {
     }
 }
 
-static void launch_cycle(const GDev &d, int lanes, hipStream_t st, hipEvent_t *pev) {
+static int launch_cycle(const GDev &d, int lanes, hipStream_t st, hipEvent_t *pev, npg_gmres *dist = nullptr) {
     switch (lanes) {
-        case 4: launch_cycle_L<4>(d, st, pev); break;
-        case 8: launch_cycle_L<8>(d, st, pev); break;
-        case 16: launch_cycle_L<16>(d, st, pev); break;
-        default: launch_cycle_L<32>(d, st, pev); break;
+        case 4: return launch_cycle_L<4>(d, st, pev, dist);
+        case 8: return launch_cycle_L<8>(d, st, pev, dist);
+        case 16: return launch_cycle_L<16>(d, st, pev, dist);
+        default: return launch_cycle_L<32>(d, st, pev, dist);
     }
 }
 
@@ -569,7 +597,7 @@ NPG_API int npg_gmres_destroy(npg_gmres *ws) {
     }
     for (hipEvent_t e : ws->pev) hipEventDestroy(e);
     void *ptrs[] = {ws->Vi, ws->w, ws->wt, ws->P1, ws->P2, ws->PR, ws->C, ws->T, ws->c, ws->s,
-                    ws->z, ws->R, ws->hcol1, ws->wnorm2, ws->hist, ws->prm};
+                    ws->z, ws->R, ws->hcol1, ws->wnorm2, ws->hist, ws->prm, ws->Rg};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (ws->h_C) hipHostFree(ws->h_C);
@@ -580,8 +608,21 @@ NPG_API int npg_gmres_destroy(npg_gmres *ws) {
 
 NPG_API int npg_gmres_set_halo(npg_gmres *ws, npg_halo *h) {
     NPG_REQUIRE(ws, "npg_gmres_set_halo: NULL workspace");
+    NPG_REQUIRE(!h || h->n_owned == ws->n, "npg_gmres_set_halo: the plan owns %lld rows, the workspace %lld",
+                h ? (long long)h->n_owned : 0LL, (long long)ws->n);
+    NPG_HIP(hipStreamSynchronize(ws->ctx->stream));
     ws->halo = h;
     ws->have_graph = false;
+    ws->n_ghost = h ? h->n_ghost : 0;
+    // the SpMV input wt needs room for the ghost entries
+    NPG_HIP(hipFree(ws->wt));
+    const size_t nb = (size_t)(ws->n + ws->n_ghost) * sizeof(double);
+    NPG_HIP(hipMalloc((void **)&ws->wt, nb));
+    NPG_HIP(hipMemset(ws->wt, 0, nb));
+    if (h && !ws->Rg) {
+        NPG_HIP(hipMalloc((void **)&ws->Rg, 3 * kKP * sizeof(double)));
+        NPG_HIP(hipMemset(ws->Rg, 0, 3 * kKP * sizeof(double)));
+    }
     return NPG_OK;
 }
 
@@ -589,16 +630,19 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
                             const npg_vec *precond_diag, const npg_vec *y, npg_vec *x, double atol, double rtol,
                             int64_t itmax, double reorth_eta, npg_solve_stats *stats) {
     NPG_REQUIRE(ws && A && y && x, "npg_gmres_solve: NULL argument");
-    NPG_REQUIRE(A->m == ws->n && A->n == ws->n && y->n == ws->n && x->n == ws->n,
-                "npg_gmres_solve: workspace is for n=%lld but A is %lldx%lld, y has %lld, x has %lld", (long long)ws->n,
-                (long long)A->m, (long long)A->n, (long long)y->n, (long long)x->n);
+    const int64_t nloc = ws->n + ws->n_ghost;     // distributed: vectors the SpMV reads hold [owned | ghosts]
+    NPG_REQUIRE(A->m == ws->n && A->n == nloc && y->n == ws->n && x->n == nloc,
+                "npg_gmres_solve: workspace is for n=%lld (+%lld ghosts) but A is %lldx%lld, y has %lld, x has %lld",
+                (long long)ws->n, (long long)ws->n_ghost, (long long)A->m, (long long)A->n, (long long)y->n,
+                (long long)x->n);
     NPG_REQUIRE(precond_kind == NPG_PRECOND_NONE || precond_kind == NPG_PRECOND_SCALAR ||
                     (precond_kind == NPG_PRECOND_DIAG && precond_diag && precond_diag->n == ws->n),
                 "npg_gmres_solve: bad preconditioner");
-    NPG_REQUIRE(ws->halo == nullptr, "npg_gmres_solve: distributed solves go through npg_dist_* (halo set)");
     const auto t0 = std::chrono::steady_clock::now();
     npg_ctx *ctx = ws->ctx;
     hipStream_t st = ctx->stream;
+    npg_gmres *dist = ws->halo ? ws : nullptr;
+    if (dist) reorth_eta = 0.0;     // the on-the-fly second pass would need basis rows of ghost columns
 
     GDev d;
     memset(&d, 0, sizeof d);
@@ -626,6 +670,19 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     static const int split_env = getenv("NPG_GMRES_SPLIT") ? atoi(getenv("NPG_GMRES_SPLIT")) : -1;
     d.split = split_env >= 0 ? split_env : (ws->n >= 150000 ? 1 : 0);   // large systems: dots as a separate stream
     d.GP1 = d.split ? d.G2 : d.G1;
+    if (dist) {
+        d.Q1 = ws->Rg;
+        d.Q2 = ws->Rg + kKP;
+        d.QR = ws->Rg + 2 * kKP;
+        d.nQ1 = d.nQ2 = d.nQR = 1;
+    } else {
+        d.Q1 = d.P1;
+        d.Q2 = d.P2;
+        d.QR = d.PR;
+        d.nQ1 = d.GP1;
+        d.nQ2 = d.G2;
+        d.nQR = d.G1;
+    }
     d.C = ws->C;
     d.T = ws->T;
     d.c = ws->c;
@@ -655,7 +712,7 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     static const int trace = getenv("NPG_GMRES_TRACE") ? atoi(getenv("NPG_GMRES_TRACE")) : 0;
 
     // (re)capture the per-cycle graphs when any baked-in argument changed
-    if (!eager && !ws->profile && (!ws->have_graph || memcmp(&ws->key, &d, sizeof(GDev)) != 0)) {
+    if (!dist && !eager && !ws->profile && (!ws->have_graph || memcmp(&ws->key, &d, sizeof(GDev)) != 0)) {
         for (int k = 0; k < 2; ++k) {
             if (ws->exec[k]) hipGraphExecDestroy(ws->exec[k]);
             if (ws->graph[k]) hipGraphDestroy(ws->graph[k]);
@@ -672,16 +729,25 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     }
 
     // first true residual, then cycles until the carried state says done
+    if (dist) {
+        int rcd = halo_exchange_raw(ws->halo, d.x);
+        if (rcd) return rcd;
+    }
     launch_residual(d, A->lanes, st);
     NPG_HIP(hipGetLastError());
+    if (dist) {
+        int rcd = dist_reduce(ws, d.PR, d.G1, 2, st);
+        if (rcd) return rcd;
+    }
     const int64_t max_cycles = (itmax + ws->mem - 1) / ws->mem + 1;
     Snap last{};
     double t_launch = 0.0;
     int64_t n_launch = 0;
     auto enqueue_cycle = [&](int slot) -> int {
         const auto l0 = std::chrono::steady_clock::now();
-        if (eager) {
-            launch_cycle(d, A->lanes, st, nullptr);
+        if (eager || dist) {
+            int rcc = launch_cycle(d, A->lanes, st, nullptr, dist);
+            if (rcc) return rcc;
             NPG_HIP(hipMemcpyAsync(ws->h_C + slot, ws->C, sizeof(Snap), hipMemcpyDeviceToHost, st));
         } else {
             NPG_HIP(hipGraphLaunch(ws->exec[slot], st));
@@ -722,7 +788,8 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
             for (auto &e : ws->pev) NPG_HIP(hipEventCreate(&e));
         }
         for (int64_t cyc = 0; cyc < max_cycles; ++cyc) {
-            launch_cycle(d, A->lanes, st, ws->pev.data());
+            int rcp = launch_cycle(d, A->lanes, st, ws->pev.data(), dist);
+            if (rcp) return rcp;
             NPG_HIP(hipMemcpyAsync(ws->h_C, ws->C, sizeof(Snap), hipMemcpyDeviceToHost, st));
             NPG_HIP(hipStreamSynchronize(st));
             last = ws->h_C[0];

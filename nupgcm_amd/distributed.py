@@ -1,0 +1,228 @@
+"""Multi-GPU execution of the hot path: one process per GPU, RCCL over xGMI (new work - the reference is single-device).
+
+Decomposition.  The systems are already RCM-ordered (src/dofs.jl:27-41), so a rank owns CONTIGUOUS row blocks: of the
+inversion system a slice of the velocity rows and a slice of the pressure rows (p_inversion = [p_u; nu + p_p]), of the
+evolution system a slice of the buoyancy rows.  The Krylov solves - more than 99 % of a timestep - run distributed:
+
+  * SpMV: the rank's rows as an n_owned x (n_owned + n_ghost) CSR block; ghost entries of the input vector are filled from
+    the neighbours before every SpMV (npg_halo_exchange: one pack kernel + one grouped ncclSend/ncclRecv per neighbour),
+  * inner products: every kernel folds its partial sums to one 32-double row which ncclAllReduce sums over the ranks
+    (two all-reduces per GMRES iteration, latency-bound: 256-byte messages).
+
+The state ([u; p] and b) is REPLICATED: after each solve the owned slices are all-gathered (8 N bytes per step), and each
+rank evaluates the element kernels (advection right-hand side, < 1 % of a step) on the full mesh - so the element layer
+needs no ghost-cell plan.  `RowPartition`, `local_block` and `halo_plan` are pure host logic (numpy/scipy) and are
+exercised on CPU with gloo (tests/test_distributed_plan.py); everything that touches data on the device goes through
+libnupgcm_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib as L
+
+
+class RowPartition:
+    """Contiguous, near-equal row blocks per field."""
+
+    def __init__(self, nu, np_, nb, nranks):
+        self.nu, self.np, self.nb, self.nranks = int(nu), int(np_), int(nb), int(nranks)
+        self.u_bounds = np.linspace(0, nu, nranks + 1).astype(np.int64)
+        self.p_bounds = np.linspace(0, np_, nranks + 1).astype(np.int64)
+        self.b_bounds = np.linspace(0, nb, nranks + 1).astype(np.int64)
+
+    def inv_owned(self, r):
+        """global row ids of the inversion system [u; p] owned by rank r (ascending)"""
+        return np.concatenate([np.arange(self.u_bounds[r], self.u_bounds[r + 1]),
+                               self.nu + np.arange(self.p_bounds[r], self.p_bounds[r + 1])])
+
+    def b_owned(self, r):
+        return np.arange(self.b_bounds[r], self.b_bounds[r + 1])
+
+    def inv_owner(self):
+        o = np.empty(self.nu + self.np, dtype=np.int32)
+        for r in range(self.nranks):
+            o[self.inv_owned(r)] = r
+        return o
+
+    def b_owner(self):
+        return (np.searchsorted(self.b_bounds, np.arange(self.nb), side="right") - 1).astype(np.int32)
+
+    def inv_segments(self):
+        """(rank, local_off, global_off, len) of every owned slice - what npg_comm_allgather_segments takes"""
+        seg = []
+        for r in range(self.nranks):
+            nu_r = self.u_bounds[r + 1] - self.u_bounds[r]
+            seg.append((r, 0, int(self.u_bounds[r]), int(nu_r)))
+            seg.append((r, int(nu_r), self.nu + int(self.p_bounds[r]), int(self.p_bounds[r + 1] - self.p_bounds[r])))
+        return seg
+
+    def b_segments(self):
+        return [(r, 0, int(self.b_bounds[r]), int(self.b_bounds[r + 1] - self.b_bounds[r])) for r in range(self.nranks)]
+
+
+def local_block(A, owned, owner):
+    """Rows `owned` (ascending global ids) of the square global CSR matrix A, renumbered [owned | ghosts].
+    Returns (A_loc, ghosts) with ghosts sorted by (owner rank, global id)."""
+    A = sp.csr_matrix(A)
+    R = A[owned]
+    cols = np.unique(R.indices)
+    is_owned = np.zeros(A.shape[1], dtype=bool)
+    is_owned[owned] = True
+    ghosts = cols[~is_owned[cols]]
+    ghosts = ghosts[np.lexsort((ghosts, owner[ghosts]))]
+    lut = np.full(A.shape[1], -1, dtype=np.int64)
+    lut[owned] = np.arange(len(owned))
+    lut[ghosts] = len(owned) + np.arange(len(ghosts))
+    A_loc = sp.csr_matrix((R.data, lut[R.indices], R.indptr), shape=(len(owned), len(owned) + len(ghosts)))
+    A_loc.sort_indices()
+    return A_loc, ghosts
+
+
+def halo_plan(rank, owned, owner, ghosts_by_rank):
+    """From every rank's ghost list: whom this rank receives from / sends to.
+    Returns dict(peers, send_ptr, send_idx, recv_ptr): recv segments are consecutive in this rank's ghost order."""
+    my_ghosts = ghosts_by_rank[rank]
+    g_owner = owner[my_ghosts]
+    lut = np.full(len(owner), -1, dtype=np.int64)
+    lut[owned] = np.arange(len(owned))
+    peers, send_ptr, send_idx, recv_ptr = [], [0], [], [0]
+    for q in range(len(ghosts_by_rank)):
+        if q == rank:
+            continue
+        n_recv = int((g_owner == q).sum())                      # my ghosts owned by q (contiguous: sorted by owner)
+        needs = ghosts_by_rank[q][owner[ghosts_by_rank[q]] == rank]      # q's ghosts that I own, in q's ghost order
+        if n_recv == 0 and len(needs) == 0:
+            continue
+        peers.append(q)
+        send_idx.append(lut[needs])
+        send_ptr.append(send_ptr[-1] + len(needs))
+        recv_ptr.append(recv_ptr[-1] + n_recv)
+    sidx = np.concatenate(send_idx).astype(np.int32) if send_idx else np.zeros(0, np.int32)
+    assert recv_ptr[-1] == len(my_ghosts) and (sidx >= 0).all()
+    return dict(peers=np.asarray(peers, np.int32), send_ptr=np.asarray(send_ptr, np.int64), send_idx=sidx,
+                recv_ptr=np.asarray(recv_ptr, np.int64))
+
+
+# ---- device side ----------------------------------------------------------------------------------------------------------
+class Halo:
+    def __init__(self, ctx, n_owned, n_ghost, plan):
+        self.ctx, self.n_owned, self.n_ghost = ctx, int(n_owned), int(n_ghost)
+        h = C.c_void_p()
+        k = self._keep = {k: np.ascontiguousarray(v) for k, v in plan.items()}
+        L.check(L.lib().npg_halo_create(ctx.h, self.n_owned, self.n_ghost, len(k["peers"]), L.ptr(k["peers"]),
+                                        L.ptr(k["send_ptr"]), L.ptr(k["send_idx"]), L.ptr(k["recv_ptr"]), C.byref(h)))
+        self.h = h
+
+    def exchange(self, x):
+        L.check(L.lib().npg_halo_exchange(self.h, x.h))
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.lib().npg_halo_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def allgather_segments(ctx, local, segments, full):
+    seg = np.asarray(segments, dtype=np.int64).reshape(-1, 4)
+    r, lo, go, ln = (np.ascontiguousarray(seg[:, i]) for i in range(4))
+    r32 = np.ascontiguousarray(r, dtype=np.int32)
+    L.check(L.lib().npg_comm_allgather_segments(ctx.h, local.h, len(seg), L.ptr(r32), L.ptr(lo), L.ptr(go), L.ptr(ln),
+                                                full.h))
+
+
+class DistributedSolverToolkit:
+    """IterativeSolverToolkit whose solve runs on this rank's row block.  `x` is the FULL replicated solution (what the
+    model and the element kernels read); `x_loc` = [owned | ghosts] is the solver's own vector (warm start)."""
+
+    def __init__(self, A_loc, P, y, workspace, kwargs, label, x_full, halo, segments, y_range=None):
+        self.A, self.P, self.y, self.workspace, self.kwargs, self.label = A_loc, P, y, workspace, dict(kwargs), label
+        self.x, self.halo, self.segments, self.y_range = x_full, halo, segments, y_range
+        from .architectures import DeviceVector
+        self.x_loc = DeviceVector(A_loc.ctx, halo.n_owned + halo.n_ghost)
+        self.x_own = self.x_loc.view(0, halo.n_owned)
+
+    def load_owned_from_full(self):
+        """x_loc[owned] <- x (used after set_b! / state restores)"""
+        me = self.A.ctx.rank
+        for (r, lo, go, ln) in self.segments:
+            if r == me and ln:
+                self.x_loc.view(lo, ln).copy_from(self.x.view(go, ln))
+
+    def solve(self):
+        y = self.y if self.y_range is None else self.y.view(*self.y_range)
+        self.workspace.solve(self.A, y, self.x_loc, self.P, **self.kwargs)
+        allgather_segments(self.A.ctx, self.x_own, self.segments, self.x)
+
+
+def distribute_model(model, dist):
+    """Turn a freshly built single-GPU Model into its distributed form (call on every rank, before the first solve).
+    `dist` is torch.distributed (initialised); RCCL is bootstrapped from it."""
+    import torch
+    from .architectures import DeviceCSR, DeviceVector, comm_unique_id
+    from .iterative_solvers import CgWorkspace, Diagonal, GmresWorkspace
+    arch, ctx = model.arch, model.arch.ctx
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if model.forcings.conv_param.is_on or model.forcings.eddy_param.is_on:
+        raise NotImplementedError("distributed runs do not re-assemble coefficient-dependent matrices yet")
+    # RCCL bootstrap: rank 0's unique id travels over the launcher's process group
+    ids = [comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    ctx.comm_init(ids[0], rank, world)
+    d = model.fe_data.dofs
+    part = RowPartition(d.nu, d.np, d.nb, world)
+    model.partition = part
+
+    def make(A_dev, owned, owner):
+        A_loc, ghosts = local_block(A_dev.to_scipy_csr(), owned, owner)
+        allg = [None] * world
+        dist.all_gather_object(allg, ghosts)
+        plan = halo_plan(rank, owned, owner, allg)
+        return A_loc, Halo(ctx, len(owned), len(ghosts), plan)
+
+    # ---- inversion -------------------------------------------------------------------------------------------------
+    inv, s = model.inversion, model.inversion.solver
+    owned = part.inv_owned(rank)
+    A_loc, halo = make(s.A, owned, part.inv_owner())
+    B_loc = sp.csr_matrix(inv.B.to_scipy_csr()[owned])
+    b0_loc = inv.b.to_host()[owned]
+    x_full = s.x
+    ws = GmresWorkspace(ctx, len(owned), memory=s.workspace.memory)
+    L.check(L.lib().npg_gmres_set_halo(ws.h, halo.h))
+    inv.B = DeviceCSR.from_scipy(ctx, B_loc)
+    inv.b = DeviceVector.from_host(ctx, b0_loc)
+    inv.solver = DistributedSolverToolkit(DeviceCSR.from_scipy(ctx, A_loc), Diagonal(scalar=s.P.scalar, n=len(owned)),
+                                          DeviceVector(ctx, len(owned)), ws, s.kwargs, s.label, x_full, halo,
+                                          part.inv_segments())
+    # ---- evolution -------------------------------------------------------------------------------------------------
+    ev, se = model.evolution, model.evolution.solver
+    bo = part.b_owned(rank)
+    Ae_loc, halo_b = make(se.A, bo, part.b_owner())
+    lut = None
+
+    def loc(Mdev):
+        nonlocal lut
+        Ml, gh = local_block(Mdev.to_scipy_csr(), bo, part.b_owner())
+        return DeviceCSR.from_scipy(ctx, Ml)
+
+    # M, Kh, Kv share A_evo's pattern, hence its ghost set and column numbering
+    ev.M, ev.Kh, ev.Kv = loc(ev.M), loc(ev.Kh), loc(ev.Kv)
+    wsb = CgWorkspace(ctx, len(bo))
+    L.check(L.lib().npg_cg_set_halo(wsb.h, halo_b.h))
+    A_dev = DeviceCSR.from_scipy(ctx, Ae_loc)
+    P = Diagonal(A_dev.inv_diag(DeviceVector(ctx, len(bo))))
+    ev.solver = DistributedSolverToolkit(A_dev, P, se.y, wsb, se.kwargs, se.label, se.x, halo_b, part.b_segments(),
+                                         y_range=(int(part.b_bounds[rank]), len(bo)))
+    torch.cuda.synchronize()
+    return model
+
+
+def example_model(arch, mesh_model, dist, dt=1e-3, **kw):
+    from . import workloads
+    return distribute_model(workloads.example_model(arch, mesh_model, dt=dt, **kw), dist)

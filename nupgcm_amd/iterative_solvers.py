@@ -132,6 +132,9 @@ class IterativeSolverToolkit:
 def iterative_solve(solver: IterativeSolverToolkit):
     """iterative_solve!(solver) - src/iterative_solvers.jl:31-68.  The reference's CPU() branches (`ldiv!` with an LU,
     `A\\y`) belong to its CPU architecture and are not reproduced: this package is the GPU() architecture."""
+    if hasattr(solver, "solve"):            # distributed.DistributedSolverToolkit: row-block solve + all-gather
+        solver.solve()
+        return solver
     if not isinstance(solver.A, DeviceCSR):
         raise TypeError("iterative_solve: nupgcm_amd only implements the GPU() architecture; A must be a DeviceCSR")
     solver.workspace.solve(solver.A, solver.y, solver.x, solver.P, **solver.kwargs)
