@@ -31,17 +31,30 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s;
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("NPG_BENCH_WORKLOAD", "bowl3D_h0.02"))
     ap.add_argument("--dt", type=float, default=1e-3)
     ap.add_argument("--reorth-eta", type=float, default=None, help="override the GMRES second-pass threshold")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-pass", action="store_true",
+                    help="skip the HIP-event profile pass (use when the whole run is under rocprofv3)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU budget of the cpu_baseline sample")
     return ap.parse_args()
 
 
-def cpu_baseline(workload, mesh_model, dt, its_per_step, budget):
+def pmc_traffic(workload, kernel="k_gmres_arnoldi"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc.json, made by
+    tools/pmc_probe.py + tools/pmc_summary.py on this workload; FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
+    correction applied as described in profiles/README.md).  None when no counters were collected for the workload."""
+    p = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    if not os.path.exists(p):
+        return None
+    rec = json.load(open(p)).get(workload, {}).get(kernel)
+    return None if rec is None else rec["traffic_bytes_per_launch"]
+
+
+def cpu_baseline(workload, mesh_model, dt, its_per_step, budget, A_host=None, h=None):
     """The oracle on this host's cores, bounded sample.  Meshes small enough for a sparse LU run the reference's CPU()
     path proper (direct solves, src/iterative_solvers.jl:42-55); larger ones time the host Krylov branch
     (src/iterative_solvers.jl:58 via InversionToolkit(CPU(), A, Diagonal(1/h^3), B, b)) per GMRES iteration and scale by
@@ -51,6 +64,21 @@ def cpu_baseline(workload, mesh_model, dt, its_per_step, budget):
     from oracle import krylov_oracle as ko
     from oracle import recipe as rc
     with threadpool_limits(limits=1):
+        if A_host is not None and A_host.shape[0] > 40000:
+            # large mesh: the oracle's dense-per-cell numpy assembly would need tens of GB; time the oracle's GMRES on the
+            # same matrix (assembled by the product, downloaded) - the matrix is an input here, the solver is the port
+            y = np.sin(np.arange(A_host.shape[0], dtype=float)) * 1e-3
+            t0 = time.perf_counter()
+            its = 0
+            while time.perf_counter() - t0 < budget:
+                _, st = ko.gmres(A_host, y, M=1 / h ** 3, itmax=20)
+                its += st["niter"]
+            per_it = (time.perf_counter() - t0) / its
+            return dict(value=1.0 / (per_it * max(its_per_step, 1)), unit="timesteps/s", cores=1, kind="port",
+                        sample=f"{its} GMRES(20) iterations of the oracle's host Krylov path (scipy CSR SpMV + numpy "
+                               f"MGS, the reference's large-system branch src/iterative_solvers.jl:58) on the {workload} "
+                               f"inversion matrix: {per_it * 1e3:.0f} ms/iteration, scaled to the {its_per_step:.0f} "
+                               f"iterations a timestep took on the GPU; evolution solve and assembly not included")
         S = rc.setup("example", model=mesh_model, dt=dt)
         N = S.A.shape[0]
         if N <= 40000:
@@ -136,17 +164,20 @@ def main():
     A = model.inversion.solver.A
     N, nnz = A.shape[0], A.nnz
     ws = model.inversion.solver.workspace
-    ws.set_profile(True)
-    npg.run(model, n_steps=1)
-    ms_total, launches = ws.get_profile()
-    ws.set_profile(False)
+    ms_total, launches = 0.0, 0
+    if not a.no_profile_pass:
+        ws.set_profile(True)
+        npg.run(model, n_steps=1)
+        ms_total, launches = ws.get_profile()
+        ws.set_profile(False)
     alg_bytes = 12 * nnz + 4 * (N + 1) + 16 * N          # CSR fp64/int32 SpMV on the stored (numeric) pattern
     roofline = None
     if launches > 0:
         avg_ms = ms_total / launches
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
         roofline = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                        traffic=None, kernel="k_gmres_arnoldi (fused CSR SpMV + Gram-Schmidt dots)",
+                        traffic=pmc_traffic(a.workload), kernel="k_gmres_arnoldi (Givens prologue + CSR-stream SpMV"
+                        + (")" if N >= 150000 else " + fused Gram-Schmidt dots)"),
                         avg_launch_us=avg_ms * 1e3, launches=launches, algorithmic_bytes_per_launch=alg_bytes,
                         cache_resident=bool(alg_bytes < 256 * 2 ** 20))
     # stand-alone SpMV kernel (same tiles, no Krylov epilogue) for reference
@@ -176,7 +207,10 @@ def main():
         "spmv_standalone": {"avg_launch_us": spmv_ms * 1e3, "GBps": alg_bytes / (spmv_ms * 1e-3) / 1e9},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.workload, mesh_model, a.dt, float(np.mean(gm_its)), a.cpu_seconds)
+        big = N > 40000
+        out["cpu_baseline"] = cpu_baseline(a.workload, mesh_model, a.dt, float(np.mean(gm_its)), a.cpu_seconds,
+                                           A_host=A.to_scipy_csr() if big else None,
+                                           h=model.fe_data.mesh.median_edge_length() if big else None)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
