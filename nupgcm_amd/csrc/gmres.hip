@@ -46,6 +46,7 @@ constexpr int kNS = kKB / kKP;            // 32 row slots per workgroup pass / s
 constexpr int kMaxG = 768;                // max workgroups (= partial rows): three per CU
 constexpr int kMaxI = kMaxG / kNS;        // loads per thread in the partial reduction (8)
 constexpr int kNormSlot = kKP - 1;        // partial rows carry the squared norm in their last entry
+constexpr int kMaxRows = 2048;            // capacity of the partial-row buffers (row-streaming kernels use up to 2048 workgroups)
 
 struct Snap {
     double eps, rnorm0, rnorm, beta, zeta;
@@ -70,7 +71,8 @@ struct GDev {
     const double *b;
     double *x, *Vi, *w, *wt;
     double *P1, *P2, *PR;
-    int G1, G2, GP1;      // GP1 = partial rows in P1: G1 when the dots are fused into K1, G2 in split mode
+    int G1, G2, GP1, GP2; // GP1/GP2 = partial rows in P1/P2: G1/G2 in fused mode, GR in split mode
+    int GR;               // grid of the row-streaming kernels (split mode)
     int split;
     // what the CONSUMER prologues reduce: the producers' partial rows on one GPU, or the single all-reduced row when
     // the system is distributed over several GPUs
@@ -363,6 +365,100 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_dots(GDev d, int j) {
     store_partial_row(acc, tmp, d.P1);
 }
 
+// ---- row-streaming variants for large systems (split mode) -------------------------------------------------------------
+// One thread per row: a lane reads its row's 64-byte group entries with four 16-byte loads, consecutive lanes read
+// consecutive rows, so a wave streams 4 KiB contiguous per group and instruction - the access shape that reaches the HBM
+// rate - and every thread keeps 8*NG accumulators.  Partial rows go through k_reduce_rows (one extra 5 us kernel, free
+// at this size), so these kernels may use any grid.
+constexpr int kRB = 256;
+
+template <int NG>
+__device__ __forceinline__ void load_row_groups(const double *__restrict__ Vi, int64_t row, int64_t n, double (&v)[8 * NG]) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const double2 *p = reinterpret_cast<const double2 *>(Vi + ((size_t)g * (size_t)n + (size_t)row) * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double2 t = p[q];
+            v[8 * g + 2 * q] = t.x;
+            v[8 * g + 2 * q + 1] = t.y;
+        }
+    }
+}
+
+template <int NG>
+__device__ __forceinline__ void store_partial_row_rows(const double (&acc)[8 * NG], double nrm, double *tmp, double *part) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane < kKP) tmp[wave * kKP + lane] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8 * NG; ++k) {
+        const double s = group_sum_dpp<64>(acc[k]);
+        if (lane == 0 && k < kNormSlot) tmp[wave * kKP + k] = s;
+    }
+    const double sn = group_sum_dpp<64>(nrm);
+    if (lane == 0) tmp[wave * kKP + kNormSlot] = sn;
+    __syncthreads();
+    if (threadIdx.x < kKP) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kRB / 64; ++w) s += tmp[w * kKP + threadIdx.x];
+        part[(size_t)blockIdx.x * kKP + threadIdx.x] = s;
+    }
+}
+
+template <int NG>
+__global__ void __launch_bounds__(kRB) k_gmres_dots_rows(GDev d, int j) {
+    __shared__ double tmp[(kRB / 64) * kKP];
+    double acc[8 * NG];
+#pragma unroll
+    for (int k = 0; k < 8 * NG; ++k) acc[k] = 0.0;
+    double nrm = 0.0;
+    if (d.T[j].done == 0) {
+        for (int64_t row = blockIdx.x * (int64_t)kRB + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kRB) {
+            double v[8 * NG];
+            load_row_groups<NG>(d.Vi, row, d.n, v);
+            const double wv = d.w[row];
+#pragma unroll
+            for (int k = 0; k < 8 * NG; ++k) acc[k] += v[k] * wv;
+            nrm += wv * wv;
+        }
+    }
+    store_partial_row_rows<NG>(acc, nrm, tmp, d.P1);
+}
+
+template <int NG>
+__global__ void __launch_bounds__(kRB) k_gmres_orth_rows(GDev d, int j) {
+    __shared__ double tmp[(kRB / 64) * kKP];
+    const Snap T = d.T[j];
+    double h[8 * NG], acc[8 * NG];
+#pragma unroll
+    for (int k = 0; k < 8 * NG; ++k) {
+        h[k] = (k <= j) ? d.Q1[k] : 0.0;       // split mode: Q1 is the single folded row (wave-uniform loads)
+        acc[k] = 0.0;
+    }
+    double nrm = 0.0;
+    if (T.done == 0) {
+        if (blockIdx.x == 0 && threadIdx.x < kKP) {
+            d.hcol1[j * kKP + threadIdx.x] = ((int)threadIdx.x <= j) ? d.Q1[threadIdx.x] : 0.0;
+            if (threadIdx.x == 0) d.wnorm2[j] = d.Q1[kNormSlot];
+        }
+        for (int64_t row = blockIdx.x * (int64_t)kRB + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kRB) {
+            double v[8 * NG];
+            load_row_groups<NG>(d.Vi, row, d.n, v);
+            double wp = d.w[row];
+#pragma unroll
+            for (int k = 0; k < 8 * NG; ++k) wp -= h[k] * v[k];
+            d.wt[row] = wp;
+#pragma unroll
+            for (int k = 0; k < 8 * NG; ++k) acc[k] += v[k] * wp;
+            nrm += wp * wp;
+        }
+    }
+    store_partial_row_rows<NG>(acc, nrm, tmp, d.P2);
+}
+
 // ---- K2 ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kKB, 6) k_gmres_orth(GDev d, int j) {
     __shared__ KShared sh;
@@ -447,11 +543,28 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_update(GDev d) {
 }
 
 // distributed mode: fold this rank's partial rows into one row, which RCCL then sums over the ranks
-__global__ void __launch_bounds__(kKB) k_reduce_rows(const double *part, int nrows, double *out) {
-    __shared__ double tmp[kNS * kKP];
-    __shared__ double red[kKP];
-    reduce_partials<kNS, kMaxI>(part, nrows, kKP, tmp, red);
-    if (threadIdx.x < kKP) out[threadIdx.x] = red[threadIdx.x];
+__global__ void __launch_bounds__(1024) k_reduce_rows(const double *__restrict__ part, int nrows, double *out) {
+    __shared__ double tmp[32 * kKP];
+    const int k = threadIdx.x & (kKP - 1), slice = threadIdx.x >> 5;      // 32 slices of 32 lanes
+    double s = 0.0;
+    for (int b0 = slice; b0 < nrows; b0 += 32 * 8) {
+        double v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int b = b0 + 32 * i;
+            v[i] = b < nrows ? part[(size_t)b * kKP + k] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    tmp[slice * kKP + k] = s;
+    __syncthreads();
+    if (threadIdx.x < kKP) {
+        double t = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < 32; ++sl) t += tmp[sl * kKP + threadIdx.x];
+        out[threadIdx.x] = t;
+    }
 }
 
 }  // namespace npg
@@ -489,35 +602,57 @@ struct npg_gmres {
     int64_t n_ghost = 0;
 };
 
-// fold + all-reduce one set of partial rows (distributed mode only)
-static int dist_reduce(npg_gmres *ws, const double *part, int nrows, int slot, hipStream_t st) {
+// fold one set of partial rows into a single row (split and distributed modes) and sum it over the ranks (distributed)
+static int fold_rows(npg_gmres *ws, const double *part, int nrows, int slot, hipStream_t st, bool dist) {
     double *out = ws->Rg + slot * kKP;
-    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(kKB), 0, st, part, nrows, out);
-    return allreduce_sum_device(ws->ctx, out, kKP);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(1024), 0, st, part, nrows, out);
+    return dist ? allreduce_sum_device(ws->ctx, out, kKP) : NPG_OK;
 }
 
+template <int NG>
+static void launch_rows(const GDev &d, int j, hipStream_t st, bool orth) {
+    if (orth)
+        hipLaunchKernelGGL(k_gmres_orth_rows<NG>, dim3(d.GR), dim3(kRB), 0, st, d, j);
+    else
+        hipLaunchKernelGGL(k_gmres_dots_rows<NG>, dim3(d.GR), dim3(kRB), 0, st, d, j);
+}
+
+static void launch_rows_kernel(const GDev &d, int j, hipStream_t st, bool orth) {
+    switch ((j + 8) / 8) {       // groups of 8 basis vectors needed for j+1 vectors
+        case 1: launch_rows<1>(d, j, st, orth); break;
+        case 2: launch_rows<2>(d, j, st, orth); break;
+        case 3: launch_rows<3>(d, j, st, orth); break;
+        default: launch_rows<4>(d, j, st, orth); break;
+    }
+}
+
+// One restart cycle.  `ws` is needed whenever partial rows are folded (split and/or distributed mode).
 template <int L>
-static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gmres *dist) {
+static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gmres *ws, bool dist) {
     int rc = NPG_OK;
+    const bool fold = d.split || dist;
     for (int j = 0; j < d.mem; ++j) {
-        if (dist && (rc = halo_exchange_raw(dist->halo, d.wt))) return rc;
+        if (dist && (rc = halo_exchange_raw(ws->halo, d.wt))) return rc;
         if (pev) hipEventRecord(pev[2 * j], st);
         if (d.split) {
             hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(d.G1), dim3(kKB), 0, st, d, j);
             if (pev) hipEventRecord(pev[2 * j + 1], st);
-            hipLaunchKernelGGL(k_gmres_dots, dim3(d.G2), dim3(kKB), 0, st, d, j);
+            launch_rows_kernel(d, j, st, false);
         } else {
             hipLaunchKernelGGL((k_gmres_arnoldi<L, true>), dim3(d.G1), dim3(kKB), 0, st, d, j);
             if (pev) hipEventRecord(pev[2 * j + 1], st);
         }
-        if (dist && (rc = dist_reduce(dist, d.P1, d.GP1, 0, st))) return rc;
-        hipLaunchKernelGGL(k_gmres_orth, dim3(d.G2), dim3(kKB), 0, st, d, j);
-        if (dist && (rc = dist_reduce(dist, d.P2, d.G2, 1, st))) return rc;
+        if (fold && (rc = fold_rows(ws, d.P1, d.GP1, 0, st, dist))) return rc;
+        if (d.split)
+            launch_rows_kernel(d, j, st, true);
+        else
+            hipLaunchKernelGGL(k_gmres_orth, dim3(d.G2), dim3(kKB), 0, st, d, j);
+        if (fold && (rc = fold_rows(ws, d.P2, d.GP2, 1, st, dist))) return rc;
     }
     hipLaunchKernelGGL(k_gmres_update, dim3(d.G2), dim3(kKB), 0, st, d);
-    if (dist && (rc = halo_exchange_raw(dist->halo, d.x))) return rc;
+    if (dist && (rc = halo_exchange_raw(ws->halo, d.x))) return rc;
     hipLaunchKernelGGL(k_gmres_residual<L>, dim3(d.G1), dim3(kKB), 0, st, d);
-    if (dist && (rc = dist_reduce(dist, d.PR, d.G1, 2, st))) return rc;
+    if (fold && (rc = fold_rows(ws, d.PR, d.G1, 2, st, dist))) return rc;
     return rc;
 }
 
@@ -530,12 +665,12 @@ static void launch_residual(const GDev &d, int lanes, hipStream_t st) {
     }
 }
 
-static int launch_cycle(const GDev &d, int lanes, hipStream_t st, hipEvent_t *pev, npg_gmres *dist = nullptr) {
+static int launch_cycle(const GDev &d, int lanes, hipStream_t st, hipEvent_t *pev, npg_gmres *ws, bool dist) {
     switch (lanes) {
-        case 4: return launch_cycle_L<4>(d, st, pev, dist);
-        case 8: return launch_cycle_L<8>(d, st, pev, dist);
-        case 16: return launch_cycle_L<16>(d, st, pev, dist);
-        default: return launch_cycle_L<32>(d, st, pev, dist);
+        case 4: return launch_cycle_L<4>(d, st, pev, ws, dist);
+        case 8: return launch_cycle_L<8>(d, st, pev, ws, dist);
+        case 16: return launch_cycle_L<16>(d, st, pev, ws, dist);
+        default: return launch_cycle_L<32>(d, st, pev, ws, dist);
     }
 }
 
@@ -552,7 +687,7 @@ NPG_API int npg_gmres_create(npg_ctx *ctx, int64_t n, int memory, npg_gmres **ou
     NPG_HIP(hipMalloc((void **)&ws->Vi, vb * kKP));
     NPG_HIP(hipMalloc((void **)&ws->w, vb));
     NPG_HIP(hipMalloc((void **)&ws->wt, vb));
-    const size_t pb = (size_t)kMaxG * kKP * sizeof(double);
+    const size_t pb = (size_t)kMaxRows * kKP * sizeof(double);
     NPG_HIP(hipMalloc((void **)&ws->P1, pb));
     NPG_HIP(hipMalloc((void **)&ws->P2, pb));
     NPG_HIP(hipMalloc((void **)&ws->PR, pb));
@@ -567,6 +702,8 @@ NPG_API int npg_gmres_create(npg_ctx *ctx, int64_t n, int memory, npg_gmres **ou
     ws->hist_cap = (int)std::min<int64_t>(2 * n + 2, 1 << 22);
     NPG_HIP(hipMalloc((void **)&ws->hist, sizeof(double) * ws->hist_cap));
     NPG_HIP(hipMalloc((void **)&ws->prm, sizeof(GParams)));
+    NPG_HIP(hipMalloc((void **)&ws->Rg, 3 * kKP * sizeof(double)));
+    NPG_HIP(hipMemsetAsync(ws->Rg, 0, 3 * kKP * sizeof(double), ctx->stream));
     NPG_HIP(hipHostMalloc((void **)&ws->h_C, 2 * sizeof(Snap), hipHostMallocDefault));
     NPG_HIP(hipEventCreateWithFlags(&ws->ev[0], hipEventDisableTiming));
     NPG_HIP(hipEventCreateWithFlags(&ws->ev[1], hipEventDisableTiming));
@@ -619,10 +756,6 @@ NPG_API int npg_gmres_set_halo(npg_gmres *ws, npg_halo *h) {
     const size_t nb = (size_t)(ws->n + ws->n_ghost) * sizeof(double);
     NPG_HIP(hipMalloc((void **)&ws->wt, nb));
     NPG_HIP(hipMemset(ws->wt, 0, nb));
-    if (h && !ws->Rg) {
-        NPG_HIP(hipMalloc((void **)&ws->Rg, 3 * kKP * sizeof(double)));
-        NPG_HIP(hipMemset(ws->Rg, 0, 3 * kKP * sizeof(double)));
-    }
     return NPG_OK;
 }
 
@@ -669,8 +802,10 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     d.G2 = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kNS - 1) / kNS, std::min(kMaxG, 3 * ctx->num_cu)));
     static const int split_env = getenv("NPG_GMRES_SPLIT") ? atoi(getenv("NPG_GMRES_SPLIT")) : -1;
     d.split = split_env >= 0 ? split_env : (ws->n >= 150000 ? 1 : 0);   // large systems: dots as a separate stream
-    d.GP1 = d.split ? d.G2 : d.G1;
-    if (dist) {
+    d.GR = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kRB - 1) / kRB, std::min(kMaxRows, 8 * ctx->num_cu)));
+    d.GP1 = d.split ? d.GR : d.G1;
+    d.GP2 = d.split ? d.GR : d.G2;
+    if (dist || d.split) {
         d.Q1 = ws->Rg;
         d.Q2 = ws->Rg + kKP;
         d.QR = ws->Rg + 2 * kKP;
@@ -680,7 +815,7 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
         d.Q2 = d.P2;
         d.QR = d.PR;
         d.nQ1 = d.GP1;
-        d.nQ2 = d.G2;
+        d.nQ2 = d.GP2;
         d.nQR = d.G1;
     }
     d.C = ws->C;
@@ -719,7 +854,8 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
             ws->exec[k] = nullptr;
             ws->graph[k] = nullptr;
             NPG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            launch_cycle(d, A->lanes, st, nullptr);
+            int rcg = launch_cycle(d, A->lanes, st, nullptr, ws, false);
+            if (rcg) return rcg;
             NPG_HIP(hipMemcpyAsync(ws->h_C + k, ws->C, sizeof(Snap), hipMemcpyDeviceToHost, st));
             NPG_HIP(hipStreamEndCapture(st, &ws->graph[k]));
             NPG_HIP(hipGraphInstantiate(&ws->exec[k], ws->graph[k], nullptr, nullptr, 0));
@@ -735,8 +871,8 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     }
     launch_residual(d, A->lanes, st);
     NPG_HIP(hipGetLastError());
-    if (dist) {
-        int rcd = dist_reduce(ws, d.PR, d.G1, 2, st);
+    if (dist || d.split) {
+        int rcd = fold_rows(ws, d.PR, d.G1, 2, st, dist != nullptr);
         if (rcd) return rcd;
     }
     const int64_t max_cycles = (itmax + ws->mem - 1) / ws->mem + 1;
@@ -746,7 +882,7 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     auto enqueue_cycle = [&](int slot) -> int {
         const auto l0 = std::chrono::steady_clock::now();
         if (eager || dist) {
-            int rcc = launch_cycle(d, A->lanes, st, nullptr, dist);
+            int rcc = launch_cycle(d, A->lanes, st, nullptr, ws, dist != nullptr);
             if (rcc) return rcc;
             NPG_HIP(hipMemcpyAsync(ws->h_C + slot, ws->C, sizeof(Snap), hipMemcpyDeviceToHost, st));
         } else {
@@ -788,7 +924,7 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
             for (auto &e : ws->pev) NPG_HIP(hipEventCreate(&e));
         }
         for (int64_t cyc = 0; cyc < max_cycles; ++cyc) {
-            int rcp = launch_cycle(d, A->lanes, st, ws->pev.data(), dist);
+            int rcp = launch_cycle(d, A->lanes, st, ws->pev.data(), ws, dist != nullptr);
             if (rcp) return rcp;
             NPG_HIP(hipMemcpyAsync(ws->h_C, ws->C, sizeof(Snap), hipMemcpyDeviceToHost, st));
             NPG_HIP(hipStreamSynchronize(st));
