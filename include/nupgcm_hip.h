@@ -97,6 +97,13 @@ int npg_csr_zero_values(npg_csr *A);
 /* out = a*X + b*(Y + Z) on identical patterns: `A = M + theta*(Kh + Kv)` (src/evolution.jl:144,162; src/model.jl:254)
  * done on the device instead of a host SparseMatrixCSC add + re-upload */
 int npg_csr_combine(npg_csr *out, double a, const npg_csr *X, double b, const npg_csr *Y, const npg_csr *Z);
+/* Store the (x, y) velocity block [K -C; C K] of rows/columns 0 .. 2*npairs-1 ONCE: with constant viscosity the rows 2q and
+ * 2q+1 of A_inversion (the two horizontal components of one node - the ordering of nupgcm_amd.fe interleaves them) hold the
+ * same friction entry K and the Coriolis entries +-C at columns 2c, 2c+1 (src/inversion.jl:183-192).  Four 12-byte CSR
+ * entries and four 8-byte gathers become one 20-byte record and one 16-byte gather.  The structure is verified entry by
+ * entry (relative tolerance rtol); *paired = 0 and the matrix is untouched if it does not hold (e.g. function-valued nu).
+ * A paired matrix can be multiplied and solved with, but not downloaded, cloned or re-assembled. */
+int npg_csr_pair_xy(npg_csr *A, int64_t npairs, double rtol, int *paired);
 /* d[i] = 1 / A[i,i]   -- `Diagonal(1 ./ diag(A))` (src/evolution.jl:149,167; src/model.jl:256) */
 int npg_csr_inv_diag(const npg_csr *A, npg_vec *d);
 /* y = alpha * A x + beta * y   -- mul!(y, A, x) / A*x  (cuSPARSE SpMV in the reference) */

@@ -283,6 +283,14 @@ class DeviceCSR:
         L.check(L.lib().npg_csr_download(self.h, L.ptr(rp), L.ptr(ci), L.ptr(v)))
         return sp.csr_matrix((v, ci, rp), shape=(m, n))
 
+    def pair_xy(self, npairs, rtol=1e-12):
+        """store the [K -C; C K] block of the first 2*npairs rows/columns once (npg_csr_pair_xy); returns True if the
+        structure held and the matrix is now paired"""
+        flag = C.c_int()
+        L.check(L.lib().npg_csr_pair_xy(self.h, int(npairs), float(rtol), C.byref(flag)))
+        self.paired = bool(flag.value)
+        return self.paired
+
     def mul(self, x: DeviceVector, y: DeviceVector = None, alpha=1.0, beta=0.0):
         """mul!(y, A, x) / A*x"""
         if y is None:

@@ -62,8 +62,7 @@ class DeviceFE:
             fd = self.fe_data
             rp, ci, shape = {"A": fd.pattern_A, "B": fd.pattern_B}[kind](structural) if kind != "b" else fd.pattern_b()
             self._patterns[key] = DeviceCSR.from_pattern(self.ctx, shape[0], shape[1], rp, ci)
-            return self._patterns[key]
-        return self._patterns[key].clone()
+        return self._patterns[key].clone()       # the cached matrix only ever serves as the pattern owner
 
     def assemble(self, which, A: DeviceCSR, scale=1.0, full_stress=False, lift: DeviceVector = None):
         L.check(L.lib().npg_fe_assemble_matrix(self.h, which, float(scale), int(bool(full_stress)), A.h,

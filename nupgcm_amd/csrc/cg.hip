@@ -28,11 +28,8 @@ struct CParams {
 };
 
 struct CDev {
-    const int64_t *rowptr;
-    const int32_t *col;
-    const double *val;
+    CsrDev A;
     const int32_t *tile_ptr;
-    int64_t nnz;
     int ntiles, n;
     int pkind;
     double pscalar;
@@ -75,7 +72,7 @@ __global__ void __launch_bounds__(kKB) k_cg_init(CDev d) {
     double acc[1] = {0.0};
     for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
         const int r0 = d.tile_ptr[t], r1 = d.tile_ptr[t + 1];
-        spmv_tile<kKB, L>(d.rowptr, d.col, d.val, d.nnz, PlainX{d.x}, r0, r1, tl, sw);
+        spmv_tile<kKB, L>(d.A, PlainX{d.x}, r0, r1, tl, sw);
         if ((int)threadIdx.x < r1 - r0) {
             const int row = r0 + threadIdx.x;
             const double r = d.b[row] - sw[threadIdx.x];
@@ -137,7 +134,7 @@ __global__ void __launch_bounds__(kKB) k_cg_spmv(CDev d, int slot) {
     double acc[1] = {0.0};
     for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
         const int r0 = d.tile_ptr[t], r1 = d.tile_ptr[t + 1];
-        spmv_tile<kKB, L>(d.rowptr, d.col, d.val, d.nnz, PlainX{d.p}, r0, r1, tl, sw);
+        spmv_tile<kKB, L>(d.A, PlainX{d.p}, r0, r1, tl, sw);
         if ((int)threadIdx.x < r1 - r0) {
             const int row = r0 + threadIdx.x;
             const double ap = sw[threadIdx.x];
@@ -307,11 +304,8 @@ NPG_API int npg_cg_solve(npg_cg *ws, const npg_csr *A, int precond_kind, double 
     npg_ctx *ctx = ws->ctx;
     CDev d;
     memset(&d, 0, sizeof d);
-    d.rowptr = A->rowptr;
-    d.col = A->col;
-    d.val = A->val;
+    d.A = csr_view(A);
     d.tile_ptr = A->tile_ptr;
-    d.nnz = A->nnz;
     d.ntiles = A->ntiles;
     d.n = (int)ws->n;
     d.pkind = precond_kind;

@@ -79,6 +79,14 @@ struct npg_csr {
     int32_t ntiles = 0;
     int32_t lanes = 16;          // lanes per row chosen from the mean row length
     std::vector<int64_t> h_rowptr;
+    // xy-paired part (npg_csr_pair_xy): rows 2q, 2q+1 for q < npairs keep only their non-paired entries in rowptr/col/val;
+    // `nnz` stays the LOGICAL entry count of the matrix, `rnnz` counts what is left in col/val
+    int64_t rnnz = 0;
+    int32_t npairs = 0;
+    int64_t *prow = nullptr;     // device, npairs + 1
+    int32_t *pcol = nullptr;     // device
+    double *pkc = nullptr;       // device, {K, C} per paired entry
+    std::vector<int64_t> h_prow;
 };
 
 // interface exchange plan of a row-block distributed vector [owned | ghosts] (comm.hip)
@@ -98,6 +106,8 @@ int halo_exchange_raw(npg_halo *h, double *x);
 int allreduce_sum_device(npg_ctx *ctx, double *buf, int n);
 int ensure_stage(npg_ctx *ctx, size_t doubles);
 int build_tiles(npg_csr *A);
+struct CsrDev;
+CsrDev csr_view(const npg_csr *A);
 // reductions that return a scalar to the host (synchronous)
 int reduce_dot(npg_ctx *ctx, const double *x, const double *y, int64_t n, double *out);
 int reduce_maxabs(npg_ctx *ctx, const double *x, int64_t n, double *out, int *has_nan);

@@ -9,21 +9,33 @@ namespace npg {
 // Row tiles for the CSR-stream kernels: consecutive whole rows, at most kTileNnz stored entries and kTileRows rows per
 // tile; small matrices get about one tile per CU.  A row longer than kTileNnz becomes a tile of its own.
 int build_tiles(npg_csr *A) {
-    const int64_t m = A->m, nnz = A->nnz;
+    const int64_t m = A->m;
     const int64_t *rp = A->h_rowptr.data();
-    int64_t target = nnz / (int64_t)A->ctx->num_cu;
+    const int64_t *pp = A->npairs ? A->h_prow.data() : nullptr;
+    const int64_t np2 = 2 * (int64_t)A->npairs;
+    const int64_t slots_total = rp[m] + (pp ? 2 * pp[A->npairs] : 0);      // LDS product slots of the whole matrix
+    int64_t target = slots_total / (int64_t)A->ctx->num_cu;
     target = std::max<int64_t>(1024, std::min<int64_t>(kTileNnz, target));   // >= 1 tile per CU on small matrices
+    // product slots rows [a, b) need: their CSR entries + two per paired entry (a, b even inside the paired region)
+    auto slots = [&](int64_t a, int64_t b) {
+        int64_t s = rp[b] - rp[a];
+        if (pp && a < np2) s += 2 * (pp[b >> 1] - pp[a >> 1]);
+        return s;
+    };
     std::vector<int32_t> tp;
     tp.push_back(0);
     int64_t r = 0;
     while (r < m) {
-        int64_t r1 = r + 1;
-        while (r1 < m && r1 - r < kTileRows && rp[r1 + 1] - rp[r] <= target) ++r1;
+        const bool inpair = r < np2;
+        const int64_t step = inpair ? 2 : 1, lim = inpair ? np2 : m;
+        int64_t r1 = r + step;
+        while (r1 < lim && r1 - r < kTileRows && slots(r, r1 + step) <= target) r1 += step;
+        NPG_REQUIRE(!inpair || slots(r, r1) <= kTileNnz, "build_tiles: a paired row pair does not fit one tile");
         tp.push_back((int32_t)r1);
         r = r1;
     }
     A->ntiles = (int32_t)tp.size() - 1;
-    const double mean = m > 0 ? (double)nnz / (double)m : 0.0;
+    const double mean = m > 0 ? (double)A->nnz / (double)m : 0.0;
     A->lanes = mean <= 6 ? 4 : mean <= 24 ? 8 : mean <= 96 ? 16 : 32;
     if (A->tile_ptr) NPG_HIP(hipFree(A->tile_ptr));
     NPG_HIP(hipMalloc((void **)&A->tile_ptr, tp.size() * sizeof(int32_t)));
@@ -34,16 +46,14 @@ int build_tiles(npg_csr *A) {
 constexpr int kSpmvThreads = 512;
 
 template <int L>
-__global__ void __launch_bounds__(kSpmvThreads) k_spmv(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                        const double *__restrict__ val,
-                                                        const int32_t *__restrict__ tile_ptr, int ntiles, int64_t nnz,
+__global__ void __launch_bounds__(kSpmvThreads) k_spmv(CsrDev A, const int32_t *__restrict__ tile_ptr, int ntiles,
                                                         const double *__restrict__ x, double *__restrict__ y,
                                                         double alpha, double beta) {
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int r0 = tile_ptr[t], r1 = tile_ptr[t + 1];
-        spmv_tile<kSpmvThreads, L>(rowptr, col, val, nnz, PlainX{x}, r0, r1, tl, sw);
+        spmv_tile<kSpmvThreads, L>(A, PlainX{x}, r0, r1, tl, sw);
         for (int r = threadIdx.x; r < r1 - r0; r += kSpmvThreads) {
             const int row = r0 + r;
             y[row] = (beta == 0.0) ? alpha * sw[r] : alpha * sw[r] + beta * y[row];
@@ -73,6 +83,7 @@ static int upload_csr(npg_ctx *ctx, int64_t m, int64_t n, std::vector<int64_t> &
     A->m = m;
     A->n = n;
     A->nnz = (int64_t)col.size();
+    A->rnnz = A->nnz;
     NPG_HIP(hipSetDevice(ctx->device));
     NPG_HIP(hipMalloc((void **)&A->rowptr, (size_t)(m + 1) * sizeof(int64_t)));
     NPG_HIP(hipMalloc((void **)&A->col, std::max<size_t>(1, col.size()) * sizeof(int32_t)));
@@ -92,13 +103,125 @@ static int upload_csr(npg_ctx *ctx, int64_t m, int64_t n, std::vector<int64_t> &
 template <int L>
 static void launch_spmv(const npg_csr *A, const double *x, double *y, double alpha, double beta) {
     const int grid = std::min<int>(A->ntiles, 3 * A->ctx->num_cu);      // 3 x 38 KiB of LDS per CU
-    hipLaunchKernelGGL(k_spmv<L>, dim3(std::max(grid, 1)), dim3(kSpmvThreads), 0, A->ctx->stream, A->rowptr, A->col,
-                       A->val, A->tile_ptr, A->ntiles, A->nnz, x, y, alpha, beta);
+    hipLaunchKernelGGL(k_spmv<L>, dim3(std::max(grid, 1)), dim3(kSpmvThreads), 0, A->ctx->stream, csr_view(A),
+                       A->tile_ptr, A->ntiles, x, y, alpha, beta);
+}
+
+CsrDev csr_view(const npg_csr *A) {
+    CsrDev v;
+    v.rowptr = A->rowptr;
+    v.col = A->col;
+    v.val = A->val;
+    v.nnz = A->rnnz;
+    v.prow = A->prow;
+    v.pcol = A->pcol;
+    v.pkc = reinterpret_cast<const double2 *>(A->pkc);
+    v.npairs = A->npairs;
+    return v;
 }
 
 }  // namespace npg
 
 using namespace npg;
+
+// Store the (x, y) velocity block [K -C; C K] of rows/columns 0 .. 2*npairs once (see spmv_device.h).  Verifies the
+// structure entry by entry on the host (|K_xx - K_yy|, |C_xy + C_yx| <= rtol * row scale); if anything does not match the
+// matrix is left untouched and *paired = 0.
+NPG_API int npg_csr_pair_xy(npg_csr *A, int64_t npairs, double rtol, int *paired) {
+    NPG_REQUIRE(A && paired && npairs >= 0 && 2 * npairs <= A->m && 2 * npairs <= A->n, "npg_csr_pair_xy: bad argument");
+    NPG_REQUIRE(A->npairs == 0, "npg_csr_pair_xy: matrix is already paired");
+    *paired = 0;
+    if (npairs == 0) return NPG_OK;
+    NPG_HIP(hipStreamSynchronize(A->ctx->stream));
+    std::vector<int32_t> col((size_t)A->nnz);
+    std::vector<double> val((size_t)A->nnz);
+    NPG_HIP(hipMemcpy(col.data(), A->col, col.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    NPG_HIP(hipMemcpy(val.data(), A->val, val.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const std::vector<int64_t> &rp = A->h_rowptr;
+    const int64_t np2 = 2 * npairs;
+    std::vector<int64_t> prow((size_t)npairs + 1, 0), nrp((size_t)A->m + 1, 0);
+    std::vector<int32_t> pcol, ncol;
+    std::vector<double> pkc, nval;
+    pcol.reserve((size_t)A->nnz / 6);
+    pkc.reserve((size_t)A->nnz / 3);
+    ncol.reserve((size_t)A->nnz);
+    nval.reserve((size_t)A->nnz);
+    for (int64_t q = 0; q < npairs; ++q) {
+        const int64_t a0 = rp[2 * q], a1 = rp[2 * q + 1], b0 = a1, b1 = rp[2 * q + 2];
+        // entries with column < 2*npairs come first in a sorted row
+        int64_t ia = a0, ib = b0;
+        double scale = 0.0;
+        for (int64_t k = a0; k < a1 && col[k] < np2; ++k) scale = std::max(scale, std::fabs(val[k]));
+        while (ia < a1 && col[ia] < np2) {
+            // row 2q: (2c, K) (2c+1, C) ; row 2q+1: (2c, -C) (2c+1, K)
+            if (ia + 1 >= a1 || ib + 1 >= b1) return NPG_OK;
+            const int32_t c0 = col[ia];
+            if ((c0 & 1) || col[ia + 1] != c0 + 1 || col[ib] != c0 || col[ib + 1] != c0 + 1) return NPG_OK;
+            const double K = val[ia], Cc = val[ia + 1];
+            if (std::fabs(val[ib + 1] - K) > rtol * scale || std::fabs(val[ib] + Cc) > rtol * scale) return NPG_OK;
+            pcol.push_back(c0 >> 1);
+            pkc.push_back(K);
+            pkc.push_back(Cc);
+            ia += 2;
+            ib += 2;
+        }
+        if (ib < b1 && col[ib] < np2) return NPG_OK;     // row 2q+1 has extra entries in the paired block
+        prow[q + 1] = (int64_t)pcol.size();
+        for (int64_t k = ia; k < a1; ++k) {
+            ncol.push_back(col[k]);
+            nval.push_back(val[k]);
+        }
+        nrp[2 * q + 1] = (int64_t)ncol.size();
+        for (int64_t k = ib; k < b1; ++k) {
+            ncol.push_back(col[k]);
+            nval.push_back(val[k]);
+        }
+        nrp[2 * q + 2] = (int64_t)ncol.size();
+    }
+    for (int64_t r = np2; r < A->m; ++r) {
+        for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
+            ncol.push_back(col[k]);
+            nval.push_back(val[k]);
+        }
+        nrp[r + 1] = (int64_t)ncol.size();
+    }
+    // swap the device arrays; a clone shares rowptr / col / tiles with its pattern owner and must detach from them
+    if (A->owns_pattern) {
+        NPG_HIP(hipFree(A->col));
+        NPG_HIP(hipFree(A->rowptr));
+        if (A->tile_ptr) NPG_HIP(hipFree(A->tile_ptr));
+    }
+    NPG_HIP(hipFree(A->val));
+    A->col = nullptr;
+    A->val = nullptr;
+    A->rowptr = nullptr;
+    A->tile_ptr = nullptr;
+    A->owns_pattern = true;
+    NPG_HIP(hipMalloc((void **)&A->rowptr, nrp.size() * sizeof(int64_t)));
+    NPG_HIP(hipMalloc((void **)&A->col, std::max<size_t>(1, ncol.size()) * sizeof(int32_t)));
+    NPG_HIP(hipMalloc((void **)&A->val, std::max<size_t>(1, nval.size()) * sizeof(double)));
+    NPG_HIP(hipMalloc((void **)&A->prow, prow.size() * sizeof(int64_t)));
+    NPG_HIP(hipMalloc((void **)&A->pcol, std::max<size_t>(1, pcol.size()) * sizeof(int32_t)));
+    NPG_HIP(hipMalloc((void **)&A->pkc, std::max<size_t>(2, pkc.size()) * sizeof(double)));
+    NPG_HIP(hipMemcpy(A->rowptr, nrp.data(), nrp.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (!ncol.empty()) {
+        NPG_HIP(hipMemcpy(A->col, ncol.data(), ncol.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        NPG_HIP(hipMemcpy(A->val, nval.data(), nval.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    NPG_HIP(hipMemcpy(A->prow, prow.data(), prow.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (!pcol.empty()) {
+        NPG_HIP(hipMemcpy(A->pcol, pcol.data(), pcol.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        NPG_HIP(hipMemcpy(A->pkc, pkc.data(), pkc.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    A->h_rowptr = std::move(nrp);
+    A->h_prow = std::move(prow);
+    A->rnnz = (int64_t)ncol.size();
+    A->npairs = (int32_t)npairs;
+    int rc = build_tiles(A);
+    if (rc) return rc;
+    *paired = 1;
+    return NPG_OK;
+}
 
 NPG_API int npg_csr_create_from_csc(npg_ctx *ctx, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval,
                                     const double *nzval, int drop_zeros, npg_csr **out) {
@@ -156,6 +279,9 @@ NPG_API int npg_csr_destroy(npg_csr *A) {
         if (A->tile_ptr) hipFree(A->tile_ptr);
     }
     if (A->val) hipFree(A->val);
+    if (A->prow) hipFree(A->prow);
+    if (A->pcol) hipFree(A->pcol);
+    if (A->pkc) hipFree(A->pkc);
     delete A;
     return NPG_OK;
 }
@@ -170,6 +296,7 @@ NPG_API int npg_csr_shape(const npg_csr *A, int64_t *m, int64_t *n, int64_t *nnz
 
 NPG_API int npg_csr_download(const npg_csr *A, int64_t *rowptr, int32_t *colind, double *val) {
     NPG_REQUIRE(A, "npg_csr_download: NULL matrix");
+    NPG_REQUIRE(A->npairs == 0, "npg_csr_download: the matrix is stored xy-paired; download it before npg_csr_pair_xy");
     NPG_HIP(hipStreamSynchronize(A->ctx->stream));
     if (rowptr) std::copy(A->h_rowptr.begin(), A->h_rowptr.end(), rowptr);
     if (colind && A->nnz) NPG_HIP(hipMemcpy(colind, A->col, (size_t)A->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -198,11 +325,13 @@ NPG_API int npg_csr_to_csc(const npg_csr *A, int64_t *colptr, int64_t *rowval, d
 
 NPG_API int npg_csr_clone(const npg_csr *A, npg_csr **out) {
     NPG_REQUIRE(A && out, "npg_csr_clone: NULL argument");
+    NPG_REQUIRE(A->npairs == 0, "npg_csr_clone: the matrix is stored xy-paired");
     npg_csr *B = new npg_csr();
     B->ctx = A->ctx;
     B->m = A->m;
     B->n = A->n;
     B->nnz = A->nnz;
+    B->rnnz = A->rnnz;
     B->rowptr = A->rowptr;        // pattern is shared; the original must outlive the clone
     B->col = A->col;
     B->tile_ptr = A->tile_ptr;

@@ -59,11 +59,8 @@ struct GParams {
 };
 
 struct GDev {
-    const int64_t *rowptr;
-    const int32_t *col;
-    const double *val;
+    CsrDev A;
     const int32_t *tile_ptr;
-    int64_t nnz;
     int ntiles, n, mem;
     int pkind;
     double pscalar;
@@ -223,6 +220,7 @@ struct CorrectedX {
         for (int k = 0; k < nb; ++k) v -= h2[k] * Vi[vidx(c, k, n)];
         return v;
     }
+    __device__ __forceinline__ double2 pair(int c) const { return make_double2((*this)(2 * c), (*this)(2 * c + 1)); }
 };
 
 // ---- R1: wt = P (b - A x), partial ||wt||^2 ---------------------------------------------------------------------------
@@ -236,7 +234,7 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_residual(GDev d) {
     if (c.done == 0) {
         for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
             const int r0 = d.tile_ptr[t], r1 = d.tile_ptr[t + 1];
-            spmv_tile<kKB, L>(d.rowptr, d.col, d.val, d.nnz, PlainX{d.x}, r0, r1, tl, sw);
+            spmv_tile<kKB, L>(d.A, PlainX{d.x}, r0, r1, tl, sw);
             const int r = threadIdx.x;
             if (r < r1 - r0) {
                 const int row = r0 + r;
@@ -297,9 +295,9 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_arnoldi(GDev d, int j) {
     for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
         const int r0 = d.tile_ptr[t], r1 = d.tile_ptr[t + 1];
         if (!ro)
-            spmv_tile<kKB, L>(d.rowptr, d.col, d.val, d.nnz, PlainX{d.wt}, r0, r1, tl, sw);
+            spmv_tile<kKB, L>(d.A, PlainX{d.wt}, r0, r1, tl, sw);
         else
-            spmv_tile<kKB, L>(d.rowptr, d.col, d.val, d.nnz, CorrectedX{d.wt, d.Vi, sh.h2, j, d.n}, r0, r1, tl, sw);
+            spmv_tile<kKB, L>(d.A, CorrectedX{d.wt, d.Vi, sh.h2, j, d.n}, r0, r1, tl, sw);
         const int nr = r1 - r0;
         if (!FUSED) {
             // split mode (large systems): only what depends on the SpMV result; the dots stream in k_gmres_dots
@@ -779,11 +777,8 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
 
     GDev d;
     memset(&d, 0, sizeof d);
-    d.rowptr = A->rowptr;
-    d.col = A->col;
-    d.val = A->val;
+    d.A = csr_view(A);
     d.tile_ptr = A->tile_ptr;
-    d.nnz = A->nnz;
     d.ntiles = A->ntiles;
     d.n = (int)ws->n;
     d.mem = ws->mem;

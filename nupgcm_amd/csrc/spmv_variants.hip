@@ -16,9 +16,10 @@ __global__ void __launch_bounds__(NT) k_spmv_var(const int64_t *__restrict__ row
                                                  double *__restrict__ y) {
     __shared__ TileLdsT<TNNZ> tl;
     __shared__ double sw[kTileRows];
+    const CsrDev A{rowptr, col, val, nnz, nullptr, nullptr, nullptr, 0};
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int r0 = tile_ptr[t], r1 = tile_ptr[t + 1];
-        spmv_tile<NT, L, PlainX, TNNZ, U>(rowptr, col, val, nnz, PlainX{x}, r0, r1, tl, sw);
+        spmv_tile<NT, L, PlainX, TNNZ, U>(A, PlainX{x}, r0, r1, tl, sw);
         for (int r = threadIdx.x; r < r1 - r0; r += NT) y[r0 + r] = sw[r];
     }
 }
@@ -175,6 +176,7 @@ using namespace npg;
 NPG_API int npg_spmv_variant(const npg_csr *A, const npg_vec *x, npg_vec *y, int variant, int blocks_per_cu, int reps,
                              double *ms) {
     NPG_REQUIRE(A && x && y && ms && x->n == A->n && y->n == A->m && reps > 0, "npg_spmv_variant: bad argument");
+    NPG_REQUIRE(A->npairs == 0, "npg_spmv_variant: plain CSR matrices only");
     switch (variant) {
         case 0: return run_var<512, 4096, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 1: return run_var<512, 4096, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);

@@ -354,3 +354,36 @@ def test_distributed_path_single_rank(arch):
         assert rel(m.state.b, ref.state.b) < 1e-10 and rel(m.state.u, ref.state.u) < 1e-5
     finally:
         dist.destroy_process_group()
+
+
+def test_xy_paired_storage(arch):
+    """npg_csr_pair_xy: the [K -C; C K] block stored once gives the same SpMV and the same GMRES solve; matrices without
+    the structure are left alone."""
+    fed, prm, frc, dt, b0 = build_fe_data("bowl_mixing")
+    d = fed.dofs
+    assert d.n_pairs == 5412
+    A = npg.build_A_inversion(arch, fed, prm, 1.0)
+    ref = A.to_scipy_csr()
+    x = np.sin(np.arange(ref.shape[1], dtype=float))
+    y0 = A.mul(npg.on_architecture(arch, x)).to_host()
+    nnz0 = A.nnz
+    assert A.pair_xy(d.n_pairs)
+    assert A.nnz == nnz0                                       # logical size unchanged
+    y1 = A.mul(npg.on_architecture(arch, x)).to_host()
+    assert rel(y1, ref @ x) < 1e-13 and rel(y1, y0) < 1e-13
+    with pytest.raises(L.DeviceError):
+        A.to_scipy_csr()
+    # solve with the paired matrix
+    h = fed.mesh.median_edge_length()
+    rhs = npg.on_architecture(arch, ref @ np.cos(np.arange(ref.shape[1], dtype=float)) * 1e-3)
+    ws = npg.GmresWorkspace(arch.ctx, ref.shape[0])
+    st = ws.solve(A, rhs, ws.x, npg.Diagonal(scalar=1 / h ** 3))
+    A2 = npg.build_A_inversion(arch, fed, prm, 1.0)
+    ws2 = npg.GmresWorkspace(arch.ctx, ref.shape[0])
+    st2 = ws2.solve(A2, rhs, ws2.x, npg.Diagonal(scalar=1 / h ** 3))
+    assert st["solved"] == st2["solved"] == 1 and abs(st["niter"] - st2["niter"]) <= 0.02 * st2["niter"]
+    assert rel(ws.x.to_host(), ws2.x.to_host()) < 1e-4
+    # a matrix without the structure (the evolution mass matrix) is refused, not damaged
+    M = npg.on_architecture(arch, rc.setup("bowl_mixing").M)
+    assert not M.pair_xy(10)
+    assert M.to_scipy_csr().nnz == M.nnz
