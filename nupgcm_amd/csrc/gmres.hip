@@ -250,8 +250,9 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_residual(GDev d) {
 }
 
 // ---- K1 ---------------------------------------------------------------------------------------------------------------
+// (the fused form serves small, latency-bound systems: it may take 128 registers, two workgroups per CU)
 template <int L, bool FUSED>
-__global__ void __launch_bounds__(kKB, 6) k_gmres_arnoldi(GDev d, int j) {
+__global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, int j) {
     __shared__ KShared sh;
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
@@ -524,9 +525,8 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_update(GDev d) {
         }
         if (lane < kKP) sh.y[lane] = (lane < kk) ? y : 0.0;
         if (blockIdx.x == 0 && lane == 0) {
-            Snap c = T;
-            c.inner = 0;
-            *d.C = c;
+            *d.C = sh.T;            // (no local Snap copy: it would live in scratch)
+            d.C->inner = 0;
         }
     }
     __syncthreads();

@@ -288,13 +288,24 @@ class Oracle:
         self.n2 = self.cn2.shape[1]
 
     # -- inversion ------------------------------------------------------------------------------------------------
-    def A_inversion(self):
-        """src/inversion.jl:133-147,183-192 (constant nu: Laplacian form).  N x N CSR, structural zeros stored."""
+    def A_inversion(self, nu_q=None):
+        """src/inversion.jl:133-147,183-192.  Constant nu (nu_q None): Laplacian form, pinned by fixtures K1/K2.
+        nu_q = table (nc, nq) of a function-valued viscosity: full-stress form 2 a2e2 nu sigma(u):sigma(v)
+        (src/inversion.jl:172-181; NOT pinned by any fixture - restated from the source).  N x N CSR, structural zeros
+        stored."""
         s, t = self.sp, self.topo
         nc, n2, n1 = len(t.cells), self.n2, t.dim + 1
-        a2e2nu = self.alpha ** 2 * self.eps ** 2 * float(self.nu)
         fq = _const_or_fn(self.f, self.geo.xq)                                          # (nc, nq)
-        Kloc = a2e2nu * np.einsum("cq,cqia,cqja->cij", self.wdet, self.gradN2, self.gradN2)
+        if nu_q is None:
+            a2e2nu = self.alpha ** 2 * self.eps ** 2 * float(self.nu)
+            Kloc = a2e2nu * np.einsum("cq,cqia,cqja->cij", self.wdet, self.gradN2, self.gradN2)
+            Sloc = None
+        else:
+            a2e2 = self.alpha ** 2 * self.eps ** 2
+            wn = self.wdet * nu_q
+            Kloc = a2e2 * np.einsum("cq,cqia,cqja->cij", wn, self.gradN2, self.gradN2)
+            # [(i,a),(j,c)] += a2e2 int nu d_c phi_i d_a phi_j
+            Sloc = a2e2 * np.einsum("eq,eqic,eqja->eacij", wn, self.gradN2, self.gradN2)
         Cloc = np.einsum("cq,cq,qi,qj->cij", self.wdet, fq, self.N2q, self.N2q)        # int f phi_i phi_j
         Dloc = np.einsum("cq,cqia,qj->caij", self.wdet, self.gradN2, self.N1q)         # int d_a phi_i psi_j
         udof = s.u_dof[self.cn2]                                                        # (nc, n2, 3)
@@ -311,6 +322,8 @@ class Oracle:
                     v = Cloc
                 else:
                     v = zero
+                if Sloc is not None:
+                    v = v + Sloc[:, a, c]
                 rows.append(np.broadcast_to(udof[:, :, None, a], (nc, n2, n2)).ravel())
                 cols.append(np.broadcast_to(udof[:, None, :, c], (nc, n2, n2)).ravel())
                 vals.append(v.ravel())

@@ -134,8 +134,15 @@ def rcm_perms(sysm: System):
     return np.concatenate([p_u, s.nu + p_p]), p_b
 
 
+def cfl_dt(orc, u_free, cfl_factor, u_min=0.01):
+    """update_dt! (src/timesteppers.jl:108-119): CFL_factor * min_K h_K / max(max_q |u|, u_min)"""
+    un = orc.u_nodal(u_free)[orc.cn2]
+    speed = np.linalg.norm(np.einsum("qi,cia->cqa", orc.N2q, un), axis=-1).max(axis=1)
+    return cfl_factor * float((orc.h_cells() / np.maximum(speed, u_min)).min())
+
+
 def run(sysm: System, nsteps, solver="direct", first_step_lhs="bdf1", invert_first=False, scheme="BDF2",
-        krylov_kw=None, record=None, timer=None):
+        krylov_kw=None, record=None, timer=None, cfl_factor=None, adaptive=False):
     """Returns (u, p, b) free values in native order after `nsteps` steps from the configuration's initial condition.
     timer: optional dict; receives 'loop_seconds' = wall time of the step loop only (factorisations excluded, as the
     reference's CPU() path factorises at set-up time, src/inversion.jl:58, src/evolution.jl:152)."""
@@ -183,6 +190,12 @@ def run(sysm: System, nsteps, solver="direct", first_step_lhs="bdf1", invert_fir
         lhs(sysm.theta(scheme))
     _t0 = _time.perf_counter()
     for i in range(1, nsteps + 1):
+        if scheme == "BDF1" and cfl_factor is not None:
+            # the reference updates dt on EVERY BDF1 step (src/model.jl:131) but rebuilds the LHS only when the
+            # timestepper is adaptive (src/model.jl:251-261)
+            sysm.dt = cfl_dt(orc, u, cfl_factor)
+            if adaptive:
+                lhs_cache.clear()
         theta_rhs = sysm.theta(scheme)
         if scheme == "BDF2" and i == 1 and first_step_lhs == "bdf1":
             theta_lhs = sysm.theta("BDF1")          # src/evolution.jl:110-111 + src/model.jl:134-137

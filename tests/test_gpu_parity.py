@@ -284,6 +284,56 @@ def test_cfl_and_closures(arch, diri):
     assert abs(got - (S.orc.h_cells() / np.maximum(sq, 0.01)).min()) < 1e-13 * got
 
 
+def _alpha_bz(S, b_free, alpha, N2):
+    """alpha d_z(N2 z + b) at the quadrature points, (nc, nq) - the argument of both closures (src/model.jl:204-207)"""
+    bn = S.orc.b_nodal(b_free)[S.orc.cn2]
+    return alpha * (N2 + np.einsum("cqi,ci->cq", S.orc.gradN2[..., 2], bn))
+
+
+def test_convection_closure(arch, diri):
+    """kappa_v_convection (src/inputs.jl:87-91) evaluated per quadrature point on the device, checked through the K_v it
+    produces (src/evolution.jl:167-180)."""
+    fed, prm, S, fe = diri
+    d, ctx = fed.dofs, arch.ctx
+    kv0 = lambda x: 1.0 + 0.3 * x[..., 0] + np.exp(x[..., 2])
+    b = 0.3 * np.random.default_rng(11).standard_normal(d.nb)
+    kc, N2min, N2 = 7.0, 0.05, 0.4
+    fe.set_coeff("kappa_v", kv0)
+    fe.update_kappa_convection(kc, N2min, prm.alpha, N2, npg.DeviceVector.from_host(ctx, b, d.p_b))
+    abz = _alpha_bz(S, b, prm.alpha, N2)
+    kq = kv0(S.orc.geo.xq) + kc * (1 + np.tanh(-abz / N2min)) / 2
+    assert kq.max() > 1.5 * kv0(S.orc.geo.xq).max()                  # the closure is active somewhere
+    Ao, lo = S.orc.K_v(kappa=lambda x: kq)
+    lift = npg.DeviceVector(ctx, d.nb)
+    A = fe.assemble(L.NPG_MAT_KV, fe.new_matrix("b"), lift=lift).to_scipy_csr()
+    ref = _perm(Ao, d.p_b, d.p_b)
+    assert abs(A - ref).max() <= 1e-12 * abs(ref).max()
+    assert rel(lift.to_host(), lo[d.p_b]) < 1e-11
+    fe.set_coeff("kappa_v", kv0)                                     # leave the shared engine as the fixture set it
+
+
+def test_eddy_closure_full_stress(arch, diri):
+    """nu_eddy (src/inputs.jl:130-137) + the full-stress A_inversion it requires (src/inversion.jl:172-181)."""
+    fed, prm, S, fe = diri
+    d, ctx = fed.dofs, arch.ctx
+    b = 0.3 * np.random.default_rng(12).standard_normal(d.nb)
+    N2min, N2, sm, numin = 0.2, 0.4, 10.0, 1.0
+    fe.set_coeff("f", prm.f)
+    fe.update_nu_eddy(N2min, prm.alpha, N2, npg.DeviceVector.from_host(ctx, b, d.p_b), smoothing=sm, nu_min=numin)
+    abz = _alpha_bz(S, b, prm.alpha, N2)
+    f = prm.f(S.orc.geo.xq)
+    nu = f * (f / np.sqrt(N2min ** 2 + abz ** 2))
+    nuq = np.logaddexp(sm * numin, sm * nu) / sm
+    A = npg.build_A_inversion(arch, fed, prm, None).to_scipy_csr()   # nu None: use the device table just computed
+    ref = _perm(S.orc.A_inversion(nu_q=nuq), d.p_inversion, d.p_inversion)
+    assert abs(A - ref).max() <= 1e-12 * abs(ref).max()
+    # a function-valued nu goes through the same full-stress kernel
+    nuf = lambda x: 1.0 + 0.5 * x[..., 2] ** 2
+    A = npg.build_A_inversion(arch, fed, prm, nuf).to_scipy_csr()
+    ref = _perm(S.orc.A_inversion(nu_q=nuf(S.orc.geo.xq)), d.p_inversion, d.p_inversion)
+    assert abs(A - ref).max() <= 1e-12 * abs(ref).max()
+
+
 # ---- the timestep loop --------------------------------------------------------------------------------------------------
 def test_state_roundtrip_and_invert(arch, flux, golden_dir):
     """configs[1]: inversion-only loop on bowl3D h=0.1 - set b, invert!, read the flow back (src/model.jl:302-317)."""
@@ -387,3 +437,19 @@ def test_xy_paired_storage(arch):
     M = npg.on_architecture(arch, rc.setup("bowl_mixing").M)
     assert not M.pair_xy(10)
     assert M.to_scipy_csr().nnz == M.nnz
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_bdf1_cfl_steps_against_oracle(arch, adaptive):
+    """BDF1: dt follows the CFL condition on every step (src/model.jl:131, src/timesteppers.jl:108-119) while the LHS is
+    rebuilt only for an adaptive timestepper (src/model.jl:251-261) - both reproduced against the oracle."""
+    m = build_model("bowl_surface_flux", scheme="BDF1")
+    m.timestepper.adaptive = adaptive
+    m.timestepper.CFL_factor = 0.5
+    m.timestepper.t_stop = 1e9
+    S = rc.setup("bowl_surface_flux")
+    u, p, b = rc.run(S, 4, solver="direct", scheme="BDF1", cfl_factor=0.5, adaptive=adaptive)
+    npg.run(m, n_steps=4)
+    assert abs(m.timestepper.dt - S.dt) < 1e-4 * S.dt
+    assert rel(m.state.b, b) < 3e-4
+    assert rel(m.state.u, u) < 5e-3
