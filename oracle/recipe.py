@@ -188,6 +188,7 @@ def run(sysm: System, nsteps, solver="direct", first_step_lhs="bdf1", invert_fir
     if solver == "direct":
         lhs(sysm.theta("BDF1" if (scheme == "BDF2" and first_step_lhs == "bdf1") else scheme))
         lhs(sysm.theta(scheme))
+    theta0 = sysm.theta(scheme)
     _t0 = _time.perf_counter()
     for i in range(1, nsteps + 1):
         if scheme == "BDF1" and cfl_factor is not None:
@@ -199,6 +200,8 @@ def run(sysm: System, nsteps, solver="direct", first_step_lhs="bdf1", invert_fir
         theta_rhs = sysm.theta(scheme)
         if scheme == "BDF2" and i == 1 and first_step_lhs == "bdf1":
             theta_lhs = sysm.theta("BDF1")          # src/evolution.jl:110-111 + src/model.jl:134-137
+        elif scheme == "BDF1" and cfl_factor is not None and not adaptive:
+            theta_lhs = theta0                      # LHS still the one built with the initial dt (src/model.jl:251)
         else:
             theta_lhs = theta_rhs
         u_curr, b_curr = u.copy(), b.copy()
