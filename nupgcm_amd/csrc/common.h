@@ -57,6 +57,7 @@ struct npg_ctx {
     size_t stage_doubles = 0;
     // communicator (RCCL), opaque here
     void *comm = nullptr;
+    void *shm = nullptr;    // loop-back rehearsal transport (NPG_COMM_TRANSPORT=shm, comm.hip)
     int rank = 0, nranks = 1;
 };
 

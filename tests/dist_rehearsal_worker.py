@@ -1,0 +1,47 @@
+"""One rank of the multi-rank rehearsal (launched by tests/test_gpu_distributed.py through torch.distributed.run).
+
+All ranks share GPU 0 (NPG_FORCE_DEVICE=0) and talk through the shared-memory loop-back transport of
+nupgcm_amd/csrc/comm.hip (NPG_COMM_TRANSPORT=shm): RCCL refuses two ranks on one device, everything else - partition,
+local blocks, halo plan, the distributed GMRES/CG kernels and their collective call sequence - is the production path."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import nupgcm_amd as npg                                     # noqa: E402
+from nupgcm_amd import distributed, workloads                # noqa: E402
+
+
+def main():
+    out, nsteps = sys.argv[1], int(sys.argv[2])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    arch = npg.GPU(int(os.environ.get("NPG_FORCE_DEVICE", 0)))
+    ctx = arch.ctx
+    mm = workloads.bowl_mesh_model("bowl3D_h0.1")
+    m = distributed.example_model(arch, mm, dist)
+    # distributed SpMV: owned rows of A x for a known global x
+    s = m.inversion.solver
+    part = m.partition
+    owned = part.inv_owned(rank)
+    N = part.nu + part.np
+    xg = np.sin(0.37 * np.arange(N))
+    x_loc = npg.DeviceVector(ctx, s.A.shape[1])
+    x_loc.view(0, len(owned)).copy_from(npg.DeviceVector.from_host(ctx, xg[owned]))
+    s.halo.exchange(x_loc)
+    y_loc = s.A.mul(x_loc).to_host()
+    ghosts = x_loc.to_host()[len(owned):]
+    npg.invert(m)
+    npg.run(m, n_steps=nsteps)
+    ctx.sync()
+    np.savez(f"{out}.rank{rank}.npz", owned=owned, y_loc=y_loc, n_ghost=len(ghosts), u=m.state.u, p=m.state.p,
+             b=m.state.b, gm=[st[1]["niter"] for st in m.stats], cg=[st[0]["niter"] for st in m.stats],
+             solved=[bool(st[1]["solved"]) and bool(st[0]["solved"]) for st in m.stats])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
