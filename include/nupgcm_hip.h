@@ -104,6 +104,9 @@ int npg_csr_combine(npg_csr *out, double a, const npg_csr *X, double b, const np
  * entry (relative tolerance rtol); *paired = 0 and the matrix is untouched if it does not hold (e.g. function-valued nu).
  * A paired matrix can be multiplied and solved with, but not downloaded, cloned or re-assembled. */
 int npg_csr_pair_xy(npg_csr *A, int64_t npairs, double rtol, int *paired);
+/* how the matrix is laid out in HBM: number of paired node rows, {c, K, C} records (20 bytes each, standing for 4 CSR entries)
+ * and plain CSR entries (12 bytes each).  Unpaired matrix: 0, 0, nnz. */
+int npg_csr_storage(const npg_csr *A, int64_t *npairs, int64_t *paired_records, int64_t *csr_entries);
 /* d[i] = 1 / A[i,i]   -- `Diagonal(1 ./ diag(A))` (src/evolution.jl:149,167; src/model.jl:256) */
 int npg_csr_inv_diag(const npg_csr *A, npg_vec *d);
 /* y = alpha * A x + beta * y   -- mul!(y, A, x) / A*x  (cuSPARSE SpMV in the reference) */
@@ -140,6 +143,10 @@ int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, double pr
  * Arnoldi kernel - the fused SpMV + Gram-Schmidt-dots kernel that dominates the solve - and accumulate their durations
  * over complete restart cycles.  npg_gmres_get_profile returns the accumulated milliseconds and launch count. */
 int npg_gmres_set_profile(npg_gmres *ws, int on);
+/* kernel organisation of the Arnoldi step: 0 = fused (SpMV + Gram-Schmidt dots in one kernel, group-interleaved basis:
+ * latency-bound sizes), 1 = split (SpMV kernel + row-streaming dots/orthogonalisation kernels, column-major basis:
+ * bandwidth-bound sizes), -1 = by size (split from 150 000 rows; default).  Same arithmetic either way. */
+int npg_gmres_set_split(npg_gmres *ws, int mode);
 int npg_gmres_get_profile(npg_gmres *ws, double *ms_total, int64_t *launches);
 /* residual history of the last solve (workspace.stats.residuals with history=true): returns entries written */
 int64_t npg_gmres_history(npg_gmres *ws, double *buf, int64_t cap);

@@ -77,11 +77,12 @@ def _declare(L):
         "npg_csr_create": [P, I64, I64, VP, VP, VP, PP], "npg_csr_destroy": [P],
         "npg_csr_shape": [P, C.POINTER(I64), C.POINTER(I64), C.POINTER(I64)],
         "npg_csr_to_csc": [P, VP, VP, VP], "npg_csr_download": [P, VP, VP, VP], "npg_csr_clone": [P, PP],
-        "npg_csr_zero_values": [P], "npg_csr_pair_xy": [P, I64, D, C.POINTER(C.c_int)], "npg_csr_combine": [P, D, P, D, P, P], "npg_csr_inv_diag": [P, P],
+        "npg_csr_zero_values": [P], "npg_csr_pair_xy": [P, I64, D, C.POINTER(C.c_int)],
+        "npg_csr_storage": [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)], "npg_csr_combine": [P, D, P, D, P, P], "npg_csr_inv_diag": [P, P],
         "npg_spmv": [P, P, P, D, D],
         "npg_gmres_create": [P, I64, C.c_int, PP], "npg_gmres_destroy": [P],
         "npg_gmres_solve": [P, P, C.c_int, D, P, P, P, D, D, I64, D, C.POINTER(SolveStats)],
-        "npg_gmres_set_profile": [P, C.c_int], "npg_gmres_get_profile": [P, C.POINTER(D), C.POINTER(I64)],
+        "npg_gmres_set_profile": [P, C.c_int], "npg_gmres_set_split": [P, C.c_int], "npg_gmres_get_profile": [P, C.POINTER(D), C.POINTER(I64)],
         "npg_cg_create": [P, I64, PP], "npg_cg_destroy": [P],
         "npg_cg_solve": [P, P, C.c_int, D, P, P, P, D, D, I64, C.POINTER(SolveStats)],
         "npg_fe_create": [P, C.POINTER(FeDesc), PP], "npg_fe_destroy": [P], "npg_fe_set_coeff": [P, C.c_char_p, VP],

@@ -291,6 +291,18 @@ class DeviceCSR:
         self.paired = bool(flag.value)
         return self.paired
 
+    def storage(self):
+        """(paired node rows, 20-byte {c, K, C} records, 12-byte CSR entries) as laid out in HBM"""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(L.lib().npg_csr_storage(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def stored_spmv_bytes(self):
+        """bytes one SpMV streams from HBM with this layout (matrix arrays + x once + y once)"""
+        npairs, rec, ent = self.storage()
+        m, n = self.shape
+        return 20 * rec + 12 * ent + 8 * (m + 1) + (8 * (npairs + 1) if npairs else 0) + 8 * n + 8 * m
+
     def mul(self, x: DeviceVector, y: DeviceVector = None, alpha=1.0, beta=0.0):
         """mul!(y, A, x) / A*x"""
         if y is None:

@@ -107,6 +107,8 @@ int halo_exchange_raw(npg_halo *h, double *x);
 int allreduce_sum_device(npg_ctx *ctx, double *buf, int n);
 int ensure_stage(npg_ctx *ctx, size_t doubles);
 int build_tiles(npg_csr *A);
+// tile boundaries (consecutive whole rows, at most tile_slots LDS product slots) for any tile size: tuning harness
+int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp);
 struct CsrDev;
 CsrDev csr_view(const npg_csr *A);
 // reductions that return a scalar to the host (synchronous)

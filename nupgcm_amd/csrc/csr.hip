@@ -8,21 +8,21 @@ namespace npg {
 
 // Row tiles for the CSR-stream kernels: consecutive whole rows, at most kTileNnz stored entries and kTileRows rows per
 // tile; small matrices get about one tile per CU.  A row longer than kTileNnz becomes a tile of its own.
-int build_tiles(npg_csr *A) {
+int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp) {
     const int64_t m = A->m;
     const int64_t *rp = A->h_rowptr.data();
     const int64_t *pp = A->npairs ? A->h_prow.data() : nullptr;
     const int64_t np2 = 2 * (int64_t)A->npairs;
     const int64_t slots_total = rp[m] + (pp ? 2 * pp[A->npairs] : 0);      // LDS product slots of the whole matrix
     int64_t target = slots_total / (int64_t)A->ctx->num_cu;
-    target = std::max<int64_t>(1024, std::min<int64_t>(kTileNnz, target));   // >= 1 tile per CU on small matrices
+    target = std::max<int64_t>(1024, std::min<int64_t>(tile_slots, target)); // >= 1 tile per CU on small matrices
     // product slots rows [a, b) need: their CSR entries + two per paired entry (a, b even inside the paired region)
     auto slots = [&](int64_t a, int64_t b) {
         int64_t s = rp[b] - rp[a];
         if (pp && a < np2) s += 2 * (pp[b >> 1] - pp[a >> 1]);
         return s;
     };
-    std::vector<int32_t> tp;
+    tp.clear();
     tp.push_back(0);
     int64_t r = 0;
     while (r < m) {
@@ -30,10 +30,18 @@ int build_tiles(npg_csr *A) {
         const int64_t step = inpair ? 2 : 1, lim = inpair ? np2 : m;
         int64_t r1 = r + step;
         while (r1 < lim && r1 - r < kTileRows && slots(r, r1 + step) <= target) r1 += step;
-        NPG_REQUIRE(!inpair || slots(r, r1) <= kTileNnz, "build_tiles: a paired row pair does not fit one tile");
+        NPG_REQUIRE(!inpair || slots(r, r1) <= tile_slots, "build_tiles: a paired row pair does not fit one tile");
         tp.push_back((int32_t)r1);
         r = r1;
     }
+    return NPG_OK;
+}
+
+int build_tiles(npg_csr *A) {
+    std::vector<int32_t> tp;
+    int rc = tile_boundaries(A, kTileNnz, tp);
+    if (rc) return rc;
+    const int64_t m = A->m;
     A->ntiles = (int32_t)tp.size() - 1;
     const double mean = m > 0 ? (double)A->nnz / (double)m : 0.0;
     A->lanes = mean <= 6 ? 4 : mean <= 24 ? 8 : mean <= 96 ? 16 : 32;
@@ -291,6 +299,14 @@ NPG_API int npg_csr_shape(const npg_csr *A, int64_t *m, int64_t *n, int64_t *nnz
     if (m) *m = A->m;
     if (n) *n = A->n;
     if (nnz) *nnz = A->nnz;
+    return NPG_OK;
+}
+
+NPG_API int npg_csr_storage(const npg_csr *A, int64_t *npairs, int64_t *paired_records, int64_t *csr_entries) {
+    NPG_REQUIRE(A, "npg_csr_storage: NULL matrix");
+    if (npairs) *npairs = A->npairs;
+    if (paired_records) *paired_records = A->npairs ? A->h_prow[A->npairs] : 0;
+    if (csr_entries) *csr_entries = A->rnnz;
     return NPG_OK;
 }
 

@@ -46,7 +46,7 @@ constexpr int kNS = kKB / kKP;            // 32 row slots per workgroup pass / s
 constexpr int kMaxG = 768;                // max workgroups (= partial rows): three per CU
 constexpr int kMaxI = kMaxG / kNS;        // loads per thread in the partial reduction (8)
 constexpr int kNormSlot = kKP - 1;        // partial rows carry the squared norm in their last entry
-constexpr int kMaxRows = 2048;            // capacity of the partial-row buffers (row-streaming kernels use up to 2048 workgroups)
+constexpr int kMaxRows = 2048;            // capacity of the partial-row buffers
 
 struct Snap {
     double eps, rnorm0, rnorm, beta, zeta;
@@ -71,6 +71,7 @@ struct GDev {
     int G1, G2, GP1, GP2; // GP1/GP2 = partial rows in P1/P2: G1/G2 in fused mode, GR in split mode
     int GR;               // grid of the row-streaming kernels (split mode)
     int split;
+    int64_t ldv;          // split mode stores the basis column-major, Vi[k * ldv + row] (0: group-interleaved layout)
     // what the CONSUMER prologues reduce: the producers' partial rows on one GPU, or the single all-reduced row when
     // the system is distributed over several GPUs
     const double *Q1, *Q2, *QR;
@@ -202,8 +203,13 @@ __device__ void finalize_column(const GDev &d, int colj, KShared &sh, double *tm
 
 // Basis storage: four groups of eight basis vectors, each group a dense [row][8] array (64 B per row and group), so that
 // reading the first j+1 entries of consecutive rows touches ceil((j+1)/8) fully used, fully contiguous streams.
-__device__ __forceinline__ size_t vidx(int64_t row, int k, int64_t n) {
-    return ((size_t)(k >> 3) * (size_t)n + (size_t)row) * 8 + (size_t)(k & 7);
+//
+// Large systems (split mode) use plain column-major storage instead, Vi[k * ldv + row] (ldv = n rounded up to 32): every
+// kernel there is a thread-per-row stream, so column k is read by consecutive lanes contiguously, exactly the j+1 columns
+// in use are read (the grouped layout always moves whole groups of 8), and the new column is written without partial lines.
+__device__ __forceinline__ size_t vidx(int64_t row, int k, int64_t n, int64_t ldv) {
+    return ldv ? (size_t)k * (size_t)ldv + (size_t)row
+               : ((size_t)(k >> 3) * (size_t)n + (size_t)row) * 8 + (size_t)(k & 7);
 }
 
 __device__ __forceinline__ double precond_row(const GDev &d, int row) {
@@ -214,10 +220,10 @@ __device__ __forceinline__ double precond_row(const GDev &d, int row) {
 struct CorrectedX {
     const double *wt, *Vi, *h2;
     int nb;
-    int64_t n;
+    int64_t n, ldv;
     __device__ __forceinline__ double operator()(int c) const {
         double v = wt[c];
-        for (int k = 0; k < nb; ++k) v -= h2[k] * Vi[vidx(c, k, n)];
+        for (int k = 0; k < nb; ++k) v -= h2[k] * Vi[vidx(c, k, n, ldv)];
         return v;
     }
     __device__ __forceinline__ double2 pair(int c) const { return make_double2((*this)(2 * c), (*this)(2 * c + 1)); }
@@ -298,7 +304,7 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
         if (!ro)
             spmv_tile<kKB, L>(d.A, PlainX{d.wt}, r0, r1, tl, sw);
         else
-            spmv_tile<kKB, L>(d.A, CorrectedX{d.wt, d.Vi, sh.h2, j, d.n}, r0, r1, tl, sw);
+            spmv_tile<kKB, L>(d.A, CorrectedX{d.wt, d.Vi, sh.h2, j, d.n, d.ldv}, r0, r1, tl, sw);
         const int nr = r1 - r0;
         if (!FUSED) {
             // split mode (large systems): only what depends on the SpMV result; the dots stream in k_gmres_dots
@@ -307,8 +313,8 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
                 d.w[row] = sw[r] * inv_beta * precond_row(d, row);
                 double tv = d.wt[row];
                 if (ro)
-                    for (int q = 0; q < j; ++q) tv -= sh.h2[q] * d.Vi[vidx(row, q, d.n)];
-                d.Vi[vidx(row, j, d.n)] = tv * inv_beta;
+                    for (int q = 0; q < j; ++q) tv -= sh.h2[q] * d.Vi[vidx(row, q, d.n, d.ldv)];
+                d.Vi[vidx(row, j, d.n, d.ldv)] = tv * inv_beta;
             }
             continue;
         }
@@ -318,8 +324,8 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
             const int rb = r + kNS;
             const bool hb = rb < nr;
             const int rowa = r0 + r, rowb = r0 + (hb ? rb : r);
-            double va = (k < j) ? d.Vi[vidx(rowa, k, d.n)] : 0.0;
-            double vb = (hb && k < j) ? d.Vi[vidx(rowb, k, d.n)] : 0.0;
+            double va = (k < j) ? d.Vi[vidx(rowa, k, d.n, d.ldv)] : 0.0;
+            double vb = (hb && k < j) ? d.Vi[vidx(rowb, k, d.n, d.ldv)] : 0.0;
             double ta = d.wt[rowa], tb = d.wt[rowb];
             const double wa = sw[r] * inv_beta * precond_row(d, rowa);
             const double wb = hb ? sw[rb] * inv_beta * precond_row(d, rowb) : 0.0;
@@ -329,10 +335,10 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
             }
             if (k == j) {
                 va = ta * inv_beta;
-                d.Vi[vidx(rowa, j, d.n)] = va;
+                d.Vi[vidx(rowa, j, d.n, d.ldv)] = va;
                 if (hb) {
                     vb = tb * inv_beta;
-                    d.Vi[vidx(rowb, j, d.n)] = vb;
+                    d.Vi[vidx(rowb, j, d.n, d.ldv)] = vb;
                 }
             }
             if (k == 0) {
@@ -355,8 +361,8 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_dots(GDev d, int j) {
     for (int64_t row = (int64_t)blockIdx.x * kNS + slot; row < d.n; row += 2 * stride) {
         const int64_t rowb = row + stride;
         const bool hb = rowb < d.n;
-        const double va = (k <= j) ? d.Vi[vidx(row, k, d.n)] : 0.0;
-        const double vb = (hb && k <= j) ? d.Vi[vidx(rowb, k, d.n)] : 0.0;
+        const double va = (k <= j) ? d.Vi[vidx(row, k, d.n, d.ldv)] : 0.0;
+        const double vb = (hb && k <= j) ? d.Vi[vidx(rowb, k, d.n, d.ldv)] : 0.0;
         const double wa = d.w[row];
         const double wb = hb ? d.w[rowb] : 0.0;
         acc += (k == kNormSlot) ? wa * wa + wb * wb : va * wa + vb * wb;
@@ -370,6 +376,7 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_dots(GDev d, int j) {
 // rate - and every thread keeps 8*NG accumulators.  Partial rows go through k_reduce_rows (one extra 5 us kernel, free
 // at this size), so these kernels may use any grid.
 constexpr int kRB = 256;
+constexpr int kMaxRowsI = kMaxG / (kRB / 32);      // chunks of reduce_partials over at most kMaxG partial rows
 
 template <int NG>
 __device__ __forceinline__ void load_row_groups(const double *__restrict__ Vi, int64_t row, int64_t n, double (&v)[8 * NG]) {
@@ -383,6 +390,14 @@ __device__ __forceinline__ void load_row_groups(const double *__restrict__ Vi, i
             v[8 * g + 2 * q + 1] = t.y;
         }
     }
+}
+
+// column-major layout: the j+1 columns in use, one coalesced 8-byte stream each (k <= j is wave-uniform)
+template <int NG>
+__device__ __forceinline__ void load_row_cols(const double *__restrict__ Vi, int64_t row, int64_t ldv, int j,
+                                              double (&v)[8 * NG]) {
+#pragma unroll
+    for (int k = 0; k < 8 * NG; ++k) v[k] = (k <= j) ? Vi[(size_t)k * (size_t)ldv + (size_t)row] : 0.0;
 }
 
 template <int NG>
@@ -417,7 +432,10 @@ __global__ void __launch_bounds__(kRB) k_gmres_dots_rows(GDev d, int j) {
     if (d.T[j].done == 0) {
         for (int64_t row = blockIdx.x * (int64_t)kRB + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kRB) {
             double v[8 * NG];
-            load_row_groups<NG>(d.Vi, row, d.n, v);
+            if (d.ldv)
+                load_row_cols<NG>(d.Vi, row, d.ldv, j, v);
+            else
+                load_row_groups<NG>(d.Vi, row, d.n, v);
             const double wv = d.w[row];
 #pragma unroll
             for (int k = 0; k < 8 * NG; ++k) acc[k] += v[k] * wv;
@@ -429,23 +447,30 @@ __global__ void __launch_bounds__(kRB) k_gmres_dots_rows(GDev d, int j) {
 
 template <int NG>
 __global__ void __launch_bounds__(kRB) k_gmres_orth_rows(GDev d, int j) {
-    __shared__ double tmp[(kRB / 64) * kKP];
+    __shared__ double tmp[(kRB / 32) * kKP];
+    __shared__ double red[kKP];
     const Snap T = d.T[j];
+    // h1 = the dots kernel's partial rows summed in a fixed order by every workgroup (one GPU), or the single all-reduced
+    // row (several GPUs)
+    reduce_partials<kRB / 32, kMaxRowsI>(d.Q1, d.nQ1, kKP, tmp, red);
     double h[8 * NG], acc[8 * NG];
 #pragma unroll
     for (int k = 0; k < 8 * NG; ++k) {
-        h[k] = (k <= j) ? d.Q1[k] : 0.0;       // split mode: Q1 is the single folded row (wave-uniform loads)
+        h[k] = (k <= j) ? red[k] : 0.0;
         acc[k] = 0.0;
     }
     double nrm = 0.0;
     if (T.done == 0) {
         if (blockIdx.x == 0 && threadIdx.x < kKP) {
-            d.hcol1[j * kKP + threadIdx.x] = ((int)threadIdx.x <= j) ? d.Q1[threadIdx.x] : 0.0;
-            if (threadIdx.x == 0) d.wnorm2[j] = d.Q1[kNormSlot];
+            d.hcol1[j * kKP + threadIdx.x] = ((int)threadIdx.x <= j) ? red[threadIdx.x] : 0.0;
+            if (threadIdx.x == 0) d.wnorm2[j] = red[kNormSlot];
         }
         for (int64_t row = blockIdx.x * (int64_t)kRB + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kRB) {
             double v[8 * NG];
-            load_row_groups<NG>(d.Vi, row, d.n, v);
+            if (d.ldv)
+                load_row_cols<NG>(d.Vi, row, d.ldv, j, v);
+            else
+                load_row_groups<NG>(d.Vi, row, d.n, v);
             double wp = d.w[row];
 #pragma unroll
             for (int k = 0; k < 8 * NG; ++k) wp -= h[k] * v[k];
@@ -477,8 +502,8 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_orth(GDev d, int j) {
     for (int64_t row = (int64_t)blockIdx.x * kNS + slot; row < d.n; row += 2 * stride) {
         const int64_t rowb = row + stride;
         const bool hb = rowb < d.n;
-        const double va = (k <= j) ? d.Vi[vidx(row, k, d.n)] : 0.0;
-        const double vb = (hb && k <= j) ? d.Vi[vidx(rowb, k, d.n)] : 0.0;
+        const double va = (k <= j) ? d.Vi[vidx(row, k, d.n, d.ldv)] : 0.0;
+        const double vb = (hb && k <= j) ? d.Vi[vidx(rowb, k, d.n, d.ldv)] : 0.0;
         const double wa = d.w[row];
         const double wb = hb ? d.w[rowb] : 0.0;
         const double pa = wa - group_sum_dpp<kKP>(hk * va);
@@ -531,10 +556,20 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_update(GDev d) {
     }
     __syncthreads();
     if (kk == 0) return;
+    if (d.ldv) {
+        // column-major basis: one thread per row, kk coalesced column streams
+        for (int64_t row = (int64_t)blockIdx.x * kKB + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kKB) {
+            double s = 0.0;
+#pragma unroll 4
+            for (int q = 0; q < kk; ++q) s += sh.y[q] * d.Vi[(size_t)q * (size_t)d.ldv + (size_t)row];
+            d.x[row] += s;
+        }
+        return;
+    }
     const int k = threadIdx.x & (kKP - 1), slot = threadIdx.x >> 5;
     const double yk = sh.y[k];             // zero for k >= kk
     for (int64_t row = (int64_t)blockIdx.x * kNS + slot; row < d.n; row += (int64_t)gridDim.x * kNS) {
-        const double vk = (k < kk) ? d.Vi[vidx(row, k, d.n)] : 0.0;
+        const double vk = (k < kk) ? d.Vi[vidx(row, k, d.n, d.ldv)] : 0.0;
         const double s = group_sum_dpp<kKP>(yk * vk);
         if (k == 0) d.x[row] += s;
     }
@@ -592,6 +627,7 @@ struct npg_gmres {
     bool have_graph = false;
     // profile mode: eager launches with HIP events around every Arnoldi (SpMV) kernel
     bool profile = false;
+    int split_mode = -1;
     std::vector<hipEvent_t> pev;
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
@@ -628,7 +664,7 @@ static void launch_rows_kernel(const GDev &d, int j, hipStream_t st, bool orth) 
 template <int L>
 static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gmres *ws, bool dist) {
     int rc = NPG_OK;
-    const bool fold = d.split || dist;
+    const bool fold = dist;
     for (int j = 0; j < d.mem; ++j) {
         if (dist && (rc = halo_exchange_raw(ws->halo, d.wt))) return rc;
         if (pev) hipEventRecord(pev[2 * j], st);
@@ -682,7 +718,8 @@ NPG_API int npg_gmres_create(npg_ctx *ctx, int64_t n, int memory, npg_gmres **ou
     ws->mem = memory;
     NPG_HIP(hipSetDevice(ctx->device));
     const size_t vb = (size_t)n * sizeof(double);
-    NPG_HIP(hipMalloc((void **)&ws->Vi, vb * kKP));
+    const size_t vbytes = ((size_t)n + 32) * sizeof(double) * kKP;     // either layout: 32 columns of n (+ padding) doubles
+    NPG_HIP(hipMalloc((void **)&ws->Vi, vbytes));
     NPG_HIP(hipMalloc((void **)&ws->w, vb));
     NPG_HIP(hipMalloc((void **)&ws->wt, vb));
     const size_t pb = (size_t)kMaxRows * kKP * sizeof(double);
@@ -706,7 +743,7 @@ NPG_API int npg_gmres_create(npg_ctx *ctx, int64_t n, int memory, npg_gmres **ou
     NPG_HIP(hipEventCreateWithFlags(&ws->ev[0], hipEventDisableTiming));
     NPG_HIP(hipEventCreateWithFlags(&ws->ev[1], hipEventDisableTiming));
     NPG_HIP(hipHostMalloc((void **)&ws->h_prm, sizeof(GParams), hipHostMallocDefault));
-    NPG_HIP(hipMemsetAsync(ws->Vi, 0, vb * kKP, ctx->stream));
+    NPG_HIP(hipMemsetAsync(ws->Vi, 0, vbytes, ctx->stream));
     NPG_HIP(hipMemsetAsync(ws->w, 0, vb, ctx->stream));
     NPG_HIP(hipMemsetAsync(ws->wt, 0, vb, ctx->stream));
     NPG_HIP(hipMemsetAsync(ws->P1, 0, pb, ctx->stream));
@@ -796,11 +833,13 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     d.G1 = std::max(1, std::min<int>(A->ntiles, std::min(kMaxG, 3 * ctx->num_cu)));
     d.G2 = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kNS - 1) / kNS, std::min(kMaxG, 3 * ctx->num_cu)));
     static const int split_env = getenv("NPG_GMRES_SPLIT") ? atoi(getenv("NPG_GMRES_SPLIT")) : -1;
-    d.split = split_env >= 0 ? split_env : (ws->n >= 150000 ? 1 : 0);   // large systems: dots as a separate stream
-    d.GR = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kRB - 1) / kRB, std::min(kMaxRows, 8 * ctx->num_cu)));
+    const int split_req = ws->split_mode >= 0 ? ws->split_mode : split_env;
+    d.split = split_req >= 0 ? (split_req != 0) : (ws->n >= 150000 ? 1 : 0);   // large systems: dots as separate streams
+    d.GR = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kRB - 1) / kRB, std::min(kMaxG, 3 * ctx->num_cu)));
+    d.ldv = d.split ? (int64_t)((ws->n + 31) / 32) * 32 : 0;
     d.GP1 = d.split ? d.GR : d.G1;
     d.GP2 = d.split ? d.GR : d.G2;
-    if (dist || d.split) {
+    if (dist) {
         d.Q1 = ws->Rg;
         d.Q2 = ws->Rg + kKP;
         d.QR = ws->Rg + 2 * kKP;
@@ -866,8 +905,8 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     }
     launch_residual(d, A->lanes, st);
     NPG_HIP(hipGetLastError());
-    if (dist || d.split) {
-        int rcd = fold_rows(ws, d.PR, d.G1, 2, st, dist != nullptr);
+    if (dist) {
+        int rcd = fold_rows(ws, d.PR, d.G1, 2, st, true);
         if (rcd) return rcd;
     }
     const int64_t max_cycles = (itmax + ws->mem - 1) / ws->mem + 1;
@@ -945,6 +984,12 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
         stats->rnorm = last.rnorm;
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
+    return NPG_OK;
+}
+
+NPG_API int npg_gmres_set_split(npg_gmres *ws, int mode) {
+    NPG_REQUIRE(ws && mode >= -1 && mode <= 1, "npg_gmres_set_split: bad argument");
+    ws->split_mode = mode;
     return NPG_OK;
 }
 

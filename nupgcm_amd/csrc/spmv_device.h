@@ -173,4 +173,108 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, int r0, i
     __syncthreads();
 }
 
+// Variant of spmv_tile that issues the loads of BOTH streams of a tile (paired records and CSR entries) before the first
+// gather, so that a paired tile has all of its bytes in flight at once instead of in two dependent phases.
+template <int NT, int L, class XF, int TNNZ = kTileNnz, int U2 = 4>
+__device__ __forceinline__ void spmv_tile2(const CsrDev &A, const XF x, int r0, int r1, TileLdsT<TNNZ> &t,
+                                           double *__restrict__ out) {
+    const int64_t base = A.rowptr[r0];
+    const int n = (int)(A.rowptr[r1] - base);
+    const int nrows = r1 - r0;
+    const bool paired = r0 < 2 * A.npairs;
+    int npe = 0;
+    int64_t pbase = 0;
+    if (paired) {
+        pbase = A.prow[r0 >> 1];
+        npe = (int)(A.prow[r1 >> 1] - pbase);
+    }
+    const int64_t abase = base & ~1LL;
+    const int off = (int)(base - abase);
+    const int total = n + off;
+    const int slot0 = 2 * npe;
+    if (slot0 + total > TNNZ + 2 || npe > NT * U2 || total > 2 * NT * U2) {
+        spmv_tile<NT, L, XF, TNNZ, U2>(A, x, r0, r1, t, out);      // generic path (long rows)
+        return;
+    }
+    // ---- issue: paired records, CSR entry pairs, row offsets
+    int32_t pc[U2];
+    double2 kc[U2];
+    int2 c[U2];
+    double2 v[U2];
+#pragma unroll
+    for (int u = 0; u < U2; ++u) {
+        const int e = threadIdx.x + u * NT;
+        if (e < npe) {
+            pc[u] = __builtin_nontemporal_load(A.pcol + pbase + e);
+            const double *p = reinterpret_cast<const double *>(A.pkc + pbase + e);
+            kc[u].x = __builtin_nontemporal_load(p);
+            kc[u].y = __builtin_nontemporal_load(p + 1);
+        } else {
+            pc[u] = 0;
+            kc[u] = make_double2(0.0, 0.0);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U2; ++u) {
+        const int k = 2 * threadIdx.x + u * 2 * NT;
+        if (k < total && abase + k + 1 < A.nnz) {
+            const long long cc = __builtin_nontemporal_load(reinterpret_cast<const long long *>(A.col + abase + k));
+            c[u] = make_int2((int)(cc & 0xffffffffLL), (int)(cc >> 32));
+            v[u].x = __builtin_nontemporal_load(A.val + abase + k);
+            v[u].y = __builtin_nontemporal_load(A.val + abase + k + 1);
+        } else if (k < total && abase + k < A.nnz) {
+            c[u] = make_int2(A.col[abase + k], 0);
+            v[u] = make_double2(A.val[abase + k], 0.0);
+        } else {
+            c[u] = make_int2(0, 0);
+            v[u] = make_double2(0.0, 0.0);
+        }
+    }
+    for (int r = threadIdx.x; r <= nrows; r += NT) t.rp[r] = (int32_t)(A.rowptr[r0 + r] - base) + off + slot0;
+    if (paired)
+        for (int q = threadIdx.x; q <= (nrows >> 1); q += NT) t.prp[q] = (int32_t)(A.prow[(r0 >> 1) + q] - pbase);
+    // ---- gathers + products
+    {
+        double2 xx[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) xx[u] = x.pair(pc[u]);
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const int e = threadIdx.x + u * NT;
+            if (e < npe) {
+                t.prod[e] = kc[u].x * xx[u].x + kc[u].y * xx[u].y;
+                t.prod[npe + e] = kc[u].x * xx[u].y - kc[u].y * xx[u].x;
+            }
+        }
+    }
+    {
+        double xa[U2], xb[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            xa[u] = x(c[u].x);
+            xb[u] = x(c[u].y);
+        }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const int k = 2 * threadIdx.x + u * 2 * NT;
+            if (k < total) t.prod[slot0 + k] = (k >= off) ? v[u].x * xa[u] : 0.0;
+            if (k + 1 < total) t.prod[slot0 + k + 1] = v[u].y * xb[u];
+        }
+    }
+    __syncthreads();
+    const int g = threadIdx.x / L, l = threadIdx.x % L;
+    for (int r = g; r < nrows; r += NT / L) {
+        double s = 0.0;
+        const int e = t.rp[r + 1];
+        for (int k = t.rp[r] + l; k < e; k += L) s += t.prod[k];
+        if (paired) {
+            const int q = r >> 1, pb = (r & 1) ? npe : 0, pe = t.prp[q + 1];
+            for (int k = t.prp[q] + l; k < pe; k += L) s += t.prod[pb + k];
+        }
+        s = group_sum_dpp<L>(s);
+        if (l == 0) out[r] = s;
+    }
+    __syncthreads();
+}
+
 }  // namespace npg

@@ -169,6 +169,79 @@ static int run_wide(const npg_csr *A, const double *x, double *y, int bpc, int r
     return NPG_OK;
 }
 
+// ---- variants on the product tile functions (work on xy-paired matrices too)
+// diagnostic input: no memory access for x (prices the gathers)
+struct FakeX {
+    const double *x;
+    __device__ __forceinline__ double operator()(int c) const { return 1e-9 * (double)c; }
+    __device__ __forceinline__ double2 pair(int c) const { return make_double2(1e-9 * (double)c, 2e-9 * (double)c); }
+};
+
+template <int NT, int L, int TNNZ, int U2, int WPE>
+__global__ void __launch_bounds__(NT, WPE) k_spmv_nogather(CsrDev A, const int32_t *__restrict__ tile_ptr, int ntiles,
+                                                           const double *__restrict__ x, double *__restrict__ y) {
+    __shared__ TileLdsT<TNNZ> tl;
+    __shared__ double sw[kTileRows];
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int r0 = tile_ptr[t], r1 = tile_ptr[t + 1];
+        spmv_tile<NT, L, FakeX, TNNZ, U2>(A, FakeX{x}, r0, r1, tl, sw);
+        for (int r = threadIdx.x; r < r1 - r0; r += NT) y[r0 + r] = sw[r];
+    }
+}
+
+template <int NT, int L, int TNNZ, int U2, int WPE, bool MERGED>
+__global__ void __launch_bounds__(NT, WPE) k_spmv_prod(CsrDev A, const int32_t *__restrict__ tile_ptr, int ntiles,
+                                                       const double *__restrict__ x, double *__restrict__ y) {
+    __shared__ TileLdsT<TNNZ> tl;
+    __shared__ double sw[kTileRows];
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int r0 = tile_ptr[t], r1 = tile_ptr[t + 1];
+        if (MERGED)
+            spmv_tile2<NT, L, PlainX, TNNZ, U2>(A, PlainX{x}, r0, r1, tl, sw);
+        else
+            spmv_tile<NT, L, PlainX, TNNZ, U2>(A, PlainX{x}, r0, r1, tl, sw);
+        for (int r = threadIdx.x; r < r1 - r0; r += NT) y[r0 + r] = sw[r];
+    }
+}
+
+static std::map<std::pair<const void *, int>, VarTiles> g_ptiles;
+
+template <int NT, int TNNZ, int U2, int WPE, bool MERGED, bool NOGATHER = false>
+static int run_prod(const npg_csr *A, const double *x, double *y, int bpc, int reps, double *ms) {
+    auto key = std::make_pair((const void *)A, TNNZ);
+    if (!g_ptiles.count(key)) {
+        std::vector<int32_t> tp;
+        int rc = tile_boundaries(A, TNNZ, tp);
+        if (rc) return rc;
+        VarTiles v;
+        v.n = (int)tp.size() - 1;
+        NPG_HIP(hipMalloc((void **)&v.d, tp.size() * sizeof(int32_t)));
+        NPG_HIP(hipMemcpy(v.d, tp.data(), tp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        g_ptiles[key] = v;
+    }
+    const VarTiles t = g_ptiles[key];
+    npg_ctx *ctx = A->ctx;
+    const int grid = std::max(1, std::min(t.n, bpc * ctx->num_cu));
+    const CsrDev Av = csr_view(A);
+    auto go = [&]() {
+        if (NOGATHER)
+            hipLaunchKernelGGL((k_spmv_nogather<NT, 16, TNNZ, U2, WPE>), dim3(grid), dim3(NT), 0, ctx->stream, Av, t.d, t.n,
+                               x, y);
+        else
+            hipLaunchKernelGGL((k_spmv_prod<NT, 16, TNNZ, U2, WPE, MERGED>), dim3(grid), dim3(NT), 0, ctx->stream, Av, t.d,
+                               t.n, x, y);
+    };
+    for (int i = 0; i < 2; ++i) go();
+    NPG_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; ++i) go();
+    NPG_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    NPG_HIP(hipEventSynchronize(ctx->ev1));
+    float f = 0.f;
+    NPG_HIP(hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    *ms = f / reps;
+    return NPG_OK;
+}
+
 }  // namespace npg
 
 using namespace npg;
@@ -176,8 +249,19 @@ using namespace npg;
 NPG_API int npg_spmv_variant(const npg_csr *A, const npg_vec *x, npg_vec *y, int variant, int blocks_per_cu, int reps,
                              double *ms) {
     NPG_REQUIRE(A && x && y && ms && x->n == A->n && y->n == A->m && reps > 0, "npg_spmv_variant: bad argument");
-    NPG_REQUIRE(A->npairs == 0, "npg_spmv_variant: plain CSR matrices only");
+    NPG_REQUIRE(A->npairs == 0 || variant >= 30, "npg_spmv_variant: variants < 30 take plain CSR matrices only");
     switch (variant) {
+        case 30: return run_prod<512, 4096, 4, 6, false>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 31: return run_prod<512, 4096, 4, 4, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 32: return run_prod<512, 4096, 4, 6, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 33: return run_prod<512, 2048, 2, 6, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 34: return run_prod<512, 2048, 2, 8, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 35: return run_prod<256, 2048, 4, 4, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 36: return run_prod<256, 1024, 2, 8, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 37: return run_prod<512, 2048, 2, 6, false>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 38: return run_prod<512, 3072, 3, 6, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 40: return run_prod<512, 4096, 4, 6, false, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 39: return run_prod<1024, 4096, 2, 8, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 0: return run_var<512, 4096, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 1: return run_var<512, 4096, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 2: return run_var<1024, 8192, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);

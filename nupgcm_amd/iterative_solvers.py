@@ -73,6 +73,10 @@ class GmresWorkspace(_Workspace):
         k = L.lib().npg_gmres_history(self.h, L.ptr(buf), buf.size)
         return buf[:max(k, 0)]
 
+    def set_split(self, mode):
+        """-1: by size (default), 0: fused Arnoldi kernel, 1: split kernels + column-major basis (npg_gmres_set_split)"""
+        L.check(L.lib().npg_gmres_set_split(self.h, int(mode)))
+
     def set_profile(self, on=True):
         """eager launches with HIP events around every Arnoldi (SpMV) kernel; see npg_gmres_set_profile"""
         L.check(L.lib().npg_gmres_set_profile(self.h, int(bool(on))))

@@ -185,6 +185,30 @@ def test_gmres_inversion_K5(arch, flux, golden_dir):
     assert st2["solved"] == 1 and st2["niter"] < 0.6 * st["niter"]
 
 
+@pytest.mark.parametrize("eta", [0.1, 0.9])
+def test_gmres_split_mode_matches_fused(arch, flux, golden_dir, eta):
+    """The two kernel organisations (fused: group-interleaved basis; split: row-streaming kernels on a column-major basis)
+    run the same arithmetic: same iteration count, same solution.  eta = 0.9 makes the selective second Gram-Schmidt pass
+    (and its on-the-fly corrected SpMV input) fire on most columns."""
+    z = np.load(f"{golden_dir}/state_bowl_surface_flux.npz")
+    S = flux
+    y = S.B @ z["b"] + S.b0
+    h, _ = S.orc.precond_h()
+    dA = npg.on_architecture(arch, S.A, drop_zeros=True)
+    dy = npg.on_architecture(arch, y)
+    out = []
+    for mode in (0, 1):
+        ws = npg.GmresWorkspace(arch.ctx, S.A.shape[0], memory=20)
+        ws.set_split(mode)
+        st = ws.solve(dA, dy, ws.x, npg.Diagonal(scalar=1 / h ** 3), reorth_eta=eta)
+        assert st["solved"] == 1
+        if eta > 0.5:
+            assert st["nreorth"] > 0.2 * st["niter"]
+        out.append((st["niter"], ws.x.to_host()))
+    assert abs(out[0][0] - out[1][0]) <= 0.02 * out[0][0] + 2, (out[0][0], out[1][0])
+    assert rel(out[1][1], out[0][1]) < 1e-4
+
+
 def test_cg_evolution_system(arch, flux, golden_dir):
     z = np.load(f"{golden_dir}/state_bowl_surface_flux.npz")
     Am = (flux.M + flux.theta("BDF2") * (flux.Kh + flux.Kv)).tocsr()

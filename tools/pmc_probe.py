@@ -19,6 +19,9 @@ fed = workloads.example_fe_data(workloads.bowl_mesh_model(wl))
 prm, frc = workloads.example_parameters()
 A = npg.build_A_inversion(arch, fed, prm, frc.nu)
 N = A.shape[0]
+nnz_csr = A.nnz
+paired = N >= 100000 and A.pair_xy(fed.dofs.n_pairs)      # what InversionToolkit does (nupgcm_amd/inversion.py)
+npairs, npe, nnz_rem = A.storage()
 h = fed.mesh.median_edge_length()
 y = npg.DeviceVector.from_host(arch.ctx, np.sin(np.arange(N, dtype=float)) * 1e-3)
 ws = npg.GmresWorkspace(arch.ctx, N, memory=20)
@@ -28,4 +31,6 @@ out = npg.DeviceVector(arch.ctx, N)
 for _ in range(5):
     A.mul(x, out)
 arch.ctx.sync()
-print(f"{wl}: N={N} nnz={A.nnz} algorithmic SpMV bytes={12 * A.nnz + 4 * (N + 1) + 16 * N} iterations={st['niter']}")
+print(f"{wl}: N={N} nnz={nnz_csr} algorithmic SpMV bytes={12 * nnz_csr + 4 * (N + 1) + 16 * N} iterations={st['niter']} "
+      f"xy_paired={bool(paired)} paired_entries={npe} remainder_nnz={nnz_rem} "
+      f"stored SpMV bytes={A.stored_spmv_bytes()}")
