@@ -199,8 +199,8 @@ def main():
         "config": {"workload": f"{a.workload}: example parameters of examples/bowl_mixing.jl (eps=0.2, alpha=1/2, "
                                f"mu_rho=1, N2=2, BDF2 dt={a.dt:g}), full evolve!+invert! timestep loop",
                    "tets": int(model.fe_data.mesh.ncell), "nu": int(d.nu), "np": int(d.np), "nb": int(d.nb),
-                   "N_inversion": int(N), "nnz_A": int(nnz), "xy_paired_storage": bool(getattr(A, "paired", False)),
-                   "xy_pairs": int(d.n_pairs), "gmres_iterations_per_step": gm_its,
+                   "N_inversion": int(N), "nnz_A": int(nnz), "node_block_storage": bool(getattr(A, "paired", False)),
+                   "full_nodes": int(d.n_full), "surface_nodes": int(d.n_surf), "gmres_iterations_per_step": gm_its,
                    "cg_iterations_per_step": cg_its, "gmres_second_gs_passes_per_step": [s[1]["nreorth"] for s in stats],
                    "gmres_memory": 20, "atol": 1e-6, "rtol": 1e-6,
                    "setup_seconds": round(t_setup, 1), "parallelism": f"row-partitioned x{world}" if world > 1 else "1 GPU"},
@@ -211,7 +211,7 @@ def main():
         big = N > 40000
         A_host = None
         if big:
-            # the solver's A may be stored xy-paired; the oracle gets a plain CSR copy assembled afresh
+            # the solver's A may be stored by node blocks; the oracle gets a plain CSR copy assembled afresh
             A_plain = A if not getattr(A, "paired", False) else npg.build_A_inversion(arch, model.fe_data, model.params,
                                                                                       model.forcings.nu)
             A_host = A_plain.to_scipy_csr()

@@ -97,16 +97,20 @@ int npg_csr_zero_values(npg_csr *A);
 /* out = a*X + b*(Y + Z) on identical patterns: `A = M + theta*(Kh + Kv)` (src/evolution.jl:144,162; src/model.jl:254)
  * done on the device instead of a host SparseMatrixCSC add + re-upload */
 int npg_csr_combine(npg_csr *out, double a, const npg_csr *X, double b, const npg_csr *Y, const npg_csr *Z);
-/* Store the (x, y) velocity block [K -C; C K] of rows/columns 0 .. 2*npairs-1 ONCE: with constant viscosity the rows 2q and
- * 2q+1 of A_inversion (the two horizontal components of one node - the ordering of nupgcm_amd.fe interleaves them) hold the
- * same friction entry K and the Coriolis entries +-C at columns 2c, 2c+1 (src/inversion.jl:183-192).  Four 12-byte CSR
- * entries and four 8-byte gathers become one 20-byte record and one 16-byte gather.  The structure is verified entry by
- * entry (relative tolerance rtol); *paired = 0 and the matrix is untouched if it does not hold (e.g. function-valued nu).
- * A paired matrix can be multiplied and solved with, but not downloaded, cloned or re-assembled. */
+/* Store the velocity block of A_inversion node by node.  With constant viscosity node q couples to node c through one
+ * friction number K (the x-x, y-y and z-z entries) and one Coriolis number C (x-y entry, -C for y-x)
+ * (src/inversion.jl:183-192).  The ordering of nupgcm_amd.fe puts first the n_full nodes with all three components free
+ * (rows 3q..3q+2), then the n_surf nodes with free x and y only (w = 0 at the surface; rows 3 n_full + 2 (q - n_full) + {0,1}).
+ * Five (four) 12-byte CSR entries and five (four) 8-byte gathers become one 20-byte record {c, K, C} and one gather of the
+ * node's contiguous components.  The structure is verified entry by entry (relative tolerance rtol); *blocked = 0 and the
+ * matrix is untouched if it does not hold (e.g. function-valued nu).  A node-blocked matrix can be multiplied and solved
+ * with, but not downloaded, cloned or re-assembled. */
+int npg_csr_block_nodes(npg_csr *A, int64_t n_full, int64_t n_surf, double rtol, int *blocked);
+/* the two-component special case: npg_csr_block_nodes(A, 0, npairs, ...) */
 int npg_csr_pair_xy(npg_csr *A, int64_t npairs, double rtol, int *paired);
-/* how the matrix is laid out in HBM: number of paired node rows, {c, K, C} records (20 bytes each, standing for 4 CSR entries)
- * and plain CSR entries (12 bytes each).  Unpaired matrix: 0, 0, nnz. */
-int npg_csr_storage(const npg_csr *A, int64_t *npairs, int64_t *paired_records, int64_t *csr_entries);
+/* how the matrix is laid out in HBM: number of block nodes, {c, K, C} records (20 bytes each, standing for 4 or 5 CSR
+ * entries) and plain CSR entries (12 bytes each).  Plain matrix: 0, 0, nnz. */
+int npg_csr_storage(const npg_csr *A, int64_t *nodes, int64_t *records, int64_t *csr_entries);
 /* d[i] = 1 / A[i,i]   -- `Diagonal(1 ./ diag(A))` (src/evolution.jl:149,167; src/model.jl:256) */
 int npg_csr_inv_diag(const npg_csr *A, npg_vec *d);
 /* y = alpha * A x + beta * y   -- mul!(y, A, x) / A*x  (cuSPARSE SpMV in the reference) */

@@ -283,25 +283,29 @@ class DeviceCSR:
         L.check(L.lib().npg_csr_download(self.h, L.ptr(rp), L.ptr(ci), L.ptr(v)))
         return sp.csr_matrix((v, ci, rp), shape=(m, n))
 
-    def pair_xy(self, npairs, rtol=1e-12):
-        """store the [K -C; C K] block of the first 2*npairs rows/columns once (npg_csr_pair_xy); returns True if the
-        structure held and the matrix is now paired"""
+    def block_nodes(self, n_full, n_surf, rtol=1e-12):
+        """store the velocity block node by node: one {c, K, C} record per coupled node pair (npg_csr_block_nodes); returns
+        True if the structure held and the matrix is now node-blocked"""
         flag = C.c_int()
-        L.check(L.lib().npg_csr_pair_xy(self.h, int(npairs), float(rtol), C.byref(flag)))
+        L.check(L.lib().npg_csr_block_nodes(self.h, int(n_full), int(n_surf), float(rtol), C.byref(flag)))
         self.paired = bool(flag.value)
         return self.paired
 
+    def pair_xy(self, npairs, rtol=1e-12):
+        """two-component special case of block_nodes: rows 2q, 2q+1 for q < npairs"""
+        return self.block_nodes(0, npairs, rtol)
+
     def storage(self):
-        """(paired node rows, 20-byte {c, K, C} records, 12-byte CSR entries) as laid out in HBM"""
+        """(block nodes, 20-byte {c, K, C} records, 12-byte CSR entries) as laid out in HBM"""
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         L.check(L.lib().npg_csr_storage(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
     def stored_spmv_bytes(self):
         """bytes one SpMV streams from HBM with this layout (matrix arrays + x once + y once)"""
-        npairs, rec, ent = self.storage()
+        nodes, rec, ent = self.storage()
         m, n = self.shape
-        return 20 * rec + 12 * ent + 8 * (m + 1) + (8 * (npairs + 1) if npairs else 0) + 8 * n + 8 * m
+        return 20 * rec + 12 * ent + 8 * (m + 1) + (8 * (nodes + 1) if nodes else 0) + 8 * n + 8 * m
 
     def mul(self, x: DeviceVector, y: DeviceVector = None, alpha=1.0, beta=0.0):
         """mul!(y, A, x) / A*x"""

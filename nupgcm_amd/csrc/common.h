@@ -80,14 +80,17 @@ struct npg_csr {
     int32_t ntiles = 0;
     int32_t lanes = 16;          // lanes per row chosen from the mean row length
     std::vector<int64_t> h_rowptr;
-    // xy-paired part (npg_csr_pair_xy): rows 2q, 2q+1 for q < npairs keep only their non-paired entries in rowptr/col/val;
-    // `nnz` stays the LOGICAL entry count of the matrix, `rnnz` counts what is left in col/val
+    // node-block part (npg_csr_block_nodes, spmv_device.h): the rows of the first nfull (x, y, z) nodes and of the nsurf
+    // (x, y) nodes after them keep only their non-block entries in rowptr/col/val; `nnz` stays the LOGICAL entry count of
+    // the matrix, `rnnz` counts what is left in col/val
     int64_t rnnz = 0;
-    int32_t npairs = 0;
-    int64_t *prow = nullptr;     // device, npairs + 1
-    int32_t *pcol = nullptr;     // device
-    double *pkc = nullptr;       // device, {K, C} per paired entry
+    int32_t nfull = 0, nsurf = 0;
+    int64_t *prow = nullptr;     // device, nfull + nsurf + 1
+    int32_t *pcol = nullptr;     // device, column node of a record
+    double *pkc = nullptr;       // device, {K, C} per record
     std::vector<int64_t> h_prow;
+    int64_t nnode() const { return (int64_t)nfull + nsurf; }
+    int64_t block_rows() const { return 3 * (int64_t)nfull + 2 * (int64_t)nsurf; }
 };
 
 // interface exchange plan of a row-block distributed vector [owned | ghosts] (comm.hip)

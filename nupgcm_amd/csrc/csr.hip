@@ -11,26 +11,28 @@ namespace npg {
 int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp) {
     const int64_t m = A->m;
     const int64_t *rp = A->h_rowptr.data();
-    const int64_t *pp = A->npairs ? A->h_prow.data() : nullptr;
-    const int64_t np2 = 2 * (int64_t)A->npairs;
-    const int64_t slots_total = rp[m] + (pp ? 2 * pp[A->npairs] : 0);      // LDS product slots of the whole matrix
+    const int64_t *pp = A->nnode() ? A->h_prow.data() : nullptr;
+    const int64_t nf3 = 3 * (int64_t)A->nfull, nbr = A->block_rows();
+    auto node = [&](int64_t r) { return r < nf3 ? r / 3 : A->nfull + (r - nf3) / 2; };      // r starts a node
+    const int64_t slots_total = rp[m] + (pp ? 3 * pp[A->nfull] + 2 * (pp[A->nnode()] - pp[A->nfull]) : 0);
     int64_t target = slots_total / (int64_t)A->ctx->num_cu;
     target = std::max<int64_t>(1024, std::min<int64_t>(tile_slots, target)); // >= 1 tile per CU on small matrices
-    // product slots rows [a, b) need: their CSR entries + two per paired entry (a, b even inside the paired region)
+    // LDS product slots of rows [a, b): their CSR entries + one per component per record (a, b on node boundaries of
+    // one kind inside the block rows)
     auto slots = [&](int64_t a, int64_t b) {
         int64_t s = rp[b] - rp[a];
-        if (pp && a < np2) s += 2 * (pp[b >> 1] - pp[a >> 1]);
+        if (pp && a < nbr) s += (a < nf3 ? 3 : 2) * (pp[node(b)] - pp[node(a)]);
         return s;
     };
     tp.clear();
     tp.push_back(0);
     int64_t r = 0;
     while (r < m) {
-        const bool inpair = r < np2;
-        const int64_t step = inpair ? 2 : 1, lim = inpair ? np2 : m;
+        const bool inblk = r < nbr;
+        const int64_t step = !inblk ? 1 : (r < nf3 ? 3 : 2), lim = !inblk ? m : (r < nf3 ? nf3 : nbr);
         int64_t r1 = r + step;
-        while (r1 < lim && r1 - r < kTileRows && slots(r, r1 + step) <= target) r1 += step;
-        NPG_REQUIRE(!inpair || slots(r, r1) <= tile_slots, "build_tiles: a paired row pair does not fit one tile");
+        while (r1 < lim && r1 + step - r <= kTileRows && slots(r, r1 + step) <= target) r1 += step;
+        NPG_REQUIRE(!inblk || slots(r, r1) <= tile_slots, "build_tiles: the rows of one node do not fit one tile");
         tp.push_back((int32_t)r1);
         r = r1;
     }
@@ -54,7 +56,7 @@ int build_tiles(npg_csr *A) {
 constexpr int kSpmvThreads = 512;
 
 template <int L>
-__global__ void __launch_bounds__(kSpmvThreads) k_spmv(CsrDev A, const int32_t *__restrict__ tile_ptr, int ntiles,
+__global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv(CsrDev A, const int32_t *__restrict__ tile_ptr, int ntiles,
                                                         const double *__restrict__ x, double *__restrict__ y,
                                                         double alpha, double beta) {
     __shared__ TileLds tl;
@@ -124,7 +126,8 @@ CsrDev csr_view(const npg_csr *A) {
     v.prow = A->prow;
     v.pcol = A->pcol;
     v.pkc = reinterpret_cast<const double2 *>(A->pkc);
-    v.npairs = A->npairs;
+    v.nfull = A->nfull;
+    v.nsurf = A->nsurf;
     return v;
 }
 
@@ -132,61 +135,71 @@ CsrDev csr_view(const npg_csr *A) {
 
 using namespace npg;
 
-// Store the (x, y) velocity block [K -C; C K] of rows/columns 0 .. 2*npairs once (see spmv_device.h).  Verifies the
-// structure entry by entry on the host (|K_xx - K_yy|, |C_xy + C_yx| <= rtol * row scale); if anything does not match the
-// matrix is left untouched and *paired = 0.
-NPG_API int npg_csr_pair_xy(npg_csr *A, int64_t npairs, double rtol, int *paired) {
-    NPG_REQUIRE(A && paired && npairs >= 0 && 2 * npairs <= A->m && 2 * npairs <= A->n, "npg_csr_pair_xy: bad argument");
-    NPG_REQUIRE(A->npairs == 0, "npg_csr_pair_xy: matrix is already paired");
-    *paired = 0;
-    if (npairs == 0) return NPG_OK;
+// Store the velocity block of A_inversion node by node (see spmv_device.h): one record {c, K, C} per coupled node pair.
+// The structure is verified entry by entry on the host (K_xx = K_yy = K_zz, C_xy = -C_yx within rtol * row scale, nothing
+// else in the block); if anything does not match the matrix is left untouched and *blocked = 0.
+NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double rtol, int *blocked) {
+    NPG_REQUIRE(A && blocked && nfull >= 0 && nsurf >= 0, "npg_csr_block_nodes: bad argument");
+    const int64_t nf3 = 3 * nfull, nbr = nf3 + 2 * nsurf, nnode = nfull + nsurf;
+    NPG_REQUIRE(nbr <= A->m && nbr <= A->n, "npg_csr_block_nodes: more block rows than the matrix has");
+    NPG_REQUIRE(A->nnode() == 0, "npg_csr_block_nodes: matrix is already stored by node blocks");
+    *blocked = 0;
+    if (nnode == 0) return NPG_OK;
     NPG_HIP(hipStreamSynchronize(A->ctx->stream));
     std::vector<int32_t> col((size_t)A->nnz);
     std::vector<double> val((size_t)A->nnz);
     NPG_HIP(hipMemcpy(col.data(), A->col, col.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     NPG_HIP(hipMemcpy(val.data(), A->val, val.size() * sizeof(double), hipMemcpyDeviceToHost));
     const std::vector<int64_t> &rp = A->h_rowptr;
-    const int64_t np2 = 2 * npairs;
-    std::vector<int64_t> prow((size_t)npairs + 1, 0), nrp((size_t)A->m + 1, 0);
+    std::vector<int64_t> prow((size_t)nnode + 1, 0), nrp((size_t)A->m + 1, 0);
     std::vector<int32_t> pcol, ncol;
     std::vector<double> pkc, nval;
-    pcol.reserve((size_t)A->nnz / 6);
-    pkc.reserve((size_t)A->nnz / 3);
-    ncol.reserve((size_t)A->nnz);
-    nval.reserve((size_t)A->nnz);
-    for (int64_t q = 0; q < npairs; ++q) {
-        const int64_t a0 = rp[2 * q], a1 = rp[2 * q + 1], b0 = a1, b1 = rp[2 * q + 2];
-        // entries with column < 2*npairs come first in a sorted row
-        int64_t ia = a0, ib = b0;
+    pcol.reserve((size_t)A->nnz / 5);
+    pkc.reserve((size_t)A->nnz / 5 * 2);
+    ncol.reserve((size_t)A->nnz / 2);
+    nval.reserve((size_t)A->nnz / 2);
+    // first DoF of column node c / node and component of a block column
+    auto first = [&](int64_t c) { return c < nfull ? 3 * c : nf3 + 2 * (c - nfull); };
+    for (int64_t q = 0; q < nnode; ++q) {
+        const bool qfull = q < nfull;
+        const int64_t rx = first(q), ry = rx + 1, rz = rx + 2;
+        int64_t ia = rp[rx], ib = rp[ry], iz = qfull ? rp[rz] : 0;
+        const int64_t a1 = rp[rx + 1], b1 = rp[ry + 1], z1 = qfull ? rp[rz + 1] : 0;
         double scale = 0.0;
-        for (int64_t k = a0; k < a1 && col[k] < np2; ++k) scale = std::max(scale, std::fabs(val[k]));
-        while (ia < a1 && col[ia] < np2) {
-            // row 2q: (2c, K) (2c+1, C) ; row 2q+1: (2c, -C) (2c+1, K)
+        for (int64_t k = ia; k < a1 && col[k] < nbr; ++k) scale = std::max(scale, std::fabs(val[k]));
+        const double tol = rtol * scale;
+        // sorted rows: the block columns come first.  x row: (x_c, K) (y_c, C); y row: (x_c, -C) (y_c, K); z row: (z_c, K)
+        while (ia < a1 && col[ia] < nbr) {
             if (ia + 1 >= a1 || ib + 1 >= b1) return NPG_OK;
-            const int32_t c0 = col[ia];
-            if ((c0 & 1) || col[ia + 1] != c0 + 1 || col[ib] != c0 || col[ib + 1] != c0 + 1) return NPG_OK;
+            const int64_t c0 = col[ia];
+            const int64_t c = c0 < nf3 ? c0 / 3 : nfull + (c0 - nf3) / 2;
+            if (c0 != first(c) || col[ia + 1] != c0 + 1 || col[ib] != c0 || col[ib + 1] != c0 + 1) return NPG_OK;
             const double K = val[ia], Cc = val[ia + 1];
-            if (std::fabs(val[ib + 1] - K) > rtol * scale || std::fabs(val[ib] + Cc) > rtol * scale) return NPG_OK;
-            pcol.push_back(c0 >> 1);
+            if (std::fabs(val[ib + 1] - K) > tol || std::fabs(val[ib] + Cc) > tol) return NPG_OK;
+            if (qfull && c < nfull) {
+                if (iz >= z1 || col[iz] != c0 + 2 || std::fabs(val[iz] - K) > tol) return NPG_OK;
+                ++iz;
+            }
+            pcol.push_back((int32_t)c);
             pkc.push_back(K);
             pkc.push_back(Cc);
             ia += 2;
             ib += 2;
         }
-        if (ib < b1 && col[ib] < np2) return NPG_OK;     // row 2q+1 has extra entries in the paired block
+        // nothing of the block may be left in the y and z rows
+        if (ib < b1 && col[ib] < nbr) return NPG_OK;
+        if (qfull && iz < z1 && col[iz] < nbr) return NPG_OK;
         prow[q + 1] = (int64_t)pcol.size();
-        for (int64_t k = ia; k < a1; ++k) {
-            ncol.push_back(col[k]);
-            nval.push_back(val[k]);
+        const int64_t lo[3] = {ia, ib, iz}, hi[3] = {a1, b1, z1};
+        for (int a = 0; a < (qfull ? 3 : 2); ++a) {
+            for (int64_t k = lo[a]; k < hi[a]; ++k) {
+                ncol.push_back(col[k]);
+                nval.push_back(val[k]);
+            }
+            nrp[rx + a + 1] = (int64_t)ncol.size();
         }
-        nrp[2 * q + 1] = (int64_t)ncol.size();
-        for (int64_t k = ib; k < b1; ++k) {
-            ncol.push_back(col[k]);
-            nval.push_back(val[k]);
-        }
-        nrp[2 * q + 2] = (int64_t)ncol.size();
     }
-    for (int64_t r = np2; r < A->m; ++r) {
+    for (int64_t r = nbr; r < A->m; ++r) {
         for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
             ncol.push_back(col[k]);
             nval.push_back(val[k]);
@@ -224,11 +237,17 @@ NPG_API int npg_csr_pair_xy(npg_csr *A, int64_t npairs, double rtol, int *paired
     A->h_rowptr = std::move(nrp);
     A->h_prow = std::move(prow);
     A->rnnz = (int64_t)ncol.size();
-    A->npairs = (int32_t)npairs;
+    A->nfull = (int32_t)nfull;
+    A->nsurf = (int32_t)nsurf;
     int rc = build_tiles(A);
     if (rc) return rc;
-    *paired = 1;
+    *blocked = 1;
     return NPG_OK;
+}
+
+// the (x, y)-only special case kept for callers that interleave two components: rows 2q, 2q+1 for q < npairs
+NPG_API int npg_csr_pair_xy(npg_csr *A, int64_t npairs, double rtol, int *paired) {
+    return npg_csr_block_nodes(A, 0, npairs, rtol, paired);
 }
 
 NPG_API int npg_csr_create_from_csc(npg_ctx *ctx, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval,
@@ -304,15 +323,15 @@ NPG_API int npg_csr_shape(const npg_csr *A, int64_t *m, int64_t *n, int64_t *nnz
 
 NPG_API int npg_csr_storage(const npg_csr *A, int64_t *npairs, int64_t *paired_records, int64_t *csr_entries) {
     NPG_REQUIRE(A, "npg_csr_storage: NULL matrix");
-    if (npairs) *npairs = A->npairs;
-    if (paired_records) *paired_records = A->npairs ? A->h_prow[A->npairs] : 0;
+    if (npairs) *npairs = A->nnode();
+    if (paired_records) *paired_records = A->nnode() ? A->h_prow[A->nnode()] : 0;
     if (csr_entries) *csr_entries = A->rnnz;
     return NPG_OK;
 }
 
 NPG_API int npg_csr_download(const npg_csr *A, int64_t *rowptr, int32_t *colind, double *val) {
     NPG_REQUIRE(A, "npg_csr_download: NULL matrix");
-    NPG_REQUIRE(A->npairs == 0, "npg_csr_download: the matrix is stored xy-paired; download it before npg_csr_pair_xy");
+    NPG_REQUIRE(A->nnode() == 0, "npg_csr_download: the matrix is stored by node blocks; download it before npg_csr_block_nodes");
     NPG_HIP(hipStreamSynchronize(A->ctx->stream));
     if (rowptr) std::copy(A->h_rowptr.begin(), A->h_rowptr.end(), rowptr);
     if (colind && A->nnz) NPG_HIP(hipMemcpy(colind, A->col, (size_t)A->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -341,7 +360,7 @@ NPG_API int npg_csr_to_csc(const npg_csr *A, int64_t *colptr, int64_t *rowval, d
 
 NPG_API int npg_csr_clone(const npg_csr *A, npg_csr **out) {
     NPG_REQUIRE(A && out, "npg_csr_clone: NULL argument");
-    NPG_REQUIRE(A->npairs == 0, "npg_csr_clone: the matrix is stored xy-paired");
+    NPG_REQUIRE(A->nnode() == 0, "npg_csr_clone: the matrix is stored by node blocks");
     npg_csr *B = new npg_csr();
     B->ctx = A->ctx;
     B->m = A->m;

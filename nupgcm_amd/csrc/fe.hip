@@ -690,7 +690,7 @@ NPG_API int npg_fe_assemble_rhs_diff(npg_fe *fe, double N2, npg_vec *out) {
 
 NPG_API int npg_fe_assemble_matrix(npg_fe *fe, int which, double scale, int full_stress, npg_csr *A, npg_vec *lift) {
     NPG_REQUIRE(fe && A, "npg_fe_assemble_matrix: NULL argument");
-    NPG_REQUIRE(A->npairs == 0, "npg_fe_assemble_matrix: the matrix is stored xy-paired and cannot be re-assembled");
+    NPG_REQUIRE(A->nnode() == 0, "npg_fe_assemble_matrix: the matrix is stored by node blocks and cannot be re-assembled");
     hipStream_t st = fe->ctx->stream;
     const FeDev &d = fe->d;
     NPG_HIP(hipMemsetAsync(A->val, 0, (size_t)A->nnz * sizeof(double), st));

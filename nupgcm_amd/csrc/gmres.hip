@@ -226,7 +226,7 @@ struct CorrectedX {
         for (int k = 0; k < nb; ++k) v -= h2[k] * Vi[vidx(c, k, n, ldv)];
         return v;
     }
-    __device__ __forceinline__ double2 pair(int c) const { return make_double2((*this)(2 * c), (*this)(2 * c + 1)); }
+    __device__ __forceinline__ double2 two(int i) const { return make_double2((*this)(i), (*this)(i + 1)); }
 };
 
 // ---- R1: wt = P (b - A x), partial ||wt||^2 ---------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 // CSR SpMV building blocks shared by the stand-alone SpMV and by the fused Krylov kernels.
 //
 // Layout in HBM: rowptr int64[m+1], col int32[nnz], val fp64[nnz] - 12 bytes streamed per stored entry - plus, for the
-// inversion matrix with constant viscosity, an "xy-paired" part (below).
+// inversion matrix with constant viscosity, a "node-block" part (below).
 //
 // "CSR-stream" tiles.  The host groups consecutive whole rows into tiles of at most TNNZ LDS product slots and kTileRows
 // rows.  A workgroup handles a tile in two phases:
@@ -15,11 +15,14 @@
 // Streaming is therefore independent of the row-length distribution: short velocity rows and long pressure rows cost the
 // same per stored entry.  A row longer than TNNZ forms a tile of its own and is handled by the whole workgroup.
 //
-// xy-paired part.  With constant viscosity the velocity block of A_inversion is [K -C; C K] on the (x, y) components
-// (/root/reference/src/inversion.jl:183-192: same-component friction + f z-cross-u): rows 2q and 2q+1 (the DoF ordering
-// interleaves the two components of a node, fe.py) hold the same K_qc and +-C_qc at columns 2c, 2c+1.  Those four CSR
-// entries (48 bytes, four 8-byte gathers) are stored ONCE as {col c, K, C} (20 bytes) and cost one 16-byte gather of
-// (x[2c], x[2c+1]).  Everything else (z rows, pressure rows, the u-p couplings of the paired rows) stays plain CSR.
+// Node-block part.  With constant viscosity the velocity block of A_inversion couples node q to node c through ONE friction
+// number K_qc (the same for the x-x, y-y and z-z entries) and ONE Coriolis number C_qc (x-y entry, minus it for y-x)
+// (/root/reference/src/inversion.jl:183-192: same-component friction + f z-cross-u).  The DoF ordering of nupgcm_amd.fe
+// puts the components of a node next to each other: first the nodes with all three components free ("full", rows
+// 3q .. 3q+2), then the nodes with free x and y only ("surface": w = 0 at z = 0, rows 3 nfull + 2 (q - nfull) + {0, 1}).
+// Those five (four) CSR entries - 60 (48) bytes and five (four) 8-byte gathers - are stored ONCE as a record {c, K, C} of
+// 20 bytes and cost one 16-byte gather of (x, y)_c plus one 8-byte gather of z_c from the same cache line.  Everything else
+// (the velocity-pressure couplings, the pressure rows) stays plain CSR.
 //
 // Configuration (512 threads, 4096 product slots, 4 pairs per lane, 3 workgroups per CU: fp64 + 64-bit addressing needs
 // ~80 VGPRs, which rules out two 1024-thread workgroups per CU) chosen from the sweep in profiles/r01_spmv_variants.txt
@@ -31,63 +34,82 @@ namespace npg {
 
 constexpr int kTileNnz = 4096;   // LDS product slots per tile: 32 KiB of fp64
 
-// device view of a matrix: the (remainder) CSR arrays + the optional xy-paired part
+// device view of a matrix: the (remainder) CSR arrays + the optional node-block part
 struct CsrDev {
     const int64_t *rowptr;
     const int32_t *col;
     const double *val;
     int64_t nnz;              // entries in col/val
-    const int64_t *prow;      // [npairs + 1] offsets of pair-row q (= rows 2q, 2q+1) into pcol / pkc; null if npairs == 0
-    const int32_t *pcol;      // pair index c of the column node (columns 2c, 2c+1)
-    const double2 *pkc;       // {K, C}: A[2q,2c] = A[2q+1,2c+1] = K ; A[2q,2c+1] = C ; A[2q+1,2c] = -C
-    int npairs;
+    const int64_t *prow;      // [nfull + nsurf + 1] offsets of node q's records into pcol / pkc; null without node blocks
+    const int32_t *pcol;      // column node c
+    const double2 *pkc;       // {K, C}: A[x_q,x_c] = A[y_q,y_c] = A[z_q,z_c] = K ; A[x_q,y_c] = C ; A[y_q,x_c] = -C
+    int nfull, nsurf;         // nodes with (x, y, z) rows / with (x, y) rows; block rows = 3 nfull + 2 nsurf
 };
+
+__device__ __forceinline__ int block_rows(const CsrDev &A) { return 3 * A.nfull + 2 * A.nsurf; }
+// node of a block row that starts a node
+__device__ __forceinline__ int node_of_row(const CsrDev &A, int r) {
+    return r < 3 * A.nfull ? r / 3 : A.nfull + ((r - 3 * A.nfull) >> 1);
+}
 
 // SpMV input accessor: a plain contiguous vector (the Krylov kernels also plug in an on-the-fly corrected input)
 struct PlainX {
     const double *x;
     __device__ __forceinline__ double operator()(int c) const { return x[c]; }
-    __device__ __forceinline__ double2 pair(int c) const { return *reinterpret_cast<const double2 *>(x + 2 * (size_t)c); }
+    // (x[i], x[i+1]); i is any element offset (8-byte aligned address)
+    __device__ __forceinline__ double2 two(int i) const {
+        double2 r;
+        __builtin_memcpy(&r, x + i, sizeof r);
+        return r;
+    }
 };
 
 template <int TNNZ>
 struct TileLdsT {
     double prod[TNNZ + 2];           // +2: the CSR part of a tile may start on an odd entry
     int32_t rp[kTileRows + 1];       // CSR row offsets into prod
-    int32_t prp[kTileRows / 2 + 1];  // pair-row offsets into the paired products
+    int32_t prp[kTileRows / 2 + 1];  // node offsets into the block products
 };
 using TileLds = TileLdsT<kTileNnz>;
 
 // Phase 1 + 2 for one tile of rows [r0, r1).  On return (after the trailing barrier) out[r - r0] holds (A x)[r].
 // NT = threads in the workgroup, L = lanes per row, U2 = independent entry pairs per lane and trip.
-// Tiles never straddle the end of the paired region and start on even rows inside it.
+// Inside the block rows a tile holds whole nodes of one kind (full or surface).
 template <int NT, int L, class XF, int TNNZ = kTileNnz, int U2 = 4>
 __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, int r0, int r1, TileLdsT<TNNZ> &t,
                                           double *__restrict__ out) {
     const int64_t base = A.rowptr[r0];
     const int n = (int)(A.rowptr[r1] - base);
     const int nrows = r1 - r0;
-    const bool paired = r0 < 2 * A.npairs;
-    int npe = 0;                      // paired entries of this tile
+    const bool blk = r0 < block_rows(A);
+    const bool full = r0 < 3 * A.nfull;
+    const int ncomp = full ? 3 : 2;
+    int npe = 0, nnode = 0;           // records / nodes of this tile
     int64_t pbase = 0;
-    if (paired) {
-        pbase = A.prow[r0 >> 1];
-        npe = (int)(A.prow[r1 >> 1] - pbase);
+    int q0 = 0;
+    if (blk) {
+        q0 = node_of_row(A, r0);
+        nnode = node_of_row(A, r1) - q0;
+        pbase = A.prow[q0];
+        npe = (int)(A.prow[q0 + nnode] - pbase);
     }
     const int64_t abase = base & ~1LL;
     const int off = (int)(base - abase);
     const int total = n + off;
-    const int slot0 = 2 * npe;        // CSR products live behind the two paired product arrays
+    const int slot0 = blk ? ncomp * npe : 0;   // CSR products live behind the block product arrays
     for (int r = threadIdx.x; r <= nrows; r += NT) t.rp[r] = (int32_t)(A.rowptr[r0 + r] - base) + off + slot0;
-    if (paired)
-        for (int q = threadIdx.x; q <= (nrows >> 1); q += NT) t.prp[q] = (int32_t)(A.prow[(r0 >> 1) + q] - pbase);
+    if (blk)
+        for (int q = threadIdx.x; q <= nnode; q += NT) t.prp[q] = (int32_t)(A.prow[q0 + q] - pbase);
     if (slot0 + total <= TNNZ + 2) {
-        // ---- paired stream: {c, K, C} -> products for row 2q (first npe slots) and row 2q+1 (next npe slots)
-        for (int e0 = threadIdx.x; e0 < npe; e0 += U2 * NT) {
-            int32_t c[U2];
-            double2 kc[U2], xx[U2];
+        // ---- record stream: {c, K, C} -> products for the x row (first npe slots), the y row (next npe) and the z row.
+        // A full tile holds at most TNNZ / 3 records: three per lane cover it in one trip.
+        constexpr int UP = U2 > 3 ? 3 : U2;
+        for (int e0 = threadIdx.x; e0 < npe; e0 += UP * NT) {
+            int32_t c[UP];
+            double2 kc[UP], xx[UP];
+            double zz[UP];
 #pragma unroll
-            for (int u = 0; u < U2; ++u) {
+            for (int u = 0; u < UP; ++u) {
                 const int e = e0 + u * NT;
                 if (e < npe) {
                     c[u] = __builtin_nontemporal_load(A.pcol + pbase + e);
@@ -100,13 +122,19 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, int r0, i
                 }
             }
 #pragma unroll
-            for (int u = 0; u < U2; ++u) xx[u] = x.pair(c[u]);
+            for (int u = 0; u < UP; ++u) {
+                const int cf = c[u] < A.nfull ? c[u] : A.nfull;
+                const int xo = 2 * c[u] + cf;                       // first DoF of node c
+                xx[u] = x.two(xo);
+                zz[u] = (full && c[u] < A.nfull) ? x(xo + 2) : 0.0;
+            }
 #pragma unroll
-            for (int u = 0; u < U2; ++u) {
+            for (int u = 0; u < UP; ++u) {
                 const int e = e0 + u * NT;
                 if (e < npe) {
                     t.prod[e] = kc[u].x * xx[u].x + kc[u].y * xx[u].y;
                     t.prod[npe + e] = kc[u].x * xx[u].y - kc[u].y * xx[u].x;
+                    if (full) t.prod[2 * npe + e] = kc[u].x * zz[u];
                 }
             }
         }
@@ -149,15 +177,15 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, int r0, i
             double s = 0.0;
             const int e = t.rp[r + 1];
             for (int k = t.rp[r] + l; k < e; k += L) s += t.prod[k];
-            if (paired) {
-                const int q = r >> 1, pb = (r & 1) ? npe : 0, pe = t.prp[q + 1];
+            if (blk) {
+                const int q = full ? r / 3 : r >> 1, pb = (r - q * ncomp) * npe, pe = t.prp[q + 1];
                 for (int k = t.prp[q] + l; k < pe; k += L) s += t.prod[pb + k];
             }
             s = group_sum_dpp<L>(s);
             if (l == 0) out[r] = s;
         }
     } else {
-        // one very long (unpaired) row: the whole workgroup strides over it, tree-reduce through LDS
+        // one very long (plain CSR) row: the whole workgroup strides over it, tree-reduce through LDS
         double s = 0.0;
         for (int k = threadIdx.x; k < n; k += NT) s += A.val[base + k] * x(A.col[base + k]);
         s = wave_sum(s);
@@ -169,110 +197,6 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, int r0, i
             for (int w = 0; w < NT / 64; ++w) tot += t.prod[w];
             out[0] = tot;
         }
-    }
-    __syncthreads();
-}
-
-// Variant of spmv_tile that issues the loads of BOTH streams of a tile (paired records and CSR entries) before the first
-// gather, so that a paired tile has all of its bytes in flight at once instead of in two dependent phases.
-template <int NT, int L, class XF, int TNNZ = kTileNnz, int U2 = 4>
-__device__ __forceinline__ void spmv_tile2(const CsrDev &A, const XF x, int r0, int r1, TileLdsT<TNNZ> &t,
-                                           double *__restrict__ out) {
-    const int64_t base = A.rowptr[r0];
-    const int n = (int)(A.rowptr[r1] - base);
-    const int nrows = r1 - r0;
-    const bool paired = r0 < 2 * A.npairs;
-    int npe = 0;
-    int64_t pbase = 0;
-    if (paired) {
-        pbase = A.prow[r0 >> 1];
-        npe = (int)(A.prow[r1 >> 1] - pbase);
-    }
-    const int64_t abase = base & ~1LL;
-    const int off = (int)(base - abase);
-    const int total = n + off;
-    const int slot0 = 2 * npe;
-    if (slot0 + total > TNNZ + 2 || npe > NT * U2 || total > 2 * NT * U2) {
-        spmv_tile<NT, L, XF, TNNZ, U2>(A, x, r0, r1, t, out);      // generic path (long rows)
-        return;
-    }
-    // ---- issue: paired records, CSR entry pairs, row offsets
-    int32_t pc[U2];
-    double2 kc[U2];
-    int2 c[U2];
-    double2 v[U2];
-#pragma unroll
-    for (int u = 0; u < U2; ++u) {
-        const int e = threadIdx.x + u * NT;
-        if (e < npe) {
-            pc[u] = __builtin_nontemporal_load(A.pcol + pbase + e);
-            const double *p = reinterpret_cast<const double *>(A.pkc + pbase + e);
-            kc[u].x = __builtin_nontemporal_load(p);
-            kc[u].y = __builtin_nontemporal_load(p + 1);
-        } else {
-            pc[u] = 0;
-            kc[u] = make_double2(0.0, 0.0);
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < U2; ++u) {
-        const int k = 2 * threadIdx.x + u * 2 * NT;
-        if (k < total && abase + k + 1 < A.nnz) {
-            const long long cc = __builtin_nontemporal_load(reinterpret_cast<const long long *>(A.col + abase + k));
-            c[u] = make_int2((int)(cc & 0xffffffffLL), (int)(cc >> 32));
-            v[u].x = __builtin_nontemporal_load(A.val + abase + k);
-            v[u].y = __builtin_nontemporal_load(A.val + abase + k + 1);
-        } else if (k < total && abase + k < A.nnz) {
-            c[u] = make_int2(A.col[abase + k], 0);
-            v[u] = make_double2(A.val[abase + k], 0.0);
-        } else {
-            c[u] = make_int2(0, 0);
-            v[u] = make_double2(0.0, 0.0);
-        }
-    }
-    for (int r = threadIdx.x; r <= nrows; r += NT) t.rp[r] = (int32_t)(A.rowptr[r0 + r] - base) + off + slot0;
-    if (paired)
-        for (int q = threadIdx.x; q <= (nrows >> 1); q += NT) t.prp[q] = (int32_t)(A.prow[(r0 >> 1) + q] - pbase);
-    // ---- gathers + products
-    {
-        double2 xx[U2];
-#pragma unroll
-        for (int u = 0; u < U2; ++u) xx[u] = x.pair(pc[u]);
-#pragma unroll
-        for (int u = 0; u < U2; ++u) {
-            const int e = threadIdx.x + u * NT;
-            if (e < npe) {
-                t.prod[e] = kc[u].x * xx[u].x + kc[u].y * xx[u].y;
-                t.prod[npe + e] = kc[u].x * xx[u].y - kc[u].y * xx[u].x;
-            }
-        }
-    }
-    {
-        double xa[U2], xb[U2];
-#pragma unroll
-        for (int u = 0; u < U2; ++u) {
-            xa[u] = x(c[u].x);
-            xb[u] = x(c[u].y);
-        }
-#pragma unroll
-        for (int u = 0; u < U2; ++u) {
-            const int k = 2 * threadIdx.x + u * 2 * NT;
-            if (k < total) t.prod[slot0 + k] = (k >= off) ? v[u].x * xa[u] : 0.0;
-            if (k + 1 < total) t.prod[slot0 + k + 1] = v[u].y * xb[u];
-        }
-    }
-    __syncthreads();
-    const int g = threadIdx.x / L, l = threadIdx.x % L;
-    for (int r = g; r < nrows; r += NT / L) {
-        double s = 0.0;
-        const int e = t.rp[r + 1];
-        for (int k = t.rp[r] + l; k < e; k += L) s += t.prod[k];
-        if (paired) {
-            const int q = r >> 1, pb = (r & 1) ? npe : 0, pe = t.prp[q + 1];
-            for (int k = t.prp[q] + l; k < pe; k += L) s += t.prod[pb + k];
-        }
-        s = group_sum_dpp<L>(s);
-        if (l == 0) out[r] = s;
     }
     __syncthreads();
 }

@@ -16,7 +16,7 @@ __global__ void __launch_bounds__(NT) k_spmv_var(const int64_t *__restrict__ row
                                                  double *__restrict__ y) {
     __shared__ TileLdsT<TNNZ> tl;
     __shared__ double sw[kTileRows];
-    const CsrDev A{rowptr, col, val, nnz, nullptr, nullptr, nullptr, 0};
+    const CsrDev A{rowptr, col, val, nnz, nullptr, nullptr, nullptr, 0, 0};
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int r0 = tile_ptr[t], r1 = tile_ptr[t + 1];
         spmv_tile<NT, L, PlainX, TNNZ, U>(A, PlainX{x}, r0, r1, tl, sw);
@@ -174,7 +174,7 @@ static int run_wide(const npg_csr *A, const double *x, double *y, int bpc, int r
 struct FakeX {
     const double *x;
     __device__ __forceinline__ double operator()(int c) const { return 1e-9 * (double)c; }
-    __device__ __forceinline__ double2 pair(int c) const { return make_double2(1e-9 * (double)c, 2e-9 * (double)c); }
+    __device__ __forceinline__ double2 two(int c) const { return make_double2(1e-9 * (double)c, 2e-9 * (double)c); }
 };
 
 template <int NT, int L, int TNNZ, int U2, int WPE>
@@ -196,10 +196,7 @@ __global__ void __launch_bounds__(NT, WPE) k_spmv_prod(CsrDev A, const int32_t *
     __shared__ double sw[kTileRows];
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int r0 = tile_ptr[t], r1 = tile_ptr[t + 1];
-        if (MERGED)
-            spmv_tile2<NT, L, PlainX, TNNZ, U2>(A, PlainX{x}, r0, r1, tl, sw);
-        else
-            spmv_tile<NT, L, PlainX, TNNZ, U2>(A, PlainX{x}, r0, r1, tl, sw);
+        spmv_tile<NT, L, PlainX, TNNZ, U2>(A, PlainX{x}, r0, r1, tl, sw);
         for (int r = threadIdx.x; r < r1 - r0; r += NT) y[r0 + r] = sw[r];
     }
 }
@@ -249,19 +246,12 @@ using namespace npg;
 NPG_API int npg_spmv_variant(const npg_csr *A, const npg_vec *x, npg_vec *y, int variant, int blocks_per_cu, int reps,
                              double *ms) {
     NPG_REQUIRE(A && x && y && ms && x->n == A->n && y->n == A->m && reps > 0, "npg_spmv_variant: bad argument");
-    NPG_REQUIRE(A->npairs == 0 || variant >= 30, "npg_spmv_variant: variants < 30 take plain CSR matrices only");
+    NPG_REQUIRE(A->nnode() == 0 || variant >= 30, "npg_spmv_variant: variants < 30 take plain CSR matrices only");
     switch (variant) {
         case 30: return run_prod<512, 4096, 4, 6, false>(A, x->d, y->d, blocks_per_cu, reps, ms);
-        case 31: return run_prod<512, 4096, 4, 4, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
-        case 32: return run_prod<512, 4096, 4, 6, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
-        case 33: return run_prod<512, 2048, 2, 6, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
-        case 34: return run_prod<512, 2048, 2, 8, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
-        case 35: return run_prod<256, 2048, 4, 4, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
-        case 36: return run_prod<256, 1024, 2, 8, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
-        case 37: return run_prod<512, 2048, 2, 6, false>(A, x->d, y->d, blocks_per_cu, reps, ms);
-        case 38: return run_prod<512, 3072, 3, 6, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 31: return run_prod<512, 2048, 2, 6, false>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 32: return run_prod<1024, 4096, 2, 8, false>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 40: return run_prod<512, 4096, 4, 6, false, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
-        case 39: return run_prod<1024, 4096, 2, 8, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 0: return run_var<512, 4096, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 1: return run_var<512, 4096, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 2: return run_var<1024, 8192, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);

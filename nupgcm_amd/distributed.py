@@ -225,4 +225,4 @@ def distribute_model(model, dist):
 
 def example_model(arch, mesh_model, dist, dt=1e-3, **kw):
     from . import workloads
-    return distribute_model(workloads.example_model(arch, mesh_model, dt=dt, pair_xy=False, **kw), dist)
+    return distribute_model(workloads.example_model(arch, mesh_model, dt=dt, block_nodes=False, **kw), dist)

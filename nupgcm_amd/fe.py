@@ -280,10 +280,10 @@ class DoFHandler:
             p_u = np.asarray(reverse_cuthill_mckee(sp.csr_matrix(Mu), symmetric_mode=True), dtype=np.int64)
             p_p = np.asarray(reverse_cuthill_mckee(sp.csr_matrix(Mp), symmetric_mode=True), dtype=np.int64)
             p_b = np.asarray(reverse_cuthill_mckee(sp.csr_matrix(Mb), symmetric_mode=True), dtype=np.int64)
-            p_u, self.n_pairs = _interleave_components(p_u, spaces)
+            p_u, self.n_full, self.n_surf = _node_block_order(p_u, spaces)
         else:
             p_u, p_p, p_b = (np.asarray(p, dtype=np.int64) for p in perms)
-            self.n_pairs = 0
+            self.n_full = self.n_surf = 0
         self.p_u, self.p_p, self.p_b = p_u, p_p, p_b
         self.inv_p_u, self.inv_p_p, self.inv_p_b = (_invperm(p) for p in (p_u, p_p, p_b))
         self.p_inversion = np.concatenate([p_u, self.nu + p_p])
@@ -293,37 +293,37 @@ class DoFHandler:
         return f"DoFHandler with (nu={self.nu}, np={self.np}, nb={self.nb}) DOFs"
 
 
-def _interleave_components(p_u, spaces):
+def _node_block_order(p_u, spaces):
     """The velocity mass-matrix graph has one connected component per vector component, so an RCM of it comes out
-    component-blocked.  When the first two blocks hold the SAME nodes in the SAME order (true whenever two components share
-    their Dirichlet masks - x and y in every reference configuration), interleave them: rows 2q and 2q+1 are then the two
-    components of one node.  This is still "a valid RCM-type ordering" for the reference, and it is what lets the device
-    store the identical friction blocks K_xx = K_yy and the antisymmetric Coriolis blocks once (npg_csr_pair_xy).
-    Returns (permutation, number of interleaved node pairs)."""
+    component-blocked.  Re-arrange it node by node, keeping the RCM order of the nodes (taken from the x component):
+
+        [ (x, y, z) of every node with three free components | (x, y) of every node with free x, y only | the rest ]
+
+    (in the reference configurations: interior nodes; surface nodes, where w = 0 is imposed; nothing).  This is still "a
+    valid RCM-type ordering" for the reference, and it is what lets the device store the friction entries K_xx = K_yy = K_zz
+    and the antisymmetric Coriolis entries of a node pair once and fetch a node's components with one gather
+    (npg_csr_block_nodes).  Returns (permutation, n_full, n_surf)."""
+    free = spaces.u_dof >= 0                                   # (nn, 3)
     nu = len(p_u)
-    comp_of = np.empty(nu, dtype=np.int64)
-    node_of = np.empty(nu, dtype=np.int64)
+    node_of = np.full(nu, -1, dtype=np.int64)
+    comp_of = np.full(nu, -1, dtype=np.int64)
     for a in range(3):
-        m = spaces.u_dof[:, a] >= 0
-        comp_of[spaces.u_dof[m, a]] = a
-        node_of[spaces.u_dof[m, a]] = np.nonzero(m)[0]
-    c = comp_of[p_u]
-    starts = np.concatenate([[0], np.nonzero(np.diff(c))[0] + 1, [nu]])
-    runs = [p_u[starts[i]:starts[i + 1]] for i in range(len(starts) - 1)]
-    if len(runs) < 2 or len(runs) > 3:
-        return p_u, 0
-    # the pair: two runs with the same nodes in the same order, x before y so that A[2q, 2c+1] = -int f phi phi
-    for i in range(len(runs)):
-        for k in range(len(runs)):
-            a, b = runs[i], runs[k]
-            if i == k or len(a) != len(b) or comp_of[a[0]] > comp_of[b[0]]:
-                continue
-            if np.array_equal(node_of[a], node_of[b]):
-                inter = np.empty(2 * len(a), dtype=np.int64)
-                inter[0::2], inter[1::2] = a, b
-                rest = [runs[m] for m in range(len(runs)) if m not in (i, k)]
-                return np.concatenate([inter] + rest), len(a)
-    return p_u, 0
+        nodes = np.nonzero(free[:, a])[0]
+        node_of[spaces.u_dof[nodes, a]] = nodes
+        comp_of[spaces.u_dof[nodes, a]] = a
+    xs = p_u[comp_of[p_u] == 0]                                 # x DoFs in RCM order
+    if len(xs) == 0:
+        return p_u, 0, 0
+    order = node_of[xs]                                         # nodes in RCM order
+    full = order[free[order].all(axis=1)]
+    surf = order[free[order, 0] & free[order, 1] & ~free[order, 2]]
+    used = np.zeros(nu, dtype=bool)
+    tri = spaces.u_dof[full][:, :3].reshape(-1)                # x, y, z of node 0, x, y, z of node 1, ...
+    par = spaces.u_dof[surf][:, :2].reshape(-1)
+    used[tri] = True
+    used[par] = True
+    rest = p_u[~used[p_u]]
+    return np.concatenate([tri, par, rest]).astype(np.int64), len(full), len(surf)
 
 
 def _invperm(p):

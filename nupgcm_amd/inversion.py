@@ -70,7 +70,7 @@ class InversionToolkit:
     """src/inversion.jl:1-5: {B, b, solver}"""
 
     def __init__(self, arch, *args, atol=1e-6, rtol=1e-6, itmax=0, memory=20, history=True, verbose=False, restart=True,
-                 reorth_eta=0.1, pair_xy=None):
+                 reorth_eta=0.1, block_nodes=None):
         if not isinstance(arch, GPU):
             raise TypeError("nupgcm_amd implements the GPU() architecture only (no CPU fallback)")
         if not restart:
@@ -79,12 +79,13 @@ class InversionToolkit:
             fe_data, params, forcings = args
             b0 = DeviceVector(arch.ctx, fe_data.dofs.nu + fe_data.dofs.np)
             A = build_A_inversion(arch, fe_data, params, forcings.nu)
-            if pair_xy is None:
+            if block_nodes is None:
                 # bandwidth-bound sizes only: below ~1e5 rows the solve is latency-bound and the extra stream costs time
-                pair_xy = A.shape[0] >= 100000
-            if pair_xy and not callable(forcings.nu) and not forcings.eddy_param.is_on:
-                # constant nu: K_xx = K_yy and C_xy = -C_yx, stored once (no-op if the structure does not hold)
-                A.pair_xy(fe_data.dofs.n_pairs)
+                block_nodes = A.shape[0] >= 100000
+            if block_nodes and not callable(forcings.nu) and not forcings.eddy_param.is_on:
+                # constant nu: K_xx = K_yy = K_zz and C_xy = -C_yx per node pair, stored once (no-op if the structure
+                # does not hold)
+                A.block_nodes(fe_data.dofs.n_full, fe_data.dofs.n_surf)
             B = build_B_inversion(arch, fe_data, params, lift=b0)
             b0 = build_b_inversion(arch, fe_data, params, forcings, b0)
             # GPU preconditioner: Diagonal(1/h^dim) with the median edge length (src/inversion.jl:42-54)

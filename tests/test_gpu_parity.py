@@ -430,24 +430,44 @@ def test_distributed_path_single_rank(arch):
         dist.destroy_process_group()
 
 
-def test_xy_paired_storage(arch):
-    """npg_csr_pair_xy: the [K -C; C K] block stored once gives the same SpMV and the same GMRES solve; matrices without
-    the structure are left alone."""
+def test_node_block_storage(arch):
+    """npg_csr_block_nodes: the velocity block stored as one {c, K, C} record per coupled node pair gives the same SpMV and
+    the same GMRES solve; matrices without the structure are left alone."""
     fed, prm, frc, dt, b0 = build_fe_data("bowl_mixing")
     d = fed.dofs
-    assert d.n_pairs == 5412
+    free = fed.spaces.u_dof >= 0
+    assert d.n_full == int(free.all(axis=1).sum()) and d.n_surf == int((free[:, 0] & free[:, 1] & ~free[:, 2]).sum())
+    assert d.n_full > 0 and d.n_surf > 0 and 3 * d.n_full + 2 * d.n_surf == d.nu
     A = npg.build_A_inversion(arch, fed, prm, 1.0)
     ref = A.to_scipy_csr()
     x = np.sin(np.arange(ref.shape[1], dtype=float))
     y0 = A.mul(npg.on_architecture(arch, x)).to_host()
     nnz0 = A.nnz
-    assert A.pair_xy(d.n_pairs)
+    assert A.block_nodes(d.n_full, d.n_surf)
     assert A.nnz == nnz0                                       # logical size unchanged
+    nodes, rec, ent = A.storage()
+    assert nodes == d.n_full + d.n_surf and ent < 0.5 * nnz0 and 4 * rec <= nnz0 - ent <= 5 * rec
     y1 = A.mul(npg.on_architecture(arch, x)).to_host()
     assert rel(y1, ref @ x) < 1e-13 and rel(y1, y0) < 1e-13
     with pytest.raises(L.DeviceError):
         A.to_scipy_csr()
-    # solve with the paired matrix
+    # the two-component special case on a synthetic [K -C; C K] matrix with interleaved components
+    rng = np.random.default_rng(4)
+    nq = 300
+    Kp = sp.random(nq, nq, 0.03, random_state=5, format="csr") + sp.eye(nq)
+    Kp.data[:] = rng.standard_normal(Kp.nnz)
+    Cp = Kp.copy()
+    Cp.data[:] = rng.standard_normal(Cp.nnz)
+    blk = sp.kron(Kp, np.eye(2)) + sp.kron(Cp, np.array([[0.0, 1.0], [-1.0, 0.0]]))
+    extra = sp.random(2 * nq + 40, 2 * nq + 40, 0.01, random_state=6, format="lil")
+    extra[:2 * nq, :2 * nq] = 0
+    P2 = sp.csr_matrix(sp.bmat([[blk, None], [None, sp.eye(40)]]) + extra.tocsr())
+    P2.eliminate_zeros()
+    dP = npg.on_architecture(arch, P2)
+    xs = rng.standard_normal(P2.shape[1])
+    assert dP.pair_xy(nq)
+    assert rel(dP.mul(npg.on_architecture(arch, xs)).to_host(), P2 @ xs) < 1e-13
+    # solve with the node-blocked matrix
     h = fed.mesh.median_edge_length()
     rhs = npg.on_architecture(arch, ref @ np.cos(np.arange(ref.shape[1], dtype=float)) * 1e-3)
     ws = npg.GmresWorkspace(arch.ctx, ref.shape[0])
@@ -459,7 +479,7 @@ def test_xy_paired_storage(arch):
     assert rel(ws.x.to_host(), ws2.x.to_host()) < 1e-4
     # a matrix without the structure (the evolution mass matrix) is refused, not damaged
     M = npg.on_architecture(arch, rc.setup("bowl_mixing").M)
-    assert not M.pair_xy(10)
+    assert not M.block_nodes(5, 10) and not M.pair_xy(10)
     assert M.to_scipy_csr().nnz == M.nnz
 
 

@@ -20,7 +20,7 @@ prm, frc = workloads.example_parameters()
 A = npg.build_A_inversion(arch, fed, prm, frc.nu)
 N = A.shape[0]
 nnz_csr = A.nnz
-paired = N >= 100000 and A.pair_xy(fed.dofs.n_pairs)      # what InversionToolkit does (nupgcm_amd/inversion.py)
+paired = N >= 100000 and A.block_nodes(fed.dofs.n_full, fed.dofs.n_surf)   # as InversionToolkit (nupgcm_amd/inversion.py)
 npairs, npe, nnz_rem = A.storage()
 h = fed.mesh.median_edge_length()
 y = npg.DeviceVector.from_host(arch.ctx, np.sin(np.arange(N, dtype=float)) * 1e-3)
@@ -32,5 +32,5 @@ for _ in range(5):
     A.mul(x, out)
 arch.ctx.sync()
 print(f"{wl}: N={N} nnz={nnz_csr} algorithmic SpMV bytes={12 * nnz_csr + 4 * (N + 1) + 16 * N} iterations={st['niter']} "
-      f"xy_paired={bool(paired)} paired_entries={npe} remainder_nnz={nnz_rem} "
+      f"node_blocks={bool(paired)} records={npe} csr_entries={nnz_rem} "
       f"stored SpMV bytes={A.stored_spmv_bytes()}")

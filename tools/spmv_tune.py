@@ -21,8 +21,8 @@ A = npg.build_A_inversion(arch, fed, prm, frc.nu)
 N, nnz = A.shape[0], A.nnz
 if "--paired" in sys.argv:
     sys.argv.remove("--paired")
-    assert A.pair_xy(fed.dofs.n_pairs)
-    print("xy-paired storage:", A.storage(), "stored bytes", A.stored_spmv_bytes())
+    assert A.block_nodes(fed.dofs.n_full, fed.dofs.n_surf)
+    print("node-block storage:", A.storage(), "stored bytes", A.stored_spmv_bytes())
 alg = 12 * nnz + 4 * (N + 1) + 16 * N
 x = npg.DeviceVector.from_host(arch.ctx, np.sin(np.arange(N, dtype=float)))
 yref = A.mul(x).to_host()
@@ -35,10 +35,8 @@ names = {0: "NT512 T4096 U4", 1: "NT512 T4096 U8", 2: "NT1024 T8192 U8", 3: "NT2
          9: "wide NT1024 T8192 U2x4", 10: "wide NT256 T2048 U2x4",
          11: "wide NT1024 T4096 U2x2", 12: "wide+nt NT1024 T8192", 13: "wide+nt NT512 T4096", 14: "wide NT1024 T8192 U2x2",
          15: "wide NT512 T8192 U2x4",
-         30: "product NT512 T4096 U4 wpe6", 31: "merged NT512 T4096 U4 wpe4", 32: "merged NT512 T4096 U4 wpe6",
-         33: "merged NT512 T2048 U2 wpe6", 34: "merged NT512 T2048 U2 wpe8", 35: "merged NT256 T2048 U4 wpe4",
-         36: "merged NT256 T1024 U2 wpe8", 37: "product NT512 T2048 U2 wpe6", 38: "merged NT512 T3072 U3 wpe6",
-         39: "merged NT1024 T4096 U2 wpe8", 40: "product, gathers removed (diagnostic)"}
+         30: "product NT512 T4096 U4 wpe6", 31: "product NT512 T2048 U2 wpe6", 32: "product NT1024 T4096 U2 wpe8",
+         40: "product, gathers removed (diagnostic)"}
 print(f"{wl}: N={N} nnz={nnz} algorithmic bytes={alg / 1e6:.1f} MB")
 vs = [int(a) for a in sys.argv[3].split(',')] if len(sys.argv) > 3 else range(16)
 for v in vs:
