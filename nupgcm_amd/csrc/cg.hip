@@ -29,7 +29,7 @@ struct CParams {
 
 struct CDev {
     CsrDev A;
-    const int32_t *tile_ptr;
+    const TileDesc *tile_ptr;
     int ntiles, n;
     int pkind;
     double pscalar;
@@ -70,9 +70,12 @@ __global__ void __launch_bounds__(kKB) k_cg_init(CDev d) {
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
     double acc[1] = {0.0};
+    TileDesc nd = d.tile_ptr[blockIdx.x < (unsigned)d.ntiles ? blockIdx.x : 0];
     for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
-        const int r0 = d.tile_ptr[t], r1 = d.tile_ptr[t + 1];
-        spmv_tile<kKB, L>(d.A, PlainX{d.x}, r0, r1, tl, sw);
+        const TileDesc td = nd;
+        if (t + (int)gridDim.x < d.ntiles) nd = d.tile_ptr[t + gridDim.x];      // in flight during this tile
+        const int r0 = td.r0, r1 = td.r0 + td.nrows;
+        spmv_tile<kKB, L>(d.A, PlainX{d.x}, td, tl, sw);
         if ((int)threadIdx.x < r1 - r0) {
             const int row = r0 + threadIdx.x;
             const double r = d.b[row] - sw[threadIdx.x];
@@ -132,9 +135,12 @@ __global__ void __launch_bounds__(kKB) k_cg_spmv(CDev d, int slot) {
     __shared__ double sw[kTileRows];
     if (d.S[slot].done != 0) return;
     double acc[1] = {0.0};
+    TileDesc nd = d.tile_ptr[blockIdx.x < (unsigned)d.ntiles ? blockIdx.x : 0];
     for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
-        const int r0 = d.tile_ptr[t], r1 = d.tile_ptr[t + 1];
-        spmv_tile<kKB, L>(d.A, PlainX{d.p}, r0, r1, tl, sw);
+        const TileDesc td = nd;
+        if (t + (int)gridDim.x < d.ntiles) nd = d.tile_ptr[t + gridDim.x];      // in flight during this tile
+        const int r0 = td.r0, r1 = td.r0 + td.nrows;
+        spmv_tile<kKB, L>(d.A, PlainX{d.p}, td, tl, sw);
         if ((int)threadIdx.x < r1 - r0) {
             const int row = r0 + threadIdx.x;
             const double ap = sw[threadIdx.x];

@@ -41,6 +41,13 @@ constexpr int kPartStride = 32;    // doubles per block in a partial-sum row (25
 constexpr int kTileRows = 512;     // most rows in one SpMV tile
 constexpr int kMaxMem = 30;        // largest GMRES memory supported (partial rows hold mem + 2 values)
 
+// one SpMV tile: rows [r0, r0 + nrows), its n CSR entries from `base` and (node-block rows) npe records from `pbase`.
+// 32 bytes = one scalar load; kernels fetch the next tile's descriptor while they work on the current one.
+struct TileDesc {
+    int64_t base, pbase;
+    int32_t r0, nrows, n, npe;
+};
+
 }  // namespace npg
 
 struct npg_ctx {
@@ -76,7 +83,7 @@ struct npg_csr {
     double *val = nullptr;       // device, nnz
     bool owns_pattern = true;
     // nnz-balanced row tiles for the tiled SpMV kernels (device + host copy)
-    int32_t *tile_ptr = nullptr; // device, ntiles+1 row boundaries
+    npg::TileDesc *tile_ptr = nullptr; // device, ntiles descriptors
     int32_t ntiles = 0;
     int32_t lanes = 16;          // lanes per row chosen from the mean row length
     std::vector<int64_t> h_rowptr;

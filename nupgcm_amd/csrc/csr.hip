@@ -47,27 +47,53 @@ int build_tiles(npg_csr *A) {
     A->ntiles = (int32_t)tp.size() - 1;
     const double mean = m > 0 ? (double)A->nnz / (double)m : 0.0;
     A->lanes = mean <= 6 ? 4 : mean <= 24 ? 8 : mean <= 96 ? 16 : 32;
+    const int64_t *rp = A->h_rowptr.data();
+    const int64_t nf3 = 3 * (int64_t)A->nfull, nbr = A->block_rows();
+    auto node = [&](int64_t r) { return r < nf3 ? r / 3 : A->nfull + (r - nf3) / 2; };
+    std::vector<TileDesc> td((size_t)A->ntiles);
+    for (int t = 0; t < A->ntiles; ++t) {
+        const int64_t r0 = tp[t], r1 = tp[t + 1];
+        TileDesc &q = td[t];
+        q.r0 = (int32_t)r0;
+        q.nrows = (int32_t)(r1 - r0);
+        q.base = rp[r0];
+        q.n = (int32_t)(rp[r1] - rp[r0]);
+        q.pbase = 0;
+        q.npe = 0;
+        if (r0 < nbr) {
+            q.pbase = A->h_prow[node(r0)];
+            q.npe = (int32_t)(A->h_prow[node(r1)] - q.pbase);
+        }
+    }
     if (A->tile_ptr) NPG_HIP(hipFree(A->tile_ptr));
-    NPG_HIP(hipMalloc((void **)&A->tile_ptr, tp.size() * sizeof(int32_t)));
-    NPG_HIP(hipMemcpy(A->tile_ptr, tp.data(), tp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    NPG_HIP(hipMalloc((void **)&A->tile_ptr, std::max<size_t>(1, td.size()) * sizeof(TileDesc)));
+    NPG_HIP(hipMemcpy(A->tile_ptr, td.data(), td.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
     return NPG_OK;
 }
 
 constexpr int kSpmvThreads = 512;
 
 template <int L>
-__global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv(CsrDev A, const int32_t *__restrict__ tile_ptr, int ntiles,
+__global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv(CsrDev A, const TileDesc *__restrict__ tile_ptr, int ntiles,
                                                         const double *__restrict__ x, double *__restrict__ y,
                                                         double alpha, double beta) {
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int r0 = tile_ptr[t], r1 = tile_ptr[t + 1];
-        spmv_tile<kSpmvThreads, L>(A, PlainX{x}, r0, r1, tl, sw);
-        for (int r = threadIdx.x; r < r1 - r0; r += kSpmvThreads) {
-            const int row = r0 + r;
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    TileDesc td = tile_ptr[t];
+    while (true) {
+        const int tn = t + gridDim.x;
+        TileDesc nd = td;
+        if (tn < ntiles) nd = tile_ptr[tn];              // in flight during this tile
+        spmv_tile<kSpmvThreads, L>(A, PlainX{x}, td, tl, sw);
+        for (int r = threadIdx.x; r < td.nrows; r += kSpmvThreads) {
+            const int row = td.r0 + r;
             y[row] = (beta == 0.0) ? alpha * sw[r] : alpha * sw[r] + beta * y[row];
         }
+        if (tn >= ntiles) break;
+        t = tn;
+        td = nd;
     }
 }
 

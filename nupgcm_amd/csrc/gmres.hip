@@ -60,7 +60,7 @@ struct GParams {
 
 struct GDev {
     CsrDev A;
-    const int32_t *tile_ptr;
+    const TileDesc *tile_ptr;
     int ntiles, n, mem;
     int pkind;
     double pscalar;
@@ -238,9 +238,12 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_residual(GDev d) {
     const Snap c = *d.C;
     double acc = 0.0;
     if (c.done == 0) {
+        TileDesc nd = d.tile_ptr[blockIdx.x < (unsigned)d.ntiles ? blockIdx.x : 0];
         for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
-            const int r0 = d.tile_ptr[t], r1 = d.tile_ptr[t + 1];
-            spmv_tile<kKB, L>(d.A, PlainX{d.x}, r0, r1, tl, sw);
+            const TileDesc td = nd;
+            if (t + (int)gridDim.x < d.ntiles) nd = d.tile_ptr[t + gridDim.x];      // in flight during this tile
+            const int r0 = td.r0, r1 = td.r0 + td.nrows;
+            spmv_tile<kKB, L>(d.A, PlainX{d.x}, td, tl, sw);
             const int r = threadIdx.x;
             if (r < r1 - r0) {
                 const int row = r0 + r;
@@ -299,12 +302,13 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
     const bool ro = sh.reorth != 0;
     const double h2k = (ro && k < j) ? sh.h2[k] : 0.0;
     double acc = 0.0;
+    TileDesc nd = d.tile_ptr[blockIdx.x < (unsigned)d.ntiles ? blockIdx.x : 0];
     for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
-        const int r0 = d.tile_ptr[t], r1 = d.tile_ptr[t + 1];
-        if (!ro)
-            spmv_tile<kKB, L>(d.A, PlainX{d.wt}, r0, r1, tl, sw);
-        else
-            spmv_tile<kKB, L>(d.A, CorrectedX{d.wt, d.Vi, sh.h2, j, d.n, d.ldv}, r0, r1, tl, sw);
+        const TileDesc td = nd;
+        if (t + (int)gridDim.x < d.ntiles) nd = d.tile_ptr[t + gridDim.x];      // in flight during this tile
+        const int r0 = td.r0, r1 = td.r0 + td.nrows;
+        // one instantiation for both cases: without a second pass the correction loop has no trips
+        spmv_tile<kKB, L>(d.A, CorrectedX{d.wt, d.Vi, sh.h2, ro ? j : 0, d.n, d.ldv}, td, tl, sw);
         const int nr = r1 - r0;
         if (!FUSED) {
             // split mode (large systems): only what depends on the SpMV result; the dots stream in k_gmres_dots

@@ -64,6 +64,11 @@ struct PlainX {
     }
 };
 
+// optional phase profiling of spmv_tile (tuning harness): the default does nothing
+struct NoProf {
+    __device__ __forceinline__ void stamp(int) const {}
+};
+
 template <int TNNZ>
 struct TileLdsT {
     double prod[TNNZ + 2];           // +2: the CSR part of a tile may start on an odd entry
@@ -75,23 +80,21 @@ using TileLds = TileLdsT<kTileNnz>;
 // Phase 1 + 2 for one tile of rows [r0, r1).  On return (after the trailing barrier) out[r - r0] holds (A x)[r].
 // NT = threads in the workgroup, L = lanes per row, U2 = independent entry pairs per lane and trip.
 // Inside the block rows a tile holds whole nodes of one kind (full or surface).
-template <int NT, int L, class XF, int TNNZ = kTileNnz, int U2 = 4>
-__device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, int r0, int r1, TileLdsT<TNNZ> &t,
-                                          double *__restrict__ out) {
-    const int64_t base = A.rowptr[r0];
-    const int n = (int)(A.rowptr[r1] - base);
-    const int nrows = r1 - r0;
+template <int NT, int L, class XF, int TNNZ = kTileNnz, int U2 = 4, class PROF = NoProf>
+__device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const TileDesc &td, TileLdsT<TNNZ> &t,
+                                          double *__restrict__ out, PROF prof = PROF()) {
+    const int r0 = td.r0, nrows = td.nrows, r1 = r0 + nrows;
+    const int64_t base = td.base;
+    const int n = td.n;
     const bool blk = r0 < block_rows(A);
     const bool full = r0 < 3 * A.nfull;
     const int ncomp = full ? 3 : 2;
-    int npe = 0, nnode = 0;           // records / nodes of this tile
-    int64_t pbase = 0;
-    int q0 = 0;
+    const int npe = td.npe;           // records of this tile
+    const int64_t pbase = td.pbase;
+    int nnode = 0, q0 = 0;
     if (blk) {
         q0 = node_of_row(A, r0);
         nnode = node_of_row(A, r1) - q0;
-        pbase = A.prow[q0];
-        npe = (int)(A.prow[q0 + nnode] - pbase);
     }
     const int64_t abase = base & ~1LL;
     const int off = (int)(base - abase);
@@ -171,19 +174,32 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, int r0, i
                 if (k + 1 < total) t.prod[slot0 + k + 1] = v[u].y * xb[u];
             }
         }
+        prof.stamp(0);
         __syncthreads();
+        prof.stamp(1);
+        // segmented sums: L lanes per row, two adjacent products per lane and trip (one ds_read2_b64): this phase is bound
+        // by instruction issue (every wave of the CU is in it at once), not by LDS latency - an unrolled
+        // several-rows-in-flight version measured 1.5x slower
         const int g = threadIdx.x / L, l = threadIdx.x % L;
         for (int r = g; r < nrows; r += NT / L) {
             double s = 0.0;
             const int e = t.rp[r + 1];
-            for (int k = t.rp[r] + l; k < e; k += L) s += t.prod[k];
+            for (int k = t.rp[r] + 2 * l; k < e; k += 2 * L) {
+                const double a = t.prod[k], b = t.prod[k + 1];       // k + 1 <= TNNZ + 2 stays inside the tile struct
+                s += a + (k + 1 < e ? b : 0.0);
+            }
             if (blk) {
-                const int q = full ? r / 3 : r >> 1, pb = (r - q * ncomp) * npe, pe = t.prp[q + 1];
-                for (int k = t.prp[q] + l; k < pe; k += L) s += t.prod[pb + k];
+                const int q = full ? (r * 21846) >> 16 : r >> 1;     // r / 3 for r < 2^15
+                const int pb = (r - q * ncomp) * npe, pe = pb + t.prp[q + 1];
+                for (int k = pb + t.prp[q] + 2 * l; k < pe; k += 2 * L) {
+                    const double a = t.prod[k], b = t.prod[k + 1];
+                    s += a + (k + 1 < pe ? b : 0.0);
+                }
             }
             s = group_sum_dpp<L>(s);
             if (l == 0) out[r] = s;
         }
+        prof.stamp(2);
     } else {
         // one very long (plain CSR) row: the whole workgroup strides over it, tree-reduce through LDS
         double s = 0.0;
@@ -199,6 +215,24 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, int r0, i
         }
     }
     __syncthreads();
+}
+
+// boundaries-only entry (tuning harness): builds the descriptor with the dependent loads the product kernels avoid
+template <int NT, int L, class XF, int TNNZ = kTileNnz, int U2 = 4>
+__device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, int r0, int r1, TileLdsT<TNNZ> &t,
+                                          double *__restrict__ out) {
+    TileDesc td;
+    td.r0 = r0;
+    td.nrows = r1 - r0;
+    td.base = A.rowptr[r0];
+    td.n = (int)(A.rowptr[r1] - td.base);
+    td.pbase = 0;
+    td.npe = 0;
+    if (r0 < block_rows(A)) {
+        td.pbase = A.prow[node_of_row(A, r0)];
+        td.npe = (int)(A.prow[node_of_row(A, r1)] - td.pbase);
+    }
+    spmv_tile<NT, L, XF, TNNZ, U2>(A, x, td, t, out);
 }
 
 }  // namespace npg

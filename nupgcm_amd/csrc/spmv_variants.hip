@@ -177,6 +177,7 @@ struct FakeX {
     __device__ __forceinline__ double2 two(int c) const { return make_double2(1e-9 * (double)c, 2e-9 * (double)c); }
 };
 
+
 template <int NT, int L, int TNNZ, int U2, int WPE>
 __global__ void __launch_bounds__(NT, WPE) k_spmv_nogather(CsrDev A, const int32_t *__restrict__ tile_ptr, int ntiles,
                                                            const double *__restrict__ x, double *__restrict__ y) {
@@ -239,9 +240,80 @@ static int run_prod(const npg_csr *A, const double *x, double *y, int bpc, int r
     return NPG_OK;
 }
 
+// ---- phase timing (diagnostic): the PRODUCT tile function with cycle stamps taken by every wave's lane 0 of workgroup
+// thread 0.  acc[0..4] += cycles in: descriptor wait | stream loads + gathers + products | barrier 1 | segmented sums |
+// barrier 2 + output ; acc[6] = tiles
+struct CycleProf {
+    unsigned long long *c;      // c[0..2] stamps
+    __device__ __forceinline__ void stamp(int i) const {
+        __builtin_amdgcn_s_waitcnt(0);
+        c[i] = clock64();
+    }
+};
+
+template <int NT, int L, int TNNZ, int U2, bool GATHER>
+__global__ void __launch_bounds__(NT, 6) k_spmv_timed(CsrDev A, const TileDesc *__restrict__ tile_ptr, int ntiles,
+                                                      const double *__restrict__ x, double *__restrict__ y,
+                                                      unsigned long long *acc) {
+    __shared__ TileLdsT<TNNZ> tl;
+    __shared__ double sw[kTileRows];
+    unsigned long long a[5] = {0, 0, 0, 0, 0}, nt = 0, st[3];
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    TileDesc td = tile_ptr[t];
+    while (true) {
+        const unsigned long long c0 = clock64();
+        const int tn = t + gridDim.x;
+        TileDesc nd = td;
+        if (tn < ntiles) nd = tile_ptr[tn];
+        const unsigned long long c1 = clock64();
+        if (GATHER)
+            spmv_tile<NT, L, PlainX, TNNZ, U2, CycleProf>(A, PlainX{x}, td, tl, sw, CycleProf{st});
+        else
+            spmv_tile<NT, L, FakeX, TNNZ, U2, CycleProf>(A, FakeX{x}, td, tl, sw, CycleProf{st});
+        for (int r = threadIdx.x; r < td.nrows; r += NT) y[td.r0 + r] = sw[r];
+        const unsigned long long c5 = clock64();
+        a[0] += c1 - c0;
+        a[1] += st[0] - c1;
+        a[2] += st[1] - st[0];
+        a[3] += st[2] - st[1];
+        a[4] += c5 - st[2];
+        ++nt;
+        if (tn >= ntiles) break;
+        t = tn;
+        td = nd;
+    }
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(acc + i, a[i]);
+        atomicAdd(acc + 6, nt);
+    }
+}
+
 }  // namespace npg
 
 using namespace npg;
+
+// phase timing of the product configuration: out7 = cycles per phase summed over workgroups (thread 0), [6] = tiles
+NPG_API int npg_spmv_phase_cycles(const npg_csr *A, const npg_vec *x, npg_vec *y, int blocks_per_cu, int gather,
+                                  unsigned long long *out7) {
+    NPG_REQUIRE(A && x && y && out7 && x->n == A->n && y->n == A->m, "npg_spmv_phase_cycles: bad argument");
+    unsigned long long *acc;
+    NPG_HIP(hipMalloc((void **)&acc, 8 * sizeof(unsigned long long)));
+    NPG_HIP(hipMemset(acc, 0, 8 * sizeof(unsigned long long)));
+    npg_ctx *ctx = A->ctx;
+    const int grid = std::max(1, std::min<int>(A->ntiles, blocks_per_cu * ctx->num_cu));
+    const CsrDev Av = csr_view(A);
+    if (gather)
+        hipLaunchKernelGGL((k_spmv_timed<512, 16, kTileNnz, 4, true>), dim3(grid), dim3(512), 0, ctx->stream, Av,
+                           A->tile_ptr, A->ntiles, x->d, y->d, acc);
+    else
+        hipLaunchKernelGGL((k_spmv_timed<512, 16, kTileNnz, 4, false>), dim3(grid), dim3(512), 0, ctx->stream, Av,
+                           A->tile_ptr, A->ntiles, x->d, y->d, acc);
+    NPG_HIP(hipStreamSynchronize(ctx->stream));
+    NPG_HIP(hipMemcpy(out7, acc, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    NPG_HIP(hipFree(acc));
+    return NPG_OK;
+}
 
 NPG_API int npg_spmv_variant(const npg_csr *A, const npg_vec *x, npg_vec *y, int variant, int blocks_per_cu, int reps,
                              double *ms) {
