@@ -450,17 +450,21 @@ __global__ void __launch_bounds__(kRB) k_gmres_dots_rows(GDev d, int j) {
 }
 
 template <int NG>
-__global__ void __launch_bounds__(kRB) k_gmres_orth_rows(GDev d, int j) {
+__global__ void __launch_bounds__(kRB, NG < 4 ? 3 : 2) k_gmres_orth_rows(GDev d, int j) {
     __shared__ double tmp[(kRB / 32) * kKP];
     __shared__ double red[kKP];
     const Snap T = d.T[j];
     // h1 = the dots kernel's partial rows summed in a fixed order by every workgroup (one GPU), or the single all-reduced
     // row (several GPUs)
     reduce_partials<kRB / 32, kMaxRowsI>(d.Q1, d.nQ1, kKP, tmp, red);
+    // h is wave-uniform: keep it in scalar registers (the kernel needs 16 NG vector registers for v and as many for acc)
     double h[8 * NG], acc[8 * NG];
 #pragma unroll
     for (int k = 0; k < 8 * NG; ++k) {
-        h[k] = (k <= j) ? red[k] : 0.0;
+        const double hv = (k <= j) ? red[k] : 0.0;
+        const unsigned long long b = __double_as_longlong(hv);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        h[k] = __longlong_as_double(((unsigned long long)hi << 32) | lo);
         acc[k] = 0.0;
     }
     double nrm = 0.0;
