@@ -110,6 +110,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    force_dist = bool(os.environ.get("NPG_BENCH_FORCE_DIST")) and world == 1     # 1-rank run of the distributed code path
+    if force_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("gloo", rank=0, world_size=1)
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -126,7 +132,7 @@ def main():
     ctx = arch.ctx
     t_setup = time.time()
     mesh_model = workloads.bowl_mesh_model(a.workload)
-    if world > 1:
+    if world > 1 or force_dist:
         from nupgcm_amd import distributed
         model = distributed.example_model(arch, mesh_model, dist, dt=a.dt)
     else:

@@ -26,13 +26,32 @@ from . import _lib as L
 
 
 class RowPartition:
-    """Contiguous, near-equal row blocks per field."""
+    """Contiguous, near-equal row blocks per field.  With the node-block DoF order of nupgcm_amd.fe (n_full nodes of three
+    components, then n_surf nodes of two) the velocity boundaries are moved to node starts, so that every rank owns whole
+    nodes and can store its owned-by-owned velocity block by node records (npg_csr_block_nodes)."""
 
-    def __init__(self, nu, np_, nb, nranks):
+    def __init__(self, nu, np_, nb, nranks, n_full=0, n_surf=0):
         self.nu, self.np, self.nb, self.nranks = int(nu), int(np_), int(nb), int(nranks)
+        self.n_full, self.n_surf = int(n_full), int(n_surf)
         self.u_bounds = np.linspace(0, nu, nranks + 1).astype(np.int64)
+        nf3, nbr = 3 * self.n_full, 3 * self.n_full + 2 * self.n_surf
+        for i in range(1, nranks):
+            b = int(self.u_bounds[i])
+            if b < nf3:
+                b -= b % 3
+            elif b < nbr:
+                b -= (b - nf3) % 2
+            self.u_bounds[i] = b
         self.p_bounds = np.linspace(0, np_, nranks + 1).astype(np.int64)
         self.b_bounds = np.linspace(0, nb, nranks + 1).astype(np.int64)
+
+    def local_nodes(self, r):
+        """(full nodes, surface nodes) whose rows rank r owns - they lead its local numbering, in this order"""
+        a, b = int(self.u_bounds[r]), int(self.u_bounds[r + 1])
+        nf3, nbr = 3 * self.n_full, 3 * self.n_full + 2 * self.n_surf
+        nfull = (min(b, nf3) - min(a, nf3)) // 3
+        nsurf = (min(b, nbr) - min(max(a, nf3), nbr)) // 2 if b > nf3 else 0
+        return nfull, nsurf
 
     def inv_owned(self, r):
         """global row ids of the inversion system [u; p] owned by rank r (ascending)"""
@@ -161,9 +180,10 @@ class DistributedSolverToolkit:
         allgather_segments(self.A.ctx, self.x_own, self.segments, self.x)
 
 
-def distribute_model(model, dist):
+def distribute_model(model, dist, block_nodes=None):
     """Turn a freshly built single-GPU Model into its distributed form (call on every rank, before the first solve).
-    `dist` is torch.distributed (initialised); RCCL is bootstrapped from it."""
+    `dist` is torch.distributed (initialised); RCCL is bootstrapped from it.  block_nodes: store each rank's
+    owned-by-owned velocity block by node records (None: from 100 000 global rows, as InversionToolkit does)."""
     import torch
     from .architectures import DeviceCSR, DeviceVector, comm_unique_id
     from .iterative_solvers import CgWorkspace, Diagonal, GmresWorkspace
@@ -176,8 +196,11 @@ def distribute_model(model, dist):
     dist.broadcast_object_list(ids, src=0)
     ctx.comm_init(ids[0], rank, world)
     d = model.fe_data.dofs
-    part = RowPartition(d.nu, d.np, d.nb, world)
+    part = RowPartition(d.nu, d.np, d.nb, world, d.n_full, d.n_surf)
     model.partition = part
+    if block_nodes is None:
+        block_nodes = d.nu + d.np >= 100000
+    block_nodes = block_nodes and not callable(model.forcings.nu)
 
     def make(A_dev, owned, owner):
         A_loc, ghosts = local_block(A_dev.to_scipy_csr(), owned, owner)
@@ -197,7 +220,11 @@ def distribute_model(model, dist):
     L.check(L.lib().npg_gmres_set_halo(ws.h, halo.h))
     inv.B = DeviceCSR.from_scipy(ctx, B_loc)
     inv.b = DeviceVector.from_host(ctx, b0_loc)
-    inv.solver = DistributedSolverToolkit(DeviceCSR.from_scipy(ctx, A_loc), Diagonal(scalar=s.P.scalar, n=len(owned)),
+    A_loc_dev = DeviceCSR.from_scipy(ctx, A_loc)
+    if block_nodes:
+        # owned nodes lead the local numbering in the global order [full | surface]; couplings to ghosts stay CSR
+        A_loc_dev.block_nodes(*part.local_nodes(rank))
+    inv.solver = DistributedSolverToolkit(A_loc_dev, Diagonal(scalar=s.P.scalar, n=len(owned)),
                                           DeviceVector(ctx, len(owned)), ws, s.kwargs, s.label, x_full, halo,
                                           part.inv_segments())
     # ---- evolution -------------------------------------------------------------------------------------------------
@@ -223,6 +250,8 @@ def distribute_model(model, dist):
     return model
 
 
-def example_model(arch, mesh_model, dist, dt=1e-3, **kw):
+def example_model(arch, mesh_model, dist, dt=1e-3, block_nodes=None, **kw):
     from . import workloads
-    return distribute_model(workloads.example_model(arch, mesh_model, dt=dt, block_nodes=False, **kw), dist)
+    # the global matrix stays plain CSR (it is downloaded and cut into row blocks); the local blocks get the node records
+    return distribute_model(workloads.example_model(arch, mesh_model, dt=dt, block_nodes=False, **kw), dist,
+                            block_nodes=block_nodes)

@@ -16,12 +16,13 @@ from nupgcm_amd import distributed, workloads                # noqa: E402
 
 def main():
     out, nsteps = sys.argv[1], int(sys.argv[2])
+    block_nodes = len(sys.argv) > 3 and sys.argv[3] == "blocks"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     arch = npg.GPU(int(os.environ.get("NPG_FORCE_DEVICE", 0)))
     ctx = arch.ctx
     mm = workloads.bowl_mesh_model("bowl3D_h0.1")
-    m = distributed.example_model(arch, mm, dist)
+    m = distributed.example_model(arch, mm, dist, block_nodes=block_nodes)
     # distributed SpMV: owned rows of A x for a known global x
     s = m.inversion.solver
     part = m.partition
@@ -36,7 +37,7 @@ def main():
     npg.invert(m)
     npg.run(m, n_steps=nsteps)
     ctx.sync()
-    np.savez(f"{out}.rank{rank}.npz", owned=owned, y_loc=y_loc, n_ghost=len(ghosts), u=m.state.u, p=m.state.p,
+    np.savez(f"{out}.rank{rank}.npz", storage=np.array(s.A.storage()), owned=owned, y_loc=y_loc, n_ghost=len(ghosts), u=m.state.u, p=m.state.p,
              b=m.state.b, gm=[st[1]["niter"] for st in m.stats], cg=[st[0]["niter"] for st in m.stats],
              solved=[bool(st[1]["solved"]) and bool(st[0]["solved"]) for st in m.stats])
     dist.barrier()

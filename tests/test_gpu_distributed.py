@@ -36,14 +36,15 @@ def serial():
     return m, y
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_multi_rank_rehearsal(serial, world, tmp_path):
+@pytest.mark.parametrize("world,blocks", [(2, False), (3, False), (3, True), (4, True)])
+def test_multi_rank_rehearsal(serial, world, blocks, tmp_path):
     ref, y = serial
     out = str(tmp_path / "dist")
     env = dict(os.environ, NPG_COMM_TRANSPORT="shm", NPG_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
                OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_rehearsal_worker.py"), out, "3"]
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_rehearsal_worker.py"), out, "3",
+           "blocks" if blocks else "csr"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     ranks = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
@@ -54,6 +55,7 @@ def test_multi_rank_rehearsal(serial, world, tmp_path):
     for z in ranks:
         yd[z["owned"]] = z["y_loc"]
         assert z["n_ghost"] > 0
+        assert (z["storage"][1] > 0) == blocks                   # node records in the local block iff asked for
     assert rel(yd, y) < 1e-14
     # replicated state: identical on all ranks, equal to the single-GPU run up to the Krylov tolerance
     for z in ranks[1:]:
