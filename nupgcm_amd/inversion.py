@@ -78,7 +78,9 @@ class InversionToolkit:
         if len(args) == 3:                          # InversionToolkit(arch, fe_data, params, forcings; kwargs...)
             fe_data, params, forcings = args
             b0 = DeviceVector(arch.ctx, fe_data.dofs.nu + fe_data.dofs.np)
-            A = build_A_inversion(arch, fe_data, params, forcings.nu)
+            # the eddy closure re-assembles A in the full-stress form later: keep all nine component pairs in the pattern
+            # then (Gridap's structural pattern, src/model.jl:160-170 assembles into it in place)
+            A = build_A_inversion(arch, fe_data, params, forcings.nu, structural=forcings.eddy_param.is_on)
             if block_nodes is None:
                 # bandwidth-bound sizes only: below ~1e5 rows the solve is latency-bound and the extra stream costs time
                 block_nodes = A.shape[0] >= 100000

@@ -142,7 +142,7 @@ def cfl_dt(orc, u_free, cfl_factor, u_min=0.01):
 
 
 def run(sysm: System, nsteps, solver="direct", first_step_lhs="bdf1", invert_first=False, scheme="BDF2",
-        krylov_kw=None, record=None, timer=None, cfl_factor=None, adaptive=False):
+        krylov_kw=None, record=None, timer=None, cfl_factor=None, adaptive=False, conv=None, eddy=None):
     """Returns (u, p, b) free values in native order after `nsteps` steps from the configuration's initial condition.
     timer: optional dict; receives 'loop_seconds' = wall time of the step loop only (factorisations excluded, as the
     reference's CPU() path factorises at set-up time, src/inversion.jl:58, src/evolution.jl:152)."""
@@ -174,6 +174,15 @@ def run(sysm: System, nsteps, solver="direct", first_step_lhs="bdf1", invert_fir
                 record.append(("gmres", st["niter"], st["solved"]))
         return x[:nu], x[nu:]
 
+    def alpha_bz(bv):
+        """alpha d_z(N2 z + b) at the quadrature points (src/model.jl:229, 163)"""
+        bn = orc.b_nodal(bv)[orc.cn2]
+        return orc.alpha * (orc.N2 + np.einsum("cqi,ci->cq", orc.gradN2[..., 2], bn))
+
+    kv0_q = None
+    if conv is not None:                            # (kappa_c, N2min): src/inputs.jl:87-91
+        kv0_q = fo._const_or_fn(orc.kappa_v, orc.geo.xq)
+
     if invert_first:
         u, p = invert(b)
     u_prev, b_prev = u.copy(), b.copy()
@@ -197,6 +206,13 @@ def run(sysm: System, nsteps, solver="direct", first_step_lhs="bdf1", invert_fir
             sysm.dt = cfl_dt(orc, u, cfl_factor)
             if adaptive:
                 lhs_cache.clear()
+        if conv is not None:
+            # evolve! with the convection closure (src/model.jl:229-261): kappa_v from the current b, then K_v, its lift,
+            # rhs_diff and the LHS are rebuilt
+            kq = kv0_q + conv[0] * (1 + np.tanh(-alpha_bz(b) / conv[1])) / 2
+            sysm.Kv, sysm.rhs_v = orc.K_v(kappa=lambda x: kq)
+            sysm.rhs_diff = orc.rhs_diff(kappa=lambda x: kq)
+            lhs_cache.clear()
         theta_rhs = sysm.theta(scheme)
         if scheme == "BDF2" and i == 1 and first_step_lhs == "bdf1":
             theta_lhs = sysm.theta("BDF1")          # src/evolution.jl:110-111 + src/model.jl:134-137
@@ -220,6 +236,15 @@ def run(sysm: System, nsteps, solver="direct", first_step_lhs="bdf1", invert_fir
         if max(np.abs(u).max(), np.abs(b).max()) > 1e3 or not np.isfinite(u).all():
             raise RuntimeError("Blow-up detected, stopping simulation")                  # src/model.jl:149-153
         u_prev, b_prev = u_curr, b_curr
+        if eddy is not None and i % 10 == 0:
+            # nu_eddy from the new b, A re-assembled in the full-stress form (src/model.jl:160-170, src/inputs.jl:130-137)
+            N2min, smoothing, nu_min = eddy
+            fq = fo._const_or_fn(orc.f, orc.geo.xq)
+            nu_e = fq * (fq / np.sqrt(N2min ** 2 + alpha_bz(b) ** 2))
+            nuq = np.logaddexp(smoothing * nu_min, smoothing * nu_e) / smoothing
+            sysm.A = orc.A_inversion(nu_q=nuq)
+            if solver == "direct":
+                luA = spla.splu(sp.csc_matrix(sysm.A))
     if timer is not None:
         timer["loop_seconds"] = _time.perf_counter() - _t0
     return u, p, b

@@ -4,6 +4,8 @@
 Tolerances: deterministic fp64 kernels (SpMV, BLAS-1, element integrals) <= 1e-12 relative; Krylov solutions are
 tolerance-limited by the reference's own stopping rule (atol = rtol = 1e-6 on the 1/h^3-scaled residual): <= 3e-3 in u for
 a cold GMRES start, which is the floor the oracle's own MGS-GMRES shows against the direct solve."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -16,7 +18,7 @@ from nupgcm_amd import _lib as L  # noqa: E402
 from nupgcm_amd.inversion import device_fe  # noqa: E402
 from oracle import krylov_oracle as ko  # noqa: E402
 from oracle import recipe as rc  # noqa: E402
-from tests.helpers import build_fe_data, build_model, rel  # noqa: E402
+from tests.helpers import U_MASKS, U_TAGS, U_VALS, build_fe_data, build_model, product_config, rel  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -497,3 +499,30 @@ def test_bdf1_cfl_steps_against_oracle(arch, adaptive):
     assert abs(m.timestepper.dt - S.dt) < 1e-4 * S.dt
     assert rel(m.state.b, b) < 3e-4
     assert rel(m.state.u, u) < 5e-3
+
+
+def test_closures_in_the_timestep_loop(arch):
+    """The channel-basin style path (scratch/run.jl): BDF1 with the adaptive CFL step, the convection closure
+    refreshing kappa_v / K_v / rhs_diff / the LHS every step (src/model.jl:229-261) and the eddy closure re-assembling A
+    in the full-stress form every 10th step (src/model.jl:160-170) - 12 steps against the oracle's direct-solve recipe."""
+    prm, frc, btags, bvals, dt, b0 = product_config("bowl_surface_flux")
+    frc.conv_param = npg.ConvectionParameterization(kappa_c=0.5, N2min=0.5, is_on=True)
+    frc.eddy_param = npg.EddyParameterization(f=prm.f, N2min=0.5, is_on=True)
+    mesh = npg.Mesh(f"{os.path.dirname(os.path.abspath(__file__))}/golden/mesh_bowl3D_h0.1.npz")
+    spaces = npg.Spaces(mesh, u_diri_tags=U_TAGS, u_diri_vals=U_VALS, u_diri_masks=U_MASKS, b_diri_tags=btags,
+                        b_diri_vals=bvals)
+    fed = npg.FEData(mesh, spaces)
+    ts = npg.BDF1(t_start=0.0, t_stop=1e9, dt=dt, adaptive=True, CFL_factor=0.3)
+    inv = npg.InversionToolkit(arch, fed, prm, frc)
+    evo = npg.EvolutionToolkit(arch, fed, prm, frc, ts)
+    m = npg.Model(arch, prm, frc, fed, inv, evo, ts)
+    npg.set_b(m, lambda x: x[..., 2] / prm.alpha * (1 + 0.3 * np.sin(3 * x[..., 0])))     # unstable columns somewhere
+    npg.invert(m)
+    npg.run(m, n_steps=12)
+
+    S = rc.setup("bowl_surface_flux", b0=lambda x: x[..., 2] / 0.5 * (1 + 0.3 * np.sin(3 * x[..., 0])))
+    u, p, b = rc.run(S, 12, solver="direct", scheme="BDF1", cfl_factor=0.3, adaptive=True, invert_first=True,
+                     conv=(0.5, 0.5), eddy=(0.5, 10.0, 1.0))
+    assert abs(m.timestepper.dt - S.dt) < 1e-3 * S.dt
+    assert rel(m.state.b, b) < 1e-3
+    assert rel(m.state.u, u) < 1e-2
