@@ -526,3 +526,62 @@ def test_closures_in_the_timestep_loop(arch):
     assert abs(m.timestepper.dt - S.dt) < 1e-3 * S.dt
     assert rel(m.state.b, b) < 1e-3
     assert rel(m.state.u, u) < 1e-2
+
+
+def test_p1_buoyancy_space(arch):
+    """b_order = 1 (scratch/run.jl, the channel-basin configuration): the P1 instances of the element kernels against
+    closed forms that need no oracle - on a tetrahedron K with barycentric gradients g_i,
+    M_ij = |K| (1 + delta_ij) / 20,  K_h,ij = |K| (g_i,x g_j,x + g_i,y g_j,y),  K_v,ij = |K| g_i,z g_j,z  (kappa = 1) -
+    and the advection right-hand side through its total integral, which for a linear b must equal the P2 oracle's."""
+    golden = f"{os.path.dirname(os.path.abspath(__file__))}/golden/mesh_bowl3D_h0.1.npz"
+    mesh = npg.Mesh(golden)
+    spaces = npg.Spaces(mesh, u_diri_tags=U_TAGS, u_diri_vals=U_VALS, u_diri_masks=U_MASKS, b_diri_tags=["coastline"],
+                        b_diri_vals=[lambda x: 1.0 + x[..., 0]], b_order=1)
+    fed = npg.FEData(mesh, spaces)
+    d, ctx = fed.dofs, arch.ctx
+    assert spaces.nb == int((spaces.b_dof >= 0).sum()) < mesh.nv
+    fe = device_fe(arch, fed)
+    for name in ("kappa_h", "kappa_v"):
+        fe.set_coeff(name, 1.0)
+    X = mesh.coords[mesh.cells]                                         # (nc, 4, 3)
+    T = np.concatenate([np.ones((len(X), 4, 1)), X], axis=2)            # barycentric: lambda = T^-1 [1; x]
+    Ti = np.linalg.inv(T)
+    vol = np.abs(np.linalg.det(T)) / 6
+    g = np.transpose(Ti[:, 1:, :], (0, 2, 1))                           # (nc, 4, 3): grad lambda_i
+    loc = {L.NPG_MAT_M: vol[:, None, None] * (1 + np.eye(4)) / 20,
+           L.NPG_MAT_KH: vol[:, None, None] * np.einsum("cia,cja->cij", g[..., :2], g[..., :2]),
+           L.NPG_MAT_KV: vol[:, None, None] * np.einsum("ci,cj->cij", g[..., 2], g[..., 2])}
+    bd = spaces.b_dof[mesh.cells]                                       # (nc, 4) free index or -1
+    diri = np.where(spaces.b_dof < 0, spaces.b_diri_val if hasattr(spaces, "b_diri_val") else 0.0, 0.0)
+    for which, Al in loc.items():
+        rows, cols = np.broadcast_to(bd[:, :, None], Al.shape), np.broadcast_to(bd[:, None, :], Al.shape)
+        ff = (rows >= 0) & (cols >= 0)
+        ref = sp.csr_matrix((Al[ff], (rows[ff], cols[ff])), shape=(spaces.nb, spaces.nb))
+        lift_ref = np.zeros(spaces.nb)
+        fd = (rows >= 0) & (cols < 0)
+        gcol = np.broadcast_to(mesh.cells[:, None, :], Al.shape)
+        np.add.at(lift_ref, rows[fd], Al[fd] * diri[gcol[fd]])
+        lift = npg.DeviceVector(ctx, d.nb)
+        A = fe.assemble(which, fe.new_matrix("b"), lift=lift).to_scipy_csr()
+        refp = ref[d.p_b][:, d.p_b]
+        assert abs(A - refp).max() <= 1e-13 * abs(refp).max()
+        assert np.linalg.norm(lift.to_host() - lift_ref[d.p_b]) <= 1e-12 * max(np.linalg.norm(lift_ref), 1e-30)
+    # advection: every b node free, b linear => sum_i rhs_i = int (b - dt (u.grad b + w N2)) for P1 and P2 test spaces alike
+    sp1 = npg.Spaces(mesh, u_diri_tags=U_TAGS, u_diri_vals=U_VALS, u_diri_masks=U_MASKS, b_diri_tags=[], b_diri_vals=[],
+                     b_order=1)
+    fed1 = npg.FEData(mesh, sp1)
+    d1 = fed1.dofs
+    fe1 = device_fe(arch, fed1)
+    S = rc.setup("bowl_surface_flux")                                   # same velocity space, P2 buoyancy, nothing fixed
+    lin = lambda x: 0.3 + 0.5 * x[..., 0] - 0.2 * x[..., 1] + 1.5 * x[..., 2]
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(d1.nu + d1.np)
+    b1 = sp1.interpolate_b(lin)
+    dv = lambda v, p: npg.DeviceVector.from_host(ctx, v, p)
+    out = npg.DeviceVector(ctx, d1.nb)
+    fe1.advection_rhs(L.NPG_BDF1, 0.1, 2.0, dv(b1, d1.p_b), dv(b1, d1.p_b), dv(x, d1.p_inversion), dv(x, d1.p_inversion),
+                      out)
+    S.orc.N2 = 2.0
+    b2 = S.orc.interpolate_b(lin)
+    ref = S.orc.advection_rhs(b2, b2, x[:d1.nu], x[:d1.nu], 0.1, "BDF1")
+    assert abs(out.to_host().sum() - ref.sum()) <= 1e-11 * abs(ref).sum()
