@@ -585,3 +585,27 @@ def test_p1_buoyancy_space(arch):
     b2 = S.orc.interpolate_b(lin)
     ref = S.orc.advection_rhs(b2, b2, x[:d1.nu], x[:d1.nu], 0.1, "BDF1")
     assert abs(out.to_host().sum() - ref.sum()) <= 1e-11 * abs(ref).sum()
+
+
+def test_config2_bowl3D_h008_timestep_loop(arch):
+    """BASELINE configs[2]: bowl3D h = 0.08, the parameters of examples/bowl_mixing.jl (invert!, then the evolve! + invert!
+    loop, BDF2 dt = 1e-3), GPU Krylov path against the oracle's direct-solve recipe on the same mesh.  Starting from b = 0
+    the buoyancy is O(1e-3) after five steps, so at the reference's tolerances (atol = 1e-6 ABSOLUTE) the Krylov error is
+    O(1e-3) relative; the discretisation is therefore compared at tight tolerances and the default run only has to stay
+    within its own tolerance class."""
+    from nupgcm_amd import workloads
+    S = rc.setup("example", mesh="mesh_bowl3D_h0.08")
+    u, p, b = rc.run(S, 5, solver="direct", invert_first=True)
+    fed = workloads.example_fe_data(workloads.bowl_mesh_model("bowl3D_h0.08"))
+    prm, frc = workloads.example_parameters()
+    for tol, bar_b, bar_u, bar_p in ((1e-10, 1e-6, 1e-5, 1e-5), (1e-6, 1e-2, 1e-2, 1e-1)):
+        ts = npg.BDF2(t_start=0.0, t_stop=1e9, dt=1e-3)
+        inv = npg.InversionToolkit(arch, fed, prm, frc, atol=tol, rtol=tol)
+        evo = npg.EvolutionToolkit(arch, fed, prm, frc, ts, atol=tol, rtol=tol)
+        m = npg.Model(arch, prm, frc, fed, inv, evo, ts)
+        assert S.A.shape[0] == m.inversion.solver.A.shape[0] == 31395
+        npg.invert(m)
+        npg.run(m, n_steps=5)
+        assert all(st[1]["solved"] == 1 and st[0]["solved"] == 1 for st in m.stats)
+        assert rel(m.state.b, b) < bar_b, (tol, rel(m.state.b, b))
+        assert rel(m.state.u, u) < bar_u and rel(m.state.p, p) < bar_p, (tol, rel(m.state.u, u), rel(m.state.p, p))
