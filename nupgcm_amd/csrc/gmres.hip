@@ -40,7 +40,6 @@
 namespace npg {
 
 constexpr int kKB = 512;                  // threads per Krylov workgroup: 8 waves, three workgroups per CU (<= 80 VGPRs)
-constexpr int kKW = kKB / 64;
 constexpr int kKP = kPartStride;          // 32: lanes per row group = padded basis size = doubles per partial row
 constexpr int kNS = kKB / kKP;            // 32 row slots per workgroup pass / slices of the partial reduction
 constexpr int kMaxG = 768;                // max workgroups (= partial rows): three per CU
@@ -311,7 +310,7 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
         spmv_tile<kKB, L>(d.A, CorrectedX{d.wt, d.Vi, sh.h2, ro ? j : 0, d.n, d.ldv}, td, tl, sw);
         const int nr = r1 - r0;
         if (!FUSED) {
-            // split mode (large systems): only what depends on the SpMV result; the dots stream in k_gmres_dots
+            // split mode (large systems): only what depends on the SpMV result; the dots stream in k_gmres_dots_rows
             for (int r = threadIdx.x; r < nr; r += kKB) {
                 const int row = r0 + r;
                 d.w[row] = sw[r] * inv_beta * precond_row(d, row);
@@ -355,30 +354,11 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
     if (FUSED) store_partial_row(acc, tmp, d.P1);
 }
 
-// ---- Kd (split mode): partial h1 = V_{0..j}' w and ||w||^2 as a pure stream over the rows -------------------------
-__global__ void __launch_bounds__(kKB, 6) k_gmres_dots(GDev d, int j) {
-    __shared__ double tmp[kNS * kKP];
-    if (d.T[j].done != 0) return;
-    const int k = threadIdx.x & (kKP - 1), slot = threadIdx.x >> 5;
-    double acc = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * kNS;
-    for (int64_t row = (int64_t)blockIdx.x * kNS + slot; row < d.n; row += 2 * stride) {
-        const int64_t rowb = row + stride;
-        const bool hb = rowb < d.n;
-        const double va = (k <= j) ? d.Vi[vidx(row, k, d.n, d.ldv)] : 0.0;
-        const double vb = (hb && k <= j) ? d.Vi[vidx(rowb, k, d.n, d.ldv)] : 0.0;
-        const double wa = d.w[row];
-        const double wb = hb ? d.w[rowb] : 0.0;
-        acc += (k == kNormSlot) ? wa * wa + wb * wb : va * wa + vb * wb;
-    }
-    store_partial_row(acc, tmp, d.P1);
-}
-
 // ---- row-streaming variants for large systems (split mode) -------------------------------------------------------------
 // One thread per row: a lane reads its row's 64-byte group entries with four 16-byte loads, consecutive lanes read
 // consecutive rows, so a wave streams 4 KiB contiguous per group and instruction - the access shape that reaches the HBM
-// rate - and every thread keeps 8*NG accumulators.  Partial rows go through k_reduce_rows (one extra 5 us kernel, free
-// at this size), so these kernels may use any grid.
+// rate - and every thread keeps 8*NG accumulators.  On one GPU the consumer kernels reduce the partial rows themselves
+// (at most kMaxG rows); distributed runs fold them to one row first (k_reduce_rows) for the all-reduce.
 constexpr int kRB = 256;
 constexpr int kMaxRowsI = kMaxG / (kRB / 32);      // chunks of reduce_partials over at most kMaxG partial rows
 

@@ -135,3 +135,20 @@ def test_local_block_and_plan_serial():
             j = list(peer_plan["peers"]).index(r)
             sent = part.inv_owned(int(q))[peer_plan["send_idx"][peer_plan["send_ptr"][j]:peer_plan["send_ptr"][j + 1]]]
             assert np.array_equal(sent, gh[plan["recv_ptr"][i]:plan["recv_ptr"][i + 1]])
+
+
+def test_partition_boundaries_on_node_starts():
+    """with the node-block DoF order every rank owns whole velocity nodes: [its full nodes | its surface nodes | rest]"""
+    n_full, n_surf, rest = 1001, 77, 5
+    nu = 3 * n_full + 2 * n_surf + rest
+    for world in (1, 2, 3, 5, 8):
+        part = D.RowPartition(nu, 300, 500, world, n_full, n_surf)
+        assert part.u_bounds[0] == 0 and part.u_bounds[-1] == nu and np.all(np.diff(part.u_bounds) > 0)
+        for b in part.u_bounds[1:-1]:
+            assert (b % 3 == 0) if b < 3 * n_full else ((b - 3 * n_full) % 2 == 0 or b >= 3 * n_full + 2 * n_surf)
+        tot = np.array([part.local_nodes(r) for r in range(world)]).sum(axis=0)
+        assert tuple(tot) == (n_full, n_surf)
+        for r in range(world):
+            nf, ns = part.local_nodes(r)
+            assert 3 * nf + 2 * ns <= part.u_bounds[r + 1] - part.u_bounds[r]
+        assert np.array_equal(np.sort(np.concatenate([part.inv_owned(r) for r in range(world)])), np.arange(nu + 300))

@@ -106,3 +106,26 @@ def test_gmsh_roundtrip(tmp_path, golden_dir):
     gmsh_io.save_npz(m, str(tmp_path / "m.npz"))
     m2 = gmsh_io.load_npz(str(tmp_path / "m.npz"))
     assert np.array_equal(m.cells, m2.cells) and m.phys_names == m2.phys_names
+
+
+def test_node_block_dof_order(both):
+    """fe._node_block_order: [x,y,z of every node with three free components | x,y of the nodes with free x,y only | rest],
+    nodes in the RCM order of the x component - a permutation, with the components of a node adjacent."""
+    fed = both[0]
+    s, d = fed.spaces, fed.dofs
+    free = s.u_dof >= 0
+    nfull, nsurf = int(free.all(axis=1).sum()), int((free[:, 0] & free[:, 1] & ~free[:, 2]).sum())
+    assert (d.n_full, d.n_surf) == (nfull, nsurf) and nfull > 0 and nsurf > 0
+    assert np.array_equal(np.sort(d.p_u), np.arange(d.nu))
+    node_of = np.full(d.nu, -1)
+    comp_of = np.full(d.nu, -1)
+    for a in range(3):
+        n = np.nonzero(free[:, a])[0]
+        node_of[s.u_dof[n, a]] = n
+        comp_of[s.u_dof[n, a]] = a
+    tri = d.p_u[:3 * nfull].reshape(-1, 3)
+    assert np.array_equal(comp_of[tri], np.tile([0, 1, 2], (nfull, 1)))
+    assert (node_of[tri] == node_of[tri][:, :1]).all() and free[node_of[tri[:, 0]]].all()
+    par = d.p_u[3 * nfull:3 * nfull + 2 * nsurf].reshape(-1, 2)
+    assert np.array_equal(comp_of[par], np.tile([0, 1], (nsurf, 1)))
+    assert (node_of[par[:, 0]] == node_of[par[:, 1]]).all() and not free[node_of[par[:, 0]], 2].any()
