@@ -71,6 +71,7 @@ struct GDev {
     int GR;               // grid of the row-streaming kernels (split mode)
     int split;
     int64_t ldv;          // split mode stores the basis column-major, Vi[k * ldv + row] (0: group-interleaved layout)
+    int pyth;             // distributed runs: ||w - V h||^2 = ||w||^2 - ||h||^2 instead of a second all-reduce
     // what the CONSUMER prologues reduce: the producers' partial rows on one GPU, or the single all-reduced row when
     // the system is distributed over several GPUs
     const double *Q1, *Q2, *QR;
@@ -135,10 +136,10 @@ __device__ void finalize_column(const GDev &d, int colj, KShared &sh, double *tm
     const double cv = d.c[t32], sv = d.s[t32];
     const Snap prev = d.T[colj];
     const double wnorm2 = d.wnorm2[colj];
-    reduce_partials<kNS, kMaxI>(d.Q2, d.nQ2, kKP, tmp, sh.red);         // [0..colj] = h2, [31] = ||wt||^2
+    if (!d.pyth) reduce_partials<kNS, kMaxI>(d.Q2, d.nQ2, kKP, tmp, sh.red);      // [0..colj] = h2, [31] = ||wt||^2
     if (threadIdx.x < kKP) {
         sh.h[threadIdx.x] = h1;
-        sh.h2[threadIdx.x] = ((int)threadIdx.x <= colj) ? sh.red[threadIdx.x] : 0.0;
+        sh.h2[threadIdx.x] = (!d.pyth && (int)threadIdx.x <= colj) ? sh.red[threadIdx.x] : 0.0;
         sh.cc[threadIdx.x] = cv;
         sh.ss[threadIdx.x] = sv;
     }
@@ -148,8 +149,19 @@ __device__ void finalize_column(const GDev &d, int colj, KShared &sh, double *tm
         sh.fin = (t.done == 0) ? 1 : 0;
         sh.reorth = 0;
         if (t.done == 0) {
-            double n2 = sh.red[kNormSlot];
-            const bool reorth = n2 < d.prm->eta2 * wnorm2;
+            double n2;
+            if (d.pyth) {
+                // V orthonormal, h = V'w  =>  ||w - V h||^2 = ||w||^2 - ||h||^2: both already summed over the ranks by
+                // the first all-reduce of this step.  Cancellation is flagged (pad0) and the host falls back to the
+                // explicitly reduced norm for the following cycles.
+                double q = 0.0;
+                for (int i = 0; i <= colj; ++i) q += sh.h[i] * sh.h[i];
+                n2 = fmax(wnorm2 - q, 0.0);
+                if (n2 < 1e-4 * wnorm2) t.pad0 += 1;
+            } else {
+                n2 = sh.red[kNormSlot];
+            }
+            const bool reorth = !d.pyth && n2 < d.prm->eta2 * wnorm2;
             if (reorth) {
                 double q = 0.0;
                 for (int i = 0; i <= colj; ++i) {
@@ -615,6 +627,7 @@ struct npg_gmres {
     bool have_graph = false;
     // profile mode: eager launches with HIP events around every Arnoldi (SpMV) kernel
     bool profile = false;
+    bool explicit_norm = false;   // distributed: a solve met cancellation in the Pythagorean norm
     int split_mode = -1;
     std::vector<hipEvent_t> pev;
     double prof_ms = 0.0;
@@ -669,7 +682,7 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
             launch_rows_kernel(d, j, st, true);
         else
             hipLaunchKernelGGL(k_gmres_orth, dim3(d.G2), dim3(kKB), 0, st, d, j);
-        if (fold && (rc = fold_rows(ws, d.P2, d.GP2, 1, st, dist))) return rc;
+        if (fold && !d.pyth && (rc = fold_rows(ws, d.P2, d.GP2, 1, st, dist))) return rc;
     }
     hipLaunchKernelGGL(k_gmres_update, dim3(d.G2), dim3(kKB), 0, st, d);
     if (dist && (rc = halo_exchange_raw(ws->halo, d.x))) return rc;
@@ -823,6 +836,10 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     static const int split_env = getenv("NPG_GMRES_SPLIT") ? atoi(getenv("NPG_GMRES_SPLIT")) : -1;
     const int split_req = ws->split_mode >= 0 ? ws->split_mode : split_env;
     d.split = split_req >= 0 ? (split_req != 0) : (ws->n >= 150000 ? 1 : 0);   // large systems: dots as separate streams
+    // distributed: one all-reduce per Arnoldi step (norm of the orthogonalised vector by Pythagoras); NPG_GMRES_PYTH=0
+    // or a cancellation flagged by an earlier cycle selects the explicitly reduced norm (a second all-reduce)
+    static const int pyth_env = getenv("NPG_GMRES_PYTH") ? atoi(getenv("NPG_GMRES_PYTH")) : 1;
+    d.pyth = (dist && pyth_env && !ws->explicit_norm) ? 1 : 0;
     d.GR = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kRB - 1) / kRB, std::min(kMaxG, 3 * ctx->num_cu)));
     d.ldv = d.split ? (int64_t)((ws->n + 31) / 32) * 32 : 0;
     d.GP1 = d.split ? d.GR : d.G1;
@@ -929,6 +946,10 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
             }
             NPG_HIP(hipEventSynchronize(ws->ev[cur]));
             last = ws->h_C[cur];
+            if (d.pyth && last.pad0 > 0) {      // cancellation in ||w||^2 - ||h||^2: explicit norms from the next launch on
+                d.pyth = 0;
+                ws->explicit_norm = true;
+            }
             if (last.done != 0 || !more) break;
         }
         NPG_HIP(hipStreamSynchronize(st));
@@ -967,7 +988,7 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
         stats->npass = last.npass;
         stats->status = last.done;
         stats->nreorth = last.nreorth;
-        stats->reserved = 0;
+        stats->reserved = last.pad0;      // distributed: Arnoldi steps whose Pythagorean norm lost > 4 digits
         stats->rnorm0 = last.rnorm0;
         stats->rnorm = last.rnorm;
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

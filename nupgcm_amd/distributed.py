@@ -7,7 +7,8 @@ evolution system a slice of the buoyancy rows.  The Krylov solves - more than 99
   * SpMV: the rank's rows as an n_owned x (n_owned + n_ghost) CSR block; ghost entries of the input vector are filled from
     the neighbours before every SpMV (npg_halo_exchange: one pack kernel + one grouped ncclSend/ncclRecv per neighbour),
   * inner products: every kernel folds its partial sums to one 32-double row which ncclAllReduce sums over the ranks
-    (two all-reduces per GMRES iteration, latency-bound: 256-byte messages).
+    (one all-reduce per GMRES iteration - h = V'w and ||w||^2 together, ||w - V h||^2 by Pythagoras - and two per CG
+    iteration; latency-bound: 256-byte messages).
 
 The state ([u; p] and b) is REPLICATED: after each solve the owned slices are all-gathered (8 N bytes per step), and each
 rank evaluates the element kernels (advection right-hand side, < 1 % of a step) on the full mesh - so the element layer
