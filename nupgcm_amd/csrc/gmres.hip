@@ -238,6 +238,7 @@ struct CorrectedX {
         return v;
     }
     __device__ __forceinline__ double2 two(int i) const { return make_double2((*this)(i), (*this)(i + 1)); }
+    __device__ __forceinline__ double third(int i) const { return (*this)(i); }
 };
 
 // ---- R1: wt = P (b - A x), partial ||wt||^2 ---------------------------------------------------------------------------

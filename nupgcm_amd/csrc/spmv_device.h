@@ -62,6 +62,8 @@ struct PlainX {
         __builtin_memcpy(&r, x + i, sizeof r);
         return r;
     }
+    // the z component of a node whose (x, y) were fetched with two(): separate hook so that diagnostics can price it
+    __device__ __forceinline__ double third(int i) const { return x[i]; }
 };
 
 // optional phase profiling of spmv_tile (tuning harness): the default does nothing
@@ -129,7 +131,7 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
                 const int cf = c[u] < A.nfull ? c[u] : A.nfull;
                 const int xo = 2 * c[u] + cf;                       // first DoF of node c
                 xx[u] = x.two(xo);
-                zz[u] = (full && c[u] < A.nfull) ? x(xo + 2) : 0.0;
+                zz[u] = (full && c[u] < A.nfull) ? x.third(xo + 2) : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < UP; ++u) {

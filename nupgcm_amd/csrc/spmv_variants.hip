@@ -175,17 +175,30 @@ struct FakeX {
     const double *x;
     __device__ __forceinline__ double operator()(int c) const { return 1e-9 * (double)c; }
     __device__ __forceinline__ double2 two(int c) const { return make_double2(1e-9 * (double)c, 2e-9 * (double)c); }
+    __device__ __forceinline__ double third(int c) const { return 3e-9 * (double)c; }
+};
+
+// diagnostic input: everything gathered except the z component of the record columns (prices that one load)
+struct NoZX {
+    const double *x;
+    __device__ __forceinline__ double operator()(int c) const { return x[c]; }
+    __device__ __forceinline__ double2 two(int i) const {
+        double2 r;
+        __builtin_memcpy(&r, x + i, sizeof r);
+        return r;
+    }
+    __device__ __forceinline__ double third(int c) const { return 3e-9 * (double)c; }
 };
 
 
-template <int NT, int L, int TNNZ, int U2, int WPE>
+template <int NT, int L, int TNNZ, int U2, int WPE, class XF = FakeX>
 __global__ void __launch_bounds__(NT, WPE) k_spmv_nogather(CsrDev A, const int32_t *__restrict__ tile_ptr, int ntiles,
                                                            const double *__restrict__ x, double *__restrict__ y) {
     __shared__ TileLdsT<TNNZ> tl;
     __shared__ double sw[kTileRows];
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int r0 = tile_ptr[t], r1 = tile_ptr[t + 1];
-        spmv_tile<NT, L, FakeX, TNNZ, U2>(A, FakeX{x}, r0, r1, tl, sw);
+        spmv_tile<NT, L, XF, TNNZ, U2>(A, XF{x}, r0, r1, tl, sw);
         for (int r = threadIdx.x; r < r1 - r0; r += NT) y[r0 + r] = sw[r];
     }
 }
@@ -204,7 +217,7 @@ __global__ void __launch_bounds__(NT, WPE) k_spmv_prod(CsrDev A, const int32_t *
 
 static std::map<std::pair<const void *, int>, VarTiles> g_ptiles;
 
-template <int NT, int TNNZ, int U2, int WPE, bool MERGED, bool NOGATHER = false>
+template <int NT, int TNNZ, int U2, int WPE, bool MERGED, int NOGATHER = 0>
 static int run_prod(const npg_csr *A, const double *x, double *y, int bpc, int reps, double *ms) {
     auto key = std::make_pair((const void *)A, TNNZ);
     if (!g_ptiles.count(key)) {
@@ -222,9 +235,12 @@ static int run_prod(const npg_csr *A, const double *x, double *y, int bpc, int r
     const int grid = std::max(1, std::min(t.n, bpc * ctx->num_cu));
     const CsrDev Av = csr_view(A);
     auto go = [&]() {
-        if (NOGATHER)
+        if (NOGATHER == 1)
             hipLaunchKernelGGL((k_spmv_nogather<NT, 16, TNNZ, U2, WPE>), dim3(grid), dim3(NT), 0, ctx->stream, Av, t.d, t.n,
                                x, y);
+        else if (NOGATHER == 2)
+            hipLaunchKernelGGL((k_spmv_nogather<NT, 16, TNNZ, U2, WPE, NoZX>), dim3(grid), dim3(NT), 0, ctx->stream, Av, t.d,
+                               t.n, x, y);
         else
             hipLaunchKernelGGL((k_spmv_prod<NT, 16, TNNZ, U2, WPE, MERGED>), dim3(grid), dim3(NT), 0, ctx->stream, Av, t.d,
                                t.n, x, y);
@@ -323,7 +339,8 @@ NPG_API int npg_spmv_variant(const npg_csr *A, const npg_vec *x, npg_vec *y, int
         case 30: return run_prod<512, 4096, 4, 6, false>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 31: return run_prod<512, 2048, 2, 6, false>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 32: return run_prod<1024, 4096, 2, 8, false>(A, x->d, y->d, blocks_per_cu, reps, ms);
-        case 40: return run_prod<512, 4096, 4, 6, false, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 40: return run_prod<512, 4096, 4, 6, false, 1>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 42: return run_prod<512, 4096, 4, 6, false, 2>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 0: return run_var<512, 4096, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 1: return run_var<512, 4096, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 2: return run_var<1024, 8192, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);
