@@ -183,7 +183,7 @@ def main():
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
         roofline = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                         traffic=pmc_traffic(a.workload), kernel="k_gmres_arnoldi (Givens prologue + CSR-stream SpMV"
-                        + (")" if N >= 150000 else " + fused Gram-Schmidt dots)"),
+                        + (")" if N >= 8192 else " + fused Gram-Schmidt dots)"),
                         avg_launch_us=avg_ms * 1e3, launches=launches, algorithmic_bytes_per_launch=alg_bytes,
                         cache_resident=bool(alg_bytes < 256 * 2 ** 20))
     # stand-alone SpMV kernel (same tiles, no Krylov epilogue) for reference

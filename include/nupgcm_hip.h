@@ -149,7 +149,7 @@ int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, double pr
 int npg_gmres_set_profile(npg_gmres *ws, int on);
 /* kernel organisation of the Arnoldi step: 0 = fused (SpMV + Gram-Schmidt dots in one kernel, group-interleaved basis:
  * latency-bound sizes), 1 = split (SpMV kernel + row-streaming dots/orthogonalisation kernels, column-major basis:
- * bandwidth-bound sizes), -1 = by size (split from 150 000 rows; default).  Same arithmetic either way. */
+ * bandwidth-bound sizes), -1 = by size (split from 8192 rows; default).  Same arithmetic either way. */
 int npg_gmres_set_split(npg_gmres *ws, int mode);
 int npg_gmres_get_profile(npg_gmres *ws, double *ms_total, int64_t *launches);
 /* residual history of the last solve (workspace.stats.residuals with history=true): returns entries written */

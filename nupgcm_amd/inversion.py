@@ -7,6 +7,8 @@ directly in the RCM-permuted numbering the solver uses; only the wind-stress sur
 boundary triangles) is evaluated on the host."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import _lib as L
@@ -81,6 +83,8 @@ class InversionToolkit:
             # the eddy closure re-assembles A in the full-stress form later: keep all nine component pairs in the pattern
             # then (Gridap's structural pattern, src/model.jl:160-170 assembles into it in place)
             A = build_A_inversion(arch, fe_data, params, forcings.nu, structural=forcings.eddy_param.is_on)
+            if block_nodes is None and os.environ.get("NPG_BLOCK_NODES"):
+                block_nodes = os.environ["NPG_BLOCK_NODES"] != "0"          # tuning override
             if block_nodes is None:
                 # bandwidth-bound sizes only: below ~1e5 rows the solve is latency-bound and the extra stream costs time
                 block_nodes = A.shape[0] >= 100000
