@@ -38,7 +38,7 @@ constexpr int kWave = 64;          // CDNA4 wavefront
 constexpr int kBlock = 256;        // 4 waves per workgroup everywhere
 constexpr int kNumCU = 256;        // MI355X
 constexpr int kPartStride = 32;    // doubles per block in a partial-sum row (256 B)
-constexpr int kTileRows = 512;     // most rows in one SpMV tile
+constexpr int kTileRows = 256;     // most rows in one SpMV tile
 constexpr int kMaxMem = 30;        // largest GMRES memory supported (partial rows hold mem + 2 values)
 
 // one SpMV tile: rows [r0, r0 + nrows), its n CSR entries from `base` and (node-block rows) npe records from `pbase`.

@@ -24,17 +24,19 @@
 // 20 bytes and cost one 16-byte gather of (x, y)_c plus one 8-byte gather of z_c from the same cache line.  Everything else
 // (the velocity-pressure couplings, the pressure rows) stays plain CSR.
 //
-// Configuration (512 threads, 5376 product slots, 4 pairs per lane, 3 workgroups per CU: fp64 + 64-bit addressing needs
-// ~80 VGPRs, which rules out two 1024-thread workgroups per CU) chosen from the sweep in profiles/r01_spmv_variants.txt
-// (tools/spmv_tune.py) and from whole-timestep runs with 4096 / 4608 / 5120 / 5376 / 5632 slots (3818 / 3677 / 3606 / 3601 /
-// 4703 ms per step on bowl3D h = 0.02; at 5632 only two workgroups of the Arnoldi kernel fit a CU).
+// Configuration (512 threads, 5824 product slots and at most 256 rows per tile, 4 pairs per lane, 3 workgroups per CU: fp64
+// + 64-bit addressing needs ~80 VGPRs, which rules out two 1024-thread workgroups per CU) chosen from the sweep in
+// profiles/r01_spmv_variants.txt (tools/spmv_tune.py) and from whole-timestep runs on bowl3D h = 0.02: 4096 / 4608 / 5120 /
+// 5376 slots with 512-row tiles 3818 / 3677 / 3606 / 3601 ms per step (5632: 4703, only two workgroups of the Arnoldi kernel
+// fit a CU); with 256-row tiles (3.5 KiB less row bookkeeping) 5824 slots 3514 ms, 6000 slots 3585 ms (more than 3 x 512
+// records in many tiles: a second dependent trip).
 #pragma once
 #include "device_utils.h"
 
 namespace npg {
 
-constexpr int kTileNnz = 5376;   // LDS product slots per tile: 42 KiB of fp64 (three workgroups of the Arnoldi kernel
-                                 // = 3 x 50 KiB of the CU's 160 KiB); tiles are latency-bound, so the largest that keeps three fits best
+constexpr int kTileNnz = 5824;   // LDS product slots per tile: 45.5 KiB of fp64 (three workgroups of the Arnoldi kernel
+                                 // = 3 x 51 KiB of the CU's 160 KiB); tiles are latency-bound, so the largest that keeps three fits best
 
 // device view of a matrix: the (remainder) CSR arrays + the optional node-block part
 struct CsrDev {
