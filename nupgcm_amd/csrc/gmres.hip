@@ -72,6 +72,7 @@ struct GDev {
     int split;
     int64_t ldv;          // split mode stores the basis column-major, Vi[k * ldv + row] (0: group-interleaved layout)
     int pyth;             // distributed runs: ||w - V h||^2 = ||w||^2 - ||h||^2 instead of a second all-reduce
+    int lazy2;            // one GPU: the same identity decides whether the second-pass sums need reducing at all
     // what the CONSUMER prologues reduce: the producers' partial rows on one GPU, or the single all-reduced row when
     // the system is distributed over several GPUs
     const double *Q1, *Q2, *QR;
@@ -136,10 +137,16 @@ __device__ void finalize_column(const GDev &d, int colj, KShared &sh, double *tm
     const double cv = d.c[t32], sv = d.s[t32];
     const Snap prev = d.T[colj];
     const double wnorm2 = d.wnorm2[colj];
-    if (!d.pyth) reduce_partials<kNS, kMaxI>(d.Q2, d.nQ2, kKP, tmp, sh.red);      // [0..colj] = h2, [31] = ||wt||^2
+    // ||w - V h||^2 by Pythagoras from the first-pass sums (every 32-lane group computes the same number).  While it is
+    // far from cancellation (and from the second-pass threshold) the orthogonalisation kernel's own partial sums - the
+    // exact norm and h2 = V'(w - V h) - are not needed and their reduction over <= 768 rows is skipped.
+    const double q1 = group_sum_dpp<kKP>(t32 <= colj ? h1 * h1 : 0.0);
+    const double n2f = wnorm2 - q1;
+    const bool need2 = !d.pyth && (!d.lazy2 || !(n2f >= fmax(d.prm->eta2, 1e-4) * wnorm2));
+    if (need2) reduce_partials<kNS, kMaxI>(d.Q2, d.nQ2, kKP, tmp, sh.red);        // [0..colj] = h2, [31] = ||wt||^2
     if (threadIdx.x < kKP) {
         sh.h[threadIdx.x] = h1;
-        sh.h2[threadIdx.x] = (!d.pyth && (int)threadIdx.x <= colj) ? sh.red[threadIdx.x] : 0.0;
+        sh.h2[threadIdx.x] = (need2 && (int)threadIdx.x <= colj) ? sh.red[threadIdx.x] : 0.0;
         sh.cc[threadIdx.x] = cv;
         sh.ss[threadIdx.x] = sv;
     }
@@ -158,10 +165,12 @@ __device__ void finalize_column(const GDev &d, int colj, KShared &sh, double *tm
                 for (int i = 0; i <= colj; ++i) q += sh.h[i] * sh.h[i];
                 n2 = fmax(wnorm2 - q, 0.0);
                 if (n2 < 1e-4 * wnorm2) t.pad0 += 1;
+            } else if (!need2) {
+                n2 = fmax(n2f, 0.0);
             } else {
                 n2 = sh.red[kNormSlot];
             }
-            const bool reorth = !d.pyth && n2 < d.prm->eta2 * wnorm2;
+            const bool reorth = need2 && n2 < d.prm->eta2 * wnorm2;
             if (reorth) {
                 double q = 0.0;
                 for (int i = 0; i <= colj; ++i) {
@@ -843,6 +852,8 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     // or a cancellation flagged by an earlier cycle selects the explicitly reduced norm (a second all-reduce)
     static const int pyth_env = getenv("NPG_GMRES_PYTH") ? atoi(getenv("NPG_GMRES_PYTH")) : 1;
     d.pyth = (dist && pyth_env && !ws->explicit_norm) ? 1 : 0;
+    static const int lazy_env = getenv("NPG_GMRES_LAZY2") ? atoi(getenv("NPG_GMRES_LAZY2")) : 1;
+    d.lazy2 = (!dist && lazy_env) ? 1 : 0;
     d.GR = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kRB - 1) / kRB, std::min(kMaxG, 3 * ctx->num_cu)));
     d.ldv = d.split ? (int64_t)((ws->n + 31) / 32) * 32 : 0;
     d.GP1 = d.split ? d.GR : d.G1;
