@@ -328,15 +328,21 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
         const TileDesc td = nd;
         if (t + (int)gridDim.x < d.ntiles) nd = d.tile_ptr[t + gridDim.x];      // in flight during this tile
         const int r0 = td.r0, r1 = td.r0 + td.nrows;
+        // split mode: this thread's row of wt for the epilogue, fetched now so that its latency hides behind the tile
+        // (a tile has at most kTileRows <= kKB rows: one row per thread)
+        static_assert(kTileRows <= kKB, "one epilogue row per thread");
+        double wt_row = 0.0;
+        if (!FUSED && (int)threadIdx.x < td.nrows) wt_row = d.wt[td.r0 + threadIdx.x];
         // one instantiation for both cases: without a second pass the correction loop has no trips
         spmv_tile<kKB, L>(d.A, CorrectedX{d.wt, d.Vi, sh.h2, ro ? j : 0, d.n, d.ldv}, td, tl, sw);
         const int nr = r1 - r0;
         if (!FUSED) {
             // split mode (large systems): only what depends on the SpMV result; the dots stream in k_gmres_dots_rows
-            for (int r = threadIdx.x; r < nr; r += kKB) {
+            const int r = threadIdx.x;
+            if (r < nr) {
                 const int row = r0 + r;
                 d.w[row] = sw[r] * inv_beta * precond_row(d, row);
-                double tv = d.wt[row];
+                double tv = wt_row;
                 if (ro)
                     for (int q = 0; q < j; ++q) tv -= sh.h2[q] * d.Vi[vidx(row, q, d.n, d.ldv)];
                 d.Vi[vidx(row, j, d.n, d.ldv)] = tv * inv_beta;
