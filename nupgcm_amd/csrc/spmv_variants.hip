@@ -203,6 +203,31 @@ __global__ void __launch_bounds__(NT, WPE) k_spmv_nogather(CsrDev A, const int32
     }
 }
 
+// diagnostic: what a tile-local gather list would cost - x values served from an LDS stage filled by ~1000 coalesced
+// gathers per tile (wrong results on purpose: the stage holds x[r0 ...], the indices are folded into it)
+struct StageX {
+    const double *xs;
+    __device__ __forceinline__ double operator()(int c) const { return xs[c & 1023]; }
+    __device__ __forceinline__ double2 two(int c) const { return make_double2(xs[c & 1023], xs[(c + 1) & 1023]); }
+    __device__ __forceinline__ double third(int c) const { return xs[c & 1023]; }
+};
+
+template <int NT, int L, int TNNZ, int U2, int WPE>
+__global__ void __launch_bounds__(NT, WPE) k_spmv_stage(CsrDev A, const int32_t *__restrict__ tile_ptr, int ntiles,
+                                                        const double *__restrict__ x, double *__restrict__ y,
+                                                        const int32_t *__restrict__ glist) {
+    __shared__ TileLdsT<TNNZ> tl;
+    __shared__ double sw[kTileRows];
+    __shared__ double xs[1024];
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int r0 = tile_ptr[t], r1 = tile_ptr[t + 1];
+        for (int i = threadIdx.x; i < 1024; i += NT) xs[i] = x[glist[(size_t)t * 1024 + i]];
+        __syncthreads();
+        spmv_tile<NT, L, StageX, TNNZ, U2>(A, StageX{xs}, r0, r1, tl, sw);
+        for (int r = threadIdx.x; r < r1 - r0; r += NT) y[r0 + r] = sw[r];
+    }
+}
+
 template <int NT, int L, int TNNZ, int U2, int WPE, bool MERGED>
 __global__ void __launch_bounds__(NT, WPE) k_spmv_prod(CsrDev A, const int32_t *__restrict__ tile_ptr, int ntiles,
                                                        const double *__restrict__ x, double *__restrict__ y) {
@@ -234,8 +259,32 @@ static int run_prod(const npg_csr *A, const double *x, double *y, int bpc, int r
     npg_ctx *ctx = A->ctx;
     const int grid = std::max(1, std::min(t.n, bpc * ctx->num_cu));
     const CsrDev Av = csr_view(A);
+    static std::map<std::pair<const void *, int>, int32_t *> g_lists;
+    int32_t *glist = nullptr;
+    if (NOGATHER == 3) {
+        // a plausible gather list per tile: the tile's own rows first, then columns spread over a window around them
+        if (!g_lists.count(key)) {
+            std::vector<int32_t> tp((size_t)t.n + 1);
+            NPG_HIP(hipMemcpy(tp.data(), t.d, tp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            std::vector<int32_t> gl((size_t)t.n * 1024);
+            for (int q = 0; q < t.n; ++q)
+                for (int i = 0; i < 1024; ++i) {
+                    const int64_t c = (int64_t)tp[q] + (i < 256 ? i : (i - 640) * 37);
+                    gl[(size_t)q * 1024 + i] = (int32_t)std::min<int64_t>(std::max<int64_t>(c, 0), A->n - 1);
+                }
+            for (int q = 0; q < t.n; ++q) std::sort(gl.begin() + (size_t)q * 1024, gl.begin() + (size_t)(q + 1) * 1024);
+            int32_t *dg;
+            NPG_HIP(hipMalloc((void **)&dg, gl.size() * sizeof(int32_t)));
+            NPG_HIP(hipMemcpy(dg, gl.data(), gl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            g_lists[key] = dg;
+        }
+        glist = g_lists[key];
+    }
     auto go = [&]() {
-        if (NOGATHER == 1)
+        if (NOGATHER == 3)
+            hipLaunchKernelGGL((k_spmv_stage<NT, 16, TNNZ, U2, WPE>), dim3(grid), dim3(NT), 0, ctx->stream, Av, t.d, t.n, x, y,
+                               glist);
+        else if (NOGATHER == 1)
             hipLaunchKernelGGL((k_spmv_nogather<NT, 16, TNNZ, U2, WPE>), dim3(grid), dim3(NT), 0, ctx->stream, Av, t.d, t.n,
                                x, y);
         else if (NOGATHER == 2)
@@ -341,6 +390,9 @@ NPG_API int npg_spmv_variant(const npg_csr *A, const npg_vec *x, npg_vec *y, int
         case 32: return run_prod<1024, 4096, 2, 8, false>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 40: return run_prod<512, 4096, 4, 6, false, 1>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 42: return run_prod<512, 4096, 4, 6, false, 2>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 43: return run_prod<512, 4800, 4, 6, false, 3>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 44: return run_prod<512, 4800, 4, 6, false, 0>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 45: return run_prod<512, 4800, 4, 6, false, 1>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 0: return run_var<512, 4096, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 1: return run_var<512, 4096, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 2: return run_var<1024, 8192, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);

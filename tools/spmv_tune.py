@@ -36,7 +36,9 @@ names = {0: "NT512 T4096 U4", 1: "NT512 T4096 U8", 2: "NT1024 T8192 U8", 3: "NT2
          11: "wide NT1024 T4096 U2x2", 12: "wide+nt NT1024 T8192", 13: "wide+nt NT512 T4096", 14: "wide NT1024 T8192 U2x2",
          15: "wide NT512 T8192 U2x4",
          30: "product NT512 T4096 U4 wpe6", 31: "product NT512 T2048 U2 wpe6", 32: "product NT1024 T4096 U2 wpe8",
-         40: "product, gathers removed (diagnostic)", 42: "product, z gather of the records removed (diagnostic)"}
+         40: "product, gathers removed (diagnostic)", 42: "product, z gather of the records removed (diagnostic)",
+         43: "T4800: gathers from an LDS stage filled per tile (diagnostic)", 44: "T4800 product",
+         45: "T4800 gathers removed (diagnostic)"}
 print(f"{wl}: N={N} nnz={nnz} algorithmic bytes={alg / 1e6:.1f} MB")
 vs = [int(a) for a in sys.argv[3].split(',')] if len(sys.argv) > 3 else range(16)
 for v in vs:
