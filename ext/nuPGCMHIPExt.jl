@@ -104,7 +104,7 @@ end
 
 # ---- iterative_solve!: one ccall per solve instead of Krylov.krylov_solve! (src/iterative_solvers.jl:58) -------------------
 struct SolveStats
-    solved::Int32; niter::Int32; npass::Int32; status::Int32; nreorth::Int32; reserved::Int32
+    solved::Int32; niter::Int32; npass::Int32; status::Int32; nreorth::Int32; nflagged::Int32
     rnorm0::Float64; rnorm::Float64; seconds::Float64
 end
 mutable struct HIPGmresWorkspace

@@ -127,7 +127,9 @@ typedef struct npg_solve_stats {
     int32_t npass;        /* GMRES restart cycles started                                       */
     int32_t status;       /* 1 solved, 2 itmax reached, 3 breakdown, 4 zero residual at start   */
     int32_t nreorth;      /* GMRES: second Gram-Schmidt passes taken                            */
-    int32_t reserved;
+    int32_t nflagged;   /* GMRES: Arnoldi steps flagged by the device - a Pythagorean norm that lost > 4 digits (distributed), or a
+                         * column that was due a second Gram-Schmidt pass while the fast kernels ran (the next solves use the
+                         * full kernels); 0 for CG */
     double rnorm0;        /* || M r0 ||                                                         */
     double rnorm;         /* last residual estimate                                             */
     double seconds;       /* host wall time of the call                                         */

@@ -23,11 +23,11 @@ class DeviceError(RuntimeError):
 
 class SolveStats(C.Structure):
     _fields_ = [("solved", C.c_int32), ("niter", C.c_int32), ("npass", C.c_int32), ("status", C.c_int32),
-                ("nreorth", C.c_int32), ("reserved", C.c_int32), ("rnorm0", C.c_double), ("rnorm", C.c_double),
+                ("nreorth", C.c_int32), ("nflagged", C.c_int32), ("rnorm0", C.c_double), ("rnorm", C.c_double),
                 ("seconds", C.c_double)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class FeDesc(C.Structure):

@@ -358,7 +358,7 @@ NPG_API int npg_cg_solve(npg_cg *ws, const npg_csr *A, int precond_kind, double 
         stats->npass = 1;
         stats->status = last.done;
         stats->nreorth = 0;
-        stats->reserved = 0;
+        stats->nflagged = 0;
         stats->rnorm0 = last.rnorm0;
         stats->rnorm = last.rnorm;
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

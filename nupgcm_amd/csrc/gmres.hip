@@ -73,6 +73,8 @@ struct GDev {
     int64_t ldv;          // split mode stores the basis column-major, Vi[k * ldv + row] (0: group-interleaved layout)
     int pyth;             // distributed runs: ||w - V h||^2 = ||w||^2 - ||h||^2 instead of a second all-reduce
     int lazy2;            // one GPU: the same identity decides whether the second-pass sums need reducing at all
+    int fast;             // one GPU, split mode: the orthogonalisation kernel does not form the second-pass sums at all; a
+                          // column that would have needed them is counted (pad1) and later solves run the full kernels
     // what the CONSUMER prologues reduce: the producers' partial rows on one GPU, or the single all-reduced row when
     // the system is distributed over several GPUs
     const double *Q1, *Q2, *QR;
@@ -142,7 +144,7 @@ __device__ void finalize_column(const GDev &d, int colj, KShared &sh, double *tm
     // exact norm and h2 = V'(w - V h) - are not needed and their reduction over <= 768 rows is skipped.
     const double q1 = group_sum_dpp<kKP>(t32 <= colj ? h1 * h1 : 0.0);
     const double n2f = wnorm2 - q1;
-    const bool need2 = !d.pyth && (!d.lazy2 || !(n2f >= fmax(d.prm->eta2, 1e-4) * wnorm2));
+    const bool need2 = !d.pyth && !d.fast && (!d.lazy2 || !(n2f >= fmax(d.prm->eta2, 1e-4) * wnorm2));
     if (need2) reduce_partials<kNS, kMaxI>(d.Q2, d.nQ2, kKP, tmp, sh.red);        // [0..colj] = h2, [31] = ||wt||^2
     if (threadIdx.x < kKP) {
         sh.h[threadIdx.x] = h1;
@@ -167,6 +169,7 @@ __device__ void finalize_column(const GDev &d, int colj, KShared &sh, double *tm
                 if (n2 < 1e-4 * wnorm2) t.pad0 += 1;
             } else if (!need2) {
                 n2 = fmax(n2f, 0.0);
+                if (d.fast && !(n2f >= fmax(d.prm->eta2, 1e-4) * wnorm2)) t.pad1 += 1;    // a second pass was due
             } else {
                 n2 = sh.red[kNormSlot];
             }
@@ -457,8 +460,10 @@ __global__ void __launch_bounds__(kRB) k_gmres_dots_rows(GDev d, int j) {
     store_partial_row_rows<NG>(acc, nrm, tmp, d.P1);
 }
 
-template <int NG>
-__global__ void __launch_bounds__(kRB, NG < 4 ? 3 : 2) k_gmres_orth_rows(GDev d, int j) {
+// FAST: only wt = w - V h (one pass over the columns, nothing kept); the norm of wt follows from Pythagoras in the next
+// Arnoldi kernel.  Otherwise also h2 = V'wt and ||wt||^2 for the selective second Gram-Schmidt pass.
+template <int NG, bool FAST>
+__global__ void __launch_bounds__(kRB, (NG < 4 || FAST) ? 3 : 2) k_gmres_orth_rows(GDev d, int j) {
     __shared__ double tmp[(kRB / 32) * kKP];
     __shared__ double red[kKP];
     const Snap T = d.T[j];
@@ -491,12 +496,14 @@ __global__ void __launch_bounds__(kRB, NG < 4 ? 3 : 2) k_gmres_orth_rows(GDev d,
 #pragma unroll
             for (int k = 0; k < 8 * NG; ++k) wp -= h[k] * v[k];
             d.wt[row] = wp;
+            if (!FAST) {
 #pragma unroll
-            for (int k = 0; k < 8 * NG; ++k) acc[k] += v[k] * wp;
-            nrm += wp * wp;
+                for (int k = 0; k < 8 * NG; ++k) acc[k] += v[k] * wp;
+                nrm += wp * wp;
+            }
         }
     }
-    store_partial_row_rows<NG>(acc, nrm, tmp, d.P2);
+    if (!FAST) store_partial_row_rows<NG>(acc, nrm, tmp, d.P2);
 }
 
 // ---- K2 ---------------------------------------------------------------------------------------------------------------
@@ -644,6 +651,7 @@ struct npg_gmres {
     // profile mode: eager launches with HIP events around every Arnoldi (SpMV) kernel
     bool profile = false;
     bool explicit_norm = false;   // distributed: a solve met cancellation in the Pythagorean norm
+    bool safe_mode = false;       // one GPU: a solve in fast mode met a column that was due a second Gram-Schmidt pass
     int split_mode = -1;
     std::vector<hipEvent_t> pev;
     double prof_ms = 0.0;
@@ -662,8 +670,10 @@ static int fold_rows(npg_gmres *ws, const double *part, int nrows, int slot, hip
 
 template <int NG>
 static void launch_rows(const GDev &d, int j, hipStream_t st, bool orth) {
-    if (orth)
-        hipLaunchKernelGGL(k_gmres_orth_rows<NG>, dim3(d.GR), dim3(kRB), 0, st, d, j);
+    if (orth && d.fast)
+        hipLaunchKernelGGL((k_gmres_orth_rows<NG, true>), dim3(d.GR), dim3(kRB), 0, st, d, j);
+    else if (orth)
+        hipLaunchKernelGGL((k_gmres_orth_rows<NG, false>), dim3(d.GR), dim3(kRB), 0, st, d, j);
     else
         hipLaunchKernelGGL(k_gmres_dots_rows<NG>, dim3(d.GR), dim3(kRB), 0, st, d, j);
 }
@@ -860,6 +870,10 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     d.pyth = (dist && pyth_env && !ws->explicit_norm) ? 1 : 0;
     static const int lazy_env = getenv("NPG_GMRES_LAZY2") ? atoi(getenv("NPG_GMRES_LAZY2")) : 1;
     d.lazy2 = (!dist && lazy_env) ? 1 : 0;
+    // one GPU, split mode: no second-pass sums until a solve reports that a column needed them (NPG_GMRES_FAST=0: never)
+    static const int fast_env = getenv("NPG_GMRES_FAST") ? atoi(getenv("NPG_GMRES_FAST")) : 1;
+    // (only at the default threshold or below, where a second pass is a rare event; a caller asking for eta > 0.1 wants them)
+    d.fast = (!dist && d.split && d.lazy2 && fast_env && !ws->safe_mode && reorth_eta <= 0.1 + 1e-12) ? 1 : 0;
     d.GR = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kRB - 1) / kRB, std::min(kMaxG, 3 * ctx->num_cu)));
     d.ldv = d.split ? (int64_t)((ws->n + 31) / 32) * 32 : 0;
     d.GP1 = d.split ? d.GR : d.G1;
@@ -1008,7 +1022,10 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
         stats->npass = last.npass;
         stats->status = last.done;
         stats->nreorth = last.nreorth;
-        stats->reserved = last.pad0;      // distributed: Arnoldi steps whose Pythagorean norm lost > 4 digits
+        // distributed: Arnoldi steps whose Pythagorean norm lost > 4 digits; one GPU, fast mode: columns that were due a
+        // second Gram-Schmidt pass and did not get it (the following solves then run the full kernels)
+        stats->nflagged = last.pad0 + last.pad1;
+        if (d.fast && last.pad1 > 0) ws->safe_mode = true;
         stats->rnorm0 = last.rnorm0;
         stats->rnorm = last.rnorm;
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
