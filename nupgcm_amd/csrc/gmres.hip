@@ -144,11 +144,12 @@ __device__ void finalize_column(const GDev &d, int colj, KShared &sh, double *tm
     // exact norm and h2 = V'(w - V h) - are not needed and their reduction over <= 768 rows is skipped.
     const double q1 = group_sum_dpp<kKP>(t32 <= colj ? h1 * h1 : 0.0);
     const double n2f = wnorm2 - q1;
-    const bool need2 = !d.pyth && !d.fast && (!d.lazy2 || !(n2f >= fmax(d.prm->eta2, 1e-4) * wnorm2));
+    // (fast mode: the rows then hold the exactly summed norm only, h2 = 0 - no second pass, but no cancellation either)
+    const bool need2 = !d.pyth && (!d.lazy2 || !(n2f >= fmax(d.prm->eta2, 1e-4) * wnorm2));
     if (need2) reduce_partials<kNS, kMaxI>(d.Q2, d.nQ2, kKP, tmp, sh.red);        // [0..colj] = h2, [31] = ||wt||^2
     if (threadIdx.x < kKP) {
         sh.h[threadIdx.x] = h1;
-        sh.h2[threadIdx.x] = (need2 && (int)threadIdx.x <= colj) ? sh.red[threadIdx.x] : 0.0;
+        sh.h2[threadIdx.x] = (need2 && !d.fast && (int)threadIdx.x <= colj) ? sh.red[threadIdx.x] : 0.0;
         sh.cc[threadIdx.x] = cv;
         sh.ss[threadIdx.x] = sv;
     }
@@ -161,19 +162,24 @@ __device__ void finalize_column(const GDev &d, int colj, KShared &sh, double *tm
             double n2;
             if (d.pyth) {
                 // V orthonormal, h = V'w  =>  ||w - V h||^2 = ||w||^2 - ||h||^2: both already summed over the ranks by
-                // the first all-reduce of this step.  Cancellation is flagged (pad0) and the host falls back to the
-                // explicitly reduced norm for the following cycles.
-                double q = 0.0;
-                for (int i = 0; i <= colj; ++i) q += sh.h[i] * sh.h[i];
-                n2 = fmax(wnorm2 - q, 0.0);
-                if (n2 < 1e-4 * wnorm2) t.pad0 += 1;
+                // the first all-reduce of this step.  Close to cancellation the difference is worthless: the pass is
+                // interrupted BEFORE this column (done = 5; the update kernel applies the columns finalised so far) and
+                // the host carries on with explicitly reduced norms.
+                n2 = fmax(n2f, 0.0);
+                if (n2f < 1e-4 * wnorm2) {
+                    t.pad0 += 1;
+                    t.done = 5;
+                    sh.fin = 0;
+                }
             } else if (!need2) {
                 n2 = fmax(n2f, 0.0);
-                if (d.fast && !(n2f >= fmax(d.prm->eta2, 1e-4) * wnorm2)) t.pad1 += 1;    // a second pass was due
             } else {
                 n2 = sh.red[kNormSlot];
             }
-            const bool reorth = need2 && n2 < d.prm->eta2 * wnorm2;
+          if (t.done == 0) {
+            const bool due = need2 && n2 < d.prm->eta2 * wnorm2;
+            if (due && d.fast) t.pad1 += 1;              // a second pass was due; the fast kernels have no h2 for it
+            const bool reorth = due && !d.fast;
             if (reorth) {
                 double q = 0.0;
                 for (int i = 0; i <= colj; ++i) {
@@ -217,6 +223,7 @@ __device__ void finalize_column(const GDev &d, int colj, KShared &sh, double *tm
                 d.R[base + colj] = rho;
                 if (t.iter < d.hist_cap) d.hist[t.iter] = t.rnorm;
             }
+          }
         }
         sh.T = t;
         if (blockIdx.x == 0) d.T[colj + 1] = t;
@@ -460,8 +467,9 @@ __global__ void __launch_bounds__(kRB) k_gmres_dots_rows(GDev d, int j) {
     store_partial_row_rows<NG>(acc, nrm, tmp, d.P1);
 }
 
-// FAST: only wt = w - V h (one pass over the columns, nothing kept); the norm of wt follows from Pythagoras in the next
-// Arnoldi kernel.  Otherwise also h2 = V'wt and ||wt||^2 for the selective second Gram-Schmidt pass.
+// FAST: wt = w - V h and ||wt||^2 (one pass over the columns, nothing kept).  Otherwise also h2 = V'wt for the selective
+// second Gram-Schmidt pass.  The next Arnoldi kernel takes ||wt||^2 from Pythagoras and falls back on the sum formed here
+// when that is close to cancellation.
 template <int NG, bool FAST>
 __global__ void __launch_bounds__(kRB, (NG < 4 || FAST) ? 3 : 2) k_gmres_orth_rows(GDev d, int j) {
     __shared__ double tmp[(kRB / 32) * kKP];
@@ -499,11 +507,26 @@ __global__ void __launch_bounds__(kRB, (NG < 4 || FAST) ? 3 : 2) k_gmres_orth_ro
             if (!FAST) {
 #pragma unroll
                 for (int k = 0; k < 8 * NG; ++k) acc[k] += v[k] * wp;
-                nrm += wp * wp;
             }
+            nrm += wp * wp;
         }
     }
-    if (!FAST) store_partial_row_rows<NG>(acc, nrm, tmp, d.P2);
+    if (!FAST) {
+        store_partial_row_rows<NG>(acc, nrm, tmp, d.P2);
+    } else {
+        // the exactly summed norm only: one wave reduction, zeros in the h2 slots
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const double sn = group_sum_dpp<64>(nrm);
+        __syncthreads();
+        if (lane == 0) tmp[wave] = sn;
+        __syncthreads();
+        if (threadIdx.x < kKP) {
+            double t = 0.0;
+            if (threadIdx.x == kNormSlot)
+                for (int w = 0; w < kRB / 64; ++w) t += tmp[w];
+            d.P2[(size_t)blockIdx.x * kKP + threadIdx.x] = t;
+        }
+    }
 }
 
 // ---- K2 ---------------------------------------------------------------------------------------------------------------
@@ -980,9 +1003,25 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
             }
             NPG_HIP(hipEventSynchronize(ws->ev[cur]));
             last = ws->h_C[cur];
-            if (d.pyth && last.pad0 > 0) {      // cancellation in ||w||^2 - ||h||^2: explicit norms from the next launch on
+            if (last.done == 5) {
+                // distributed: ||w||^2 - ||h||^2 met cancellation and the device interrupted the pass before that column.
+                // Carry on from the current iterate with explicitly reduced norms (a second all-reduce per step), for
+                // this and all later solves of the workspace.
+                NPG_HIP(hipStreamSynchronize(st));           // the cycle enqueued ahead has exited at once
                 d.pyth = 0;
                 ws->explicit_norm = true;
+                last.done = 0;
+                last.inner = 0;
+                ws->h_C[cur] = last;
+                NPG_HIP(hipMemcpyAsync(ws->C, ws->h_C + cur, sizeof(Snap), hipMemcpyHostToDevice, st));
+                if (dist && (rc0 = halo_exchange_raw(ws->halo, d.x))) return rc0;
+                launch_residual(d, A->lanes, st);
+                if (dist && (rc0 = fold_rows(ws, d.PR, d.G1, 2, st, true))) return rc0;
+                NPG_HIP(hipStreamSynchronize(st));           // h_C[cur] is a result slot again from here on
+                rc0 = enqueue_cycle(cur);
+                if (rc0) return rc0;
+                cyc = -1 + (cur == 0 ? 0 : 1);               // keep the slot parity of the ping-pong
+                continue;
             }
             if (last.done != 0 || !more) break;
         }
@@ -1006,6 +1045,20 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
             NPG_HIP(hipMemcpyAsync(ws->h_C, ws->C, sizeof(Snap), hipMemcpyDeviceToHost, st));
             NPG_HIP(hipStreamSynchronize(st));
             last = ws->h_C[0];
+            if (last.done == 5) {           // see the pipelined loop: explicit norms from here on
+                d.pyth = 0;
+                ws->explicit_norm = true;
+                last.done = 0;
+                last.inner = 0;
+                ws->h_C[0] = last;
+                NPG_HIP(hipMemcpyAsync(ws->C, ws->h_C, sizeof(Snap), hipMemcpyHostToDevice, st));
+                int rcx = NPG_OK;
+                if (dist && (rcx = halo_exchange_raw(ws->halo, d.x))) return rcx;
+                launch_residual(d, A->lanes, st);
+                if (dist && (rcx = fold_rows(ws, d.PR, d.G1, 2, st, true))) return rcx;
+                NPG_HIP(hipStreamSynchronize(st));
+                continue;
+            }
             if (last.done != 0) break;      // the last (partial) cycle is not counted: some of its kernels exit early
             for (int j = 0; j < ws->mem; ++j) {
                 float ms = 0.f;

@@ -160,6 +160,50 @@ def test_gmres_small_systems(arch):
     assert st["solved"] == 1 and rel(ws.x.to_host(), xe) < 1e-7 and abs(st["niter"] - so["niter"]) <= 2
 
 
+def test_gmres_fast_mode_falls_back_when_a_second_pass_is_due(arch):
+    """Split organisation on one GPU: the first solves of a workspace run the fast orthogonalisation kernels (no second-pass
+    sums).  On a system whose new Krylov directions are tiny against A v the device flags the columns that were due a second
+    Gram-Schmidt pass (stats.nflagged) and the NEXT solve of the workspace runs the full kernels and takes those passes."""
+    rng = np.random.default_rng(42)
+    n = 600
+    # A = I + small: A v is almost v, so what is left after orthogonalising against v is tiny compared with ||A v|| - the
+    # textbook case for a second Gram-Schmidt pass
+    A = sp.csr_matrix(sp.eye(n) + 1e-3 * sp.random(n, n, density=0.05, random_state=rng, format="csr"))
+    b = rng.standard_normal(n)
+    dA, db = npg.on_architecture(arch, A), npg.on_architecture(arch, b)
+    ws = npg.GmresWorkspace(arch.ctx, n, memory=30)
+    ws.set_split(1)
+    st1 = ws.solve(dA, db, ws.x, None, atol=0.0, rtol=1e-10, itmax=300)
+    x1 = ws.x.to_host()
+    ws.x.fill(0.0)
+    st2 = ws.solve(dA, db, ws.x, None, atol=0.0, rtol=1e-10, itmax=300)
+    assert st1["solved"] == st2["solved"] == 1 and rel(x1, spla.spsolve(A.tocsc(), b)) < 1e-8
+    assert st1["nreorth"] == 0                                  # fast kernels cannot take a second pass ...
+    assert st1["nflagged"] > 0                                  # ... but they notice that one was due
+    assert st2["nreorth"] > 0 and st2["nflagged"] == 0          # full kernels from the next solve on
+    # and a workspace that is asked for eta > 0.1 starts with the full kernels
+    ws3 = npg.GmresWorkspace(arch.ctx, n, memory=30)
+    ws3.set_split(1)
+    st3 = ws3.solve(dA, db, ws3.x, None, atol=0.0, rtol=1e-10, itmax=300, reorth_eta=0.5)
+    assert st3["nreorth"] > 0 and st3["nflagged"] == 0
+    # distributed code path (one rank, no peers): the norm comes from ||w||^2 - ||h||^2 to save an all-reduce; on this system
+    # that cancels, the device interrupts the pass before the bad column and the host carries on with explicit norms
+    from nupgcm_amd import distributed
+    plan = dict(peers=np.zeros(0, np.int32), send_ptr=np.zeros(1, np.int64), send_idx=np.zeros(0, np.int32),
+                recv_ptr=np.zeros(1, np.int64))
+    halo = distributed.Halo(arch.ctx, n, 0, plan)
+    ws4 = npg.GmresWorkspace(arch.ctx, n, memory=30)
+    L.check(L.lib().npg_gmres_set_halo(ws4.h, halo.h))
+    st4 = ws4.solve(dA, db, ws4.x, None, atol=0.0, rtol=1e-10, itmax=300)
+    assert st4["solved"] == 1 and st4["nflagged"] > 0 and rel(ws4.x.to_host(), spla.spsolve(A.tocsc(), b)) < 1e-8
+    ws4.x.fill(0.0)
+    st5 = ws4.solve(dA, db, ws4.x, None, atol=0.0, rtol=1e-10, itmax=300)           # explicit norms from the start now
+    assert st5["solved"] == 1 and st5["nflagged"] == 0 and rel(ws4.x.to_host(), spla.spsolve(A.tocsc(), b)) < 1e-8
+    # the residual history of the full kernels is a true one: it matches the residual of the iterate to rounding
+    r = b - A @ ws.x.to_host()
+    assert abs(np.linalg.norm(r) - st2["rnorm"]) <= 1e-8 * np.linalg.norm(b)
+
+
 def test_gmres_inversion_K5(arch, flux, golden_dir):
     """The saddle-point inversion system at the reference's settings: GMRES(20), P = Diagonal(1/h^3), atol=rtol=1e-6."""
     z = np.load(f"{golden_dir}/state_bowl_surface_flux.npz")
