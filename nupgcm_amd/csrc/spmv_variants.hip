@@ -228,6 +228,162 @@ __global__ void __launch_bounds__(NT, WPE) k_spmv_stage(CsrDev A, const int32_t 
     }
 }
 
+// ---- "wide" variant: two workgroups per CU, 128 registers ------------------------------------------------------------------
+// Same tile, same products, same summation order; but ALL loads of a tile (UP records and UC entry pairs per lane) are issued
+// before the first gather and ALL gathers before the first product: two dependent memory round trips per tile instead of
+// four.  Needs ~115 VGPRs, i.e. two 512-thread workgroups per CU, which in turn have room for tiles twice as large.
+template <int NT, int L, class XF, int TNNZ, int UP, int UC, class PROF = NoProf>
+__device__ __forceinline__ void spmv_tile_wide(const CsrDev &A, const XF x, const TileDesc &td, TileLdsT<TNNZ> &t,
+                                               double *__restrict__ out, PROF prof = PROF()) {
+    const int r0 = td.r0, nrows = td.nrows, r1 = r0 + nrows;
+    const int64_t base = td.base;
+    const int n = td.n;
+    const bool blk = r0 < block_rows(A);
+    const bool full = r0 < 3 * A.nfull;
+    const int ncomp = full ? 3 : 2;
+    const int npe = td.npe;
+    const int64_t pbase = td.pbase;
+    int nnode = 0, q0 = 0;
+    if (blk) {
+        q0 = node_of_row(A, r0);
+        nnode = node_of_row(A, r1) - q0;
+    }
+    const int64_t abase = base & ~1LL;
+    const int off = (int)(base - abase);
+    const int total = n + off;
+    const int slot0 = blk ? ncomp * npe : 0;
+    if (slot0 + total > TNNZ + 2 || npe > UP * NT || total > 2 * NT * UC || abase + total > A.nnz) {
+        spmv_tile<NT, L, XF, TNNZ, 4, PROF>(A, x, td, t, out, prof);       // generic path (long rows, odd shapes)
+        return;
+    }
+    const int tid = threadIdx.x;
+    int32_t rc[UP];
+    double2 rkc[UP];
+    int2 cc[UC];
+    double2 cv[UC];
+    // ---- every load of the tile
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+        const int e = tid + u * NT;
+        if (e < npe) {
+            rc[u] = __builtin_nontemporal_load(A.pcol + pbase + e);
+            const double *p = reinterpret_cast<const double *>(A.pkc + pbase + e);
+            rkc[u].x = __builtin_nontemporal_load(p);
+            rkc[u].y = __builtin_nontemporal_load(p + 1);
+        } else {
+            rc[u] = 0;
+            rkc[u] = make_double2(0.0, 0.0);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < UC; ++u) {
+        const int k = 2 * tid + u * 2 * NT;
+        if (k + 1 < total) {
+            const long long c2 = __builtin_nontemporal_load(reinterpret_cast<const long long *>(A.col + abase + k));
+            cc[u] = make_int2((int)(c2 & 0xffffffffLL), (int)(c2 >> 32));
+            cv[u].x = __builtin_nontemporal_load(A.val + abase + k);
+            cv[u].y = __builtin_nontemporal_load(A.val + abase + k + 1);
+        } else if (k < total) {
+            cc[u] = make_int2(A.col[abase + k], 0);
+            cv[u] = make_double2(A.val[abase + k], 0.0);
+        } else {
+            cc[u] = make_int2(0, 0);
+            cv[u] = make_double2(0.0, 0.0);
+        }
+    }
+    for (int r = tid; r <= nrows; r += NT) t.rp[r] = (int32_t)(A.rowptr[r0 + r] - base) + off + slot0;
+    if (blk)
+        for (int q = tid; q <= nnode; q += NT) t.prp[q] = (int32_t)(A.prow[q0 + q] - pbase);
+    // ---- every gather of the tile
+    double2 xx[UP];
+    double zz[UP], xa[UC], xb[UC];
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+        const int cf = rc[u] < A.nfull ? rc[u] : A.nfull;
+        const int xo = 2 * rc[u] + cf;
+        xx[u] = x.two(xo);
+        zz[u] = (full && rc[u] < A.nfull) ? x.third(xo + 2) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < UC; ++u) {
+        xa[u] = x(cc[u].x);
+        xb[u] = x(cc[u].y);
+    }
+    // ---- products
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+        const int e = tid + u * NT;
+        if (e < npe) {
+            t.prod[e] = rkc[u].x * xx[u].x + rkc[u].y * xx[u].y;
+            t.prod[npe + e] = rkc[u].x * xx[u].y - rkc[u].y * xx[u].x;
+            if (full) t.prod[2 * npe + e] = rkc[u].x * zz[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < UC; ++u) {
+        const int k = 2 * tid + u * 2 * NT;
+        if (k < total) t.prod[slot0 + k] = (k >= off) ? cv[u].x * xa[u] : 0.0;
+        if (k + 1 < total) t.prod[slot0 + k + 1] = cv[u].y * xb[u];
+    }
+    prof.stamp(0);
+    __syncthreads();
+    prof.stamp(1);
+    const int g = threadIdx.x / L, l = threadIdx.x % L;
+    for (int r = g; r < nrows; r += NT / L) {
+        double s = 0.0;
+        const int e = t.rp[r + 1];
+        for (int k = t.rp[r] + 2 * l; k < e; k += 2 * L) {
+            const double a = t.prod[k], b = t.prod[k + 1];
+            s += a + (k + 1 < e ? b : 0.0);
+        }
+        if (blk) {
+            const int q = full ? (r * 21846) >> 16 : r >> 1;
+            const int pb = (r - q * ncomp) * npe, pe = pb + t.prp[q + 1];
+            for (int k = pb + t.prp[q] + 2 * l; k < pe; k += 2 * L) {
+                const double a = t.prod[k], b = t.prod[k + 1];
+                s += a + (k + 1 < pe ? b : 0.0);
+            }
+        }
+        s = group_sum_dpp<L>(s);
+        if (l == 0) out[r] = s;
+    }
+    prof.stamp(2);
+    __syncthreads();
+}
+
+template <int NT, int L, class XF, int TNNZ, int UP, int UC>
+__device__ __forceinline__ void spmv_tile_wide(const CsrDev &A, const XF x, int r0, int r1, TileLdsT<TNNZ> &t,
+                                               double *__restrict__ out) {
+    TileDesc td;
+    td.r0 = r0;
+    td.nrows = r1 - r0;
+    td.base = A.rowptr[r0];
+    td.n = (int)(A.rowptr[r1] - td.base);
+    td.pbase = 0;
+    td.npe = 0;
+    if (r0 < block_rows(A)) {
+        td.pbase = A.prow[node_of_row(A, r0)];
+        td.npe = (int)(A.prow[node_of_row(A, r1)] - td.pbase);
+    }
+    spmv_tile_wide<NT, L, XF, TNNZ, UP, UC>(A, x, td, t, out);
+}
+
+// the "wide" tile function: 2 workgroups per CU, everything in flight before the first gather
+template <int NT, int L, int TNNZ, int UP, int UC, int WPE>
+__global__ void __launch_bounds__(NT, WPE) k_spmv_wide2(CsrDev A, const int32_t *__restrict__ tile_ptr, int ntiles,
+                                                        const double *__restrict__ x, double *__restrict__ y) {
+    __shared__ TileLdsT<TNNZ> tl;
+    __shared__ double sw[kTileRows];
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int r0 = tile_ptr[t], r1 = tile_ptr[t + 1];
+        spmv_tile_wide<NT, L, PlainX, TNNZ, UP, UC>(A, PlainX{x}, r0, r1, tl, sw);
+        for (int r = threadIdx.x; r < r1 - r0; r += NT) y[r0 + r] = sw[r];
+    }
+}
+
+template <int NT, int TNNZ, int UP, int UC, int WPE>
+static int run_wide2(const npg_csr *A, const double *x, double *y, int bpc, int reps, double *ms);
+
 template <int NT, int L, int TNNZ, int U2, int WPE, bool MERGED>
 __global__ void __launch_bounds__(NT, WPE) k_spmv_prod(CsrDev A, const int32_t *__restrict__ tile_ptr, int ntiles,
                                                        const double *__restrict__ x, double *__restrict__ y) {
@@ -354,6 +510,38 @@ __global__ void __launch_bounds__(NT, 6) k_spmv_timed(CsrDev A, const TileDesc *
     }
 }
 
+template <int NT, int TNNZ, int UP, int UC, int WPE>
+static int run_wide2(const npg_csr *A, const double *x, double *y, int bpc, int reps, double *ms) {
+    auto key = std::make_pair((const void *)A, TNNZ);
+    if (!g_ptiles.count(key)) {
+        std::vector<int32_t> tp;
+        int rc = tile_boundaries(A, TNNZ, tp);
+        if (rc) return rc;
+        VarTiles v;
+        v.n = (int)tp.size() - 1;
+        NPG_HIP(hipMalloc((void **)&v.d, tp.size() * sizeof(int32_t)));
+        NPG_HIP(hipMemcpy(v.d, tp.data(), tp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        g_ptiles[key] = v;
+    }
+    const VarTiles t = g_ptiles[key];
+    npg_ctx *ctx = A->ctx;
+    const int grid = std::max(1, std::min(t.n, bpc * ctx->num_cu));
+    const CsrDev Av = csr_view(A);
+    auto go = [&]() {
+        hipLaunchKernelGGL((k_spmv_wide2<NT, 16, TNNZ, UP, UC, WPE>), dim3(grid), dim3(NT), 0, ctx->stream, Av, t.d, t.n, x,
+                           y);
+    };
+    for (int i = 0; i < 2; ++i) go();
+    NPG_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; ++i) go();
+    NPG_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    NPG_HIP(hipEventSynchronize(ctx->ev1));
+    float f = 0.f;
+    NPG_HIP(hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    *ms = f / reps;
+    return NPG_OK;
+}
+
 }  // namespace npg
 
 using namespace npg;
@@ -390,6 +578,11 @@ NPG_API int npg_spmv_variant(const npg_csr *A, const npg_vec *x, npg_vec *y, int
         case 32: return run_prod<1024, 4096, 2, 8, false>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 40: return run_prod<512, 4096, 4, 6, false, 1>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 42: return run_prod<512, 4096, 4, 6, false, 2>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 50: return run_wide2<512, 5824, 4, 3, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 51: return run_wide2<512, 8192, 6, 4, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 52: return run_wide2<512, 9216, 6, 4, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 53: return run_wide2<512, 8192, 6, 3, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 54: return run_wide2<1024, 9216, 3, 2, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 43: return run_prod<512, 4800, 4, 6, false, 3>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 44: return run_prod<512, 4800, 4, 6, false, 0>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 45: return run_prod<512, 4800, 4, 6, false, 1>(A, x->d, y->d, blocks_per_cu, reps, ms);

@@ -37,6 +37,8 @@ names = {0: "NT512 T4096 U4", 1: "NT512 T4096 U8", 2: "NT1024 T8192 U8", 3: "NT2
          15: "wide NT512 T8192 U2x4",
          30: "product NT512 T4096 U4 wpe6", 31: "product NT512 T2048 U2 wpe6", 32: "product NT1024 T4096 U2 wpe8",
          40: "product, gathers removed (diagnostic)", 42: "product, z gather of the records removed (diagnostic)",
+         50: "wide NT512 T5824 UP4 UC3 (2 WG/CU)", 51: "wide NT512 T8192 UP6 UC4", 52: "wide NT512 T9216 UP6 UC4",
+         53: "wide NT512 T8192 UP6 UC3", 54: "wide NT1024 T9216 UP3 UC2",
          43: "T4800: gathers from an LDS stage filled per tile (diagnostic)", 44: "T4800 product",
          45: "T4800 gathers removed (diagnostic)"}
 print(f"{wl}: N={N} nnz={nnz} algorithmic bytes={alg / 1e6:.1f} MB")
