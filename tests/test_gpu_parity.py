@@ -706,3 +706,46 @@ def test_channel_basin_style_configuration(arch):
     # vertex value and a P1 nodal value respond very differently to the boundary-concentrated increments of this run.)
     assert abs(out[1][0] - out[2][0]) < 0.05 * out[2][0]
     assert rel(out[1][1], out[2][1]) < 0.25
+
+
+def test_full_size_properties(arch):
+    """The bench workload itself (bowl3D h = 0.02, 2.15 M inversion DoF, 126.7 M non-zeros) is too large for the oracle, so
+    the hot path is checked there through size-independent properties: two independent storage formats of the same matrix
+    give the same SpMV, the SpMV is linear, and after invert! the TRUE scaled residual - recomputed with the plain-CSR
+    matrix, not taken from the solver's recurrence - meets the reference's stopping rule."""
+    from nupgcm_amd import workloads
+    fed = workloads.example_fe_data(workloads.bowl_mesh_model("bowl3D_h0.02"))
+    prm, frc = workloads.example_parameters()
+    d, ctx = fed.dofs, arch.ctx
+    N = d.nu + d.np
+    assert N == 2150791
+    A_csr = npg.build_A_inversion(arch, fed, prm, frc.nu)                  # plain CSR
+    A_blk = npg.build_A_inversion(arch, fed, prm, frc.nu)
+    assert A_blk.block_nodes(d.n_full, d.n_surf) and A_csr.nnz == A_blk.nnz == 126707207
+    nodes, rec, ent = A_blk.storage()
+    assert nodes == d.n_full + d.n_surf and ent + 4 * rec <= A_csr.nnz <= ent + 5 * rec
+    rng = np.random.default_rng(0)
+    x, y = (npg.DeviceVector.from_host(ctx, rng.standard_normal(N)) for _ in range(2))
+    ax, ay = A_csr.mul(x).to_host(), A_csr.mul(y).to_host()
+    bx = A_blk.mul(x).to_host()
+    assert rel(bx, ax) < 1e-13                                             # node records == CSR entries
+    z = x.copy()
+    z.axpby(-0.75, y, 2.5)                                                 # z = 2.5 x - 0.75 y
+    assert rel(A_blk.mul(z).to_host(), 2.5 * ax - 0.75 * ay) < 1e-13       # linearity
+    # invert! on the full model, stopped after 100 restart cycles (a cold solve takes ~1e5 iterations): the residual norm
+    # the solver reports from its Givens recurrence must be the TRUE scaled residual of its iterate, recomputed here with
+    # the other storage format
+    ts = npg.BDF2(t_start=0.0, t_stop=1e9, dt=1e-3)
+    inv = npg.InversionToolkit(arch, fed, prm, frc, itmax=2000)
+    evo = npg.EvolutionToolkit(arch, fed, prm, frc, ts)
+    m = npg.Model(arch, prm, frc, fed, inv, evo, ts)
+    npg.set_b(m, lambda p: 0.1 * np.exp(-(p[..., 2] + 0.5 * (1 - p[..., 0] ** 2 - p[..., 1] ** 2)) / 0.05))   # examples/bowl_mixing.jl:159
+    npg.invert(m)
+    st = m.inversion.solver.workspace.stats
+    assert st["niter"] == 2000 and st["status"] == 2 and m.inversion.solver.A.paired
+    assert st["rnorm"] < 0.5 * st["rnorm0"]                                # it is converging
+    rhs = inv.b.copy()
+    inv.B.mul(m.b_vec, rhs, alpha=1.0, beta=1.0)                            # B b + b0
+    r = rhs.to_host() - A_csr.mul(inv.solver.x).to_host()
+    h = fed.mesh.median_edge_length()
+    assert abs(np.linalg.norm(r) / h ** 3 - st["rnorm"]) <= 1e-6 * st["rnorm0"] + 1e-6 * st["rnorm"]
