@@ -4,6 +4,7 @@
 Tolerances: deterministic fp64 kernels (SpMV, BLAS-1, element integrals) <= 1e-12 relative; Krylov solutions are
 tolerance-limited by the reference's own stopping rule (atol = rtol = 1e-6 on the 1/h^3-scaled residual): <= 3e-3 in u for
 a cold GMRES start, which is the floor the oracle's own MGS-GMRES shows against the direct solve."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -69,6 +70,38 @@ def test_vector_errors(arch):
         v.axpby(1.0, npg.DeviceVector(arch.ctx, 11), 0.0)
     with pytest.raises(L.DeviceError):
         v.view(5, 6)
+
+
+def test_abi_argument_errors(arch):
+    """Every entry point validates shapes and ranges on the host before a kernel that would index with them is launched;
+    errors come back as status codes with a message (DeviceError), never as a fault on the device."""
+    ctx = arch.ctx
+    A = npg.on_architecture(arch, sp.csr_matrix(sp.eye(12)))
+    x, y = npg.DeviceVector(ctx, 12), npg.DeviceVector(ctx, 11)
+    with pytest.raises(L.DeviceError):
+        A.mul(x, y)                                             # y too short
+    with pytest.raises(L.DeviceError):
+        A.mul(y, x)                                             # x too short
+    with pytest.raises(L.DeviceError):
+        A.block_nodes(4, 1)                                     # 3*4 + 2*1 block rows > 12 rows
+    assert not A.block_nodes(2, 2)                              # identity lacks the [K -C; C K] couplings ...
+    assert A.to_scipy_csr().nnz == 12                           # ... and is left untouched
+    ws = npg.GmresWorkspace(ctx, 12, memory=5)
+    with pytest.raises(L.DeviceError):
+        ws.solve(A, y, ws.x, None)                              # right-hand side of the wrong length
+    with pytest.raises(L.DeviceError):
+        npg.GmresWorkspace(ctx, 12, memory=31)                  # beyond the supported restart length
+    with pytest.raises(L.DeviceError):
+        ws.set_split(3)
+    cg = npg.CgWorkspace(ctx, 12)
+    with pytest.raises(L.DeviceError):
+        cg.solve(A, y, cg.x, None)
+    # out-of-range column index at construction
+    bad = sp.csr_matrix(sp.eye(4))
+    h = C.c_void_p()
+    rp, ci, v = bad.indptr.astype(np.int64), np.array([0, 1, 2, 9], np.int32), bad.data.astype(float)
+    assert L.lib().npg_csr_create(ctx.h, 4, 4, L.ptr(rp), L.ptr(ci), L.ptr(v), C.byref(h)) != 0
+    assert b"column index" in L.lib().npg_last_error()
 
 
 # ---- CSR ----------------------------------------------------------------------------------------------------------------
