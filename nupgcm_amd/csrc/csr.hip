@@ -45,8 +45,12 @@ int build_tiles(npg_csr *A) {
     if (rc) return rc;
     const int64_t m = A->m;
     A->ntiles = (int32_t)tp.size() - 1;
-    const double mean = m > 0 ? (double)A->nnz / (double)m : 0.0;
-    A->lanes = mean <= 6 ? 4 : mean <= 24 ? 8 : mean <= 96 ? 16 : 32;
+    // lanes per row in the segmented sums, from the LDS product slots per row (a lane takes two products per trip):
+    // measured on bowl3D h = 0.02 (42 slots per row with node blocks) 8 lanes beat 16 by 2-3 % and 4 by 1 %
+    const int64_t nrec = A->nnode() ? A->h_prow[A->nnode()] : 0;
+    const double mean = m > 0 ? (double)(A->rnnz + 3 * nrec) / (double)m : 0.0;
+    A->lanes = mean <= 12 ? 4 : mean <= 64 ? 8 : mean <= 256 ? 16 : 32;
+    if (getenv("NPG_SPMV_LANES")) A->lanes = atoi(getenv("NPG_SPMV_LANES"));      // tuning override: 4, 8, 16 or 32
     const int64_t *rp = A->h_rowptr.data();
     const int64_t nf3 = 3 * (int64_t)A->nfull, nbr = A->block_rows();
     auto node = [&](int64_t r) { return r < nf3 ? r / 3 : A->nfull + (r - nf3) / 2; };
