@@ -896,7 +896,9 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     // one GPU, split mode: no second-pass sums until a solve reports that a column needed them (NPG_GMRES_FAST=0: never)
     static const int fast_env = getenv("NPG_GMRES_FAST") ? atoi(getenv("NPG_GMRES_FAST")) : 1;
     // (only at the default threshold or below, where a second pass is a rare event; a caller asking for eta > 0.1 wants them)
-    d.fast = (!dist && d.split && d.lazy2 && fast_env && !ws->safe_mode && reorth_eta <= 0.1 + 1e-12) ? 1 : 0;
+    // distributed runs take no second pass at all (reorth_eta = 0 above): they always use the fast instance, whose exactly
+    // summed norm is what the explicit-norm fallback reduces over the ranks
+    d.fast = (d.split && fast_env && reorth_eta <= 0.1 + 1e-12 && (dist || (d.lazy2 && !ws->safe_mode))) ? 1 : 0;
     d.GR = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kRB - 1) / kRB, std::min(kMaxG, 3 * ctx->num_cu)));
     d.ldv = d.split ? (int64_t)((ws->n + 31) / 32) * 32 : 0;
     d.GP1 = d.split ? d.GR : d.G1;
