@@ -1,0 +1,95 @@
+"""State checkpoints and VTK output - mirrors /root/reference/src/IO.jl:1-59 (save_state, set_state_from_file!, save_vtk).
+
+The reference stores {u, p, b, t} (free values in the native Gridap DoF order) with JLD2; no HDF5/JLD2 writer is available
+here, so the same four fields go into a NumPy `.npz` archive - same names, same order, same meaning (the fixtures under
+tests/golden/state_*.npz, extracted from the reference's own .jld2 files, use this layout too and load with
+`set_state_from_file`).  `save_vtk` writes an unstructured-grid `.vtu` (ASCII XML) with quadratic tetrahedra, as
+`writevtk(...; order=2)` does: u at the P2 nodes, p (P1, interpolated to the edge mid-points), the full buoyancy N2 z + b
+and the time as field data."""
+from __future__ import annotations
+
+import numpy as np
+
+# VTK_QUADRATIC_TETRA (type 24) lists the edge nodes as (0,1) (1,2) (0,2) (0,3) (1,3) (2,3); fe.Mesh numbers a cell's edges
+# (0,1) (0,2) (1,2) (0,3) (1,3) (2,3)
+_VTK_P2 = np.array([0, 1, 2, 3, 4, 6, 5, 7, 8, 9])
+
+
+def save_state(model, ofile):
+    """save_state(model, ofile) - src/IO.jl:1-10"""
+    s = model.state
+    t = 0.0 if model.timestepper is None else float(model.timestepper.t)
+    np.savez(ofile, u=s.u, p=s.p, b=s.b, t=t)
+    return ofile
+
+
+def set_state_from_file(model, ifile):
+    """set_state_from_file!(model, ifile) - src/IO.jl:12-23.  As in the reference only the current fields and the time are
+    restored: a run resumed from a checkpoint starts its time stepper afresh (previous-step copies = current state)."""
+    z = np.load(ifile)
+    d = model.fe_data.dofs
+    u, p, b = (np.asarray(z[k], dtype=float) for k in ("u", "p", "b"))
+    if u.shape != (d.nu,) or p.shape != (d.np,) or b.shape != (d.nb,):
+        raise ValueError(f"{ifile}: expected {d.nu}/{d.np}/{d.nb} free values of u/p/b, got {u.shape}/{p.shape}/{b.shape}")
+    model.inversion.solver.x.upload(np.concatenate([u, p]), d.p_inversion)
+    model.b_vec.upload(b, d.p_b)
+    sol = model.inversion.solver
+    if hasattr(sol, "load_owned_from_full"):                  # distributed: the solver's own slice follows the full vector
+        sol.load_owned_from_full()
+    if model.evolution is not None and hasattr(model.evolution.solver, "load_owned_from_full"):
+        model.evolution.solver.load_owned_from_full()
+    if model.timestepper is not None and "t" in z:
+        model.timestepper.t = float(np.asarray(z["t"]).reshape(-1)[0])
+    model._prev = None
+    model.step_index = 1
+    return model
+
+
+def _nodal_fields(model):
+    m, s, prm = model.fe_data.mesh, model.fe_data.spaces, model.params
+    st = model.state
+    u = np.zeros((m.nn, 3))
+    free = s.u_dof >= 0
+    u[free] = st.u[s.u_dof[free]]
+    u[~free] = s.u_diri_val[~free]
+    pv = np.zeros(m.nv)                                            # pressure: P1, the last vertex is the fixed one (p = 0)
+    pf = s.p_dof >= 0
+    pv[pf] = st.p[s.p_dof[pf]]
+    p = np.concatenate([pv, 0.5 * (pv[m.edges[:, 0]] + pv[m.edges[:, 1]])])
+    nbn = len(s.b_dof)
+    bn = np.where(s.b_dof >= 0, st.b[np.maximum(s.b_dof, 0)], s.b_diri_val)
+    if nbn == m.nv:                                               # P1 buoyancy -> P2 nodes
+        bn = np.concatenate([bn, 0.5 * (bn[m.edges[:, 0]] + bn[m.edges[:, 1]])])
+    b_full = prm.N2 * m.node_coords[:, 2] + bn
+    return u, p, b_full
+
+
+def save_vtk(model, ofile):
+    """save_vtk(model; ofile) - src/IO.jl:25-59 with order = 2 (quadratic tetrahedra), fields u, p, b = N2 z + b', t."""
+    m = model.fe_data.mesh
+    u, p, b = _nodal_fields(model)
+    t = 0.0 if model.timestepper is None else float(model.timestepper.t)
+    conn = m.cell_nodes[:, _VTK_P2]
+    nc = len(conn)
+
+    def arr(a, fmt):
+        return "\n".join(" ".join(fmt % v for v in row) for row in np.atleast_2d(a))
+
+    with open(ofile, "w") as f:
+        f.write('<?xml version="1.0"?>\n<VTKFile type="UnstructuredGrid" version="0.1" byte_order="LittleEndian">\n')
+        f.write("<UnstructuredGrid>\n<FieldData>\n")
+        f.write(f'<DataArray type="Float64" Name="t" NumberOfTuples="1" format="ascii">{t!r}</DataArray>\n</FieldData>\n')
+        f.write(f'<Piece NumberOfPoints="{m.nn}" NumberOfCells="{nc}">\n<Points>\n')
+        f.write('<DataArray type="Float64" NumberOfComponents="3" format="ascii">\n' + arr(m.node_coords, "%.17g")
+                + "\n</DataArray>\n</Points>\n<Cells>\n")
+        f.write('<DataArray type="Int64" Name="connectivity" format="ascii">\n' + arr(conn, "%d") + "\n</DataArray>\n")
+        f.write('<DataArray type="Int64" Name="offsets" format="ascii">\n'
+                + arr((10 * np.arange(1, nc + 1)).reshape(-1, 1), "%d") + "\n</DataArray>\n")
+        f.write('<DataArray type="UInt8" Name="types" format="ascii">\n' + arr(np.full((nc, 1), 24), "%d")
+                + "\n</DataArray>\n</Cells>\n<PointData>\n")
+        f.write('<DataArray type="Float64" Name="u" NumberOfComponents="3" format="ascii">\n' + arr(u, "%.17g")
+                + "\n</DataArray>\n")
+        f.write('<DataArray type="Float64" Name="p" format="ascii">\n' + arr(p.reshape(-1, 1), "%.17g") + "\n</DataArray>\n")
+        f.write('<DataArray type="Float64" Name="b" format="ascii">\n' + arr(b.reshape(-1, 1), "%.17g") + "\n</DataArray>\n")
+        f.write("</PointData>\n</Piece>\n</UnstructuredGrid>\n</VTKFile>\n")
+    return ofile

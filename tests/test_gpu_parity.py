@@ -782,3 +782,49 @@ def test_full_size_properties(arch):
     r = rhs.to_host() - A_csr.mul(inv.solver.x).to_host()
     h = fed.mesh.median_edge_length()
     assert abs(np.linalg.norm(r) / h ** 3 - st["rnorm"]) <= 1e-6 * st["rnorm0"] + 1e-6 * st["rnorm"]
+
+
+def test_checkpoint_and_vtk(arch, golden_dir, tmp_path):
+    """save_state / set_state_from_file! / save_vtk (src/IO.jl:1-59): a checkpoint restores {u, p, b, t} exactly, a run
+    resumed from it is reproducible to the solver tolerance, the reference's own state files load, and the .vtu holds the quadratic mesh and fields."""
+    import xml.etree.ElementTree as ET
+    m = build_model("bowl_surface_flux")
+    npg.run(m, n_steps=3)
+    ck = npg.save_state(m, str(tmp_path / "state.npz"))
+    u, p, b, t = m.state.u, m.state.p, m.state.b, m.timestepper.t
+    runs = []
+    for _ in range(2):
+        m2 = build_model("bowl_surface_flux")
+        npg.set_state_from_file(m2, ck)
+        assert np.array_equal(m2.state.u, u) and np.array_equal(m2.state.p, p) and np.array_equal(m2.state.b, b)
+        assert m2.timestepper.t == t and m2.step_index == 1
+        npg.run(m2, n_steps=2)
+        runs.append((m2.state.u, m2.state.b))
+    # two resumed runs agree to the Krylov tolerance (each model assembles its matrices with fp64 atomics, whose summation
+    # order - hence the last bit of A - differs from build to build)
+    assert rel(runs[0][0], runs[1][0]) < 1e-5 and rel(runs[0][1], runs[1][1]) < 1e-7
+    assert np.isfinite(runs[0][0]).all() and rel(runs[0][1], b) < 0.1
+    # a state file of the reference (extracted from test/data/bowl_surface_flux.jld2) loads the same way
+    m3 = build_model("bowl_surface_flux")
+    npg.set_state_from_file(m3, f"{golden_dir}/state_bowl_surface_flux.npz")
+    z = np.load(f"{golden_dir}/state_bowl_surface_flux.npz")
+    assert np.array_equal(m3.state.b, z["b"]) and np.array_equal(m3.state.u, z["u"])
+    with pytest.raises(ValueError):
+        npg.set_state_from_file(m3, f"{golden_dir}/state_bowl_diri.npz")             # another configuration: other sizes
+    # VTK: quadratic tetrahedra (type 24), every P2 node a point, u / p / b as point data, t as field data
+    vtu = npg.save_vtk(m, str(tmp_path / "state.vtu"))
+    root = ET.parse(vtu).getroot()
+    piece = root.find("UnstructuredGrid/Piece")
+    mesh = m.fe_data.mesh
+    assert int(piece.get("NumberOfPoints")) == mesh.nn and int(piece.get("NumberOfCells")) == mesh.ncell
+    arrays = {a.get("Name"): a for a in piece.iter("DataArray")}
+    assert set(np.array(arrays["types"].text.split(), dtype=int)) == {24}
+    conn = np.array(arrays["connectivity"].text.split(), dtype=int).reshape(-1, 10)
+    pts = np.array(piece.find("Points/DataArray").text.split(), dtype=float).reshape(-1, 3)
+    mid01 = 0.5 * (pts[conn[:, 0]] + pts[conn[:, 1]])
+    mid12 = 0.5 * (pts[conn[:, 1]] + pts[conn[:, 2]])
+    assert np.allclose(pts[conn[:, 4]], mid01) and np.allclose(pts[conn[:, 5]], mid12)      # VTK edge-node order
+    uu = np.array(arrays["u"].text.split(), dtype=float).reshape(-1, 3)
+    free = m.fe_data.spaces.u_dof >= 0
+    assert np.array_equal(uu[free], m.state.u[m.fe_data.spaces.u_dof[free]])
+    assert float(root.find("UnstructuredGrid/FieldData/DataArray").text) == m.timestepper.t
