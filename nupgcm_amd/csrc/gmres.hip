@@ -392,27 +392,12 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
     if (FUSED) store_partial_row(acc, tmp, d.P1);
 }
 
-// ---- row-streaming variants for large systems (split mode) -------------------------------------------------------------
-// One thread per row: a lane reads its row's 64-byte group entries with four 16-byte loads, consecutive lanes read
-// consecutive rows, so a wave streams 4 KiB contiguous per group and instruction - the access shape that reaches the HBM
-// rate - and every thread keeps 8*NG accumulators.  On one GPU the consumer kernels reduce the partial rows themselves
+// ---- row-streaming kernels (split mode) -----------------------------------------------------------------------------------
+// One thread per row, consecutive lanes = consecutive rows: every basis column in use is one coalesced 8-byte stream and
+// every thread keeps 8*NG accumulators (NG = groups of eight columns, a template parameter).  On one GPU the consumer kernels reduce the partial rows themselves
 // (at most kMaxG rows); distributed runs fold them to one row first (k_reduce_rows) for the all-reduce.
 constexpr int kRB = 256;
 constexpr int kMaxRowsI = kMaxG / (kRB / 32);      // chunks of reduce_partials over at most kMaxG partial rows
-
-template <int NG>
-__device__ __forceinline__ void load_row_groups(const double *__restrict__ Vi, int64_t row, int64_t n, double (&v)[8 * NG]) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const double2 *p = reinterpret_cast<const double2 *>(Vi + ((size_t)g * (size_t)n + (size_t)row) * 8);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const double2 t = p[q];
-            v[8 * g + 2 * q] = t.x;
-            v[8 * g + 2 * q + 1] = t.y;
-        }
-    }
-}
 
 // column-major layout: the j+1 columns in use, one coalesced 8-byte stream each (k <= j is wave-uniform)
 template <int NG>
@@ -454,10 +439,7 @@ __global__ void __launch_bounds__(kRB) k_gmres_dots_rows(GDev d, int j) {
     if (d.T[j].done == 0) {
         for (int64_t row = blockIdx.x * (int64_t)kRB + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kRB) {
             double v[8 * NG];
-            if (d.ldv)
-                load_row_cols<NG>(d.Vi, row, d.ldv, j, v);
-            else
-                load_row_groups<NG>(d.Vi, row, d.n, v);
+            load_row_cols<NG>(d.Vi, row, d.ldv, j, v);          // split mode: the basis is column-major
             const double wv = d.w[row];
 #pragma unroll
             for (int k = 0; k < 8 * NG; ++k) acc[k] += v[k] * wv;
@@ -496,10 +478,7 @@ __global__ void __launch_bounds__(kRB, (NG < 4 || FAST) ? 3 : 2) k_gmres_orth_ro
         }
         for (int64_t row = blockIdx.x * (int64_t)kRB + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kRB) {
             double v[8 * NG];
-            if (d.ldv)
-                load_row_cols<NG>(d.Vi, row, d.ldv, j, v);
-            else
-                load_row_groups<NG>(d.Vi, row, d.n, v);
+            load_row_cols<NG>(d.Vi, row, d.ldv, j, v);          // split mode: the basis is column-major
             double wp = d.w[row];
 #pragma unroll
             for (int k = 0; k < 8 * NG; ++k) wp -= h[k] * v[k];
