@@ -69,22 +69,6 @@ int build_tiles(npg_csr *A) {
             q.npe = (int32_t)(A->h_prow[node(r1)] - q.pbase);
         }
     }
-    // XCD-aware order.  Workgroup b runs on XCD b mod 8 and walks the descriptors b, b + grid, b + 2 grid, ... (grid a
-    // multiple of 8), so descriptor position p is handled on XCD p mod 8.  Deal the tiles out so that every XCD gets one
-    // CONTIGUOUS eighth of the rows: the x-vector windows its tiles gather from then overlap in that XCD's own L2 instead of
-    // being spread over all eight.  (Affinity only - nothing depends on where a workgroup really runs.)
-    static const int xcd_env = getenv("NPG_TILE_XCD") ? atoi(getenv("NPG_TILE_XCD")) : 1;
-    if (xcd_env && A->ntiles >= 64) {
-        const int nt = A->ntiles, chunk = (nt + 7) / 8;
-        std::vector<TileDesc> dealt;
-        dealt.reserve((size_t)nt);
-        for (int s = 0; s < chunk; ++s)
-            for (int x = 0; x < 8; ++x) {
-                const int t = x * chunk + s;
-                if (t < std::min(nt, (x + 1) * chunk)) dealt.push_back(td[(size_t)t]);
-            }
-        td.swap(dealt);
-    }
     if (A->tile_ptr) NPG_HIP(hipFree(A->tile_ptr));
     NPG_HIP(hipMalloc((void **)&A->tile_ptr, std::max<size_t>(1, td.size()) * sizeof(TileDesc)));
     NPG_HIP(hipMemcpy(A->tile_ptr, td.data(), td.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
