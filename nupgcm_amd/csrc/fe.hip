@@ -11,8 +11,9 @@
 //
 // The vector assembly is deterministic: pass 1 writes each cell's local vector to loc[i][cell]; pass 2 gives every
 // destination DoF to one thread which adds its contributions in a fixed (cell-ascending) order through an inverted index
-// - no atomics, bit-reproducible right-hand sides.  The matrix (re)assembly, which only runs at setup and on coefficient
-// refreshes, scatters with fp64 global atomics into slots found by binary search in the sorted CSR row.
+// - no atomics, bit-reproducible right-hand sides.  The matrix (re)assembly (set-up and coefficient refreshes) is
+// deterministic too: one thread per CSR row walks the (cell, local DoF) pairs that carry the row's DoF, cell-ascending,
+// recomputes the local rows it owns and adds them into its own row (slots found by binary search in the sorted row).
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -185,10 +186,11 @@ __device__ __forceinline__ int64_t csr_slot(const int64_t *rowptr, const int32_t
     return -1;
 }
 
-__device__ __forceinline__ void scatter_add(const int64_t *rowptr, const int32_t *col, double *val, int32_t row,
-                                            int32_t c, double v, int *missing) {
+// a row owner adds into its own row: no atomic, contributions arrive in the fixed order of its adjacency list
+__device__ __forceinline__ void row_add(const int64_t *rowptr, const int32_t *col, double *val, int32_t row, int32_t c,
+                                        double v, int *missing) {
     const int64_t s = csr_slot(rowptr, col, row, c);
-    if (s >= 0) atomicAdd(&val[s], v);
+    if (s >= 0) val[s] += v;
     else if (v != 0.0) atomicAdd(missing, 1);    // a numerically non-zero entry outside the pattern is an error
 }
 
@@ -210,156 +212,176 @@ __device__ __forceinline__ void grad_u(const FeTables &t, const double *G, int q
     gz = dn[0] * G[2] + dn[1] * G[5] + dn[2] * G[8] + dn[3] * G[11];
 }
 
-// M / Kh / Kv: one thread per (cell, local test node i)
+// M / Kh / Kv: one thread per buoyancy ROW; it walks the (cell, local node) pairs that carry the row's node - the inverted
+// index of the vector assembly, cell-ascending - and adds each cell's local row into its own CSR row and lift entry.
+// Deterministic: no atomics, fixed order.
 template <int NB>
-__global__ void __launch_bounds__(kBlock) k_assemble_b(FeDev d, int which, const int64_t *rowptr, const int32_t *col,
+__global__ void __launch_bounds__(kBlock) k_assemble_b(FeDev d, int which, const int64_t *gptr, const int32_t *gidx,
+                                                       int64_t nrows, const int64_t *rowptr, const int32_t *col,
                                                        double *val, double *lift, int *missing) {
     __shared__ FeTables t;
     stage_tables(d, t);
-    const int64_t gid = blockIdx.x * (int64_t)kBlock + threadIdx.x;
-    const int64_t cell = gid / NB;
-    const int i = (int)(gid % NB);
-    if (cell >= d.ncell) return;
-    const int32_t row = d.cb[(size_t)i * d.ncell + cell];
-    if (row < 0) return;
-    double G[12];
+    const int64_t r = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+    if (r >= nrows) return;
+    const int32_t row = (int32_t)r;
+    double lf = 0.0;
+    for (int64_t k = gptr[r]; k < gptr[r + 1]; ++k) {
+        const int64_t cell = gidx[k] % d.ncell;
+        const int i = (int)(gidx[k] / d.ncell);
+        double G[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) G[k] = d.G[(size_t)k * d.ncell + cell];
-    const double wdet = d.wdet[cell];
-    double acc[NB];
+        for (int e = 0; e < 12; ++e) G[e] = d.G[(size_t)e * d.ncell + cell];
+        const double wdet = d.wdet[cell];
+        double acc[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) acc[j] = 0.0;
-    for (int q = 0; q < d.nq; ++q) {
-        double wq = t.qw[q] * wdet;
-        if (which == NPG_MAT_M) {
-            wq *= t.Nb[q * NB + i];
+        for (int j = 0; j < NB; ++j) acc[j] = 0.0;
+        for (int q = 0; q < d.nq; ++q) {
+            double wq = t.qw[q] * wdet;
+            if (which == NPG_MAT_M) {
+                wq *= t.Nb[q * NB + i];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) acc[j] += wq * t.Nb[q * NB + j];
-        } else {
-            double gix, giy, giz;
-            grad_b<NB>(t, G, q, i, gix, giy, giz);
-            wq *= (which == NPG_MAT_KH ? d.kh : d.kv)[(size_t)q * d.ncell + cell];
+                for (int j = 0; j < NB; ++j) acc[j] += wq * t.Nb[q * NB + j];
+            } else {
+                double gix, giy, giz;
+                grad_b<NB>(t, G, q, i, gix, giy, giz);
+                wq *= (which == NPG_MAT_KH ? d.kh : d.kv)[(size_t)q * d.ncell + cell];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                double gx, gy, gz;
-                grad_b<NB>(t, G, q, j, gx, gy, gz);
-                acc[j] += wq * (which == NPG_MAT_KH ? (gix * gx + giy * gy) : giz * gz);
+                for (int j = 0; j < NB; ++j) {
+                    double gx, gy, gz;
+                    grad_b<NB>(t, G, q, j, gx, gy, gz);
+                    acc[j] += wq * (which == NPG_MAT_KH ? (gix * gx + giy * gy) : giz * gz);
+                }
             }
         }
-    }
-    double lf = 0.0;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int32_t c = d.cb[(size_t)j * d.ncell + cell];
-        if (c >= 0) scatter_add(rowptr, col, val, row, c, acc[j], missing);
-        else lf += acc[j] * d.b_diri[-1 - c];
+        for (int j = 0; j < NB; ++j) {
+            const int32_t c = d.cb[(size_t)j * d.ncell + cell];
+            if (c >= 0) row_add(rowptr, col, val, row, c, acc[j], missing);
+            else lf += acc[j] * d.b_diri[-1 - c];
+        }
     }
-    if (lift && lf != 0.0) atomicAdd(&lift[row], lf);
+    if (lift) lift[row] = lf;
 }
 
+// B and A: one thread per ROW of the inversion system.  iptr / iidx list, cell-ascending, the (cell, local DoF l) pairs that
+// carry the row's DoF: l = 3 i + a for component a of velocity node i, l = 30 + m for pressure vertex m (iidx = l * ncell +
+// cell).  The thread recomputes the local rows it owns (three component rows of a node repeat the friction integral - a
+// set-up cost) and adds them in that fixed order: deterministic, no atomics.
+//
 // B: rows (u node i, component z), columns buoyancy nodes: scale * int phi_i phib_j     (src/inversion.jl:208)
 template <int NB>
-__global__ void __launch_bounds__(kBlock) k_assemble_B(FeDev d, double scale, const int64_t *rowptr, const int32_t *col,
+__global__ void __launch_bounds__(kBlock) k_assemble_B(FeDev d, double scale, const int64_t *iptr, const int32_t *iidx,
+                                                       int64_t nrows, const int64_t *rowptr, const int32_t *col,
                                                        double *val, double *lift, int *missing) {
     __shared__ FeTables t;
     stage_tables(d, t);
-    const int64_t gid = blockIdx.x * (int64_t)kBlock + threadIdx.x;
-    const int64_t cell = gid / 10;
-    const int i = (int)(gid % 10);
-    if (cell >= d.ncell) return;
-    const int32_t row = d.cu[(size_t)(3 * i + 2) * d.ncell + cell];
-    if (row < 0) return;
-    const double wdet = d.wdet[cell] * scale;
-    double acc[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) acc[j] = 0.0;
-    for (int q = 0; q < d.nq; ++q) {
-        const double wq = t.qw[q] * wdet * t.N2[q * 10 + i];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) acc[j] += wq * t.Nb[q * NB + j];
-    }
+    const int64_t r = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+    if (r >= nrows) return;
+    const int32_t row = (int32_t)r;
     double lf = 0.0;
+    for (int64_t k = iptr[r]; k < iptr[r + 1]; ++k) {
+        const int64_t cell = iidx[k] % d.ncell;
+        const int l = (int)(iidx[k] / d.ncell);
+        if (l >= 30 || l % 3 != 2) continue;                 // only the vertical momentum rows feel buoyancy
+        const int i = l / 3;
+        const double wdet = d.wdet[cell] * scale;
+        double acc[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int32_t c = d.cb[(size_t)j * d.ncell + cell];
-        if (c >= 0) scatter_add(rowptr, col, val, row, c, acc[j], missing);
-        else lf += acc[j] * d.b_diri[-1 - c];
+        for (int j = 0; j < NB; ++j) acc[j] = 0.0;
+        for (int q = 0; q < d.nq; ++q) {
+            const double wq = t.qw[q] * wdet * t.N2[q * 10 + i];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[j] += wq * t.Nb[q * NB + j];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int32_t c = d.cb[(size_t)j * d.ncell + cell];
+            if (c >= 0) row_add(rowptr, col, val, row, c, acc[j], missing);
+            else lf += acc[j] * d.b_diri[-1 - c];
+        }
     }
-    if (lift && lf != 0.0) atomicAdd(&lift[row], lf);
+    if (lift) lift[row] = lf;
 }
 
-// A: one thread per (cell, u node i): the three component rows of node i and the matching pressure-row entries.
+// A:
 //   [(i,a),(j,c)] += a2e2 int nu ( d_ac grad phi_i . grad phi_j  [+ d_c phi_i d_a phi_j  if full_stress] )
 //   [(i,x),(j,y)] -= int f phi_i phi_j ; [(i,y),(j,x)] += int f phi_i phi_j
 //   [(i,a), p_m ] -= int d_a phi_i psi_m ; [p_m, (i,a)] += int psi_m d_a phi_i
-__global__ void __launch_bounds__(kBlock) k_assemble_A(FeDev d, double a2e2, int full_stress, const int64_t *rowptr,
+__global__ void __launch_bounds__(kBlock) k_assemble_A(FeDev d, double a2e2, int full_stress, const int64_t *iptr,
+                                                       const int32_t *iidx, int64_t nrows, const int64_t *rowptr,
                                                        const int32_t *col, double *val, int *missing) {
     __shared__ FeTables t;
     stage_tables(d, t);
-    const int64_t gid = blockIdx.x * (int64_t)kBlock + threadIdx.x;
-    const int64_t cell = gid / 10;
-    const int i = (int)(gid % 10);
-    if (cell >= d.ncell) return;
-    int32_t rowi[3];
+    const int64_t r = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+    if (r >= nrows) return;
+    const int32_t row = (int32_t)r;
+    for (int64_t k = iptr[r]; k < iptr[r + 1]; ++k) {
+        const int64_t cell = iidx[k] % d.ncell;
+        const int l = (int)(iidx[k] / d.ncell);
+        double G[12];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) rowi[a] = d.cu[(size_t)(3 * i + a) * d.ncell + cell];
-    double G[12];
+        for (int e = 0; e < 12; ++e) G[e] = d.G[(size_t)e * d.ncell + cell];
+        const double wdet = d.wdet[cell];
+        if (l < 30) {
+            const int i = l / 3, a = l % 3;
+            // u-u block, one trial node j at a time
+            for (int j = 0; j < 10; ++j) {
+                double kk = 0.0, cc = 0.0, fs[3] = {0.0, 0.0, 0.0};
+                for (int q = 0; q < d.nq; ++q) {
+                    const double wq = t.qw[q] * wdet;
+                    double gi[3], gj[3];
+                    grad_u(t, G, q, i, gi[0], gi[1], gi[2]);
+                    grad_u(t, G, q, j, gj[0], gj[1], gj[2]);
+                    const double wn = wq * a2e2 * d.nu[(size_t)q * d.ncell + cell];
+                    kk += wn * (gi[0] * gj[0] + gi[1] * gj[1] + gi[2] * gj[2]);
+                    cc += wq * d.f[(size_t)q * d.ncell + cell] * t.N2[q * 10 + i] * t.N2[q * 10 + j];
+                    if (full_stress) {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) G[k] = d.G[(size_t)k * d.ncell + cell];
-    const double wdet = d.wdet[cell];
-    // u-u block, one trial node j at a time
-    for (int j = 0; j < 10; ++j) {
-        double kk = 0.0, cc = 0.0, fs[9];
+                        for (int c = 0; c < 3; ++c) fs[c] += wn * gi[c] * gj[a];
+                    }
+                }
 #pragma unroll
-        for (int e = 0; e < 9; ++e) fs[e] = 0.0;
-        for (int q = 0; q < d.nq; ++q) {
-            const double wq = t.qw[q] * wdet;
-            double gi[3], gj[3];
-            grad_u(t, G, q, i, gi[0], gi[1], gi[2]);
-            grad_u(t, G, q, j, gj[0], gj[1], gj[2]);
-            const double wn = wq * a2e2 * d.nu[(size_t)q * d.ncell + cell];
-            kk += wn * (gi[0] * gj[0] + gi[1] * gj[1] + gi[2] * gj[2]);
-            cc += wq * d.f[(size_t)q * d.ncell + cell] * t.N2[q * 10 + i] * t.N2[q * 10 + j];
-            if (full_stress) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) fs[3 * a + c] += wn * gi[c] * gj[a];
+                for (int c = 0; c < 3; ++c) {
+                    const int32_t cj = d.cu[(size_t)(3 * j + c) * d.ncell + cell];
+                    if (cj < 0) continue;     // homogeneous velocity Dirichlet data: no lift (src/spaces.jl u_diri_vals = 0)
+                    double v = full_stress ? fs[c] : 0.0;
+                    if (a == c) v += kk;
+                    if (a == 0 && c == 1) v -= cc;
+                    if (a == 1 && c == 0) v += cc;
+                    if (a == c || full_stress || (a < 2 && c < 2)) row_add(rowptr, col, val, row, cj, v, missing);
+                }
             }
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            if (rowi[a] < 0) continue;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int32_t cj = d.cu[(size_t)(3 * j + c) * d.ncell + cell];
-                if (cj < 0) continue;     // homogeneous velocity Dirichlet data: no lift (src/spaces.jl u_diri_vals = 0)
-                double v = full_stress ? fs[3 * a + c] : 0.0;
-                if (a == c) v += kk;
-                if (a == 0 && c == 1) v -= cc;
-                if (a == 1 && c == 0) v += cc;
-                if (a == c || full_stress || (a < 2 && c < 2)) scatter_add(rowptr, col, val, rowi[a], cj, v, missing);
+            // u-p coupling of this momentum row
+            for (int m = 0; m < 4; ++m) {
+                const int32_t pm = d.cp[(size_t)m * d.ncell + cell];
+                if (pm < 0) continue;
+                double dd = 0.0;
+                for (int q = 0; q < d.nq; ++q) {
+                    double gi[3];
+                    grad_u(t, G, q, i, gi[0], gi[1], gi[2]);
+                    dd += t.qw[q] * wdet * t.N1[q * 4 + m] * gi[a];
+                }
+                row_add(rowptr, col, val, row, pm, -dd, missing);
             }
-        }
-    }
-    // u-p coupling
-    for (int m = 0; m < 4; ++m) {
-        const int32_t pm = d.cp[(size_t)m * d.ncell + cell];
-        if (pm < 0) continue;
-        double dd[3] = {0.0, 0.0, 0.0};
-        for (int q = 0; q < d.nq; ++q) {
-            const double wq = t.qw[q] * wdet * t.N1[q * 4 + m];
-            double gi[3];
-            grad_u(t, G, q, i, gi[0], gi[1], gi[2]);
-            dd[0] += wq * gi[0];
-            dd[1] += wq * gi[1];
-            dd[2] += wq * gi[2];
-        }
+        } else {
+            // continuity row of pressure vertex m
+            const int m = l - 30;
+            for (int i = 0; i < 10; ++i) {
+                double dd[3] = {0.0, 0.0, 0.0};
+                for (int q = 0; q < d.nq; ++q) {
+                    const double wq = t.qw[q] * wdet * t.N1[q * 4 + m];
+                    double gi[3];
+                    grad_u(t, G, q, i, gi[0], gi[1], gi[2]);
+                    dd[0] += wq * gi[0];
+                    dd[1] += wq * gi[1];
+                    dd[2] += wq * gi[2];
+                }
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            if (rowi[a] < 0) continue;
-            scatter_add(rowptr, col, val, rowi[a], pm, -dd[a], missing);
-            scatter_add(rowptr, col, val, pm, rowi[a], dd[a], missing);
+                for (int a = 0; a < 3; ++a) {
+                    const int32_t ci = d.cu[(size_t)(3 * i + a) * d.ncell + cell];
+                    if (ci >= 0) row_add(rowptr, col, val, row, ci, dd[a], missing);
+                }
+            }
         }
     }
 }
@@ -445,8 +467,10 @@ struct npg_fe {
     int64_t n_inv = 0, n_b = 0;
     std::vector<void *> allocs;
     double *loc = nullptr;          // [nb][ncell]
-    int64_t *gptr = nullptr;        // inverted index for pass 2
+    int64_t *gptr = nullptr;        // inverted index of the buoyancy rows (vector pass 2, matrix rows)
     int32_t *gidx = nullptr;
+    int64_t *iptr = nullptr;        // inverted index of the inversion rows [u; p]: (local DoF l) * ncell + cell
+    int32_t *iidx = nullptr;
     double *coef[4] = {nullptr, nullptr, nullptr, nullptr};   // nu, kappa_h, kappa_v, f
     double *kv0 = nullptr;          // background kappa_v for the convection closure
     double *hcell = nullptr;
@@ -546,6 +570,34 @@ NPG_API int npg_fe_create(npg_ctx *ctx, const npg_fe_desc *desc, npg_fe **out) {
     if ((rc = dev_copy(fe, gidx.data(), gidx.size(), &gi))) return rc;
     fe->gptr = const_cast<int64_t *>(gp);
     fe->gidx = const_cast<int32_t *>(gi);
+    {
+        // inversion rows: row -> (l * ncell + cell), l = 3 i + a (velocity node i, component a) or 30 + m (pressure vertex m)
+        NPG_REQUIRE(34 * nc < INT32_MAX, "npg_fe_create: too many cells for the 32-bit inverted index");
+        std::vector<int64_t> ip((size_t)desc->n_inv + 1, 0);
+        for (int64_t k = 0; k < nc * 30; ++k)
+            if (desc->cell_u[k] >= 0) ++ip[(size_t)desc->cell_u[k] + 1];
+        for (int64_t k = 0; k < nc * 4; ++k)
+            if (desc->cell_p[k] >= 0) ++ip[(size_t)desc->cell_p[k] + 1];
+        for (int64_t r = 0; r < desc->n_inv; ++r) ip[r + 1] += ip[r];
+        std::vector<int32_t> ii((size_t)ip[desc->n_inv]);
+        std::vector<int64_t> nx(ip.begin(), ip.end() - 1);
+        for (int64_t c = 0; c < nc; ++c) {
+            for (int l = 0; l < 30; ++l) {
+                const int32_t r = desc->cell_u[(size_t)c * 30 + l];
+                if (r >= 0) ii[(size_t)nx[r]++] = (int32_t)((int64_t)l * nc + c);
+            }
+            for (int m = 0; m < 4; ++m) {
+                const int32_t r = desc->cell_p[(size_t)c * 4 + m];
+                if (r >= 0) ii[(size_t)nx[r]++] = (int32_t)((int64_t)(30 + m) * nc + c);
+            }
+        }
+        const int64_t *ipd;
+        const int32_t *iid;
+        if ((rc = dev_copy(fe, ip.data(), ip.size(), &ipd))) return rc;
+        if ((rc = dev_copy(fe, ii.data(), ii.size(), &iid))) return rc;
+        fe->iptr = const_cast<int64_t *>(ipd);
+        fe->iidx = const_cast<int32_t *>(iid);
+    }
     NPG_HIP(hipMalloc((void **)&fe->loc, (size_t)nc * nb * sizeof(double)));
     fe->allocs.push_back(fe->loc);
     NPG_HIP(hipMalloc((void **)&fe->missing, sizeof(int)));
@@ -704,32 +756,32 @@ NPG_API int npg_fe_assemble_matrix(npg_fe *fe, int which, double scale, int full
             NPG_REQUIRE(!lift || lift->n == fe->n_b, "npg_fe_assemble_matrix: lift must have n_b entries");
             NPG_REQUIRE(which == NPG_MAT_M || (which == NPG_MAT_KH ? d.kh : d.kv),
                         "npg_fe_assemble_matrix: diffusivity coefficient has not been set");
-            const int grid = cell_grid(d.ncell * d.nb);
+            const int grid = cell_grid(fe->n_b);
             if (d.nb == 10)
-                hipLaunchKernelGGL(k_assemble_b<10>, dim3(grid), dim3(kBlock), 0, st, d, which, A->rowptr, A->col,
-                                   A->val, lift ? lift->d : nullptr, fe->missing);
+                hipLaunchKernelGGL(k_assemble_b<10>, dim3(grid), dim3(kBlock), 0, st, d, which, fe->gptr, fe->gidx, fe->n_b,
+                                   A->rowptr, A->col, A->val, lift ? lift->d : nullptr, fe->missing);
             else
-                hipLaunchKernelGGL(k_assemble_b<4>, dim3(grid), dim3(kBlock), 0, st, d, which, A->rowptr, A->col, A->val,
-                                   lift ? lift->d : nullptr, fe->missing);
+                hipLaunchKernelGGL(k_assemble_b<4>, dim3(grid), dim3(kBlock), 0, st, d, which, fe->gptr, fe->gidx, fe->n_b,
+                                   A->rowptr, A->col, A->val, lift ? lift->d : nullptr, fe->missing);
             break;
         }
         case NPG_MAT_A: {
             NPG_REQUIRE(A->m == fe->n_inv && A->n == fe->n_inv, "npg_fe_assemble_matrix: A must be n_inv x n_inv");
             NPG_REQUIRE(d.nu && d.f, "npg_fe_assemble_matrix: coefficients nu and f must be set");
-            hipLaunchKernelGGL(k_assemble_A, dim3(cell_grid(d.ncell * 10)), dim3(kBlock), 0, st, d, scale, full_stress,
-                               A->rowptr, A->col, A->val, fe->missing);
+            hipLaunchKernelGGL(k_assemble_A, dim3(cell_grid(fe->n_inv)), dim3(kBlock), 0, st, d, scale, full_stress, fe->iptr,
+                               fe->iidx, fe->n_inv, A->rowptr, A->col, A->val, fe->missing);
             break;
         }
         case NPG_MAT_B: {
             NPG_REQUIRE(A->m == fe->n_inv && A->n == fe->n_b, "npg_fe_assemble_matrix: B must be n_inv x n_b");
             NPG_REQUIRE(!lift || lift->n == fe->n_inv, "npg_fe_assemble_matrix: lift must have n_inv entries");
-            const int grid = cell_grid(d.ncell * 10);
+            const int grid = cell_grid(fe->n_inv);
             if (d.nb == 10)
-                hipLaunchKernelGGL(k_assemble_B<10>, dim3(grid), dim3(kBlock), 0, st, d, scale, A->rowptr, A->col, A->val,
-                                   lift ? lift->d : nullptr, fe->missing);
+                hipLaunchKernelGGL(k_assemble_B<10>, dim3(grid), dim3(kBlock), 0, st, d, scale, fe->iptr, fe->iidx, fe->n_inv,
+                                   A->rowptr, A->col, A->val, lift ? lift->d : nullptr, fe->missing);
             else
-                hipLaunchKernelGGL(k_assemble_B<4>, dim3(grid), dim3(kBlock), 0, st, d, scale, A->rowptr, A->col, A->val,
-                                   lift ? lift->d : nullptr, fe->missing);
+                hipLaunchKernelGGL(k_assemble_B<4>, dim3(grid), dim3(kBlock), 0, st, d, scale, fe->iptr, fe->iidx, fe->n_inv,
+                                   A->rowptr, A->col, A->val, lift ? lift->d : nullptr, fe->missing);
             break;
         }
         default:
