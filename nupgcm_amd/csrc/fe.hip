@@ -212,36 +212,42 @@ __device__ __forceinline__ void grad_u(const FeTables &t, const double *G, int q
     gz = dn[0] * G[2] + dn[1] * G[5] + dn[2] * G[8] + dn[3] * G[11];
 }
 
-// M / Kh / Kv: one thread per buoyancy ROW; it walks the (cell, local node) pairs that carry the row's node - the inverted
-// index of the vector assembly, cell-ascending - and adds each cell's local row into its own CSR row and lift entry.
-// Deterministic: no atomics, fixed order.
+// ---- matrix assembly: sixteen lanes per CSR row, lane = quadrature point ------------------------------------------------
+// A lane group owns a row.  It walks the (cell, local DoF) pairs that carry the row's DoF (an inverted index, cell-ascending);
+// for each pair every lane evaluates its quadrature point's share of the local row, the shares are summed over the lanes in
+// the fixed order of the DPP tree, and the sums go into the group's own CSR row (slots by binary search) - no atomics, the
+// same bits on every run.  The three component rows of a velocity node repeat the friction integral: a set-up cost.
+constexpr int kQL = 16;      // lanes per row = kMaxQ
+
+// M / Kh / Kv: rows = buoyancy DoFs; gptr / gidx = the inverted index of the vector assembly (i * ncell + cell)
 template <int NB>
 __global__ void __launch_bounds__(kBlock) k_assemble_b(FeDev d, int which, const int64_t *gptr, const int32_t *gidx,
                                                        int64_t nrows, const int64_t *rowptr, const int32_t *col,
                                                        double *val, double *lift, int *missing) {
     __shared__ FeTables t;
     stage_tables(d, t);
-    const int64_t r = blockIdx.x * (int64_t)kBlock + threadIdx.x;
-    if (r >= nrows) return;
+    const int64_t r = (blockIdx.x * (int64_t)kBlock + threadIdx.x) / kQL;
+    const int q = threadIdx.x % kQL;
+    if (r >= nrows) return;                                  // whole lane groups leave together
     const int32_t row = (int32_t)r;
+    const bool on = q < d.nq;
     double lf = 0.0;
     for (int64_t k = gptr[r]; k < gptr[r + 1]; ++k) {
         const int64_t cell = gidx[k] % d.ncell;
         const int i = (int)(gidx[k] / d.ncell);
-        double G[12];
-#pragma unroll
-        for (int e = 0; e < 12; ++e) G[e] = d.G[(size_t)e * d.ncell + cell];
-        const double wdet = d.wdet[cell];
         double acc[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[j] = 0.0;
-        for (int q = 0; q < d.nq; ++q) {
-            double wq = t.qw[q] * wdet;
+        if (on) {
+            double wq = t.qw[q] * d.wdet[cell];
             if (which == NPG_MAT_M) {
                 wq *= t.Nb[q * NB + i];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) acc[j] += wq * t.Nb[q * NB + j];
+                for (int j = 0; j < NB; ++j) acc[j] = wq * t.Nb[q * NB + j];
             } else {
+                double G[12];
+#pragma unroll
+                for (int e = 0; e < 12; ++e) G[e] = d.G[(size_t)e * d.ncell + cell];
                 double gix, giy, giz;
                 grad_b<NB>(t, G, q, i, gix, giy, giz);
                 wq *= (which == NPG_MAT_KH ? d.kh : d.kv)[(size_t)q * d.ncell + cell];
@@ -249,24 +255,34 @@ __global__ void __launch_bounds__(kBlock) k_assemble_b(FeDev d, int which, const
                 for (int j = 0; j < NB; ++j) {
                     double gx, gy, gz;
                     grad_b<NB>(t, G, q, j, gx, gy, gz);
-                    acc[j] += wq * (which == NPG_MAT_KH ? (gix * gx + giy * gy) : giz * gz);
+                    acc[j] = wq * (which == NPG_MAT_KH ? (gix * gx + giy * gy) : giz * gz);
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int32_t c = d.cb[(size_t)j * d.ncell + cell];
-            if (c >= 0) row_add(rowptr, col, val, row, c, acc[j], missing);
-            else lf += acc[j] * d.b_diri[-1 - c];
+        for (int j = 0; j < NB; ++j) acc[j] = group_sum_dpp<kQL>(acc[j]);
+        // lane j adds column j (distinct columns of one cell; the next cell's adds come after these in program order)
+        double mine = 0.0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) mine = (q == j) ? acc[j] : mine;
+        if (q < NB) {
+            const int32_t c = d.cb[(size_t)q * d.ncell + cell];
+            if (c >= 0) row_add(rowptr, col, val, row, c, mine, missing);
         }
+        if (q == 0) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int32_t c = d.cb[(size_t)j * d.ncell + cell];
+                if (c < 0) lf += acc[j] * d.b_diri[-1 - c];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);                       // this cell's stores are out before the next cell's loads
     }
-    if (lift) lift[row] = lf;
+    if (lift && q == 0) lift[row] = lf;
 }
 
-// B and A: one thread per ROW of the inversion system.  iptr / iidx list, cell-ascending, the (cell, local DoF l) pairs that
-// carry the row's DoF: l = 3 i + a for component a of velocity node i, l = 30 + m for pressure vertex m (iidx = l * ncell +
-// cell).  The thread recomputes the local rows it owns (three component rows of a node repeat the friction integral - a
-// set-up cost) and adds them in that fixed order: deterministic, no atomics.
+// B and A: rows of the inversion system.  iptr / iidx list, cell-ascending, the (cell, local DoF l) pairs that carry the row's
+// DoF: l = 3 i + a for component a of velocity node i, l = 30 + m for pressure vertex m (iidx = l * ncell + cell).
 //
 // B: rows (u node i, component z), columns buoyancy nodes: scale * int phi_i phib_j     (src/inversion.jl:208)
 template <int NB>
@@ -275,32 +291,38 @@ __global__ void __launch_bounds__(kBlock) k_assemble_B(FeDev d, double scale, co
                                                        double *val, double *lift, int *missing) {
     __shared__ FeTables t;
     stage_tables(d, t);
-    const int64_t r = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+    const int64_t r = (blockIdx.x * (int64_t)kBlock + threadIdx.x) / kQL;
+    const int q = threadIdx.x % kQL;
     if (r >= nrows) return;
     const int32_t row = (int32_t)r;
+    const bool on = q < d.nq;
     double lf = 0.0;
     for (int64_t k = iptr[r]; k < iptr[r + 1]; ++k) {
         const int64_t cell = iidx[k] % d.ncell;
         const int l = (int)(iidx[k] / d.ncell);
-        if (l >= 30 || l % 3 != 2) continue;                 // only the vertical momentum rows feel buoyancy
+        if (l >= 30 || l % 3 != 2) continue;                 // only the vertical momentum rows feel buoyancy (group-uniform)
         const int i = l / 3;
-        const double wdet = d.wdet[cell] * scale;
         double acc[NB];
+        const double wq = on ? t.qw[q] * d.wdet[cell] * scale * t.N2[q * 10 + i] : 0.0;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) acc[j] = 0.0;
-        for (int q = 0; q < d.nq; ++q) {
-            const double wq = t.qw[q] * wdet * t.N2[q * 10 + i];
+        for (int j = 0; j < NB; ++j) acc[j] = group_sum_dpp<kQL>(on ? wq * t.Nb[q * NB + j] : 0.0);
+        double mine = 0.0;
 #pragma unroll
-            for (int j = 0; j < NB; ++j) acc[j] += wq * t.Nb[q * NB + j];
+        for (int j = 0; j < NB; ++j) mine = (q == j) ? acc[j] : mine;
+        if (q < NB) {
+            const int32_t c = d.cb[(size_t)q * d.ncell + cell];
+            if (c >= 0) row_add(rowptr, col, val, row, c, mine, missing);
         }
+        if (q == 0) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int32_t c = d.cb[(size_t)j * d.ncell + cell];
-            if (c >= 0) row_add(rowptr, col, val, row, c, acc[j], missing);
-            else lf += acc[j] * d.b_diri[-1 - c];
+            for (int j = 0; j < NB; ++j) {
+                const int32_t c = d.cb[(size_t)j * d.ncell + cell];
+                if (c < 0) lf += acc[j] * d.b_diri[-1 - c];
+            }
         }
+        __builtin_amdgcn_s_waitcnt(0);
     }
-    if (lift) lift[row] = lf;
+    if (lift && q == 0) lift[row] = lf;
 }
 
 // A:
@@ -312,77 +334,78 @@ __global__ void __launch_bounds__(kBlock) k_assemble_A(FeDev d, double a2e2, int
                                                        const int32_t *col, double *val, int *missing) {
     __shared__ FeTables t;
     stage_tables(d, t);
-    const int64_t r = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+    const int64_t r = (blockIdx.x * (int64_t)kBlock + threadIdx.x) / kQL;
+    const int q = threadIdx.x % kQL;
     if (r >= nrows) return;
     const int32_t row = (int32_t)r;
+    const bool on = q < d.nq;
     for (int64_t k = iptr[r]; k < iptr[r + 1]; ++k) {
         const int64_t cell = iidx[k] % d.ncell;
         const int l = (int)(iidx[k] / d.ncell);
         double G[12];
 #pragma unroll
         for (int e = 0; e < 12; ++e) G[e] = d.G[(size_t)e * d.ncell + cell];
-        const double wdet = d.wdet[cell];
+        const double wq = on ? t.qw[q] * d.wdet[cell] : 0.0;
         if (l < 30) {
             const int i = l / 3, a = l % 3;
-            // u-u block, one trial node j at a time
+            double gi[3] = {0.0, 0.0, 0.0};
+            double wn = 0.0, wf = 0.0;
+            if (on) {
+                grad_u(t, G, q, i, gi[0], gi[1], gi[2]);
+                wn = wq * a2e2 * d.nu[(size_t)q * d.ncell + cell];
+                wf = wq * d.f[(size_t)q * d.ncell + cell] * t.N2[q * 10 + i];
+            }
+            // u-u block, one trial node j at a time; lane c < 3 then adds the entry of trial component c
             for (int j = 0; j < 10; ++j) {
-                double kk = 0.0, cc = 0.0, fs[3] = {0.0, 0.0, 0.0};
-                for (int q = 0; q < d.nq; ++q) {
-                    const double wq = t.qw[q] * wdet;
-                    double gi[3], gj[3];
-                    grad_u(t, G, q, i, gi[0], gi[1], gi[2]);
-                    grad_u(t, G, q, j, gj[0], gj[1], gj[2]);
-                    const double wn = wq * a2e2 * d.nu[(size_t)q * d.ncell + cell];
-                    kk += wn * (gi[0] * gj[0] + gi[1] * gj[1] + gi[2] * gj[2]);
-                    cc += wq * d.f[(size_t)q * d.ncell + cell] * t.N2[q * 10 + i] * t.N2[q * 10 + j];
-                    if (full_stress) {
+                double gj[3] = {0.0, 0.0, 0.0};
+                if (on) grad_u(t, G, q, j, gj[0], gj[1], gj[2]);
+                const double kk = group_sum_dpp<kQL>(wn * (gi[0] * gj[0] + gi[1] * gj[1] + gi[2] * gj[2]));
+                const double cc = group_sum_dpp<kQL>(on ? wf * t.N2[q * 10 + j] : 0.0);
+                double fs[3] = {0.0, 0.0, 0.0};
+                if (full_stress) {
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) fs[c] += wn * gi[c] * gj[a];
+                    for (int c = 0; c < 3; ++c) fs[c] = group_sum_dpp<kQL>(wn * gi[c] * gj[a]);
+                }
+                if (q < 3) {
+                    const int c = q;
+                    const int32_t cj = d.cu[(size_t)(3 * j + c) * d.ncell + cell];
+                    if (cj >= 0) {          // homogeneous velocity Dirichlet data: no lift (src/spaces.jl u_diri_vals = 0)
+                        double v = full_stress ? (c == 0 ? fs[0] : c == 1 ? fs[1] : fs[2]) : 0.0;
+                        if (a == c) v += kk;
+                        if (a == 0 && c == 1) v -= cc;
+                        if (a == 1 && c == 0) v += cc;
+                        if (a == c || full_stress || (a < 2 && c < 2)) row_add(rowptr, col, val, row, cj, v, missing);
                     }
                 }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const int32_t cj = d.cu[(size_t)(3 * j + c) * d.ncell + cell];
-                    if (cj < 0) continue;     // homogeneous velocity Dirichlet data: no lift (src/spaces.jl u_diri_vals = 0)
-                    double v = full_stress ? fs[c] : 0.0;
-                    if (a == c) v += kk;
-                    if (a == 0 && c == 1) v -= cc;
-                    if (a == 1 && c == 0) v += cc;
-                    if (a == c || full_stress || (a < 2 && c < 2)) row_add(rowptr, col, val, row, cj, v, missing);
-                }
             }
-            // u-p coupling of this momentum row
+            // u-p coupling of this momentum row: lane m < 4 adds the entry of pressure vertex m
+            double ddm = 0.0;
+#pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const int32_t pm = d.cp[(size_t)m * d.ncell + cell];
-                if (pm < 0) continue;
-                double dd = 0.0;
-                for (int q = 0; q < d.nq; ++q) {
-                    double gi[3];
-                    grad_u(t, G, q, i, gi[0], gi[1], gi[2]);
-                    dd += t.qw[q] * wdet * t.N1[q * 4 + m] * gi[a];
-                }
-                row_add(rowptr, col, val, row, pm, -dd, missing);
+                const double dd = group_sum_dpp<kQL>(on ? wq * t.N1[q * 4 + m] * gi[a] : 0.0);
+                ddm = (q == m) ? dd : ddm;
+            }
+            if (q < 4) {
+                const int32_t pm = d.cp[(size_t)q * d.ncell + cell];
+                if (pm >= 0) row_add(rowptr, col, val, row, pm, -ddm, missing);
             }
         } else {
-            // continuity row of pressure vertex m
+            // continuity row of pressure vertex m: lane a < 3 adds the entry of component a of node i
             const int m = l - 30;
+            const double wm = on ? wq * t.N1[q * 4 + m] : 0.0;
             for (int i = 0; i < 10; ++i) {
-                double dd[3] = {0.0, 0.0, 0.0};
-                for (int q = 0; q < d.nq; ++q) {
-                    const double wq = t.qw[q] * wdet * t.N1[q * 4 + m];
-                    double gi[3];
-                    grad_u(t, G, q, i, gi[0], gi[1], gi[2]);
-                    dd[0] += wq * gi[0];
-                    dd[1] += wq * gi[1];
-                    dd[2] += wq * gi[2];
-                }
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const int32_t ci = d.cu[(size_t)(3 * i + a) * d.ncell + cell];
-                    if (ci >= 0) row_add(rowptr, col, val, row, ci, dd[a], missing);
+                double gi[3] = {0.0, 0.0, 0.0};
+                if (on) grad_u(t, G, q, i, gi[0], gi[1], gi[2]);
+                const double d0 = group_sum_dpp<kQL>(wm * gi[0]);
+                const double d1 = group_sum_dpp<kQL>(wm * gi[1]);
+                const double d2 = group_sum_dpp<kQL>(wm * gi[2]);
+                if (q < 3) {
+                    const int32_t ci = d.cu[(size_t)(3 * i + q) * d.ncell + cell];
+                    if (ci >= 0) row_add(rowptr, col, val, row, ci, q == 0 ? d0 : q == 1 ? d1 : d2, missing);
                 }
             }
         }
+        __builtin_amdgcn_s_waitcnt(0);                       // this cell's stores are out before the next cell's loads
     }
 }
 
@@ -756,7 +779,7 @@ NPG_API int npg_fe_assemble_matrix(npg_fe *fe, int which, double scale, int full
             NPG_REQUIRE(!lift || lift->n == fe->n_b, "npg_fe_assemble_matrix: lift must have n_b entries");
             NPG_REQUIRE(which == NPG_MAT_M || (which == NPG_MAT_KH ? d.kh : d.kv),
                         "npg_fe_assemble_matrix: diffusivity coefficient has not been set");
-            const int grid = cell_grid(fe->n_b);
+            const int grid = cell_grid(fe->n_b * kQL);
             if (d.nb == 10)
                 hipLaunchKernelGGL(k_assemble_b<10>, dim3(grid), dim3(kBlock), 0, st, d, which, fe->gptr, fe->gidx, fe->n_b,
                                    A->rowptr, A->col, A->val, lift ? lift->d : nullptr, fe->missing);
@@ -768,14 +791,14 @@ NPG_API int npg_fe_assemble_matrix(npg_fe *fe, int which, double scale, int full
         case NPG_MAT_A: {
             NPG_REQUIRE(A->m == fe->n_inv && A->n == fe->n_inv, "npg_fe_assemble_matrix: A must be n_inv x n_inv");
             NPG_REQUIRE(d.nu && d.f, "npg_fe_assemble_matrix: coefficients nu and f must be set");
-            hipLaunchKernelGGL(k_assemble_A, dim3(cell_grid(fe->n_inv)), dim3(kBlock), 0, st, d, scale, full_stress, fe->iptr,
+            hipLaunchKernelGGL(k_assemble_A, dim3(cell_grid(fe->n_inv * kQL)), dim3(kBlock), 0, st, d, scale, full_stress, fe->iptr,
                                fe->iidx, fe->n_inv, A->rowptr, A->col, A->val, fe->missing);
             break;
         }
         case NPG_MAT_B: {
             NPG_REQUIRE(A->m == fe->n_inv && A->n == fe->n_b, "npg_fe_assemble_matrix: B must be n_inv x n_b");
             NPG_REQUIRE(!lift || lift->n == fe->n_inv, "npg_fe_assemble_matrix: lift must have n_inv entries");
-            const int grid = cell_grid(fe->n_inv);
+            const int grid = cell_grid(fe->n_inv * kQL);
             if (d.nb == 10)
                 hipLaunchKernelGGL(k_assemble_B<10>, dim3(grid), dim3(kBlock), 0, st, d, scale, fe->iptr, fe->iidx, fe->n_inv,
                                    A->rowptr, A->col, A->val, lift ? lift->d : nullptr, fe->missing);

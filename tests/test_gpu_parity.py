@@ -334,6 +334,35 @@ def test_assemble_evolution_matrices(arch, diri):
     assert rel(out, S.orc.rhs_diff()[d.p_b]) < 1e-12
 
 
+def test_assembly_is_bit_reproducible(arch, diri):
+    """No atomics in the matrix assembly: assembling twice, and from two independently created engines, gives identical bits."""
+    fed, prm, S, fe = diri
+    d, ctx = fed.dofs, arch.ctx
+    from nupgcm_amd.assembly import DeviceFE
+    fe2 = DeviceFE(ctx, fed)
+    for eng in (fe, fe2):
+        eng.set_coeff("kappa_h", lambda x: 1.0 + 0.3 * x[..., 0] + np.exp(x[..., 2]))
+        eng.set_coeff("kappa_v", lambda x: 1.0 + 0.3 * x[..., 0] + np.exp(x[..., 2]))
+        eng.set_coeff("nu", lambda x: 1.0 + 0.5 * x[..., 2] ** 2)
+        eng.set_coeff("f", prm.f)
+    outs = []
+    for eng in (fe, fe, fe2):
+        mats = []
+        for which, kind in ((L.NPG_MAT_M, "b"), (L.NPG_MAT_KH, "b"), (L.NPG_MAT_KV, "b")):
+            lift = npg.DeviceVector(ctx, d.nb)
+            mats.append(eng.assemble(which, eng.new_matrix(kind), lift=lift).to_scipy_csr().data)
+            mats.append(lift.to_host())
+        mats.append(eng.assemble(L.NPG_MAT_A, eng.new_matrix("A", structural=True), scale=0.3, full_stress=True)
+                    .to_scipy_csr().data)
+        lift = npg.DeviceVector(ctx, d.nu + d.np)
+        mats.append(eng.assemble(L.NPG_MAT_B, eng.new_matrix("B"), scale=2.0, lift=lift).to_scipy_csr().data)
+        mats.append(lift.to_host())
+        outs.append(mats)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
+
+
 def test_assemble_inversion_matrices(arch, diri):
     fed, prm, S, fe = diri
     d, ctx = fed.dofs, arch.ctx
