@@ -794,6 +794,29 @@ def test_full_size_properties(arch):
     z = x.copy()
     z.axpby(-0.75, y, 2.5)                                                 # z = 2.5 x - 0.75 y
     assert rel(A_blk.mul(z).to_host(), 2.5 * ax - 0.75 * ay) < 1e-13       # linearity
+    # the assembled entries themselves, through exact identities of the weak form: apply A to the linear flow u = (x, 0, 0),
+    # p = 0.  At a node none of whose neighbours is constrained the friction row must vanish (int grad(phi_i) . const = 0 for
+    # an interior basis function; no Coriolis coupling into the x row since u_y = 0), and the continuity row of a vertex with
+    # such a neighbourhood must give int psi_m d_x u_x = int psi_m = (volume of the adjacent cells) / 4.
+    s_, m_ = fed.spaces, fed.mesh
+    free = s_.u_dof >= 0
+    allfree = free.all(axis=1)
+    deep = allfree & (np.asarray(d.adj2 @ (~allfree).astype(np.float64)) == 0)
+    ulin = np.zeros(N)
+    fx = free[:, 0]
+    ulin[s_.u_dof[fx, 0]] = m_.node_coords[fx, 0]
+    ylin = A_csr.mul(npg.DeviceVector.from_host(ctx, ulin, d.p_inversion)).to_host(d.inv_p_inversion)
+    scale = np.abs(ylin).max()
+    assert deep.sum() > 0.5 * len(deep)
+    assert np.abs(ylin[s_.u_dof[deep, 0]]).max() <= 1e-11 * scale
+    vol = m_.detJ / 6.0
+    lumped = np.zeros(m_.nv)
+    np.add.at(lumped, m_.cells.ravel(), np.repeat(vol / 4.0, 4))
+    pv = deep[:m_.nv] & (s_.p_dof >= 0)
+    pv &= np.asarray(d.adj2[:m_.nv] @ (~deep).astype(np.float64)) == 0        # every P2 node around the vertex is deep
+    assert pv.sum() > 1000
+    got = ylin[d.nu + s_.p_dof[pv]]
+    assert np.abs(got - lumped[pv]).max() <= 1e-11 * lumped[pv].max()
     # invert! on the full model, stopped after 100 restart cycles (a cold solve takes ~1e5 iterations): the residual norm
     # the solver reports from its Givens recurrence must be the TRUE scaled residual of its iterate, recomputed here with
     # the other storage format
