@@ -12,10 +12,12 @@
 #include "../../include/nupgcm_hip.h"
 
 #define NPG_API extern "C" __attribute__((visibility("default")))
+// C++ internals that the separate tuning harness (libnupgcm_tune.so, tools/ only) links against; not part of the C ABI
+#define NPG_SHARED __attribute__((visibility("default")))
 
 namespace npg {
 
-void set_error(const char *fmt, ...);
+NPG_SHARED void set_error(const char *fmt, ...);
 
 #define NPG_HIP(call)                                                                             \
     do {                                                                                          \
@@ -118,9 +120,9 @@ int allreduce_sum_device(npg_ctx *ctx, double *buf, int n);
 int ensure_stage(npg_ctx *ctx, size_t doubles);
 int build_tiles(npg_csr *A);
 // tile boundaries (consecutive whole rows, at most tile_slots LDS product slots) for any tile size: tuning harness
-int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp);
+NPG_SHARED int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp);
 struct CsrDev;
-CsrDev csr_view(const npg_csr *A);
+NPG_SHARED CsrDev csr_view(const npg_csr *A);
 // reductions that return a scalar to the host (synchronous)
 int reduce_dot(npg_ctx *ctx, const double *x, const double *y, int64_t n, double *out);
 int reduce_maxabs(npg_ctx *ctx, const double *x, int64_t n, double *out, int *has_nan);

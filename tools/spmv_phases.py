@@ -25,7 +25,9 @@ if not plain:
 N = A.shape[0]
 x = npg.DeviceVector.from_host(arch.ctx, np.sin(np.arange(N, dtype=float)))
 y = npg.DeviceVector(arch.ctx, N)
-fn = L.lib().npg_spmv_phase_cycles
+L.lib()      # the product library first: the harness links against it
+_tune = C.CDLL(os.path.join(os.path.dirname(L.LIB_PATH), "libnupgcm_tune.so"))   # tuning harness, tools/ only
+fn = _tune.npg_spmv_phase_cycles
 fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
 fn.restype = C.c_int
 print(f"{wl}: N={N} storage={A.storage()} stored bytes={A.stored_spmv_bytes() / 1e6:.0f} MB; cycles per tile (s_memtime, 100 MHz ticks x?)")

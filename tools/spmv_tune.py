@@ -27,7 +27,9 @@ alg = 12 * nnz + 4 * (N + 1) + 16 * N
 x = npg.DeviceVector.from_host(arch.ctx, np.sin(np.arange(N, dtype=float)))
 yref = A.mul(x).to_host()
 y = npg.DeviceVector(arch.ctx, N)
-fn = L.lib().npg_spmv_variant
+L.lib()      # the product library first: the harness links against it
+_tune = C.CDLL(os.path.join(os.path.dirname(L.LIB_PATH), "libnupgcm_tune.so"))   # tuning harness, tools/ only
+fn = _tune.npg_spmv_variant
 fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
 fn.restype = C.c_int
 names = {0: "NT512 T4096 U4", 1: "NT512 T4096 U8", 2: "NT1024 T8192 U8", 3: "NT256 T2048 U8", 4: "NT512 T8192 U8",
