@@ -36,6 +36,8 @@ typedef struct npg_gmres npg_gmres;
 typedef struct npg_cg npg_cg;
 typedef struct npg_fe npg_fe;
 typedef struct npg_halo npg_halo;
+typedef struct npg_precond npg_precond;
+typedef struct npg_fgmres npg_fgmres;
 
 /* ---- context: replaces the implicit CUDA.jl device/stream (ext/nuPGCMCUDAExt.jl:8-16) ------------------------- */
 int npg_ctx_create(int device, npg_ctx **out);
@@ -164,6 +166,49 @@ int npg_cg_solve(npg_cg *ws, const npg_csr *A, int precond_kind, double precond_
                  const npg_vec *y, npg_vec *x, double atol, double rtol, int64_t itmax, npg_solve_stats *stats);
 int64_t npg_cg_history(npg_cg *ws, double *buf, int64_t cap);
 
+/* ---- general preconditioners + flexible GMRES: src/preconditioners.jl:1-125 and SURVEY 8f rank 1 --------------------------
+ * `P` of the IterativeSolverToolkit is a tagged union: NPG_PRECOND_NONE / _SCALAR / _DIAG are linear diagonal actions that
+ * npg_gmres_solve / npg_cg_solve fold into their SpMV epilogue; an npg_precond is an INEXACT operator application
+ * (inner iterations), which only a flexible Krylov method may use - iterative_solve! hands such a P to npg_fgmres_solve. */
+#define NPG_PC_BLOCKDIAG 1   /* BlockDiagonalPreconditioner([Block(CgPreconditioner(A_k, Diagonal), indices_k)...])
+                                (src/preconditioners.jl:53-125): nparts blocks                                        */
+#define NPG_PC_MG 2          /* geometric multigrid V-cycle on the saddle-point system (new work): nparts levels      */
+int npg_precond_create(npg_ctx *ctx, int kind, int nparts, npg_precond **out);
+int npg_precond_destroy(npg_precond *pc);
+/* Block k acts on x[offset, offset + n_k): CG on A_k with M = Diagonal(jacobi) (ldiv = false), itmax / atol / rtol as given
+ * (itmax 0 = 2 n_k), warm-started from the block's previous output - CgPreconditioner, src/preconditioners.jl:5-37.  The
+ * matrices and vectors are borrowed and must outlive the preconditioner. */
+int npg_precond_blockdiag_set(npg_precond *pc, int k, int64_t offset, const npg_csr *A_k, const npg_vec *jacobi,
+                              int64_t itmax, double atol, double rtol);
+/* Multigrid level `level` (0 = coarsest; set them coarse to fine).  A = the level's saddle-point matrix ordered [u; p]
+ * with nu velocity unknowns, G = A[0:nu, nu:], D = A[nu:, 0:nu], Dinv = inverse of the node-block diagonal of A[0:nu, 0:nu]
+ * (a node's components are adjacent; <= 3 entries per row), S = D Dinv G.  P (n_level x n_{level-1}) interpolates from the
+ * next coarser level, R = P' restricts; both NULL at level 0.  All handles are borrowed. */
+int npg_precond_mg_set_level(npg_precond *pc, int level, const npg_csr *A, int64_t nu, const npg_csr *G, const npg_csr *D,
+                             const npg_csr *Dinv, const npg_csr *S, const npg_csr *P, const npg_csr *R);
+/* replace the operators of a level by re-assembled ones of the same shapes (the eddy closure's refresh of A,
+ * src/model.jl:160-170); the previous handles are no longer referenced afterwards */
+int npg_precond_mg_update_level(npg_precond *pc, int level, const npg_csr *A, const npg_csr *G, const npg_csr *D,
+                                const npg_csr *Dinv, const npg_csr *S);
+/* omega: scaling of the node-block diagonal in the Braess-Sarazin smoother (> largest eigenvalue of Dinv F; default 2.5),
+ * jacobi_weight / schur_sweeps: damped-Jacobi relaxation of the pressure system (0.7, 3), nu1 / nu2: pre- / post-smoothing
+ * steps (2, 2), coarse_sweeps: smoothing steps that stand in for the coarsest-level solve (20). */
+int npg_precond_mg_set_params(npg_precond *pc, double omega, double jacobi_weight, int schur_sweeps, int nu1, int nu2,
+                              int coarse_sweeps);
+/* z = M^-1 r (one application: one V-cycle / one round of inner CG solves) */
+int npg_precond_apply(npg_precond *pc, const npg_vec *r, npg_vec *z);
+int npg_precond_counters(npg_precond *pc, int64_t *applications, int64_t *inner_iterations);
+
+/* Right-preconditioned flexible GMRES(memory), restarted.  x in/out (warm start, as npg_gmres_solve).  pc may be NULL.
+ * Stopping rule of the reference with its Diagonal(scale) preconditioner made explicit: scale ||y - A x|| <= atol + rtol
+ * scale ||y - A x0||  (src/inversion.jl:42-54,76; Krylov.jl gmres!).  stats->rnorm0 / rnorm are scaled residual norms; the
+ * returned rnorm is the TRUE residual recomputed after the last pass.  itmax == 0 means 2 n. */
+int npg_fgmres_create(npg_ctx *ctx, int64_t n, int memory, npg_fgmres **out);
+int npg_fgmres_destroy(npg_fgmres *ws);
+int npg_fgmres_solve(npg_fgmres *ws, const npg_csr *A, npg_precond *pc, const npg_vec *y, npg_vec *x, double scale,
+                     double atol, double rtol, int64_t itmax, npg_solve_stats *stats);
+int64_t npg_fgmres_history(npg_fgmres *ws, double *buf, int64_t cap);
+
 /* ---- element-local finite-element kernels: Gridap.assemble_vector / assemble_matrix call sites ------------------
  * The host supplies what Gridap holds: cell geometry, per-cell DoF tables and the quadrature / shape tables, so the
  * device uses the same rule as `Measure(Omega, 4)` (src/meshes.jl:33).  A DoF table entry >= 0 is an index into the
@@ -197,6 +242,16 @@ int npg_fe_destroy(npg_fe *fe);
 /* per-cell, per-quadrature-point coefficient tables [ncell][nq], pre-evaluated by the host from the user's closures
  * (nu, kappa_h, kappa_v, f): the device never runs user code.  name in {"nu","kappa_h","kappa_v","f"} */
 int npg_fe_set_coeff(npg_fe *fe, const char *name, const double *values);
+
+/* Arithmetic of the element-LOCAL work of every assembly kernel below (shape tables, geometry, nodal values, the integrand
+ * at a quadrature point).  NPG_FE_FP64 (default) matches Gridap.  NPG_FE_FP32 is the mixed mode of BASELINE.json configs[4]
+ * ("mixed fp32 assembly / fp64 solve"; new work - the reference assembles in Float64 only): local products in fp32, every
+ * sum over quadrature points / cells, all stored matrices and vectors, and the solvers in fp64.  Entries then carry a
+ * relative error of a few 1e-7 of the largest local entry. */
+#define NPG_FE_FP64 0
+#define NPG_FE_FP32 1
+int npg_fe_set_precision(npg_fe *fe, int precision);
+int npg_fe_get_precision(const npg_fe *fe);
 
 #define NPG_BDF1 1
 #define NPG_BDF2 2

@@ -86,6 +86,15 @@ def _declare(L):
         "npg_gmres_set_profile": [P, C.c_int], "npg_gmres_set_split": [P, C.c_int], "npg_gmres_get_profile": [P, C.POINTER(D), C.POINTER(I64)],
         "npg_cg_create": [P, I64, PP], "npg_cg_destroy": [P],
         "npg_cg_solve": [P, P, C.c_int, D, P, P, P, D, D, I64, C.POINTER(SolveStats)],
+        "npg_precond_create": [P, C.c_int, C.c_int, PP], "npg_precond_destroy": [P],
+        "npg_precond_blockdiag_set": [P, C.c_int, I64, P, P, I64, D, D],
+        "npg_precond_mg_set_level": [P, C.c_int, P, I64, P, P, P, P, P, P],
+        "npg_precond_mg_update_level": [P, C.c_int, P, P, P, P, P],
+        "npg_precond_mg_set_params": [P, D, D, C.c_int, C.c_int, C.c_int, C.c_int],
+        "npg_precond_apply": [P, P, P], "npg_precond_counters": [P, C.POINTER(I64), C.POINTER(I64)],
+        "npg_fgmres_create": [P, I64, C.c_int, PP], "npg_fgmres_destroy": [P],
+        "npg_fgmres_solve": [P, P, P, P, P, D, D, D, I64, C.POINTER(SolveStats)],
+        "npg_fe_set_precision": [P, C.c_int], "npg_fe_get_precision": [P],
         "npg_fe_create": [P, C.POINTER(FeDesc), PP], "npg_fe_destroy": [P], "npg_fe_set_coeff": [P, C.c_char_p, VP],
         "npg_fe_evolution_rhs": [P, C.c_int, D, D, D, P, P, P, P, P, P, P, P, P, P],
         "npg_fe_advection_rhs": [P, C.c_int, D, D, P, P, P, P, P],
@@ -112,6 +121,8 @@ def _declare(L):
     L.npg_gmres_history.argtypes = [P, VP, I64]
     L.npg_cg_history.restype = I64
     L.npg_cg_history.argtypes = [P, VP, I64]
+    L.npg_fgmres_history.restype = I64
+    L.npg_fgmres_history.argtypes = [P, VP, I64]
 
 
 def check(rc):
@@ -136,5 +147,7 @@ def as_i32(a):
 
 
 NPG_PRECOND_NONE, NPG_PRECOND_SCALAR, NPG_PRECOND_DIAG = 0, 1, 2
+NPG_PC_BLOCKDIAG, NPG_PC_MG = 1, 2
 NPG_BDF1, NPG_BDF2 = 1, 2
+NPG_FE_FP64, NPG_FE_FP32 = 0, 1
 NPG_MAT_M, NPG_MAT_KH, NPG_MAT_KV, NPG_MAT_A, NPG_MAT_B = 1, 2, 3, 4, 5

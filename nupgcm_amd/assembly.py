@@ -51,6 +51,17 @@ class DeviceFE:
         except Exception:
             pass
 
+    def set_precision(self, precision):
+        """arithmetic of the element-local work: "fp64" (default, = Gridap) or "fp32" (mixed mode of configs[4]: fp32 local
+        products, fp64 accumulation and solves) - npg_fe_set_precision"""
+        code = {"fp64": L.NPG_FE_FP64, "fp32": L.NPG_FE_FP32}[precision]
+        L.check(L.lib().npg_fe_set_precision(self.h, code))
+        return self
+
+    @property
+    def precision(self):
+        return "fp32" if L.lib().npg_fe_get_precision(self.h) == L.NPG_FE_FP32 else "fp64"
+
     def set_coeff(self, name, v):
         tab = L.as_f64(eval_at_quad_points(self.fe_data.mesh, v))
         L.check(L.lib().npg_fe_set_coeff(self.h, name.encode(), L.ptr(tab)))

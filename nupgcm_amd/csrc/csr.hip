@@ -437,17 +437,24 @@ NPG_API int npg_csr_inv_diag(const npg_csr *A, npg_vec *d) {
     return NPG_OK;
 }
 
+namespace npg {
+// y[0, m) = alpha A x[0, n) + beta y on raw device pointers (x and y may be windows into larger vectors; they must not overlap)
+int spmv_raw(const npg_csr *A, const double *x, double *y, double alpha, double beta) {
+    switch (A->lanes) {
+        case 4: launch_spmv<4>(A, x, y, alpha, beta); break;
+        case 8: launch_spmv<8>(A, x, y, alpha, beta); break;
+        case 16: launch_spmv<16>(A, x, y, alpha, beta); break;
+        default: launch_spmv<32>(A, x, y, alpha, beta); break;
+    }
+    NPG_HIP(hipGetLastError());
+    return NPG_OK;
+}
+}  // namespace npg
+
 NPG_API int npg_spmv(const npg_csr *A, const npg_vec *x, npg_vec *y, double alpha, double beta) {
     NPG_REQUIRE(A && x && y, "npg_spmv: NULL argument");
     NPG_REQUIRE(x->n == A->n && y->n == A->m, "npg_spmv: A is %lld x %lld but x has %lld and y has %lld entries",
                 (long long)A->m, (long long)A->n, (long long)x->n, (long long)y->n);
     NPG_REQUIRE(x->d != y->d, "npg_spmv: x and y must not alias");
-    switch (A->lanes) {
-        case 4: launch_spmv<4>(A, x->d, y->d, alpha, beta); break;
-        case 8: launch_spmv<8>(A, x->d, y->d, alpha, beta); break;
-        case 16: launch_spmv<16>(A, x->d, y->d, alpha, beta); break;
-        default: launch_spmv<32>(A, x->d, y->d, alpha, beta); break;
-    }
-    NPG_HIP(hipGetLastError());
-    return NPG_OK;
+    return spmv_raw(A, x->d, y->d, alpha, beta);
 }

@@ -38,22 +38,29 @@ struct FeDev {
     const double *nu, *kh, *kv, *f;   // [nq][ncell] or null
 };
 
-struct FeTables {
-    double qw[kMaxQ];
-    double N2[kMaxQ * 10];
-    double dN2[kMaxQ * 40];
-    double Nb[kMaxQ * 10];
-    double dNb[kMaxQ * 40];
-    double N1[kMaxQ * 4];
+// R = the arithmetic type of the element-LOCAL work (shape tables, geometry, nodal values, the integrand at a quadrature
+// point): double, or float for the mixed mode of BASELINE.json configs[4] ("fp32 assembly / fp64 solve").  Whatever R is,
+// sums over quadrature points, over the cells of a row and everything downstream (CSR values, right-hand sides, solvers)
+// are fp64, and all HBM tables stay fp64 (converted on load).
+template <typename R>
+struct FeTablesT {
+    R qw[kMaxQ];
+    R N2[kMaxQ * 10];
+    R dN2[kMaxQ * 40];
+    R Nb[kMaxQ * 10];
+    R dNb[kMaxQ * 40];
+    R N1[kMaxQ * 4];
 };
+using FeTables = FeTablesT<double>;
 
-__device__ __forceinline__ void stage_tables(const FeDev &d, FeTables &t) {
-    for (int i = threadIdx.x; i < d.nq; i += blockDim.x) t.qw[i] = d.qw[i];
-    for (int i = threadIdx.x; i < d.nq * 10; i += blockDim.x) t.N2[i] = d.N2[i];
-    for (int i = threadIdx.x; i < d.nq * 40; i += blockDim.x) t.dN2[i] = d.dN2[i];
-    for (int i = threadIdx.x; i < d.nq * d.nb; i += blockDim.x) t.Nb[i] = d.Nb[i];
-    for (int i = threadIdx.x; i < d.nq * d.nb * 4; i += blockDim.x) t.dNb[i] = d.dNb[i];
-    for (int i = threadIdx.x; i < d.nq * 4; i += blockDim.x) t.N1[i] = d.N1[i];
+template <typename R>
+__device__ __forceinline__ void stage_tables(const FeDev &d, FeTablesT<R> &t) {
+    for (int i = threadIdx.x; i < d.nq; i += blockDim.x) t.qw[i] = (R)d.qw[i];
+    for (int i = threadIdx.x; i < d.nq * 10; i += blockDim.x) t.N2[i] = (R)d.N2[i];
+    for (int i = threadIdx.x; i < d.nq * 40; i += blockDim.x) t.dN2[i] = (R)d.dN2[i];
+    for (int i = threadIdx.x; i < d.nq * d.nb; i += blockDim.x) t.Nb[i] = (R)d.Nb[i];
+    for (int i = threadIdx.x; i < d.nq * d.nb * 4; i += blockDim.x) t.dNb[i] = (R)d.dNb[i];
+    for (int i = threadIdx.x; i < d.nq * 4; i += blockDim.x) t.N1[i] = (R)d.N1[i];
     __syncthreads();
 }
 
@@ -63,89 +70,90 @@ __device__ __forceinline__ double field_val(const double *x, const double *diri,
 
 // ---- advection: pass 1 ------------------------------------------------------------------------------------------------
 // loc[i][cell] = int ( c1 b + c2 b_prev - cdt ( u~ . grad b~ + u~_z N2 ) ) phi_i     (src/model.jl:292-300)
-template <int NB>
+template <typename R, int NB>
 __global__ void __launch_bounds__(kBlock) k_advection_local(FeDev d, int scheme, double dt, double N2, const double *b,
                                                             const double *bp, const double *xi, const double *xip,
                                                             double *loc) {
-    __shared__ FeTables t;
+    __shared__ FeTablesT<R> t;
     stage_tables(d, t);
     const int64_t cell = blockIdx.x * (int64_t)kBlock + threadIdx.x;
     if (cell >= d.ncell) return;
     const bool bdf2 = scheme == NPG_BDF2;
     const double c1 = bdf2 ? 4.0 / 3.0 : 1.0, c2 = bdf2 ? -1.0 / 3.0 : 0.0, e1 = bdf2 ? 2.0 : 1.0,
-                 e2 = bdf2 ? -1.0 : 0.0, cdt = bdf2 ? 2.0 / 3.0 * dt : dt;
-    double G[12];
+                 e2 = bdf2 ? -1.0 : 0.0;
+    const R cdt = (R)(bdf2 ? 2.0 / 3.0 * dt : dt), rN2 = (R)N2;
+    R G[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) G[k] = d.G[(size_t)k * d.ncell + cell];
-    const double wdet = d.wdet[cell];
-    double bm[NB], bt[NB];
+    for (int k = 0; k < 12; ++k) G[k] = (R)d.G[(size_t)k * d.ncell + cell];
+    const R wdet = (R)d.wdet[cell];
+    R bm[NB], bt[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int32_t idx = d.cb[(size_t)i * d.ncell + cell];
         const double v = field_val(b, d.b_diri, idx), vp = field_val(bp, d.b_diri, idx);
-        bm[i] = c1 * v + c2 * vp;
-        bt[i] = e1 * v + e2 * vp;
+        bm[i] = (R)(c1 * v + c2 * vp);         // the BDF combinations of the fp64 state are formed before rounding
+        bt[i] = (R)(e1 * v + e2 * vp);
     }
-    double ut[30];
+    R ut[30];
 #pragma unroll
     for (int k = 0; k < 30; ++k) {
         const int32_t idx = d.cu[(size_t)k * d.ncell + cell];
-        ut[k] = e1 * field_val(xi, d.u_diri, idx) + e2 * field_val(xip, d.u_diri, idx);
+        ut[k] = (R)(e1 * field_val(xi, d.u_diri, idx) + e2 * field_val(xip, d.u_diri, idx));
     }
     double acc[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) acc[i] = 0.0;
     for (int q = 0; q < d.nq; ++q) {
-        double bq = 0.0, gl0 = 0.0, gl1 = 0.0, gl2 = 0.0, gl3 = 0.0;
+        R bq = 0, gl0 = 0, gl1 = 0, gl2 = 0, gl3 = 0;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             bq += t.Nb[q * NB + i] * bm[i];
-            const double *dn = &t.dNb[(q * NB + i) * 4];
+            const R *dn = &t.dNb[(q * NB + i) * 4];
             gl0 += dn[0] * bt[i];
             gl1 += dn[1] * bt[i];
             gl2 += dn[2] * bt[i];
             gl3 += dn[3] * bt[i];
         }
-        double ux = 0.0, uy = 0.0, uz = 0.0;
+        R ux = 0, uy = 0, uz = 0;
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
-            const double n = t.N2[q * 10 + i];
+            const R n = t.N2[q * 10 + i];
             ux += n * ut[3 * i];
             uy += n * ut[3 * i + 1];
             uz += n * ut[3 * i + 2];
         }
-        const double gx = gl0 * G[0] + gl1 * G[3] + gl2 * G[6] + gl3 * G[9];
-        const double gy = gl0 * G[1] + gl1 * G[4] + gl2 * G[7] + gl3 * G[10];
-        const double gz = gl0 * G[2] + gl1 * G[5] + gl2 * G[8] + gl3 * G[11];
-        const double integrand = bq - cdt * (ux * gx + uy * gy + uz * gz + uz * N2);
-        const double wq = t.qw[q] * wdet * integrand;
+        const R gx = gl0 * G[0] + gl1 * G[3] + gl2 * G[6] + gl3 * G[9];
+        const R gy = gl0 * G[1] + gl1 * G[4] + gl2 * G[7] + gl3 * G[10];
+        const R gz = gl0 * G[2] + gl1 * G[5] + gl2 * G[8] + gl3 * G[11];
+        const R integrand = bq - cdt * (ux * gx + uy * gy + uz * gz + uz * rN2);
+        const R wq = t.qw[q] * wdet * integrand;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) acc[i] += wq * t.Nb[q * NB + i];
+        for (int i = 0; i < NB; ++i) acc[i] += (double)(wq * t.Nb[q * NB + i]);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) loc[(size_t)i * d.ncell + cell] = acc[i];
 }
 
 // ---- rhs_diff: pass 1 : loc[i][cell] = -N2 int kappa_v d_z phi_i -------------------------------------------------------
-template <int NB>
+template <typename R, int NB>
 __global__ void __launch_bounds__(kBlock) k_rhs_diff_local(FeDev d, double N2, double *loc) {
-    __shared__ FeTables t;
+    __shared__ FeTablesT<R> t;
     stage_tables(d, t);
     const int64_t cell = blockIdx.x * (int64_t)kBlock + threadIdx.x;
     if (cell >= d.ncell) return;
-    double Gz[4];
+    R Gz[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) Gz[k] = d.G[(size_t)(3 * k + 2) * d.ncell + cell];
-    const double wdet = d.wdet[cell];
+    for (int k = 0; k < 4; ++k) Gz[k] = (R)d.G[(size_t)(3 * k + 2) * d.ncell + cell];
+    const R wdet = (R)d.wdet[cell];
     double acc[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) acc[i] = 0.0;
     for (int q = 0; q < d.nq; ++q) {
-        const double wq = -N2 * t.qw[q] * wdet * d.kv[(size_t)q * d.ncell + cell];
+        const R wq = -(R)N2 * t.qw[q] * wdet * (R)d.kv[(size_t)q * d.ncell + cell];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const double *dn = &t.dNb[(q * NB + i) * 4];
-            acc[i] += wq * (dn[0] * Gz[0] + dn[1] * Gz[1] + dn[2] * Gz[2] + dn[3] * Gz[3]);
+            const R *dn = &t.dNb[(q * NB + i) * 4];
+            acc[i] += (double)(wq * (dn[0] * Gz[0] + dn[1] * Gz[1] + dn[2] * Gz[2] + dn[3] * Gz[3]));
         }
     }
 #pragma unroll
@@ -195,18 +203,17 @@ __device__ __forceinline__ void row_add(const int64_t *rowptr, const int32_t *co
 }
 
 // physical gradient of buoyancy basis function i at quadrature point q
-template <int NB>
-__device__ __forceinline__ void grad_b(const FeTables &t, const double *G, int q, int i, double &gx, double &gy,
-                                       double &gz) {
-    const double *dn = &t.dNb[(q * NB + i) * 4];
+template <typename R, int NB>
+__device__ __forceinline__ void grad_b(const FeTablesT<R> &t, const R *G, int q, int i, R &gx, R &gy, R &gz) {
+    const R *dn = &t.dNb[(q * NB + i) * 4];
     gx = dn[0] * G[0] + dn[1] * G[3] + dn[2] * G[6] + dn[3] * G[9];
     gy = dn[0] * G[1] + dn[1] * G[4] + dn[2] * G[7] + dn[3] * G[10];
     gz = dn[0] * G[2] + dn[1] * G[5] + dn[2] * G[8] + dn[3] * G[11];
 }
 
-__device__ __forceinline__ void grad_u(const FeTables &t, const double *G, int q, int i, double &gx, double &gy,
-                                       double &gz) {
-    const double *dn = &t.dN2[(q * 10 + i) * 4];
+template <typename R>
+__device__ __forceinline__ void grad_u(const FeTablesT<R> &t, const R *G, int q, int i, R &gx, R &gy, R &gz) {
+    const R *dn = &t.dN2[(q * 10 + i) * 4];
     gx = dn[0] * G[0] + dn[1] * G[3] + dn[2] * G[6] + dn[3] * G[9];
     gy = dn[0] * G[1] + dn[1] * G[4] + dn[2] * G[7] + dn[3] * G[10];
     gz = dn[0] * G[2] + dn[1] * G[5] + dn[2] * G[8] + dn[3] * G[11];
@@ -220,11 +227,11 @@ __device__ __forceinline__ void grad_u(const FeTables &t, const double *G, int q
 constexpr int kQL = 16;      // lanes per row = kMaxQ
 
 // M / Kh / Kv: rows = buoyancy DoFs; gptr / gidx = the inverted index of the vector assembly (i * ncell + cell)
-template <int NB>
+template <typename R, int NB>
 __global__ void __launch_bounds__(kBlock) k_assemble_b(FeDev d, int which, const int64_t *gptr, const int32_t *gidx,
                                                        int64_t nrows, const int64_t *rowptr, const int32_t *col,
                                                        double *val, double *lift, int *missing) {
-    __shared__ FeTables t;
+    __shared__ FeTablesT<R> t;
     stage_tables(d, t);
     const int64_t r = (blockIdx.x * (int64_t)kBlock + threadIdx.x) / kQL;
     const int q = threadIdx.x % kQL;
@@ -239,23 +246,23 @@ __global__ void __launch_bounds__(kBlock) k_assemble_b(FeDev d, int which, const
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[j] = 0.0;
         if (on) {
-            double wq = t.qw[q] * d.wdet[cell];
+            R wq = t.qw[q] * (R)d.wdet[cell];
             if (which == NPG_MAT_M) {
                 wq *= t.Nb[q * NB + i];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) acc[j] = wq * t.Nb[q * NB + j];
+                for (int j = 0; j < NB; ++j) acc[j] = (double)(wq * t.Nb[q * NB + j]);
             } else {
-                double G[12];
+                R G[12];
 #pragma unroll
-                for (int e = 0; e < 12; ++e) G[e] = d.G[(size_t)e * d.ncell + cell];
-                double gix, giy, giz;
-                grad_b<NB>(t, G, q, i, gix, giy, giz);
-                wq *= (which == NPG_MAT_KH ? d.kh : d.kv)[(size_t)q * d.ncell + cell];
+                for (int e = 0; e < 12; ++e) G[e] = (R)d.G[(size_t)e * d.ncell + cell];
+                R gix, giy, giz;
+                grad_b<R, NB>(t, G, q, i, gix, giy, giz);
+                wq *= (R)(which == NPG_MAT_KH ? d.kh : d.kv)[(size_t)q * d.ncell + cell];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    double gx, gy, gz;
-                    grad_b<NB>(t, G, q, j, gx, gy, gz);
-                    acc[j] = wq * (which == NPG_MAT_KH ? (gix * gx + giy * gy) : giz * gz);
+                    R gx, gy, gz;
+                    grad_b<R, NB>(t, G, q, j, gx, gy, gz);
+                    acc[j] = (double)(wq * (which == NPG_MAT_KH ? (gix * gx + giy * gy) : giz * gz));
                 }
             }
         }
@@ -285,11 +292,11 @@ __global__ void __launch_bounds__(kBlock) k_assemble_b(FeDev d, int which, const
 // DoF: l = 3 i + a for component a of velocity node i, l = 30 + m for pressure vertex m (iidx = l * ncell + cell).
 //
 // B: rows (u node i, component z), columns buoyancy nodes: scale * int phi_i phib_j     (src/inversion.jl:208)
-template <int NB>
+template <typename R, int NB>
 __global__ void __launch_bounds__(kBlock) k_assemble_B(FeDev d, double scale, const int64_t *iptr, const int32_t *iidx,
                                                        int64_t nrows, const int64_t *rowptr, const int32_t *col,
                                                        double *val, double *lift, int *missing) {
-    __shared__ FeTables t;
+    __shared__ FeTablesT<R> t;
     stage_tables(d, t);
     const int64_t r = (blockIdx.x * (int64_t)kBlock + threadIdx.x) / kQL;
     const int q = threadIdx.x % kQL;
@@ -303,9 +310,9 @@ __global__ void __launch_bounds__(kBlock) k_assemble_B(FeDev d, double scale, co
         if (l >= 30 || l % 3 != 2) continue;                 // only the vertical momentum rows feel buoyancy (group-uniform)
         const int i = l / 3;
         double acc[NB];
-        const double wq = on ? t.qw[q] * d.wdet[cell] * scale * t.N2[q * 10 + i] : 0.0;
+        const R wq = on ? t.qw[q] * (R)d.wdet[cell] * (R)scale * t.N2[q * 10 + i] : (R)0;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) acc[j] = group_sum_dpp<kQL>(on ? wq * t.Nb[q * NB + j] : 0.0);
+        for (int j = 0; j < NB; ++j) acc[j] = group_sum_dpp<kQL>(on ? (double)(wq * t.Nb[q * NB + j]) : 0.0);
         double mine = 0.0;
 #pragma unroll
         for (int j = 0; j < NB; ++j) mine = (q == j) ? acc[j] : mine;
@@ -329,10 +336,11 @@ __global__ void __launch_bounds__(kBlock) k_assemble_B(FeDev d, double scale, co
 //   [(i,a),(j,c)] += a2e2 int nu ( d_ac grad phi_i . grad phi_j  [+ d_c phi_i d_a phi_j  if full_stress] )
 //   [(i,x),(j,y)] -= int f phi_i phi_j ; [(i,y),(j,x)] += int f phi_i phi_j
 //   [(i,a), p_m ] -= int d_a phi_i psi_m ; [p_m, (i,a)] += int psi_m d_a phi_i
+template <typename R>
 __global__ void __launch_bounds__(kBlock) k_assemble_A(FeDev d, double a2e2, int full_stress, const int64_t *iptr,
                                                        const int32_t *iidx, int64_t nrows, const int64_t *rowptr,
                                                        const int32_t *col, double *val, int *missing) {
-    __shared__ FeTables t;
+    __shared__ FeTablesT<R> t;
     stage_tables(d, t);
     const int64_t r = (blockIdx.x * (int64_t)kBlock + threadIdx.x) / kQL;
     const int q = threadIdx.x % kQL;
@@ -342,29 +350,29 @@ __global__ void __launch_bounds__(kBlock) k_assemble_A(FeDev d, double a2e2, int
     for (int64_t k = iptr[r]; k < iptr[r + 1]; ++k) {
         const int64_t cell = iidx[k] % d.ncell;
         const int l = (int)(iidx[k] / d.ncell);
-        double G[12];
+        R G[12];
 #pragma unroll
-        for (int e = 0; e < 12; ++e) G[e] = d.G[(size_t)e * d.ncell + cell];
-        const double wq = on ? t.qw[q] * d.wdet[cell] : 0.0;
+        for (int e = 0; e < 12; ++e) G[e] = (R)d.G[(size_t)e * d.ncell + cell];
+        const R wq = on ? t.qw[q] * (R)d.wdet[cell] : (R)0;
         if (l < 30) {
             const int i = l / 3, a = l % 3;
-            double gi[3] = {0.0, 0.0, 0.0};
-            double wn = 0.0, wf = 0.0;
+            R gi[3] = {0, 0, 0};
+            R wn = 0, wf = 0;
             if (on) {
                 grad_u(t, G, q, i, gi[0], gi[1], gi[2]);
-                wn = wq * a2e2 * d.nu[(size_t)q * d.ncell + cell];
-                wf = wq * d.f[(size_t)q * d.ncell + cell] * t.N2[q * 10 + i];
+                wn = wq * (R)a2e2 * (R)d.nu[(size_t)q * d.ncell + cell];
+                wf = wq * (R)d.f[(size_t)q * d.ncell + cell] * t.N2[q * 10 + i];
             }
             // u-u block, one trial node j at a time; lane c < 3 then adds the entry of trial component c
             for (int j = 0; j < 10; ++j) {
-                double gj[3] = {0.0, 0.0, 0.0};
+                R gj[3] = {0, 0, 0};
                 if (on) grad_u(t, G, q, j, gj[0], gj[1], gj[2]);
-                const double kk = group_sum_dpp<kQL>(wn * (gi[0] * gj[0] + gi[1] * gj[1] + gi[2] * gj[2]));
-                const double cc = group_sum_dpp<kQL>(on ? wf * t.N2[q * 10 + j] : 0.0);
+                const double kk = group_sum_dpp<kQL>((double)(wn * (gi[0] * gj[0] + gi[1] * gj[1] + gi[2] * gj[2])));
+                const double cc = group_sum_dpp<kQL>(on ? (double)(wf * t.N2[q * 10 + j]) : 0.0);
                 double fs[3] = {0.0, 0.0, 0.0};
                 if (full_stress) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) fs[c] = group_sum_dpp<kQL>(wn * gi[c] * gj[a]);
+                    for (int c = 0; c < 3; ++c) fs[c] = group_sum_dpp<kQL>((double)(wn * gi[c] * gj[a]));
                 }
                 if (q < 3) {
                     const int c = q;
@@ -382,7 +390,7 @@ __global__ void __launch_bounds__(kBlock) k_assemble_A(FeDev d, double a2e2, int
             double ddm = 0.0;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const double dd = group_sum_dpp<kQL>(on ? wq * t.N1[q * 4 + m] * gi[a] : 0.0);
+                const double dd = group_sum_dpp<kQL>(on ? (double)(wq * t.N1[q * 4 + m] * gi[a]) : 0.0);
                 ddm = (q == m) ? dd : ddm;
             }
             if (q < 4) {
@@ -392,13 +400,13 @@ __global__ void __launch_bounds__(kBlock) k_assemble_A(FeDev d, double a2e2, int
         } else {
             // continuity row of pressure vertex m: lane a < 3 adds the entry of component a of node i
             const int m = l - 30;
-            const double wm = on ? wq * t.N1[q * 4 + m] : 0.0;
+            const R wm = on ? wq * t.N1[q * 4 + m] : (R)0;
             for (int i = 0; i < 10; ++i) {
-                double gi[3] = {0.0, 0.0, 0.0};
+                R gi[3] = {0, 0, 0};
                 if (on) grad_u(t, G, q, i, gi[0], gi[1], gi[2]);
-                const double d0 = group_sum_dpp<kQL>(wm * gi[0]);
-                const double d1 = group_sum_dpp<kQL>(wm * gi[1]);
-                const double d2 = group_sum_dpp<kQL>(wm * gi[2]);
+                const double d0 = group_sum_dpp<kQL>((double)(wm * gi[0]));
+                const double d1 = group_sum_dpp<kQL>((double)(wm * gi[1]));
+                const double d2 = group_sum_dpp<kQL>((double)(wm * gi[2]));
                 if (q < 3) {
                     const int32_t ci = d.cu[(size_t)(3 * i + q) * d.ncell + cell];
                     if (ci >= 0) row_add(rowptr, col, val, row, ci, q == 0 ? d0 : q == 1 ? d1 : d2, missing);
@@ -499,6 +507,7 @@ struct npg_fe {
     double *hcell = nullptr;
     int *missing = nullptr;
     double *scratch_vec = nullptr;  // n_b doubles
+    int precision = NPG_FE_FP64;    // arithmetic of the element-local work (npg_fe_set_precision)
 };
 
 template <typename T>
@@ -638,6 +647,16 @@ NPG_API int npg_fe_destroy(npg_fe *fe) {
     return NPG_OK;
 }
 
+NPG_API int npg_fe_set_precision(npg_fe *fe, int precision) {
+    NPG_REQUIRE(fe, "npg_fe_set_precision: NULL handle");
+    NPG_REQUIRE(precision == NPG_FE_FP64 || precision == NPG_FE_FP32,
+                "npg_fe_set_precision: precision must be NPG_FE_FP64 or NPG_FE_FP32");
+    fe->precision = precision;
+    return NPG_OK;
+}
+
+NPG_API int npg_fe_get_precision(const npg_fe *fe) { return fe ? fe->precision : NPG_EINVAL; }
+
 static int coef_index(const char *name) {
     if (!strcmp(name, "nu")) return 0;
     if (!strcmp(name, "kappa_h")) return 1;
@@ -672,6 +691,8 @@ NPG_API int npg_fe_set_coeff(npg_fe *fe, const char *name, const double *values)
     std::vector<double> tmp((size_t)nc * nq);
     for (int64_t c = 0; c < nc; ++c)
         for (int q = 0; q < nq; ++q) tmp[(size_t)q * nc + c] = values[(size_t)c * nq + q];
+    // kernels that read the table run on ctx->stream (non-blocking: not ordered with the null stream) - drain it first
+    NPG_HIP(hipStreamSynchronize(fe->ctx->stream));
     NPG_HIP(hipMemcpy(fe->coef[k], tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
     if (k == 2) {      // remember the background kappa_v for the convection closure
         if (!fe->kv0) {
@@ -700,12 +721,13 @@ static int advection_pass1(npg_fe *fe, int scheme, double dt, double N2, const n
     int rc = check_state_vectors(fe, b, bp, xi, xip);
     if (rc) return rc;
     const int grid = cell_grid(fe->d.ncell);
-    if (fe->d.nb == 10)
-        hipLaunchKernelGGL(k_advection_local<10>, dim3(grid), dim3(kBlock), 0, fe->ctx->stream, fe->d, scheme, dt, N2,
-                           b->d, bp->d, xi->d, xip->d, fe->loc);
-    else
-        hipLaunchKernelGGL(k_advection_local<4>, dim3(grid), dim3(kBlock), 0, fe->ctx->stream, fe->d, scheme, dt, N2,
-                           b->d, bp->d, xi->d, xip->d, fe->loc);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, fe->ctx->stream, fe->d, scheme, dt, N2, b->d, bp->d, xi->d,
+                           xip->d, fe->loc);
+    };
+    const bool f32 = fe->precision == NPG_FE_FP32;
+    if (fe->d.nb == 10) f32 ? go(k_advection_local<float, 10>) : go(k_advection_local<double, 10>);
+    else f32 ? go(k_advection_local<float, 4>) : go(k_advection_local<double, 4>);
     NPG_HIP(hipGetLastError());
     return NPG_OK;
 }
@@ -754,10 +776,12 @@ NPG_API int npg_fe_assemble_rhs_diff(npg_fe *fe, double N2, npg_vec *out) {
     NPG_REQUIRE(fe && out, "npg_fe_assemble_rhs_diff: NULL argument");
     NPG_REQUIRE(fe->d.kv, "npg_fe_assemble_rhs_diff: coefficient kappa_v has not been set");
     const int grid = cell_grid(fe->d.ncell);
-    if (fe->d.nb == 10)
-        hipLaunchKernelGGL(k_rhs_diff_local<10>, dim3(grid), dim3(kBlock), 0, fe->ctx->stream, fe->d, N2, fe->loc);
-    else
-        hipLaunchKernelGGL(k_rhs_diff_local<4>, dim3(grid), dim3(kBlock), 0, fe->ctx->stream, fe->d, N2, fe->loc);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, fe->ctx->stream, fe->d, N2, fe->loc);
+    };
+    const bool f32 = fe->precision == NPG_FE_FP32;
+    if (fe->d.nb == 10) f32 ? go(k_rhs_diff_local<float, 10>) : go(k_rhs_diff_local<double, 10>);
+    else f32 ? go(k_rhs_diff_local<float, 4>) : go(k_rhs_diff_local<double, 4>);
     NPG_HIP(hipGetLastError());
     RhsTerms rt{};
     return gather_pass2(fe, rt, out);
@@ -768,6 +792,7 @@ NPG_API int npg_fe_assemble_matrix(npg_fe *fe, int which, double scale, int full
     NPG_REQUIRE(A->nnode() == 0, "npg_fe_assemble_matrix: the matrix is stored by node blocks and cannot be re-assembled");
     hipStream_t st = fe->ctx->stream;
     const FeDev &d = fe->d;
+    const bool f32 = fe->precision == NPG_FE_FP32;
     NPG_HIP(hipMemsetAsync(A->val, 0, (size_t)A->nnz * sizeof(double), st));
     NPG_HIP(hipMemsetAsync(fe->missing, 0, sizeof(int), st));
     if (lift) NPG_HIP(hipMemsetAsync(lift->d, 0, (size_t)lift->n * sizeof(double), st));
@@ -780,31 +805,34 @@ NPG_API int npg_fe_assemble_matrix(npg_fe *fe, int which, double scale, int full
             NPG_REQUIRE(which == NPG_MAT_M || (which == NPG_MAT_KH ? d.kh : d.kv),
                         "npg_fe_assemble_matrix: diffusivity coefficient has not been set");
             const int grid = cell_grid(fe->n_b * kQL);
-            if (d.nb == 10)
-                hipLaunchKernelGGL(k_assemble_b<10>, dim3(grid), dim3(kBlock), 0, st, d, which, fe->gptr, fe->gidx, fe->n_b,
-                                   A->rowptr, A->col, A->val, lift ? lift->d : nullptr, fe->missing);
-            else
-                hipLaunchKernelGGL(k_assemble_b<4>, dim3(grid), dim3(kBlock), 0, st, d, which, fe->gptr, fe->gidx, fe->n_b,
-                                   A->rowptr, A->col, A->val, lift ? lift->d : nullptr, fe->missing);
+            auto go = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, st, d, which, fe->gptr, fe->gidx, fe->n_b, A->rowptr,
+                                   A->col, A->val, lift ? lift->d : nullptr, fe->missing);
+            };
+            if (d.nb == 10) f32 ? go(k_assemble_b<float, 10>) : go(k_assemble_b<double, 10>);
+            else f32 ? go(k_assemble_b<float, 4>) : go(k_assemble_b<double, 4>);
             break;
         }
         case NPG_MAT_A: {
             NPG_REQUIRE(A->m == fe->n_inv && A->n == fe->n_inv, "npg_fe_assemble_matrix: A must be n_inv x n_inv");
             NPG_REQUIRE(d.nu && d.f, "npg_fe_assemble_matrix: coefficients nu and f must be set");
-            hipLaunchKernelGGL(k_assemble_A, dim3(cell_grid(fe->n_inv * kQL)), dim3(kBlock), 0, st, d, scale, full_stress, fe->iptr,
-                               fe->iidx, fe->n_inv, A->rowptr, A->col, A->val, fe->missing);
+            auto go = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(cell_grid(fe->n_inv * kQL)), dim3(kBlock), 0, st, d, scale, full_stress,
+                                   fe->iptr, fe->iidx, fe->n_inv, A->rowptr, A->col, A->val, fe->missing);
+            };
+            f32 ? go(k_assemble_A<float>) : go(k_assemble_A<double>);
             break;
         }
         case NPG_MAT_B: {
             NPG_REQUIRE(A->m == fe->n_inv && A->n == fe->n_b, "npg_fe_assemble_matrix: B must be n_inv x n_b");
             NPG_REQUIRE(!lift || lift->n == fe->n_inv, "npg_fe_assemble_matrix: lift must have n_inv entries");
             const int grid = cell_grid(fe->n_inv * kQL);
-            if (d.nb == 10)
-                hipLaunchKernelGGL(k_assemble_B<10>, dim3(grid), dim3(kBlock), 0, st, d, scale, fe->iptr, fe->iidx, fe->n_inv,
-                                   A->rowptr, A->col, A->val, lift ? lift->d : nullptr, fe->missing);
-            else
-                hipLaunchKernelGGL(k_assemble_B<4>, dim3(grid), dim3(kBlock), 0, st, d, scale, fe->iptr, fe->iidx, fe->n_inv,
-                                   A->rowptr, A->col, A->val, lift ? lift->d : nullptr, fe->missing);
+            auto go = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, st, d, scale, fe->iptr, fe->iidx, fe->n_inv, A->rowptr,
+                                   A->col, A->val, lift ? lift->d : nullptr, fe->missing);
+            };
+            if (d.nb == 10) f32 ? go(k_assemble_B<float, 10>) : go(k_assemble_B<double, 10>);
+            else f32 ? go(k_assemble_B<float, 4>) : go(k_assemble_B<double, 4>);
             break;
         }
         default:
@@ -858,6 +886,7 @@ NPG_API int npg_fe_cfl_ratio(npg_fe *fe, const double *h_cells_host, double u_mi
             NPG_HIP(hipMalloc((void **)&fe->hcell, (size_t)fe->d.ncell * sizeof(double)));
             fe->allocs.push_back(fe->hcell);
         }
+        NPG_HIP(hipStreamSynchronize(fe->ctx->stream));
         NPG_HIP(hipMemcpy(fe->hcell, h_cells_host, (size_t)fe->d.ncell * sizeof(double), hipMemcpyHostToDevice));
     }
     NPG_REQUIRE(fe->hcell, "npg_fe_cfl_ratio: cell sizes have not been provided");

@@ -1,0 +1,518 @@
+// General preconditioners for the saddle-point inversion and the flexible GMRES that drives them.
+//
+// The reference ships one experimental preconditioner, BlockDiagonalPreconditioner (src/preconditioners.jl:53-125: an inner
+// CG per block - friction-only velocity block with ILU(0) / LU, pressure mass matrix / (alpha^2 eps^2) with Jacobi), which its
+// author's own log shows to be slower in wall time than Diagonal(1/h^3) (scratch/inversion_log.md:107-191) because the
+// friction block still needs O(1/h) inner iterations.  Two kinds live here behind one handle (npg_precond):
+//
+//   NPG_PC_BLOCKDIAG  the reference's construction: z[block k] = CG(A_k, r[block k]; Jacobi), warm-started from its previous
+//                     output exactly as CgPreconditioner does (src/preconditioners.jl:24-37) - the device-resident CG of
+//                     cg.hip is the inner solver;
+//   NPG_PC_MG         geometric multigrid V-cycle on the WHOLE saddle-point system over the red-refinement hierarchy the big
+//                     bowl meshes are made from (new work): rediscretised operators per level, P2 / P1
+//                     nodal interpolation, and a Braess-Sarazin smoother built from node blocks:
+//                         [ w Dh   G ] [du]   [r_u]      Dh = node-block diagonal of the velocity block (friction on the
+//                         [ D      0 ] [dp] = [r_p]           diagonal, Coriolis coupling x and y of the same node),
+//                     whose pressure system S dp = D Dh^-1 r_u - w r_p, S = D Dh^-1 G (explicit, assembled at set-up), is
+//                     relaxed by a few damped-Jacobi sweeps.  Everything is SpMV + diagonal work: no triangular solves.
+//
+// Both are applied inexactly, so the outer solver is right-preconditioned FLEXIBLE GMRES(m) (npg_fgmres_*): classical
+// Gram-Schmidt with a full second pass (two fused multi-dot reductions per step, one host synchronisation per iteration -
+// an iteration costs a V-cycle, i.e. milliseconds on the meshes where this is used, so the host drives the loop).  The
+// stopping rule is the reference's: scale * ||r|| <= atol + rtol * scale * ||r0|| with scale = 1/h^dim, the factor its
+// Diagonal preconditioner puts on the residual (src/inversion.jl:42-54; right preconditioning leaves r the true residual).
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+#include "device_utils.h"
+
+namespace npg {
+
+static inline int grid_for(int64_t n, int cap = 2048) {
+    int64_t g = (n + kBlock - 1) / kBlock;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
+}
+
+// y = a x + b y (b == 0: y is not read)
+__global__ void k_mg_axpby(double *__restrict__ y, double a, const double *__restrict__ x, double b, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
+}
+
+// y = w d x + b y
+__global__ void k_mg_daxpby(double *__restrict__ y, double w, const double *__restrict__ d, const double *__restrict__ x,
+                            double b, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = (b == 0.0) ? w * d[i] * x[i] : w * d[i] * x[i] + b * y[i];
+}
+
+// part[block][c] = sum_i V_c[i] w[i] for c < k (k <= 8 NG); V column-major with leading dimension ld
+template <int NG>
+__global__ void __launch_bounds__(kBlock) k_mdot(const double *__restrict__ V, int64_t ld, int k,
+                                                 const double *__restrict__ w, int64_t n, double *__restrict__ part) {
+    __shared__ double sh[4 * kPartStride];
+    double acc[8 * NG];
+#pragma unroll
+    for (int c = 0; c < 8 * NG; ++c) acc[c] = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double wi = w[i];
+#pragma unroll
+        for (int c = 0; c < 8 * NG; ++c)
+            if (c < k) acc[c] += V[(size_t)c * ld + i] * wi;
+    }
+    block_store_partials<8 * NG, 4>(acc, k, sh, part);
+}
+
+// w -= sum_c h[c] V_c ; part[block][0] = sum w_new^2
+template <int NG>
+__global__ void __launch_bounds__(kBlock) k_mupdate(const double *__restrict__ V, int64_t ld, int k,
+                                                    const double *__restrict__ h, double *__restrict__ w, int64_t n,
+                                                    double *__restrict__ part) {
+    __shared__ double sh[4 * kPartStride];
+    double hc[8 * NG];
+#pragma unroll
+    for (int c = 0; c < 8 * NG; ++c) hc[c] = c < k ? h[c] : 0.0;
+    double acc[1] = {0.0};
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        double wi = w[i];
+#pragma unroll
+        for (int c = 0; c < 8 * NG; ++c)
+            if (c < k) wi -= hc[c] * V[(size_t)c * ld + i];
+        w[i] = wi;
+        acc[0] += wi * wi;
+    }
+    block_store_partials<1, 4>(acc, 1, sh, part);
+}
+
+// out[c] = sum_b part[b][c]  (one block; fixed order)
+__global__ void __launch_bounds__(kBlock) k_sum_partials(const double *__restrict__ part, int nblocks, int nvals,
+                                                         double *__restrict__ out) {
+    __shared__ double tmp[8 * kPartStride], res[kPartStride];
+    reduce_partials<8, 128>(part, nblocks, nvals, tmp, res);
+    if (threadIdx.x < nvals) out[threadIdx.x] = res[threadIdx.x];
+}
+
+// x += sum_c y[c] Z_c
+struct Coefs {
+    double y[kMaxMem];
+};
+__global__ void __launch_bounds__(kBlock) k_combine_z(double *__restrict__ x, const double *__restrict__ Z, int64_t ld,
+                                                      int k, Coefs cf, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        double s = x[i];
+        for (int c = 0; c < k; ++c) s += cf.y[c] * Z[(size_t)c * ld + i];
+        x[i] = s;
+    }
+}
+
+int spmv_raw(const npg_csr *A, const double *x, double *y, double alpha, double beta);   // csr.hip
+
+}  // namespace npg
+
+using namespace npg;
+
+struct MgLevel {
+    const npg_csr *A = nullptr, *G = nullptr, *D = nullptr, *Dinv = nullptr, *S = nullptr, *P = nullptr, *R = nullptr;
+    int64_t n = 0, nu = 0, np = 0;
+    double *sdinv = nullptr;                         // 1 / diag(S)
+    double *r = nullptr, *t = nullptr, *rhs = nullptr, *dp = nullptr, *res = nullptr, *x = nullptr, *b = nullptr;
+};
+
+struct BlockPc {
+    int64_t off = 0, n = 0;
+    const npg_csr *A = nullptr;
+    const npg_vec *jac = nullptr;
+    npg_cg *cg = nullptr;
+    npg_vec *xk = nullptr, *rk = nullptr;            // the block's warm-started solution / right-hand side
+    int64_t itmax = 0;
+    double atol = 0.0, rtol = 0.0;
+};
+
+struct npg_precond {
+    npg_ctx *ctx = nullptr;
+    int kind = 0;
+    int64_t n = 0;
+    // multigrid
+    std::vector<MgLevel> L;
+    double omega = 2.5, jw = 0.7;
+    int sweeps = 3, nu1 = 2, nu2 = 2, coarse = 20;
+    std::vector<void *> allocs;
+    // block diagonal
+    std::vector<BlockPc> blocks;
+    int64_t inner_iterations = 0, applications = 0;
+};
+
+static inline void axpby(npg_ctx *c, double *y, double a, const double *x, double b, int64_t n) {
+    hipLaunchKernelGGL(k_mg_axpby, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, y, a, x, b, n);
+}
+static inline void daxpby(npg_ctx *c, double *y, double w, const double *d, const double *x, double b, int64_t n) {
+    hipLaunchKernelGGL(k_mg_daxpby, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, y, w, d, x, b, n);
+}
+
+NPG_API int npg_precond_create(npg_ctx *ctx, int kind, int nparts, npg_precond **out) {
+    NPG_REQUIRE(ctx && out, "npg_precond_create: NULL argument");
+    NPG_REQUIRE(kind == NPG_PC_MG || kind == NPG_PC_BLOCKDIAG, "npg_precond_create: unknown kind %d", kind);
+    NPG_REQUIRE(nparts >= 1 && nparts <= 16, "npg_precond_create: need 1..16 levels / blocks");
+    npg_precond *pc = new npg_precond();
+    pc->ctx = ctx;
+    pc->kind = kind;
+    if (kind == NPG_PC_MG) pc->L.resize(nparts); else pc->blocks.resize(nparts);
+    *out = pc;
+    return NPG_OK;
+}
+
+NPG_API int npg_precond_destroy(npg_precond *pc) {
+    if (!pc) return NPG_OK;
+    hipStreamSynchronize(pc->ctx->stream);
+    for (void *p : pc->allocs) hipFree(p);
+    for (BlockPc &b : pc->blocks) {
+        if (b.cg) npg_cg_destroy(b.cg);
+        if (b.xk) npg_vec_destroy(b.xk);
+        if (b.rk) npg_vec_destroy(b.rk);
+    }
+    delete pc;
+    return NPG_OK;
+}
+
+static int mg_alloc(npg_precond *pc, double **p, int64_t n) {
+    NPG_HIP(hipMalloc((void **)p, std::max<size_t>(1, (size_t)n) * sizeof(double)));
+    pc->allocs.push_back(*p);
+    NPG_HIP(hipMemsetAsync(*p, 0, std::max<size_t>(1, (size_t)n) * sizeof(double), pc->ctx->stream));
+    return NPG_OK;
+}
+
+NPG_API int npg_precond_mg_set_level(npg_precond *pc, int level, const npg_csr *A, int64_t nu, const npg_csr *G,
+                                     const npg_csr *D, const npg_csr *Dinv, const npg_csr *S, const npg_csr *P,
+                                     const npg_csr *R) {
+    NPG_REQUIRE(pc && pc->kind == NPG_PC_MG, "npg_precond_mg_set_level: not a multigrid preconditioner");
+    NPG_REQUIRE(level >= 0 && level < (int)pc->L.size(), "npg_precond_mg_set_level: level %d out of range", level);
+    NPG_REQUIRE(A && G && D && Dinv && S, "npg_precond_mg_set_level: NULL operator");
+    const int64_t n = A->m, np = n - nu;
+    NPG_REQUIRE(A->n == n && nu > 0 && np > 0, "npg_precond_mg_set_level: A must be square with 0 < nu < n");
+    NPG_REQUIRE(G->m == nu && G->n == np && D->m == np && D->n == nu && Dinv->m == nu && Dinv->n == nu && S->m == np &&
+                    S->n == np,
+                "npg_precond_mg_set_level: block shapes do not match (n = %lld, nu = %lld)", (long long)n, (long long)nu);
+    NPG_REQUIRE((level == 0) == (P == nullptr) && (P == nullptr) == (R == nullptr),
+                "npg_precond_mg_set_level: level 0 takes no transfer operators, every other level needs P and R");
+    MgLevel &l = pc->L[level];
+    NPG_REQUIRE(l.A == nullptr, "npg_precond_mg_set_level: level %d is already set", level);
+    if (P) {
+        NPG_REQUIRE(pc->L[level - 1].A, "npg_precond_mg_set_level: set the levels coarse to fine");
+        const int64_t nc = pc->L[level - 1].n;
+        NPG_REQUIRE(P->m == n && P->n == nc && R->m == nc && R->n == n,
+                    "npg_precond_mg_set_level: P must be %lld x %lld and R its transpose", (long long)n, (long long)nc);
+    }
+    l.A = A; l.G = G; l.D = D; l.Dinv = Dinv; l.S = S; l.P = P; l.R = R;
+    l.n = n; l.nu = nu; l.np = np;
+    int rc;
+    if ((rc = mg_alloc(pc, &l.sdinv, np))) return rc;
+    npg_vec sv;
+    sv.ctx = pc->ctx; sv.n = np; sv.d = l.sdinv; sv.owns = false;
+    if ((rc = npg_csr_inv_diag(S, &sv))) return rc;
+    if ((rc = mg_alloc(pc, &l.r, n)) || (rc = mg_alloc(pc, &l.t, nu)) || (rc = mg_alloc(pc, &l.rhs, np)) ||
+        (rc = mg_alloc(pc, &l.dp, np)) || (rc = mg_alloc(pc, &l.res, np)))
+        return rc;
+    if (level + 1 < (int)pc->L.size())
+        if ((rc = mg_alloc(pc, &l.x, n)) || (rc = mg_alloc(pc, &l.b, n))) return rc;
+    pc->n = n;      // the finest level set so far
+    return NPG_OK;
+}
+
+// Swap in re-assembled operators of one level (same shapes): what the eddy closure's A refresh needs (src/model.jl:160-170)
+NPG_API int npg_precond_mg_update_level(npg_precond *pc, int level, const npg_csr *A, const npg_csr *G, const npg_csr *D,
+                                        const npg_csr *Dinv, const npg_csr *S) {
+    NPG_REQUIRE(pc && pc->kind == NPG_PC_MG, "npg_precond_mg_update_level: not a multigrid preconditioner");
+    NPG_REQUIRE(level >= 0 && level < (int)pc->L.size() && pc->L[level].A, "npg_precond_mg_update_level: level %d is not set",
+                level);
+    NPG_REQUIRE(A && G && D && Dinv && S, "npg_precond_mg_update_level: NULL operator");
+    MgLevel &l = pc->L[level];
+    NPG_REQUIRE(A->m == l.n && A->n == l.n && G->m == l.nu && G->n == l.np && D->m == l.np && D->n == l.nu &&
+                    Dinv->m == l.nu && Dinv->n == l.nu && S->m == l.np && S->n == l.np,
+                "npg_precond_mg_update_level: shapes differ from the level's");
+    NPG_HIP(hipStreamSynchronize(pc->ctx->stream));
+    l.A = A; l.G = G; l.D = D; l.Dinv = Dinv; l.S = S;
+    npg_vec sv;
+    sv.ctx = pc->ctx; sv.n = l.np; sv.d = l.sdinv; sv.owns = false;
+    return npg_csr_inv_diag(S, &sv);
+}
+
+NPG_API int npg_precond_mg_set_params(npg_precond *pc, double omega, double jacobi_weight, int schur_sweeps, int nu1,
+                                      int nu2, int coarse_sweeps) {
+    NPG_REQUIRE(pc && pc->kind == NPG_PC_MG, "npg_precond_mg_set_params: not a multigrid preconditioner");
+    NPG_REQUIRE(omega > 0 && jacobi_weight > 0 && schur_sweeps >= 1 && nu1 >= 0 && nu2 >= 0 && nu1 + nu2 >= 1 &&
+                    coarse_sweeps >= 1,
+                "npg_precond_mg_set_params: bad parameter");
+    pc->omega = omega; pc->jw = jacobi_weight; pc->sweeps = schur_sweeps;
+    pc->nu1 = nu1; pc->nu2 = nu2; pc->coarse = coarse_sweeps;
+    return NPG_OK;
+}
+
+// nsteps Braess-Sarazin steps on level l for A x = b
+static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int nsteps, bool x_is_zero) {
+    MgLevel &l = pc->L[lev];
+    npg_ctx *c = pc->ctx;
+    const int64_t nu = l.nu, np = l.np;
+    int rc;
+    for (int s = 0; s < nsteps; ++s) {
+        const bool zero = x_is_zero && s == 0;
+        axpby(c, l.r, 1.0, b, 0.0, l.n);                                             // r = b - A x
+        if (!zero && (rc = spmv_raw(l.A, x, l.r, -1.0, 1.0))) return rc;
+        if ((rc = spmv_raw(l.Dinv, l.r, l.t, 1.0, 0.0))) return rc;                  // t = Dh^-1 r_u
+        axpby(c, l.rhs, -pc->omega, l.r + nu, 0.0, np);                              // rhs = D t - w r_p
+        if ((rc = spmv_raw(l.D, l.t, l.rhs, 1.0, 1.0))) return rc;
+        daxpby(c, l.dp, pc->jw, l.sdinv, l.rhs, 0.0, np);                            // damped Jacobi on S dp = rhs
+        for (int k = 1; k < pc->sweeps; ++k) {
+            axpby(c, l.res, 1.0, l.rhs, 0.0, np);
+            if ((rc = spmv_raw(l.S, l.dp, l.res, -1.0, 1.0))) return rc;
+            daxpby(c, l.dp, pc->jw, l.sdinv, l.res, 1.0, np);
+        }
+        if ((rc = spmv_raw(l.G, l.dp, l.r, -1.0, 1.0))) return rc;                   // r_u -= G dp
+        if ((rc = spmv_raw(l.Dinv, l.r, x, 1.0 / pc->omega, zero ? 0.0 : 1.0))) return rc;   // x_u += Dh^-1 r_u / w
+        axpby(c, x + nu, 1.0, l.dp, zero ? 0.0 : 1.0, np);                           // x_p += dp
+    }
+    return NPG_OK;
+}
+
+static int mg_vcycle(npg_precond *pc, int lev, double *x, const double *b) {
+    if (lev == 0) return mg_smooth(pc, 0, x, b, pc->coarse, true);
+    MgLevel &l = pc->L[lev], &lc = pc->L[lev - 1];
+    npg_ctx *c = pc->ctx;
+    int rc;
+    if (pc->nu1 > 0) {
+        if ((rc = mg_smooth(pc, lev, x, b, pc->nu1, true))) return rc;
+        axpby(c, l.r, 1.0, b, 0.0, l.n);
+        if ((rc = spmv_raw(l.A, x, l.r, -1.0, 1.0))) return rc;
+        if ((rc = spmv_raw(l.R, l.r, lc.b, 1.0, 0.0))) return rc;
+    } else {
+        if ((rc = spmv_raw(l.R, b, lc.b, 1.0, 0.0))) return rc;
+    }
+    if ((rc = mg_vcycle(pc, lev - 1, lc.x, lc.b))) return rc;
+    if ((rc = spmv_raw(l.P, lc.x, x, 1.0, pc->nu1 > 0 ? 1.0 : 0.0))) return rc;
+    return mg_smooth(pc, lev, x, b, pc->nu2, false);
+}
+
+NPG_API int npg_precond_blockdiag_set(npg_precond *pc, int k, int64_t offset, const npg_csr *A, const npg_vec *jacobi,
+                                      int64_t itmax, double atol, double rtol) {
+    NPG_REQUIRE(pc && pc->kind == NPG_PC_BLOCKDIAG, "npg_precond_blockdiag_set: not a block-diagonal preconditioner");
+    NPG_REQUIRE(k >= 0 && k < (int)pc->blocks.size() && A && jacobi, "npg_precond_blockdiag_set: bad argument");
+    NPG_REQUIRE(A->m == A->n && jacobi->n == A->m && offset >= 0, "npg_precond_blockdiag_set: block must be square");
+    BlockPc &b = pc->blocks[k];
+    NPG_REQUIRE(!b.A, "npg_precond_blockdiag_set: block %d is already set", k);
+    b.off = offset; b.n = A->m; b.A = A; b.jac = jacobi; b.itmax = itmax; b.atol = atol; b.rtol = rtol;
+    int rc;
+    if ((rc = npg_cg_create(pc->ctx, b.n, &b.cg))) return rc;
+    if ((rc = npg_vec_create(pc->ctx, b.n, &b.xk))) return rc;       // workspace.x .= 0 (src/preconditioners.jl:20)
+    if ((rc = npg_vec_create(pc->ctx, b.n, &b.rk))) return rc;
+    pc->n = std::max(pc->n, offset + b.n);
+    return NPG_OK;
+}
+
+static int precond_apply_raw(npg_precond *pc, const double *r, double *z) {
+    ++pc->applications;
+    if (pc->kind == NPG_PC_MG) {
+        NPG_REQUIRE(pc->L.back().A, "npg_precond_apply: multigrid levels are not all set");
+        return mg_vcycle(pc, (int)pc->L.size() - 1, z, r);
+    }
+    for (BlockPc &b : pc->blocks) {
+        NPG_REQUIRE(b.A, "npg_precond_apply: a block has not been set");
+        // mul!(yb, block.P^-1, xb): CG on the block, warm-started from its previous output (src/preconditioners.jl:24-37,118-125)
+        NPG_HIP(hipMemcpyAsync(b.rk->d, r + b.off, (size_t)b.n * sizeof(double), hipMemcpyDeviceToDevice, pc->ctx->stream));
+        npg_solve_stats st{};
+        int rc = npg_cg_solve(b.cg, b.A, NPG_PRECOND_DIAG, 0.0, b.jac, b.rk, b.xk, b.atol, b.rtol, b.itmax, &st);
+        if (rc) return rc;
+        pc->inner_iterations += st.niter;
+        NPG_HIP(hipMemcpyAsync(z + b.off, b.xk->d, (size_t)b.n * sizeof(double), hipMemcpyDeviceToDevice, pc->ctx->stream));
+    }
+    return NPG_OK;
+}
+
+NPG_API int npg_precond_apply(npg_precond *pc, const npg_vec *r, npg_vec *z) {
+    NPG_REQUIRE(pc && r && z, "npg_precond_apply: NULL argument");
+    NPG_REQUIRE(r->n == pc->n && z->n == pc->n && r->d != z->d, "npg_precond_apply: vectors must have %lld entries and not alias",
+                (long long)pc->n);
+    return precond_apply_raw(pc, r->d, z->d);
+}
+
+NPG_API int npg_precond_counters(npg_precond *pc, int64_t *applications, int64_t *inner_iterations) {
+    NPG_REQUIRE(pc, "npg_precond_counters: NULL handle");
+    if (applications) *applications = pc->applications;
+    if (inner_iterations) *inner_iterations = pc->inner_iterations;
+    return NPG_OK;
+}
+
+// ---- flexible GMRES ----------------------------------------------------------------------------------------------------
+struct npg_fgmres {
+    npg_ctx *ctx = nullptr;
+    int64_t n = 0, ld = 0;
+    int mem = 20;
+    double *V = nullptr, *Z = nullptr;       // (mem + 1) and mem columns of ld doubles
+    double *part = nullptr;                  // partial rows of the reductions
+    double *dsc = nullptr;                   // device scalars: h1 [0,32), h2 [32,64), norm^2 [64]
+    double *hsc = nullptr;                   // pinned host copy
+    std::vector<double> hist;
+};
+
+constexpr int kFgBlocks = 1024;
+
+NPG_API int npg_fgmres_create(npg_ctx *ctx, int64_t n, int memory, npg_fgmres **out) {
+    NPG_REQUIRE(ctx && out && n > 0, "npg_fgmres_create: bad argument");
+    NPG_REQUIRE(memory >= 1 && memory <= 23, "npg_fgmres_create: memory must be in 1..23");
+    npg_fgmres *ws = new npg_fgmres();
+    ws->ctx = ctx; ws->n = n; ws->mem = memory;
+    ws->ld = (n + 31) / 32 * 32;
+    NPG_HIP(hipSetDevice(ctx->device));
+    NPG_HIP(hipMalloc((void **)&ws->V, (size_t)(memory + 1) * ws->ld * sizeof(double)));
+    NPG_HIP(hipMalloc((void **)&ws->Z, (size_t)memory * ws->ld * sizeof(double)));
+    NPG_HIP(hipMalloc((void **)&ws->part, (size_t)kFgBlocks * kPartStride * sizeof(double)));
+    NPG_HIP(hipMalloc((void **)&ws->dsc, 96 * sizeof(double)));
+    NPG_HIP(hipHostMalloc((void **)&ws->hsc, 96 * sizeof(double), hipHostMallocDefault));
+    *out = ws;
+    return NPG_OK;
+}
+
+NPG_API int npg_fgmres_destroy(npg_fgmres *ws) {
+    if (!ws) return NPG_OK;
+    hipStreamSynchronize(ws->ctx->stream);
+    hipFree(ws->V); hipFree(ws->Z); hipFree(ws->part); hipFree(ws->dsc); hipHostFree(ws->hsc);
+    delete ws;
+    return NPG_OK;
+}
+
+NPG_API int64_t npg_fgmres_history(npg_fgmres *ws, double *buf, int64_t cap) {
+    if (!ws || !buf) return -1;
+    const int64_t k = std::min<int64_t>(cap, (int64_t)ws->hist.size());
+    std::copy(ws->hist.begin(), ws->hist.begin() + k, buf);
+    return k;
+}
+
+template <typename F>
+static void by_groups(int k, F f) {
+    if (k <= 8) f(std::integral_constant<int, 1>());
+    else if (k <= 16) f(std::integral_constant<int, 2>());
+    else f(std::integral_constant<int, 3>());
+}
+
+NPG_API int npg_fgmres_solve(npg_fgmres *ws, const npg_csr *A, npg_precond *pc, const npg_vec *y, npg_vec *x,
+                             double scale, double atol, double rtol, int64_t itmax, npg_solve_stats *stats) {
+    NPG_REQUIRE(ws && A && y && x && stats, "npg_fgmres_solve: NULL argument");
+    const int64_t n = ws->n, ld = ws->ld;
+    NPG_REQUIRE(A->m == n && A->n == n && y->n == n && x->n == n, "npg_fgmres_solve: system must be %lld x %lld", (long long)n,
+                (long long)n);
+    NPG_REQUIRE(!pc || pc->n == n, "npg_fgmres_solve: the preconditioner is for %lld unknowns", (long long)(pc ? pc->n : 0));
+    NPG_REQUIRE(scale > 0 && atol >= 0 && rtol >= 0, "npg_fgmres_solve: bad tolerance / scale");
+    npg_ctx *c = ws->ctx;
+    hipStream_t st = c->stream;
+    hipEvent_t e0, e1;
+    NPG_HIP(hipEventCreate(&e0));
+    NPG_HIP(hipEventCreate(&e1));
+    NPG_HIP(hipEventRecord(e0, st));
+    if (itmax <= 0) itmax = 2 * n;
+    const int mem = ws->mem;
+    const int grid = std::min(kFgBlocks, grid_for(n, kFgBlocks));
+    *stats = npg_solve_stats{};
+    ws->hist.clear();
+    int rc;
+    double *V = ws->V, *Z = ws->Z;
+    // r0 = y - A x
+    axpby(c, V, 1.0, y->d, 0.0, n);
+    if ((rc = spmv_raw(A, x->d, V, -1.0, 1.0))) return rc;
+    double dd;
+    if ((rc = reduce_dot(c, V, V, n, &dd))) return rc;
+    double beta = std::sqrt(dd);
+    const double rnorm0 = scale * beta, eps = atol + rtol * rnorm0;
+    stats->rnorm0 = rnorm0;
+    stats->rnorm = rnorm0;
+    ws->hist.push_back(rnorm0);
+    int64_t it = 0;
+    bool solved = rnorm0 <= eps, breakdown = false;
+    if (beta == 0.0) stats->status = 4;
+    std::vector<double> H((size_t)(mem + 1) * mem), g(mem + 1), cs(mem), sn(mem), yk(mem);
+    while (!solved && !breakdown && it < itmax) {
+        ++stats->npass;
+        axpby(c, V, 1.0 / beta, V, 0.0, n);
+        std::fill(g.begin(), g.end(), 0.0);
+        g[0] = beta;
+        int k = 0;
+        for (int j = 0; j < mem && it < itmax; ++j) {
+            double *vj = V + (size_t)j * ld, *zj = Z + (size_t)j * ld, *w = V + (size_t)(j + 1) * ld;
+            if (pc) {
+                if ((rc = precond_apply_raw(pc, vj, zj))) return rc;
+            } else {
+                axpby(c, zj, 1.0, vj, 0.0, n);
+            }
+            if ((rc = spmv_raw(A, zj, w, 1.0, 0.0))) return rc;
+            const int kk = j + 1;
+            // classical Gram-Schmidt, two full passes; everything the host needs arrives in one copy
+            for (int pass = 0; pass < 2; ++pass) {
+                double *hd = ws->dsc + 32 * pass;
+                by_groups(kk, [&](auto ng) {
+                    hipLaunchKernelGGL(k_mdot<decltype(ng)::value>, dim3(grid), dim3(kBlock), 0, st, V, ld, kk, w, n, ws->part);
+                });
+                hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, st, ws->part, grid, kk, hd);
+                by_groups(kk, [&](auto ng) {
+                    hipLaunchKernelGGL(k_mupdate<decltype(ng)::value>, dim3(grid), dim3(kBlock), 0, st, V, ld, kk, hd, w, n,
+                                       ws->part);
+                });
+            }
+            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, st, ws->part, grid, 1, ws->dsc + 64);
+            NPG_HIP(hipMemcpyAsync(ws->hsc, ws->dsc, 65 * sizeof(double), hipMemcpyDeviceToHost, st));
+            NPG_HIP(hipStreamSynchronize(st));
+            double *Hj = &H[(size_t)j * (mem + 1)];          // column j
+            for (int i = 0; i < kk; ++i) Hj[i] = ws->hsc[i] + ws->hsc[32 + i];
+            const double hn = std::sqrt(std::max(0.0, ws->hsc[64]));
+            NPG_REQUIRE(std::isfinite(hn), "npg_fgmres_solve: non-finite Arnoldi vector at iteration %lld", (long long)it);
+            Hj[kk] = hn;
+            for (int i = 0; i < j; ++i) {
+                const double t = cs[i] * Hj[i] + sn[i] * Hj[i + 1];
+                Hj[i + 1] = -sn[i] * Hj[i] + cs[i] * Hj[i + 1];
+                Hj[i] = t;
+            }
+            const double d = std::hypot(Hj[j], Hj[j + 1]);
+            cs[j] = d > 0 ? Hj[j] / d : 1.0;
+            sn[j] = d > 0 ? Hj[j + 1] / d : 0.0;
+            Hj[j] = d;
+            Hj[j + 1] = 0.0;
+            g[j + 1] = -sn[j] * g[j];
+            g[j] = cs[j] * g[j];
+            ++it;
+            k = j + 1;
+            const double rn = scale * std::fabs(g[j + 1]);
+            ws->hist.push_back(rn);
+            stats->rnorm = rn;
+            if (rn <= eps) break;
+            if (hn <= 1e-300 || d == 0.0) { breakdown = true; break; }
+            axpby(c, w, 1.0 / hn, w, 0.0, n);
+        }
+        // x += Z y,  H y = g (upper triangular, columns stored with stride mem + 1)
+        for (int i = k - 1; i >= 0; --i) {
+            double s = g[i];
+            for (int jj = i + 1; jj < k; ++jj) s -= H[(size_t)jj * (mem + 1) + i] * yk[jj];
+            const double piv = H[(size_t)i * (mem + 1) + i];
+            yk[i] = piv != 0.0 ? s / piv : 0.0;
+        }
+        Coefs cf{};
+        for (int i = 0; i < k; ++i) cf.y[i] = yk[i];
+        if (k > 0) hipLaunchKernelGGL(k_combine_z, dim3(grid), dim3(kBlock), 0, st, x->d, Z, ld, k, cf, n);
+        // true residual: the next pass starts from it, and a pass that met the estimate is confirmed by it
+        axpby(c, V, 1.0, y->d, 0.0, n);
+        if ((rc = spmv_raw(A, x->d, V, -1.0, 1.0))) return rc;
+        if ((rc = reduce_dot(c, V, V, n, &dd))) return rc;
+        beta = std::sqrt(dd);
+        stats->rnorm = scale * beta;
+        solved = stats->rnorm <= eps;
+        if (beta == 0.0) break;
+    }
+    NPG_HIP(hipGetLastError());
+    NPG_HIP(hipEventRecord(e1, st));
+    NPG_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    NPG_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    stats->seconds = ms * 1e-3;
+    stats->solved = solved ? 1 : 0;
+    stats->niter = (int32_t)it;
+    if (stats->status == 0) stats->status = solved ? 1 : breakdown ? 3 : 2;
+    return NPG_OK;
+}

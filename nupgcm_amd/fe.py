@@ -76,9 +76,27 @@ class Mesh:
             raise NotImplementedError("nupgcm_amd covers the 3-D (tetrahedral) configurations of the hot path")
         self.model = model
         self.surface_tags = tuple(surface_tags)
-        self.coords = np.ascontiguousarray(model.coords, dtype=np.float64)
+        # Periodic meshes (meshes/channel_basin.jl:103-108): GridapGmsh glues paired nodes into one topological vertex while
+        # cells keep their own node coordinates.  `cells` / `coords` are the TOPOLOGY (vertex ids, one coordinate per vertex:
+        # the master's); `cell_geo` / `geo_coords` are the GEOMETRY (the Gmsh nodes of each cell, in the order of its sorted
+        # vertices).  Without periodicity the two coincide.
+        self.geo_coords = np.ascontiguousarray(model.coords, dtype=np.float64)
+        per = getattr(model, "periodic", None)
+        if per is None:
+            self.vertex_of = np.arange(len(self.geo_coords), dtype=np.int64)
+            masters = self.vertex_of
+        else:
+            masters, self.vertex_of = np.unique(np.asarray(per, dtype=np.int64), return_inverse=True)
+        self.periodic = per is not None
+        self.coords = self.geo_coords[masters]
         self.nv = len(self.coords)
-        self.cells = np.sort(np.asarray(model.cells, dtype=np.int64), axis=1)
+        cg = np.asarray(model.cells, dtype=np.int64)
+        ct = self.vertex_of[cg]
+        order = np.argsort(ct, axis=1, kind="stable")
+        self.cells = np.take_along_axis(ct, order, axis=1)
+        self.cell_geo = np.take_along_axis(cg, order, axis=1)
+        if (self.cells[:, 1:] == self.cells[:, :-1]).any():
+            raise ValueError("a cell touches a periodic node and its own image: the mesh needs >= 3 cells per period")
         nc = len(self.cells)
         # first-encounter edge numbering
         a = self.cells[:, _TET_EDGE_A].ravel()
@@ -95,25 +113,37 @@ class Mesh:
         self._edge_key_sorted = uniq
         self._edge_rank = rank
         self.cell_nodes = np.hstack([self.cells, self.nv + self.cell_edges])      # (nc, 10) P2 nodes
-        self.node_coords = np.vstack([self.coords, 0.5 * (self.coords[self.edges[:, 0]] + self.coords[self.edges[:, 1]])])
+        # an edge node sits at the midpoint of the edge as its first cell sees it (for an edge that crosses the periodic
+        # seam the two vertex coordinates would be a period apart)
+        ga = self.cell_geo[:, _TET_EDGE_A].ravel()[first]
+        gb = self.cell_geo[:, _TET_EDGE_B].ravel()[first]
+        mid = np.empty((self.ne, 3))
+        mid[rank] = 0.5 * (self.geo_coords[ga] + self.geo_coords[gb])
+        self.node_coords = np.vstack([self.coords, mid])
         # labels
         self.phys_names = list(model.phys_names)
         emask = np.zeros(self.ne, dtype=np.uint32)
-        fac = np.sort(np.asarray(model.facets, dtype=np.int64).reshape(-1, 3), axis=1)
+        fg = np.asarray(model.facets, dtype=np.int64).reshape(-1, 3)
+        ft = self.vertex_of[fg]
+        order = np.argsort(ft, axis=1, kind="stable")
+        fac = np.take_along_axis(ft, order, axis=1)            # sorted vertex ids; geometry in the same order
+        self._facets_geo = np.take_along_axis(fg, order, axis=1)
         fph = np.asarray(model.facets_phys, dtype=np.uint32)
         for (i, j) in ((0, 1), (0, 2), (1, 2)):
             eid = self.edge_ids(fac[:, i], fac[:, j])
             ok = eid >= 0
             np.bitwise_or.at(emask, eid[ok], fph[ok])
-        rid = np.sort(np.asarray(model.ridges, dtype=np.int64).reshape(-1, 2), axis=1)
+        rid = np.sort(self.vertex_of[np.asarray(model.ridges, dtype=np.int64).reshape(-1, 2)], axis=1)
         if len(rid):
             eid = self.edge_ids(rid[:, 0], rid[:, 1])
             ok = eid >= 0
             emask[eid[ok]] = np.asarray(model.ridges_phys, dtype=np.uint32)[ok]     # a matching 1-D element wins
-        self.node_mask = np.concatenate([np.asarray(model.node_phys, dtype=np.uint32), emask])
+        vmask = np.zeros(self.nv, dtype=np.uint32)
+        np.bitwise_or.at(vmask, self.vertex_of, np.asarray(model.node_phys, dtype=np.uint32))   # a vertex and its images
+        self.node_mask = np.concatenate([vmask, emask])
         self._facets, self._facets_phys = fac, fph
         # geometry of the (sorted) cells
-        X = self.coords[self.cells]
+        X = self.geo_coords[self.cell_geo]
         J = np.transpose(X[:, 1:, :] - X[:, :1, :], (0, 2, 1))
         self.detJ = np.abs(np.linalg.det(J))
         gref = np.linalg.inv(J)
@@ -143,24 +173,25 @@ class Mesh:
 
     def quad_points(self):
         """physical quadrature points (ncell, nq, 3) - where the host evaluates the user's coefficient closures"""
-        return np.einsum("qk,cki->cqi", self.q_lam, self.coords[self.cells])
+        return np.einsum("qk,cki->cqi", self.q_lam, self.geo_coords[self.cell_geo])
 
-    def boundary_faces(self, names):
+    def boundary_faces(self, names, with_geometry=False):
+        """boundary triangles carrying any of `names` as sorted vertex ids (and, on request, their Gmsh nodes in that order)"""
         sel = np.zeros(len(self._facets), dtype=bool)
         for nm in names:
             sel |= (self._facets_phys >> self.tag_bit(nm)) & 1 == 1
-        return self._facets[sel]
+        return (self._facets[sel], self._facets_geo[sel]) if with_geometry else self._facets[sel]
 
     def surface_load(self, g, names=None):
         """int_Gamma g phi_i dGamma for every P2 node (length nn) over the boundary triangles carrying `names`
         (dGamma = Measure(BoundaryTriangulation(model, tags=surface_tags), 4), src/meshes.jl:35-36)."""
-        faces = self.boundary_faces(self.surface_tags if names is None else names)
+        faces, fgeo = self.boundary_faces(self.surface_tags if names is None else names, with_geometry=True)
         out = np.zeros(self.nn)
         if len(faces) == 0:
             return out
         lam, w = tri_quadrature_degree4()
         N, _ = p2_tables(lam, _TRI_EDGE_A, _TRI_EDGE_B)
-        X = self.coords[faces]
+        X = self.geo_coords[fgeo]
         area2 = np.linalg.norm(np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), axis=1)
         en = np.stack([self.edge_ids(faces[:, i], faces[:, j]) for (i, j) in ((0, 1), (0, 2), (1, 2))], axis=1)
         nodes = np.hstack([faces, self.nv + en])
@@ -171,16 +202,18 @@ class Mesh:
 
     def h_cells(self):
         """compute_h_cells (src/meshes.jl:127-134): longest edge of each cell"""
-        X = self.coords[self.cells]
+        X = self.geo_coords[self.cell_geo]
         return np.linalg.norm(X[:, :, None, :] - X[:, None, :, :], axis=-1).max(axis=(1, 2))
 
     def median_edge_length(self):
         """The `h` of src/inversion.jl:44-49: median over the unique edges built from local pairs (1,2),(2,3),(3,1) only
         (all_edges, src/meshes.jl:94-108, written for triangles) - `hs[length(hs) // 2]` 1-based."""
-        t = self.cells
-        e = np.vstack([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]])
-        e = np.unique(np.sort(e, axis=1), axis=0)
-        hs = np.sort(np.linalg.norm(self.coords[e[:, 0]] - self.coords[e[:, 1]], axis=1))
+        t, g = self.cells, self.cell_geo
+        e = np.sort(np.vstack([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]]), axis=1)
+        eg = np.vstack([g[:, [0, 1]], g[:, [1, 2]], g[:, [2, 0]]])
+        _, first = np.unique(e[:, 0] * self.nv + e[:, 1], return_index=True)
+        eg = eg[first]                                          # lengths from the cell's own nodes (periodic seam)
+        hs = np.sort(np.linalg.norm(self.geo_coords[eg[:, 0]] - self.geo_coords[eg[:, 1]], axis=1))
         return float(hs[len(hs) // 2 - 1])
 
     def __repr__(self):

@@ -31,6 +31,10 @@ class GmshModel:
     ridges: np.ndarray           # (nr, dim-1) int64: (dim-2)-dimensional elements (lines in 3-D, points in 2-D)
     ridges_phys: np.ndarray      # (nr,) uint32 bitmask
     phys_names: list = field(default_factory=list)
+    # periodic meshes (`gmsh.model.mesh.setPeriodic`, /root/reference/meshes/channel_basin.jl:103-108): periodic[n] = master
+    # node of n (n itself when it has none).  GridapGmsh glues the vertices of paired nodes in the grid topology; cells keep
+    # their own node coordinates.  None = not periodic.
+    periodic: np.ndarray = None
 
     def tag_mask(self, names) -> int:
         m = 0
@@ -114,6 +118,25 @@ def read_msh(path: str) -> GmshModel:
             phys_by_dim[_DIM_OF_TYPE[ety]].append(m)
         pos += nb
 
+    periodic = None
+    if "$Periodic" in lines[pos:]:
+        seek("$Periodic")
+        nlinks = int(lines[pos]); pos += 1
+        periodic = np.arange(nn, dtype=np.int64)
+        for _ in range(nlinks):
+            pos += 1                                   # entityDim entityTag entityTagMaster
+            pos += 1                                   # numAffine value ...
+            ncorr = int(lines[pos]); pos += 1
+            for k in range(ncorr):
+                a, b = lines[pos + k].split()
+                periodic[int(a) - 1] = int(b) - 1
+            pos += ncorr
+        while True:                                    # masters of masters (corner nodes of several links)
+            nxt = periodic[periodic]
+            if np.array_equal(nxt, periodic):
+                break
+            periodic = nxt
+
     dim = 3 if by_dim[3] else 2
 
     def arr(d, k):
@@ -123,21 +146,22 @@ def read_msh(path: str) -> GmshModel:
     cells, _ = arr(dim, dim + 1)
     facets, facets_phys = arr(dim - 1, dim)
     ridges, ridges_phys = arr(dim - 2, dim - 1)
-    return GmshModel(dim, coords, node_phys, cells, facets, facets_phys, ridges, ridges_phys, names)
+    return GmshModel(dim, coords, node_phys, cells, facets, facets_phys, ridges, ridges_phys, names, periodic=periodic)
 
 
 def save_npz(model: GmshModel, path: str) -> None:
     np.savez_compressed(
         path, dim=np.int64(model.dim), coords=model.coords, node_phys=model.node_phys, cells=model.cells,
         facets=model.facets, facets_phys=model.facets_phys, ridges=model.ridges, ridges_phys=model.ridges_phys,
-        phys_names=np.frombuffer(json.dumps(model.phys_names).encode(), dtype=np.uint8))
+        phys_names=np.frombuffer(json.dumps(model.phys_names).encode(), dtype=np.uint8),
+        **({} if model.periodic is None else {"periodic": np.asarray(model.periodic, dtype=np.int64)}))
 
 
 def load_npz(path: str) -> GmshModel:
     z = np.load(path)
     names = json.loads(bytes(z["phys_names"]).decode())
     return GmshModel(int(z["dim"]), z["coords"], z["node_phys"], z["cells"], z["facets"], z["facets_phys"],
-                     z["ridges"], z["ridges_phys"], names)
+                     z["ridges"], z["ridges_phys"], names, periodic=z["periodic"] if "periodic" in z.files else None)
 
 
 def load_model(path: str) -> GmshModel:

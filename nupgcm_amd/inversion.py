@@ -72,7 +72,11 @@ class InversionToolkit:
     """src/inversion.jl:1-5: {B, b, solver}"""
 
     def __init__(self, arch, *args, atol=1e-6, rtol=1e-6, itmax=0, memory=20, history=True, verbose=False, restart=True,
-                 reorth_eta=0.1, block_nodes=None):
+                 reorth_eta=0.1, block_nodes=None, preconditioner="diagonal", hierarchy=None, precond_kw=None):
+        """preconditioner: "diagonal" = the reference's GPU choice Diagonal(1/h^dim) (src/inversion.jl:42-54, default);
+        "block_diagonal" = its experimental BlockDiagonalPreconditioner (src/inversion.jl:60, src/preconditioners.jl:53-93);
+        "multigrid" = MultigridPreconditioner over `hierarchy` (FEData coarse ... fine, the last one being fe_data).  The last
+        two are inexact operators: the workspace is then a flexible GMRES(memory) with the same stopping rule."""
         if not isinstance(arch, GPU):
             raise TypeError("nupgcm_amd implements the GPU() architecture only (no CPU fallback)")
         if not restart:
@@ -97,6 +101,17 @@ class InversionToolkit:
             # GPU preconditioner: Diagonal(1/h^dim) with the median edge length (src/inversion.jl:42-54)
             h = fe_data.mesh.median_edge_length()
             P = Diagonal(scalar=1.0 / h ** 3, n=A.shape[0])
+            if preconditioner != "diagonal":
+                from . import multigrid as mgm
+                self.scale = P.scalar                   # the residual keeps the reference's 1/h^dim scaling
+                if preconditioner == "multigrid":
+                    if not hierarchy or hierarchy[-1] is not fe_data:
+                        raise ValueError("preconditioner='multigrid' needs hierarchy=[FEData coarse, ..., fe_data]")
+                    P = mgm.MultigridPreconditioner(arch, params, forcings, hierarchy, A_fine=A, **(precond_kw or {}))
+                elif preconditioner == "block_diagonal":
+                    P = mgm.BlockDiagonalPreconditioner(arch, params, fe_data, A, **(precond_kw or {}))
+                else:
+                    raise ValueError(f"unknown preconditioner {preconditioner!r}")
             print_memory_status(arch) if verbose else None
         elif len(args) == 4:                        # InversionToolkit(arch, A, P, B, b; kwargs...) src/inversion.jl:74-94
             A, P, B, b0 = args
@@ -105,9 +120,14 @@ class InversionToolkit:
         self.arch, self.B, self.b = arch, B, b0
         N = A.shape[0]
         y = DeviceVector(arch.ctx, N)
-        ws = GmresWorkspace(arch.ctx, N, memory=memory)
         kwargs = dict(atol=atol, rtol=rtol, itmax=itmax, history=history, verbose=int(verbose), restart=restart,
                       reorth_eta=reorth_eta)
+        if isinstance(P, Diagonal) or P is None:
+            ws = GmresWorkspace(arch.ctx, N, memory=memory)
+        else:
+            from .multigrid import FgmresWorkspace
+            ws = FgmresWorkspace(arch.ctx, N, memory=memory)
+            kwargs["scale"] = getattr(self, "scale", 1.0)
         self.solver = IterativeSolverToolkit(A, P, y, ws, kwargs, "Inversion")
 
     def __repr__(self):

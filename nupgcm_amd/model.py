@@ -153,6 +153,8 @@ def run(model: Model, n_info=10, n_save=float("inf"), n_plot=float("inf"), advec
             ep = frc.eddy_param
             fe.update_nu_eddy(ep.N2min, prm.alpha, prm.N2, b)
             build_A_inversion(model.arch, model.fe_data, prm, None, A=model.inversion.solver.A)
+            if hasattr(model.inversion.solver.P, "refresh"):         # an operator-dependent preconditioner follows A
+                model.inversion.solver.P.refresh(model.inversion.solver.A)
         model.stats.append((model.evolution.solver.workspace.stats, model.inversion.solver.workspace.stats))
         if i % n_info == 0 and log is not None:
             t1 = time.time()

@@ -1,0 +1,273 @@
+"""General (inexact) preconditioners for the inversion and the flexible GMRES workspace that drives them.
+
+`BlockDiagonalPreconditioner` mirrors /root/reference/src/preconditioners.jl:53-125 (an inner Jacobi-CG per block:
+friction-only velocity block, pressure mass matrix / (alpha^2 eps^2)).  `MultigridPreconditioner` is new work (SURVEY 8f rank
+1): a geometric multigrid V-cycle on the whole saddle-point system over the red-refinement hierarchy the large bowl meshes
+are built from (nupgcm_amd.refine), with a node-block Braess-Sarazin smoother - see csrc/mg.hip.  Both are applied by
+libnupgcm_hip.so; this module only prepares their operators at set-up time:
+
+  * per level: FEData (own RCM / node-block ordering), the level's A assembled by the device kernels, its blocks
+    G = A[u, p], D = A[p, u], the inverse Dinv of the node-block diagonal of A[u, u] and S = D Dinv G (host scipy, set-up only),
+  * between levels: P2 (velocity) and P1 (pressure) nodal interpolation from the parent cell of every fine node, composed with
+    both levels' device orderings; the pressure of every level is pinned at its own last vertex (src/dofs.jl:57), so the
+    interpolated coarse pressure is shifted by its value there (constants are in the null space of the gradient block).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib as L
+from . import refine
+from .architectures import DeviceCSR, DeviceVector
+from .fe import _TET_EDGE_A, _TET_EDGE_B, FEData, Mesh
+from .inversion import build_A_inversion, device_fe
+
+
+class GeneralPreconditioner:
+    """an npg_precond handle: an inexact operator application, usable by FgmresWorkspace only"""
+
+    def __init__(self, ctx, kind, nparts):
+        h = C.c_void_p()
+        L.check(L.lib().npg_precond_create(ctx.h, int(kind), int(nparts), C.byref(h)))
+        self.h, self.ctx = h, ctx
+        self._keep = []            # device objects the library borrows
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.lib().npg_precond_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def apply(self, r: DeviceVector, z: DeviceVector):
+        L.check(L.lib().npg_precond_apply(self.h, r.h, z.h))
+        return z
+
+    def counters(self):
+        a, b = C.c_int64(), C.c_int64()
+        L.check(L.lib().npg_precond_counters(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+# ---- reference's block-diagonal preconditioner -----------------------------------------------------------------------------
+def pressure_mass_matrix(fe_data: FEData):
+    """int p q over the P1 pressure space in device (p_p) order - `assemble_matrix(a, P_trial, P_test)[p_p, p_p]`
+    (src/preconditioners.jl:83-85); P1 on a tetrahedron: |K| (1 + delta_ij) / 20."""
+    m, t, d = fe_data.mesh, fe_data.tables, fe_data.dofs
+    vol = m.detJ / 6.0
+    loc = vol[:, None, None] * (1.0 + np.eye(4)) / 20.0
+    pos = t.p_pos[m.cells]                                           # (nc, 4) device index in [u; p] or -1
+    rows = np.broadcast_to(pos[:, :, None], loc.shape)
+    cols = np.broadcast_to(pos[:, None, :], loc.shape)
+    ok = (rows >= 0) & (cols >= 0)
+    return sp.csr_matrix((loc[ok], (rows[ok] - d.nu, cols[ok] - d.nu)), shape=(d.np, d.np))
+
+
+class BlockDiagonalPreconditioner(GeneralPreconditioner):
+    """BlockDiagonalPreconditioner(arch, params, fe_data, A_inversion) - src/preconditioners.jl:53-93: velocity block = CG on
+    the friction-only A[1:nu, 1:nu] assembled with nu = 1 (:74-80; the reference preconditions that CG with ILU(0) on the
+    GPU, itmax = 100 - here Jacobi, the variant its log lists as `BlockDiagonal(I/h^3)`), pressure block = CG on the
+    pressure mass matrix / (alpha^2 eps^2) with its diagonal (:83-88, itmax = 0)."""
+
+    def __init__(self, arch, params, fe_data, A_inversion=None, u_itmax=100, p_itmax=0, atol=1e-6, rtol=1e-6):
+        super().__init__(arch.ctx, L.NPG_PC_BLOCKDIAG, 2)
+        d, ctx = fe_data.dofs, arch.ctx
+        fe = device_fe(arch, fe_data)
+        fe.set_coeff("nu", 1.0)
+        fe.set_coeff("f", 0.0)                                       # friction_only = true
+        Afr = fe.assemble(L.NPG_MAT_A, fe.new_matrix("A"), scale=params.alpha ** 2 * params.eps ** 2).to_scipy_csr()
+        fe.set_coeff("f", params.f)
+        F = sp.csr_matrix(Afr[:d.nu, :d.nu])
+        F.eliminate_zeros()                                          # dropzeros!(A)  (:80)
+        T = pressure_mass_matrix(fe_data) / (params.alpha ** 2 * params.eps ** 2)
+        for k, (off, M) in enumerate(((0, F), (d.nu, T))):
+            Ad = DeviceCSR.from_scipy(ctx, M)
+            jac = DeviceVector.from_host(ctx, 1.0 / M.diagonal())
+            self._keep += [Ad, jac]
+            L.check(L.lib().npg_precond_blockdiag_set(self.h, k, int(off), Ad.h, jac.h, int(u_itmax if k == 0 else p_itmax),
+                                                      float(atol), float(rtol)))
+
+
+# ---- multigrid -----------------------------------------------------------------------------------------------------------------
+def _p2_shape(lam):
+    return np.concatenate([lam * (2 * lam - 1), 4 * lam[..., _TET_EDGE_A] * lam[..., _TET_EDGE_B]], axis=-1)
+
+
+def nodal_interpolation(mesh_c: Mesh, mesh_f: Mesh):
+    """(P2: nn_f x nn_c, P1: nv_f x nv_c) interpolation matrices between a mesh and its red refinement (refine.refine_once:
+    fine cell 8 i + k is child k of coarse cell i).  Every fine P2 node is evaluated in its parent cell with the parent's P2
+    (P1) shape functions at the node's barycentric coordinates there (vertices: multiples of 1/2, edge nodes: of 1/4)."""
+    ncf = mesh_f.ncell
+    if ncf != 8 * mesh_c.ncell:
+        raise ValueError("nodal_interpolation: the fine mesh is not a uniform red refinement of the coarse one")
+    par, kid = np.arange(ncf) // 8, np.arange(ncf) % 8
+    lam = refine.CHILD_BARY[kid]                                     # (ncf, 4 fine verts, 4 coarse verts), model order
+    fm = mesh_f.vertex_of[np.asarray(mesh_f.model.cells, dtype=np.int64)]
+    lam = np.take_along_axis(lam, np.argsort(fm, axis=1, kind="stable")[:, :, None], axis=1)
+    cm = mesh_c.vertex_of[np.asarray(mesh_c.model.cells, dtype=np.int64)][par]
+    lam = np.take_along_axis(lam, np.argsort(cm, axis=1, kind="stable")[:, None, :], axis=2)
+    lam10 = np.concatenate([lam, 0.5 * (lam[:, _TET_EDGE_A, :] + lam[:, _TET_EDGE_B, :])], axis=1)
+
+    def build(vals, rows, cols, shape):
+        rows, cols = np.broadcast_to(rows, vals.shape).ravel(), np.broadcast_to(cols, vals.shape).ravel()
+        key, first = np.unique(rows * shape[1] + cols, return_index=True)       # a conforming field: any cell's value
+        M = sp.csr_matrix((vals.ravel()[first], (key // shape[1], key % shape[1])), shape=shape)
+        M.eliminate_zeros()
+        return M
+
+    P2 = build(_p2_shape(lam10), mesh_f.cell_nodes[:, :, None], mesh_c.cell_nodes[par][:, None, :], (mesh_f.nn, mesh_c.nn))
+    P1 = build(lam, mesh_f.cells[:, :, None], mesh_c.cells[par][:, None, :], (mesh_f.nv, mesh_c.nv))
+    return P2, P1
+
+
+def prolongation(fed_c: FEData, fed_f: FEData):
+    """[u; p] interpolation (n_f x n_c) in the DEVICE orderings of both levels"""
+    P2, P1 = nodal_interpolation(fed_c.mesh, fed_f.mesh)
+    tc, tf, dc, df = fed_c.tables, fed_f.tables, fed_c.dofs, fed_f.dofs
+    nc, nf = dc.nu + dc.np, df.nu + df.np
+    P2 = P2.tocoo()
+    rows, cols, vals = [], [], []
+    for a in range(3):
+        r, c = tf.u_pos[P2.row, a], tc.u_pos[P2.col, a]
+        ok = (r >= 0) & (c >= 0)
+        rows.append(r[ok]); cols.append(c[ok]); vals.append(P2.data[ok])
+    # pressure: free coarse vertices -> all fine vertices, minus the value at the fine level's pinned vertex
+    free_c = np.nonzero(tc.p_pos >= 0)[0]
+    Pn = P1.tocsr()[:, free_c]                                       # nv_f x np_c
+    pinned = np.nonzero(tf.p_pos < 0)[0]
+    if len(pinned) != 1:
+        raise ValueError("prolongation: expected exactly one pinned pressure vertex")
+    shift = Pn[pinned[0]]
+    Pn = (Pn - sp.csr_matrix(np.ones((Pn.shape[0], 1))) @ shift).tocoo()
+    r, c = tf.p_pos[Pn.row], tc.p_pos[free_c][Pn.col]
+    ok = r >= 0
+    rows.append(r[ok]); cols.append(c[ok]); vals.append(Pn.data[ok])
+    P = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nf, nc))
+    P.eliminate_zeros()
+    P.sort_indices()
+    return P
+
+
+def node_block_inverse(F, n_full, n_surf):
+    """inverse of the node-block diagonal of the velocity block in the node-block DoF order of nupgcm_amd.fe:
+    3 x 3 blocks for the first n_full nodes, 2 x 2 for the next n_surf, 1 x 1 for the rest"""
+    F = sp.csr_matrix(F)
+    nu = F.shape[0]
+    rows, cols, vals = [], [], []
+    for start, count, sz in ((0, n_full, 3), (3 * n_full, n_surf, 2), (3 * n_full + 2 * n_surf, nu - 3 * n_full - 2 * n_surf, 1)):
+        if count == 0:
+            continue
+        st = start + sz * np.arange(count)
+        blk = np.empty((count, sz, sz))
+        for i in range(sz):
+            for j in range(sz):
+                blk[:, i, j] = np.asarray(F[st + i, st + j]).ravel()
+        inv = np.linalg.inv(blk)
+        for i in range(sz):
+            for j in range(sz):
+                rows.append(st + i); cols.append(st + j); vals.append(inv[:, i, j])
+    return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nu, nu))
+
+
+class MultigridPreconditioner(GeneralPreconditioner):
+    """MultigridPreconditioner(arch, params, forcings, hierarchy): hierarchy = [FEData coarse, ..., FEData fine], each the
+    red refinement of the one before (workloads.bowl_hierarchy); the last one is the model's own fe_data.  `A_fine` is the
+    solver's matrix (it may be stored by node blocks); the coarser operators are re-discretised on their own meshes."""
+
+    def __init__(self, arch, params, forcings, hierarchy, A_fine: DeviceCSR = None, omega=2.5, jacobi_weight=0.7,
+                 schur_sweeps=3, nu1=2, nu2=2, coarse_sweeps=20, block_nodes=None):
+        """A function-valued nu (full-stress form) is re-discretised on every level like a constant one.  With the eddy
+        closure on, `refresh(A)` (called by run! after each re-assembly of A, src/model.jl:160-170) rebuilds the FINEST level's
+        smoother from the new matrix; the coarser levels keep the operators of the set-up viscosity - a preconditioner need
+        not be exact, the Krylov method corrects for it."""
+        super().__init__(arch.ctx, L.NPG_PC_MG, len(hierarchy))
+        ctx = arch.ctx
+        self.levels = []
+        self._top = hierarchy[-1]
+        full = callable(forcings.nu) or forcings.eddy_param.is_on
+        prev = None
+        for lev, fed in enumerate(hierarchy):
+            d = fed.dofs
+            top = lev == len(hierarchy) - 1
+            A = build_A_inversion(arch, fed, params, forcings.nu, structural=full)   # plain CSR, [u; p] device order
+            G, D, Dinv, S = self._blocks(A, d)
+            nu = d.nu
+            if top and A_fine is not None:
+                A = A_fine
+            elif not full and (block_nodes if block_nodes is not None else A.shape[0] >= 100000):
+                A.block_nodes(d.n_full, d.n_surf)
+            dev = [A] + [DeviceCSR.from_scipy(ctx, M) for M in (G, D, Dinv, S)]
+            Pd = Rd = None
+            if prev is not None:
+                P = prolongation(prev, fed)
+                Pd, Rd = DeviceCSR.from_scipy(ctx, P), DeviceCSR.from_scipy(ctx, sp.csr_matrix(P.T))
+            self._keep += dev + [Pd, Rd]
+            L.check(L.lib().npg_precond_mg_set_level(self.h, lev, dev[0].h, int(nu), dev[1].h, dev[2].h, dev[3].h, dev[4].h,
+                                                     None if Pd is None else Pd.h, None if Rd is None else Rd.h))
+            self.levels.append(dict(n=d.nu + d.np, nu=nu, S_nnz=S.nnz))
+            prev = fed
+        self.set_params(omega, jacobi_weight, schur_sweeps, nu1, nu2, coarse_sweeps)
+
+    @staticmethod
+    def _blocks(A: DeviceCSR, d):
+        """G = A[u, p], D = A[p, u], Dinv = (node-block diagonal of A[u, u])^-1, S = D Dinv G from a plain-CSR device matrix"""
+        As = A.to_scipy_csr()
+        nu = d.nu
+        G, D = sp.csr_matrix(As[:nu, nu:]), sp.csr_matrix(As[nu:, :nu])
+        Dinv = node_block_inverse(As[:nu, :nu], d.n_full, d.n_surf)
+        S = sp.csr_matrix(D @ Dinv @ G)
+        S.sort_indices()
+        return G, D, Dinv, S
+
+    def refresh(self, A: DeviceCSR):
+        """the solver's matrix has been re-assembled (eddy closure): rebuild the finest level's smoother from it"""
+        top = len(self.levels) - 1
+        dev = [A] + [DeviceCSR.from_scipy(self.ctx, M) for M in self._blocks(A, self._top.dofs)]
+        L.check(L.lib().npg_precond_mg_update_level(self.h, top, *(m.h for m in dev)))
+        self._keep += dev                       # the old handles stay alive until the preconditioner goes (they are small)
+        return self
+
+    def set_params(self, omega=2.5, jacobi_weight=0.7, schur_sweeps=3, nu1=2, nu2=2, coarse_sweeps=20):
+        L.check(L.lib().npg_precond_mg_set_params(self.h, float(omega), float(jacobi_weight), int(schur_sweeps), int(nu1),
+                                                  int(nu2), int(coarse_sweeps)))
+        self.params = dict(omega=omega, jacobi_weight=jacobi_weight, schur_sweeps=schur_sweeps, nu1=nu1, nu2=nu2,
+                           coarse_sweeps=coarse_sweeps)
+
+    def __repr__(self):
+        return f"MultigridPreconditioner({[lv['n'] for lv in self.levels]}, {self.params})"
+
+
+class FgmresWorkspace:
+    """right-preconditioned flexible GMRES(memory) - npg_fgmres_*; the Krylov workspace for a GeneralPreconditioner"""
+
+    def __init__(self, ctx, n, memory=20):
+        h = C.c_void_p()
+        L.check(L.lib().npg_fgmres_create(ctx.h, int(n), int(memory), C.byref(h)))
+        self.h, self.ctx, self.n, self.memory = h, ctx, n, memory
+        self.x = DeviceVector(ctx, n)
+        self.stats = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.lib().npg_fgmres_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def solve(self, A: DeviceCSR, y: DeviceVector, x: DeviceVector, P, atol=1e-6, rtol=1e-6, itmax=0, scale=1.0,
+              **_ignored):
+        st = L.SolveStats()
+        L.check(L.lib().npg_fgmres_solve(self.h, A.h, None if P is None else P.h, y.h, x.h, float(scale), float(atol),
+                                         float(rtol), int(itmax), C.byref(st)))
+        self.stats = st.as_dict()
+        return self.stats
+
+    def history(self):
+        buf = np.empty(int(self.stats["niter"]) + 2 if self.stats else 2)
+        k = L.lib().npg_fgmres_history(self.h, L.ptr(buf), buf.size)
+        return buf[:max(k, 0)]

@@ -15,6 +15,20 @@ from .gmsh_io import GmshModel
 _E = np.array([[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]])
 
 
+# The eight children of refine_once in terms of the parent's vertices (model order): child k's vertex v is the midpoint of
+# parent vertices CHILD_VERTS[k][v] (a vertex itself when both coincide).  CHILD_BARY[k, v, :] are its barycentric
+# coordinates in the parent - what nupgcm_amd.multigrid needs to interpolate between the levels of a refinement hierarchy.
+_M01, _M02, _M03, _M12, _M13, _M23 = (0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)
+CHILD_VERTS = (((0, 0), _M01, _M02, _M03), (_M01, (1, 1), _M12, _M13), (_M02, _M12, (2, 2), _M23),
+               (_M03, _M13, _M23, (3, 3)), (_M01, _M02, _M03, _M13), (_M01, _M02, _M12, _M13),
+               (_M02, _M03, _M13, _M23), (_M02, _M12, _M13, _M23))
+CHILD_BARY = np.zeros((8, 4, 4))
+for _k, _kid in enumerate(CHILD_VERTS):
+    for _v, (_a, _b) in enumerate(_kid):
+        CHILD_BARY[_k, _v, _a] += 0.5
+        CHILD_BARY[_k, _v, _b] += 0.5
+
+
 def _mid_ids(nv, a, b):
     """ids of midpoint nodes for node pairs (a, b): returns (unique_keys, lookup(a, b) -> nv + index)"""
     lo, hi = np.minimum(a, b), np.maximum(a, b)

@@ -6,13 +6,14 @@ import os
 
 import numpy as np
 
-from . import gmsh_io, refine
+from . import channel_basin, gmsh_io, refine
 from .evolution import EvolutionToolkit
 from .fe import FEData, Mesh, Spaces
-from .inputs import Forcings, Parameters, SurfaceDirichletBC
+from .inputs import (ConvectionParameterization, EddyParameterization, Forcings, Parameters, SurfaceDirichletBC,
+                     SurfaceFluxBC)
 from .inversion import InversionToolkit
-from .model import Model
-from .timesteppers import BDF2
+from .model import Model, invert, set_b
+from .timesteppers import BDF1, BDF2
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
@@ -30,6 +31,15 @@ def bowl_mesh_model(label) -> gmsh_io.GmshModel:
     base, levels = BOWL_MESHES[label]
     m = gmsh_io.load_npz(os.path.join(_DATA, base + ".npz"))
     return refine.refine(m, levels, refine.bowl_projector(ALPHA)) if levels else m
+
+
+def bowl_hierarchy_models(label):
+    """[coarse, ..., fine] mesh models of a named bowl mesh: the committed base mesh and each of its red refinements"""
+    base, levels = BOWL_MESHES[label]
+    ms = [gmsh_io.load_npz(os.path.join(_DATA, base + ".npz"))]
+    for _ in range(levels):
+        ms.append(refine.refine_once(ms[-1], refine.bowl_projector(ALPHA)))
+    return ms
 
 
 def _H(x):
@@ -53,12 +63,98 @@ def example_fe_data(mesh_model):
     return FEData(mesh, spaces)
 
 
-def example_model(arch, label_or_model, dt=1e-3, t_stop=1e9, **inv_kw):
-    """The full model of examples/bowl_mixing.jl:171-190 on the named mesh (BDF2, dt = 1e-3)."""
-    mm = bowl_mesh_model(label_or_model) if isinstance(label_or_model, str) else label_or_model
-    fed = example_fe_data(mm)
+def example_model(arch, label_or_model, dt=1e-3, t_stop=1e9, preconditioner="diagonal", **inv_kw):
+    """The full model of examples/bowl_mixing.jl:171-190 on the named mesh (BDF2, dt = 1e-3).  preconditioner="multigrid"
+    (named meshes with at least one refinement level) builds the refinement hierarchy of the mesh for the inversion."""
     prm, frc = example_parameters()
+    if preconditioner == "multigrid":
+        hier = [example_fe_data(m) for m in bowl_hierarchy_models(label_or_model)]
+        if len(hier) < 2:
+            raise ValueError(f"{label_or_model}: a multigrid hierarchy needs a refined mesh")
+        fed = hier[-1]
+        inv_kw = dict(inv_kw, hierarchy=hier)
+    else:
+        mm = bowl_mesh_model(label_or_model) if isinstance(label_or_model, str) else label_or_model
+        fed = example_fe_data(mm)
     ts = BDF2(t_start=0.0, t_stop=t_stop, dt=dt)
-    inv = InversionToolkit(arch, fed, prm, frc, **inv_kw)
+    inv = InversionToolkit(arch, fed, prm, frc, preconditioner=preconditioner, **inv_kw)
     evo = EvolutionToolkit(arch, fed, prm, frc, ts)
     return Model(arch, prm, frc, fed, inv, evo, ts)
+
+
+# ---- BASELINE.json configs[4]: the channel-basin production configuration (scratch/run.jl) -------------------------------
+CB_ALPHA = 1 / 8
+
+
+def channel_basin_parameters(surface="flux"):
+    """(params, forcings, b_diri_tags, b_diri_vals, dt, b0) of /root/reference/scratch/run.jl:28-172: alpha = 1/8, f = y,
+    N2 = 0, function-valued nu = 1 (full-stress form), bottom-enhanced kappa (:107-113), wind stress (:114), convection and
+    eddy closures on (:119-121), dt = one day in units of t0 (:156).  surface="dirichlet": run.jl's SurfaceDirichletBC;
+    surface="flux": the BASELINE.json configs[4] variant with a SurfaceFluxBC and no buoyancy Dirichlet tags."""
+    Om = 2 * np.pi / 86400
+    a_e = 6.371e6
+    beta = 2 * Om / a_e
+    Ld = 2 * np.pi * a_e * 60 / 360
+    f0 = beta * Ld
+    H0, k0, Ke, N0, rho0, aT, g = 4e3, 1e-5, 1000.0, 1e-3, 1035.0, 2e-4, 9.81
+    nu0 = Ke * f0 ** 2 / N0 ** 2
+    tau0 = rho0 * N0 ** 2 * H0 ** 3 / Ld
+    b0s = g * aT * 30 / (N0 ** 2 * H0)
+    eps = np.sqrt(nu0 / f0 / H0 ** 2)
+    rho = (N0 * H0 / f0 / Ld) ** 2
+    mu_rho = nu0 / k0 * rho
+    t0 = 1 / f0 / rho
+    a = CB_ALPHA
+    H = lambda x: channel_basin.depth(x[..., 0], x[..., 1], a)
+    kI, kB, d = 1.0, 1e2, 500 / 4000 * a
+    kap = lambda x: kI + (kB - kI) * np.exp(-(x[..., 2] + H(x)) / d)
+    f = lambda x: x[..., 1]
+    tau_x = lambda x: np.where(x[..., 1] > -0.5, 0.0, -0.2 / tau0 * (x[..., 1] + 1) * (x[..., 1] + 0.5) / 0.25 ** 2)
+    b_surface = lambda x: np.where(x[..., 1] > 0, 0.0, -b0s * x[..., 1] ** 2)
+    prm = Parameters(eps=eps, alpha=a, mu_rho=mu_rho, N2=0.0, f=f, H=H)
+    conv = ConvectionParameterization(kappa_c=0.2 / k0, N2min=1e-3, is_on=True)
+    eddy = EddyParameterization(f=f, N2min=np.sqrt(1e-3), is_on=True)
+    nu = lambda x: 1.0 + 0 * x[..., 0]
+    b0 = lambda x: b0s * x[..., 2] / a + b_surface(x) * np.exp(x[..., 2] / (a / 4))
+    if surface == "dirichlet":
+        frc = Forcings(nu, kap, kap, tau_x, 0.0, SurfaceDirichletBC(b_surface), conv_param=conv, eddy_param=eddy)
+        return prm, frc, ["coastline", "surface"], [b_surface, b_surface], 86400 / t0, b0
+    frc = Forcings(nu, kap, kap, tau_x, 0.0, SurfaceFluxBC(lambda x: 1e-2 * b_surface(x)), conv_param=conv,
+                   eddy_param=eddy)
+    return prm, frc, [], [], 86400 / t0, b0
+
+
+def channel_basin_fe_data(mesh_model, surface="flux"):
+    """Spaces of scratch/run.jl:146-153: b_order = 1"""
+    _, _, btags, bvals, _, _ = channel_basin_parameters(surface)
+    mesh = Mesh(mesh_model)
+    spaces = Spaces(mesh, u_diri_tags=["bottom", "coastline", "surface"], u_diri_vals=[(0, 0, 0)] * 3,
+                    u_diri_masks=[(True, True, True), (True, True, True), (False, False, True)],
+                    b_diri_tags=btags, b_diri_vals=bvals, b_order=1)
+    return FEData(mesh, spaces)
+
+
+def channel_basin_model(arch, h=None, dz=None, mesh_model=None, surface="flux", itmax=1000, CFL_factor=0.8,
+                        element_precision="fp32", conv=None, eddy_N2min=None, atol=1e-6, rtol=1e-6, **inv_kw):
+    """The model of scratch/run.jl:146-172 on the structured-to-tet channel-basin mesh (nupgcm_amd.channel_basin): BDF1 with
+    the adaptive CFL step, itmax = 1000 for the inversion (:155), initial buoyancy (:169), inverted once (:171).
+    element_precision: "fp32" = configs[4]'s mixed mode (fp32 element-local arithmetic, fp64 accumulation and solves).
+    conv / eddy_N2min override the closure strengths (tests on coarse meshes)."""
+    mm = mesh_model if mesh_model is not None else channel_basin.channel_basin_model(h, CB_ALPHA, dz)
+    fed = channel_basin_fe_data(mm, surface)
+    prm, frc, _, _, dt, b0 = channel_basin_parameters(surface)
+    if conv is not None:
+        frc.conv_param = conv
+    if eddy_N2min is not None:
+        frc.eddy_param = EddyParameterization(f=frc.eddy_param.f, N2min=eddy_N2min, is_on=True)
+    ts = BDF1(t_start=0.0, t_stop=prm.mu_rho / prm.eps ** 2, dt=dt, adaptive=True, CFL_factor=CFL_factor)
+    from .inversion import device_fe
+    device_fe(arch, fed).set_precision(element_precision)
+    if inv_kw.get("preconditioner") == "multigrid" and "hierarchy" not in inv_kw:
+        inv_kw["hierarchy"] = [fed]             # no refinement hierarchy: the smoother alone preconditions
+    inv = InversionToolkit(arch, fed, prm, frc, itmax=itmax, atol=atol, rtol=rtol, **inv_kw)
+    evo = EvolutionToolkit(arch, fed, prm, frc, ts, atol=atol, rtol=rtol)
+    model = Model(arch, prm, frc, fed, inv, evo, ts)
+    set_b(model, b0)
+    invert(model)
+    return model

@@ -107,6 +107,11 @@ class Topo:
     edge_mask: np.ndarray     # (ne,)
     surf_faces: dict          # name -> (nf, dim) boundary facets carrying that name, node ids sorted ascending
     phys_names: list
+    # periodic meshes (meshes/channel_basin.jl:103-108, GridapGmsh glues the paired nodes into one vertex; NOT pinned by
+    # any reference fixture): coordinates of every cell's / boundary facet's own Gmsh nodes, and of every P2 edge node
+    cell_X: np.ndarray = None     # (nc, dim+1, 3)
+    surf_X: dict = None           # name -> (nf, dim, 3)
+    edge_mid: np.ndarray = None   # (ne, 3)
 
     @property
     def nv(self):
@@ -117,7 +122,7 @@ class Topo:
         return len(self.edges)
 
     def p2_coords(self):
-        return np.vstack([self.coords, 0.5 * (self.coords[self.edges[:, 0]] + self.coords[self.edges[:, 1]])])
+        return np.vstack([self.coords, self.edge_mid])
 
     def cell_p2_nodes(self):
         return np.hstack([self.cells, self.nv + self.cell_edges])
@@ -135,12 +140,29 @@ class Topo:
 def build_topo(model) -> Topo:
     """model: anything with the attributes of nupgcm_amd.gmsh_io.GmshModel (the fixtures are stored in that form)."""
     dim = int(model.dim)
-    cells = np.array(model.cells, dtype=np.int64)
+    geo = np.array(model.coords, dtype=float)
+    per = getattr(model, "periodic", None)
+    if per is None:
+        vert = np.arange(len(geo))
+        coords = geo
+    else:
+        # vertices = the master nodes in node order; a paired node is the same vertex as its master
+        masters = sorted(set(int(m) for m in per))
+        index = {m: i for i, m in enumerate(masters)}
+        vert = np.array([index[int(m)] for m in per], dtype=np.int64)
+        coords = geo[masters]
+    gcells = np.array(model.cells, dtype=np.int64)
+    cells = vert[gcells]
     if dim == 3:
-        cells = np.sort(cells, axis=1)          # GridapGmsh orients simplices by sorting node ids (3-D in 3-D only)
+        # GridapGmsh orients simplices by sorting vertex ids (3-D in 3-D only); the geometry follows the same order
+        order = np.argsort(cells, axis=1, kind="stable")
+        cells = np.take_along_axis(cells, order, axis=1)
+        gcells = np.take_along_axis(gcells, order, axis=1)
+    cell_X = geo[gcells]
     local = TET_EDGES if dim == 3 else TRI_EDGES
     edge_id: dict = {}
     edges = []
+    edge_mid = []
     cell_edges = np.zeros((len(cells), len(local)), dtype=np.int64)
     for c, cell in enumerate(cells):
         for k, (a, b) in enumerate(local):
@@ -148,6 +170,7 @@ def build_topo(model) -> Topo:
             if key not in edge_id:
                 edge_id[key] = len(edges)
                 edges.append(key)
+                edge_mid.append(0.5 * (cell_X[c, a] + cell_X[c, b]))
             cell_edges[c, k] = edge_id[key]
     edges = np.array(edges, dtype=np.int64)
 
@@ -155,13 +178,13 @@ def build_topo(model) -> Topo:
     # "interior" never appears in a Dirichlet tag list)
     edge_mask = np.zeros(len(edges), dtype=np.uint32)
     if dim == 3:
-        for tri, m in zip(model.facets, model.facets_phys):
+        for tri, m in zip(vert[np.asarray(model.facets, dtype=np.int64).reshape(-1, 3)], model.facets_phys):
             t = sorted(tri)
             for (a, b) in [(0, 1), (0, 2), (1, 2)]:
                 e = edge_id.get((t[a], t[b]))
                 if e is not None:
                     edge_mask[e] |= np.uint32(m)
-        for ln, m in zip(model.ridges, model.ridges_phys):
+        for ln, m in zip(vert[np.asarray(model.ridges, dtype=np.int64).reshape(-1, 2)], model.ridges_phys):
             e = edge_id.get((min(ln), max(ln)))
             if e is not None:
                 edge_mask[e] = np.uint32(m)
@@ -171,13 +194,19 @@ def build_topo(model) -> Topo:
             if e is not None:
                 edge_mask[e] = np.uint32(m)
 
-    surf = {}
+    surf, surf_X = {}, {}
+    gfac = np.asarray(model.facets, dtype=np.int64).reshape(-1, dim)
     for i, nm in enumerate(model.phys_names):
         sel = (np.asarray(model.facets_phys) >> i) & 1 == 1
         if sel.any():
-            surf[nm] = np.sort(np.asarray(model.facets)[sel], axis=1)
-    return Topo(dim, np.array(model.coords, dtype=float), cells, edges, cell_edges,
-                np.array(model.node_phys, dtype=np.uint32), edge_mask, surf, list(model.phys_names))
+            tf = vert[gfac[sel]]
+            order = np.argsort(tf, axis=1, kind="stable")
+            surf[nm] = np.take_along_axis(tf, order, axis=1)
+            surf_X[nm] = geo[np.take_along_axis(gfac[sel], order, axis=1)]
+    vmask = np.zeros(len(coords), dtype=np.uint32)
+    np.bitwise_or.at(vmask, vert, np.array(model.node_phys, dtype=np.uint32))
+    return Topo(dim, coords, cells, edges, cell_edges, vmask, edge_mask, surf, list(model.phys_names),
+                cell_X=cell_X, surf_X=surf_X, edge_mid=np.array(edge_mid).reshape(-1, 3))
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -194,14 +223,17 @@ class Spaces:
     nu: int
     np_: int
     nb: int
+    b_order: int = 2
 
 
-def build_spaces(topo: Topo, u_diri_tags, u_diri_masks, b_diri_tags=(), b_diri_fn=None) -> Spaces:
+def build_spaces(topo: Topo, u_diri_tags, u_diri_masks, b_diri_tags=(), b_diri_fn=None, b_order=2) -> Spaces:
     """src/spaces.jl:31-72.  DoFs: vertices first then edges, vector components interleaved per node; a DoF is
     Dirichlet iff its face carries a listed tag and that tag's component mask is true; pressure: zero-mean space =
-    last vertex fixed (src/dofs.jl:57)."""
+    last vertex fixed (src/dofs.jl:57).  b_order = 1 (src/spaces.jl:31-33, used by scratch/run.jl:152): buoyancy DoFs are
+    the vertices only (not pinned by any reference fixture; cross-checked against closed forms in the tests)."""
     nmask = topo.node_mask()
     nn = len(nmask)
+    nbn = nn if b_order == 2 else topo.nv
     diri_u = np.zeros((nn, 3), dtype=bool)
     for tag, cm in zip(u_diri_tags, u_diri_masks):
         has = (nmask >> topo.phys_names.index(tag)) & 1 == 1
@@ -213,15 +245,15 @@ def build_spaces(topo: Topo, u_diri_tags, u_diri_masks, b_diri_tags=(), b_diri_f
     u_dof[free] = np.arange(free.sum())          # C order = node-major, component-minor
     p_dof = np.arange(topo.nv, dtype=np.int64)
     p_dof[-1] = -1
-    diri_b = np.zeros(nn, dtype=bool)
+    diri_b = np.zeros(nbn, dtype=bool)
     for tag in b_diri_tags:
-        diri_b |= (nmask >> topo.phys_names.index(tag)) & 1 == 1
-    b_dof = np.full(nn, -1, dtype=np.int64)
+        diri_b |= (nmask[:nbn] >> topo.phys_names.index(tag)) & 1 == 1
+    b_dof = np.full(nbn, -1, dtype=np.int64)
     b_dof[~diri_b] = np.arange((~diri_b).sum())
-    b_diri = np.zeros(nn)
+    b_diri = np.zeros(nbn)
     if b_diri_fn is not None and diri_b.any():
-        b_diri[diri_b] = b_diri_fn(topo.p2_coords()[diri_b])
-    return Spaces(topo, u_dof, p_dof, b_dof, b_diri, int(free.sum()), topo.nv - 1, int((~diri_b).sum()))
+        b_diri[diri_b] = b_diri_fn(topo.p2_coords()[:nbn][diri_b])
+    return Spaces(topo, u_dof, p_dof, b_dof, b_diri, int(free.sum()), topo.nv - 1, int((~diri_b).sum()), b_order)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -238,7 +270,7 @@ class CellGeom:
 
 
 def cell_geometry(topo: Topo, quad=None) -> CellGeom:
-    X = topo.coords[topo.cells]                          # (nc, dim+1, 3)
+    X = topo.cell_X                                      # (nc, dim+1, 3): each cell's own nodes
     J = np.transpose(X[:, 1:, :] - X[:, :1, :], (0, 2, 1))   # (nc, 3, dim): columns = edge vectors
     if topo.dim == 3:
         detJ = np.abs(np.linalg.det(J))
@@ -286,6 +318,14 @@ class Oracle:
         self.wdet = self.geo.detJ[:, None] * self.geo.w[None, :]        # (nc, nq)
         self.cn2 = topo.cell_p2_nodes()                                 # (nc, n2)
         self.n2 = self.cn2.shape[1]
+        # buoyancy space: P2 (default) or P1 (b_order = 1)
+        if getattr(spaces, "b_order", 2) == 2:
+            self.Nbq, self.gradNb, self.cnb = self.N2q, self.gradN2, self.cn2
+        else:
+            self.Nbq = self.N1q
+            self.gradNb = np.broadcast_to(self.geo.G[:, None, :, :], (len(topo.cells), len(self.geo.w)) + self.geo.G.shape[1:])
+            self.cnb = topo.cells
+        self.nbl = self.cnb.shape[1]
 
     # -- inversion ------------------------------------------------------------------------------------------------
     def A_inversion(self, nu_q=None):
@@ -337,20 +377,20 @@ class Oracle:
         return _scatter_matrix(np.concatenate(rows), np.concatenate(cols), np.concatenate(vals), (N, N))
 
     def _B_full(self):
-        """(1/alpha) int phi_i phi_j per cell, to be scattered onto (u_z rows) x (b nodes)."""
-        return np.einsum("cq,qi,qj->cij", self.wdet, self.N2q, self.N2q) / self.alpha
+        """(1/alpha) int phi_i phib_j per cell, to be scattered onto (u_z rows) x (b nodes)."""
+        return np.einsum("cq,qi,qj->cij", self.wdet, self.N2q, self.Nbq) / self.alpha
 
     def B_inversion(self):
         """src/inversion.jl:199-219.  N x nb, columns in native b order; x/y rows stored as structural zeros."""
         s = self.sp
-        nc, n2 = len(self.topo.cells), self.n2
+        nc, n2, nbl = len(self.topo.cells), self.n2, self.nbl
         Bl = self._B_full()
         udof = s.u_dof[self.cn2]
-        bdof = s.b_dof[self.cn2]
+        bdof = s.b_dof[self.cnb]
         rows, cols, vals = [], [], []
         for a in range(3):
-            rows.append(np.broadcast_to(udof[:, :, None, a], (nc, n2, n2)).ravel())
-            cols.append(np.broadcast_to(bdof[:, None, :], (nc, n2, n2)).ravel())
+            rows.append(np.broadcast_to(udof[:, :, None, a], (nc, n2, nbl)).ravel())
+            cols.append(np.broadcast_to(bdof[:, None, :], (nc, n2, nbl)).ravel())
             vals.append((Bl if a == 2 else np.zeros_like(Bl)).ravel())
         return _scatter_matrix(np.concatenate(rows), np.concatenate(cols), np.concatenate(vals),
                                (s.nu + s.np_, s.nb))
@@ -360,7 +400,7 @@ class Oracle:
         s = self.sp
         out = np.zeros(s.nu + s.np_)
         Bl = self._B_full()
-        lift = np.einsum("cij,cj->ci", Bl, s.b_diri[self.cn2])
+        lift = np.einsum("cij,cj->ci", Bl, s.b_diri[self.cnb])
         dz = s.u_dof[self.cn2][:, :, 2]
         np.add.at(out, dz[dz >= 0], lift[dz >= 0])
         for comp, tau in ((0, self.tau_x), (1, self.tau_y)):
@@ -379,7 +419,7 @@ class Oracle:
         faces = t.surf_faces[name]                              # sorted node ids per face
         if t.dim == 3:
             lam, w = duffy3x3()
-            X = t.coords[faces]
+            X = t.surf_X[name]
             area2 = np.linalg.norm(np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), axis=1)
             N, _ = p2_basis(lam, TRI_EDGES)
             emap = {tuple(e): i for i, e in enumerate(map(tuple, t.edges))}
@@ -395,36 +435,36 @@ class Oracle:
     # -- evolution ------------------------------------------------------------------------------------------------
     def _b_matrix_and_lift(self, loc):
         s = self.sp
-        nc, n2 = len(self.topo.cells), self.n2
-        bdof = s.b_dof[self.cn2]
+        nc, n2 = len(self.topo.cells), self.nbl
+        bdof = s.b_dof[self.cnb]
         rows = np.broadcast_to(bdof[:, :, None], (nc, n2, n2)).ravel()
         cols = np.broadcast_to(bdof[:, None, :], (nc, n2, n2)).ravel()
         A = _scatter_matrix(rows, cols, loc.ravel(), (s.nb, s.nb))
         lift = np.zeros(s.nb)
-        lv = np.einsum("cij,cj->ci", loc, s.b_diri[self.cn2])
+        lv = np.einsum("cij,cj->ci", loc, s.b_diri[self.cnb])
         np.add.at(lift, bdof[bdof >= 0], lv[bdof >= 0])
         return A, lift
 
     def M(self):
         """src/evolution.jl:209-212."""
-        return self._b_matrix_and_lift(np.einsum("cq,qi,qj->cij", self.wdet, self.N2q, self.N2q))
+        return self._b_matrix_and_lift(np.einsum("cq,qi,qj->cij", self.wdet, self.Nbq, self.Nbq))
 
     def K_h(self, kappa=None):
         """src/evolution.jl:225-228."""
         kq = _const_or_fn(self.kappa_h if kappa is None else kappa, self.geo.xq)
-        g = self.gradN2[..., :2]
+        g = self.gradNb[..., :2]
         return self._b_matrix_and_lift(np.einsum("cq,cq,cqia,cqja->cij", self.wdet, kq, g, g))
 
     def K_v(self, kappa=None):
         """src/evolution.jl:243-246."""
         kq = _const_or_fn(self.kappa_v if kappa is None else kappa, self.geo.xq)
-        g = self.gradN2[..., 2]
+        g = self.gradNb[..., 2]
         return self._b_matrix_and_lift(np.einsum("cq,cq,cqi,cqj->cij", self.wdet, kq, g, g))
 
     def rhs_diff(self, kappa=None):
         """src/evolution.jl:269-278: -N2 int kappa_v d_z(d)."""
         kq = _const_or_fn(self.kappa_v if kappa is None else kappa, self.geo.xq)
-        loc = -self.N2 * np.einsum("cq,cq,cqi->ci", self.wdet, kq, self.gradN2[..., 2])
+        loc = -self.N2 * np.einsum("cq,cq,cqi->ci", self.wdet, kq, self.gradNb[..., 2])
         return self._to_b(loc)
 
     def rhs_flux(self):
@@ -434,11 +474,11 @@ class Oracle:
         full = self.surface_integral(lambda x: self.alpha * _const_or_fn(self.surface_flux, x))
         d = self.sp.b_dof
         out = np.zeros(self.sp.nb)
-        out[d[d >= 0]] = full[d >= 0]
+        out[d[d >= 0]] = full[:len(d)][d >= 0]
         return out
 
     def _to_b(self, loc):
-        bdof = self.sp.b_dof[self.cn2]
+        bdof = self.sp.b_dof[self.cnb]
         out = np.zeros(self.sp.nb)
         np.add.at(out, bdof[bdof >= 0], loc[bdof >= 0])
         return out
@@ -452,37 +492,37 @@ class Oracle:
 
     def u_nodal(self, u_free):
         s = self.sp
-        full = np.zeros((len(s.b_dof), 3))
+        full = np.zeros((len(s.u_dof), 3))
         m = s.u_dof >= 0
         full[m] = u_free[s.u_dof[m]]
         return full
 
     def interpolate_b(self, fn):
-        x = self.topo.p2_coords()
+        x = self.topo.p2_coords()[:len(self.sp.b_dof)]
         return fn(x)[self.sp.b_dof >= 0]
 
     def advection_rhs(self, b, b_prev, u, u_prev, dt, scheme="BDF2"):
         """src/model.jl:292-300 assembled over B_test (src/model.jl:271-273).  b, u: free-value vectors (native)."""
-        bn, bp = self.b_nodal(b)[self.cn2], self.b_nodal(b_prev)[self.cn2]            # (nc, n2)
+        bn, bp = self.b_nodal(b)[self.cnb], self.b_nodal(b_prev)[self.cnb]            # (nc, nbl)
         un, up = self.u_nodal(u)[self.cn2], self.u_nodal(u_prev)[self.cn2]            # (nc, n2, 3)
         if scheme == "BDF1":
-            bq = np.einsum("qi,ci->cq", self.N2q, bn)
-            gb = np.einsum("cqia,ci->cqa", self.gradN2, bn)
+            bq = np.einsum("qi,ci->cq", self.Nbq, bn)
+            gb = np.einsum("cqia,ci->cqa", self.gradNb, bn)
             uq = np.einsum("qi,cia->cqa", self.N2q, un)
             integrand = bq - dt * (np.einsum("cqa,cqa->cq", uq, gb) + uq[..., 2] * self.N2)
         else:
             bt, ut = 2 * bn - bp, 2 * un - up
-            bq = np.einsum("qi,ci->cq", self.N2q, 4.0 / 3.0 * bn - 1.0 / 3.0 * bp)
-            gb = np.einsum("cqia,ci->cqa", self.gradN2, bt)
+            bq = np.einsum("qi,ci->cq", self.Nbq, 4.0 / 3.0 * bn - 1.0 / 3.0 * bp)
+            gb = np.einsum("cqia,ci->cqa", self.gradNb, bt)
             uq = np.einsum("qi,cia->cqa", self.N2q, ut)
             integrand = bq - 2.0 / 3.0 * dt * (np.einsum("cqa,cqa->cq", uq, gb) + uq[..., 2] * self.N2)
-        loc = np.einsum("cq,cq,qi->ci", self.wdet, integrand, self.N2q)
+        loc = np.einsum("cq,cq,qi->ci", self.wdet, integrand, self.Nbq)
         return self._to_b(loc)
 
     # -- norms used by the reference's tests ----------------------------------------------------------------------
     def l2_sq_b(self, b_free_a, b_free_b=None):
         d = self.b_nodal(b_free_a) - (0 if b_free_b is None else self.b_nodal(b_free_b))
-        dq = np.einsum("qi,ci->cq", self.N2q, d[self.cn2])
+        dq = np.einsum("qi,ci->cq", self.Nbq, d[self.cnb])
         return float(np.einsum("cq,cq->", self.wdet, dq * dq))
 
     def l2_sq_u(self, u_free_a, u_free_b=None):
@@ -494,14 +534,19 @@ class Oracle:
     def precond_h(self):
         """src/inversion.jl:44-49 with src/meshes.jl:94-108: median length over the unique edges enumerated from the
         local pairs (1,2),(2,3),(3,1) only (vertex-4 edges are skipped - a quirk that only moves the scalar)."""
-        t = self.topo.cells
-        e = np.vstack([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]])
-        e = np.unique(np.sort(e, axis=1), axis=0)
-        hs = np.sort(np.linalg.norm(self.topo.coords[e[:, 0]] - self.topo.coords[e[:, 1]], axis=1))
+        t, X = self.topo.cells, self.topo.cell_X
+        seen, hs = set(), []
+        for (a, b) in ((0, 1), (1, 2), (2, 0)):
+            for c in range(len(t)):
+                key = (min(t[c, a], t[c, b]), max(t[c, a], t[c, b]))
+                if key not in seen:
+                    seen.add(key)
+                    hs.append(np.linalg.norm(X[c, a] - X[c, b]))
+        hs = np.sort(np.array(hs))
         return hs[len(hs) // 2 - 1], len(hs)
 
     def h_cells(self):
         """src/meshes.jl:127-134: longest edge per cell."""
-        X = self.topo.coords[self.topo.cells]
+        X = self.topo.cell_X
         d = np.linalg.norm(X[:, :, None, :] - X[:, None, :, :], axis=-1)
         return d.max(axis=(1, 2))

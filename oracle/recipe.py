@@ -39,6 +39,7 @@ def load_mesh(name):
     m.dim = int(z["dim"])
     for k in ("coords", "node_phys", "cells", "facets", "facets_phys", "ridges", "ridges_phys"):
         setattr(m, k, z[k])
+    m.periodic = z["periodic"] if "periodic" in z.files else None
     m.phys_names = json.loads(bytes(z["phys_names"]).decode())
     return m
 
@@ -49,6 +50,56 @@ def _H(x, alpha):
 
 def _kappa_bottom(alpha):
     return lambda x: 1e-2 + np.exp(-(x[..., 2] + _H(x, alpha)) / (0.1 * alpha))
+
+
+def channel_basin_depth(x, alpha):
+    """H((x, y, z)) of /root/reference/scratch/run.jl:54-97 (geom = :tub): channel of depth alpha W shoaling to the sill at
+    y = -L/2 + L/4, basin alpha W (1 - ((x - W/2)/(W/2))^2), revolved parabola at the northern end; L = 2, W = 1."""
+    X, Y = x[..., 0], x[..., 1]
+    L, W = 2.0, 1.0
+    Lc = L / 4
+    Lf = 5 * Lc / 8
+    H0 = alpha * W
+    par = lambda s_, smax, szero: H0 * (1 - ((s_ - smax) / (szero - smax)) ** 2)
+    Hb = par(X, W / 2, 0.0)
+    Hc = np.where(Y <= -L / 2 + Lf, H0, par(Y, -L / 2 + Lf, -L / 2 + Lc))
+    r = np.sqrt((X - W / 2) ** 2 + (Y - (L / 2 - W / 2)) ** 2)
+    H = np.where(Y <= -L / 2 + Lc, np.maximum(Hc, Hb), np.where(Y <= L / 2 - W / 2, Hb, par(r, 0.0, W / 2)))
+    return np.maximum(H, 0.0)
+
+
+def channel_basin_config(surface="flux"):
+    """Parameters of /root/reference/scratch/run.jl:28-172 (the production channel-basin run): alpha = 1/8, f = y,
+    N2 = 0, P1 buoyancy, function-valued nu = 1 (hence the full-stress form), bottom-enhanced kappa, wind stress (:114),
+    convection + eddy closures (:119-120), BDF1 with the adaptive CFL step (CFL_factor 0.8, :158).  surface="dirichlet" is
+    run.jl's SurfaceDirichletBC (:116-118); surface="flux" is the BASELINE.json configs[4] variant, which swaps in a
+    SurfaceFluxBC (no buoyancy Dirichlet tags)."""
+    Om = 2 * np.pi / 86400
+    a_e = 6.371e6
+    beta = 2 * Om / a_e
+    Ld = 2 * np.pi * a_e * 60 / 360
+    f0 = beta * Ld
+    H0, k0, Ke, N0, rho0, aT, g = 4e3, 1e-5, 1000.0, 1e-3, 1035.0, 2e-4, 9.81
+    nu0 = Ke * f0 ** 2 / N0 ** 2
+    tau0 = rho0 * N0 ** 2 * H0 ** 3 / Ld
+    b0s = g * aT * 30 / (N0 ** 2 * H0)
+    eps = np.sqrt(nu0 / f0 / H0 ** 2)
+    mu_rho = (nu0 / k0) * (N0 * H0 / f0 / Ld) ** 2
+    t0 = 1 / f0 / (N0 * H0 / f0 / Ld) ** 2
+    alpha = 1 / 8
+    kI, kB, d = 1.0, 1e2, 500 / 4000 * alpha
+    kap = lambda x: kI + (kB - kI) * np.exp(-(x[..., 2] + channel_basin_depth(x, alpha)) / d)
+    b_surface = lambda x: np.where(x[..., 1] > 0, 0.0, -b0s * x[..., 1] ** 2)
+    cfg = dict(eps=eps, alpha=alpha, mu_rho=mu_rho, N2=0.0, f=lambda x: x[..., 1], nu=lambda x: 1.0 + 0 * x[..., 0],
+               kappa=kap, tau_x=lambda x: np.where(x[..., 1] > -0.5, 0.0,
+                                                   -0.2 / tau0 * (x[..., 1] + 1) * (x[..., 1] + 0.5) / 0.25 ** 2),
+               b_order=1, dt=86400 / t0, conv=(0.2 / k0, 1e-3), eddy=(np.sqrt(1e-3), 10.0, 1.0), cfl_factor=0.8,
+               b0=lambda x: b0s * x[..., 2] / alpha + b_surface(x) * np.exp(x[..., 2] / (alpha / 4)))
+    if surface == "dirichlet":
+        cfg.update(b_diri_tags=["coastline", "surface"], b_diri_fn=b_surface)
+    else:
+        cfg.update(b_diri_tags=[], b_diri_fn=None, surface_flux=lambda x: 1e-2 * b_surface(x))
+    return cfg
 
 
 U_TAGS = ["bottom", "coastline", "surface"]
@@ -106,18 +157,23 @@ class System:
 
 def setup(name, mesh="mesh_bowl3D_h0.1", model=None, **override) -> System:
     """model: an already loaded / refined mesh model (anything with GmshModel's attributes) instead of a fixture name"""
-    cfg = dict(CONFIGS[name])
+    if name.startswith("channel_basin"):
+        cfg = channel_basin_config("dirichlet" if name.endswith("dirichlet") else "flux")
+    else:
+        cfg = dict(CONFIGS[name])
     cfg.update(override)
     topo = fo.build_topo(load_mesh(mesh) if model is None else model)
-    spc = fo.build_spaces(topo, U_TAGS, U_MASKS, cfg["b_diri_tags"], cfg["b_diri_fn"])
-    kap = _kappa_bottom(cfg["alpha"]) if cfg["kappa"] == "bottom" else cfg["kappa"]
+    spc = fo.build_spaces(topo, U_TAGS, U_MASKS, cfg["b_diri_tags"], cfg["b_diri_fn"], b_order=cfg.get("b_order", 2))
+    kap = _kappa_bottom(cfg["alpha"]) if isinstance(cfg["kappa"], str) else cfg["kappa"]
     orc = fo.Oracle(topo, spc, eps=cfg["eps"], alpha=cfg["alpha"], mu_rho=cfg["mu_rho"], N2=cfg["N2"], f=cfg["f"],
                     nu=cfg["nu"], kappa_h=kap, kappa_v=kap, tau_x=cfg.get("tau_x", 0.0), tau_y=cfg.get("tau_y", 0.0),
                     surface_flux=cfg.get("surface_flux"))
     M, rM = orc.M()
     Kh, rh = orc.K_h()
     Kv, rv = orc.K_v()
-    return System(name, orc, cfg, orc.A_inversion(), orc.B_inversion(), orc.b_inversion(), M, Kh, Kv, rM, rh, rv,
+    # a function-valued nu selects the full-stress form (src/inversion.jl:172-181)
+    A = orc.A_inversion(nu_q=fo._const_or_fn(cfg["nu"], orc.geo.xq)) if callable(cfg["nu"]) else orc.A_inversion()
+    return System(name, orc, cfg, A, orc.B_inversion(), orc.b_inversion(), M, Kh, Kv, rM, rh, rv,
                   orc.rhs_diff(), orc.rhs_flux(), float(cfg["dt"]))
 
 
@@ -176,8 +232,8 @@ def run(sysm: System, nsteps, solver="direct", first_step_lhs="bdf1", invert_fir
 
     def alpha_bz(bv):
         """alpha d_z(N2 z + b) at the quadrature points (src/model.jl:229, 163)"""
-        bn = orc.b_nodal(bv)[orc.cn2]
-        return orc.alpha * (orc.N2 + np.einsum("cqi,ci->cq", orc.gradN2[..., 2], bn))
+        bn = orc.b_nodal(bv)[orc.cnb]
+        return orc.alpha * (orc.N2 + np.einsum("cqi,ci->cq", orc.gradNb[..., 2], bn))
 
     kv0_q = None
     if conv is not None:                            # (kappa_c, N2min): src/inputs.jl:87-91
