@@ -35,73 +35,94 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("NPG_BENCH_WORKLOAD", "bowl3D_h0.02"))
     ap.add_argument("--dt", type=float, default=1e-3)
+    ap.add_argument("--preconditioner", default="diagonal", choices=["diagonal", "multigrid"],
+                    help="inversion preconditioner: the reference's Diagonal(1/h^3) (default; the headline configuration) or "
+                         "the multigrid V-cycle behind flexible GMRES (refined bowl meshes)")
     ap.add_argument("--reorth-eta", type=float, default=None, help="override the GMRES second-pass threshold")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-multigrid", action="store_true", help="skip the extra multigrid-preconditioned run")
     ap.add_argument("--no-profile-pass", action="store_true",
                     help="skip the HIP-event profile pass (use when the whole run is under rocprofv3)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU budget of the cpu_baseline sample")
     return ap.parse_args()
 
 
+PMC_FILE = "profiles/r01_pmc.json"
+
+
 def pmc_traffic(workload, kernel="k_gmres_arnoldi"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc.json, made by
-    tools/pmc_probe.py + tools/pmc_summary.py on this workload; FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
-    correction applied as described in profiles/README.md).  None when no counters were collected for the workload."""
-    p = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (a builder run, not this run:
+    profiles/r01_pmc.json, made by tools/pmc_probe.py + tools/pmc_summary.py on this workload; FETCH_SIZE / WRITE_SIZE in
+    separate passes, gfx950 correction applied as described in profiles/README.md) - the line says so in `traffic_source`.
+    None when no counters were collected for the workload."""
+    p = os.path.join(ROOT, PMC_FILE)
     if not os.path.exists(p):
         return None
     rec = json.load(open(p)).get(workload, {}).get(kernel)
     return None if rec is None else rec["traffic_bytes_per_launch"]
 
 
-def cpu_baseline(workload, mesh_model, dt, its_per_step, budget, A_host=None, h=None):
-    """The oracle on this host's cores, bounded sample.  Meshes small enough for a sparse LU run the reference's CPU()
-    path proper (direct solves, src/iterative_solvers.jl:42-55); larger ones time the host Krylov branch
-    (src/iterative_solvers.jl:58 via InversionToolkit(CPU(), A, Diagonal(1/h^3), B, b)) per GMRES iteration and scale by
-    the iterations a step needs."""
-    from threadpoolctl import threadpool_limits
+def cpu_baseline(workload, mesh_model, dt, gm_its, cg_its, budget, A_host=None, h=None, ncell=None):
+    """The reference's CPU path on THIS host's cores, bounded sample (a reported baseline, not the target).
 
-    from oracle import krylov_oracle as ko
+    Meshes small enough for a sparse LU run the reference's CPU() path proper: the oracle's direct-solve recipe (advection
+    assembly + two sparse-LU back-substitutions per step, src/iterative_solvers.jl:42-55; numpy + SuperLU, effectively one
+    core).  Larger ones cannot be factorised (fill-in: ten minutes and 7.5 GB already at 135 k unknowns), so what is timed
+    is the host Krylov branch the reference takes there (src/iterative_solvers.jl:58 through
+    InversionToolkit(CPU(), A, Diagonal(1/h^3), B, b)): oracle/krylov_c.c, an OpenMP restatement of Krylov.jl's GMRES(20) /
+    CG on ALL cores, per iteration on the workload's own matrices, times the iterations a timestep needs (the GPU run's
+    counts - same algorithm, same stopping rule), plus the advection assembly measured per cell on the base mesh."""
+    import scipy.sparse as sp
+
+    from oracle import krylov_c as kc
     from oracle import recipe as rc
-    with threadpool_limits(limits=1):
-        if A_host is not None and A_host.shape[0] > 40000:
-            # large mesh: the oracle's dense-per-cell numpy assembly would need tens of GB; time the oracle's GMRES on the
-            # same matrix (assembled by the product, downloaded) - the matrix is an input here, the solver is the port
-            y = np.sin(np.arange(A_host.shape[0], dtype=float)) * 1e-3
-            t0 = time.perf_counter()
-            its = 0
-            while time.perf_counter() - t0 < budget:
-                _, st = ko.gmres(A_host, y, M=1 / h ** 3, itmax=20)
-                its += st["niter"]
-            per_it = (time.perf_counter() - t0) / its
-            return dict(value=1.0 / (per_it * max(its_per_step, 1)), unit="timesteps/s", cores=1, kind="port",
-                        sample=f"{its} GMRES(20) iterations of the oracle's host Krylov path (scipy CSR SpMV + numpy "
-                               f"MGS, the reference's large-system branch src/iterative_solvers.jl:58) on the {workload} "
-                               f"inversion matrix: {per_it * 1e3:.0f} ms/iteration, scaled to the {its_per_step:.0f} "
-                               f"iterations a timestep took on the GPU; evolution solve and assembly not included")
+    cores = kc.usable_cores()
+    if cores > 32 and not os.environ.get("NPG_CPU_CORES"):
+        cores = 16          # no cgroup quota visible but the box's share for a one-GPU job is 16 cores: do not oversubscribe
+    cores = int(os.environ.get("NPG_CPU_CORES", cores))
+    kc.set_threads(cores)
+    if A_host is None:
         S = rc.setup("example", model=mesh_model, dt=dt)
-        N = S.A.shape[0]
-        if N <= 40000:
-            timer = {}
-            rc.run(S, 1, timer=timer)                    # includes the LU factorisations outside the timed loop
-            per = max(timer["loop_seconds"], 1e-3)
-            n = int(max(2, min(50, budget / per)))
-            rc.run(S, n, timer=timer)
-            return dict(value=n / timer["loop_seconds"], unit="timesteps/s", cores=1, kind="port",
-                        sample=f"{n} timesteps of the oracle's direct-solve path (reference CPU() recipe: advection "
-                               f"assembly + 2 sparse-LU solves per step, factorisation excluded) on {workload}")
-        h, _ = S.orc.precond_h()
-        y = S.B @ (0.01 * np.sin(np.arange(S.B.shape[1]))) + S.b0
-        t0 = time.perf_counter()
-        its = 0
-        while time.perf_counter() - t0 < budget:
-            _, st = ko.gmres(S.A, y, M=1 / h ** 3, itmax=20)
-            its += st["niter"]
-        per_it = (time.perf_counter() - t0) / its
-        return dict(value=1.0 / (per_it * max(its_per_step, 1)), unit="timesteps/s", cores=1, kind="port",
-                    sample=f"{its} GMRES(20) iterations of the oracle's host Krylov path on {workload} "
-                           f"({per_it * 1e3:.1f} ms/iteration), scaled to the {its_per_step:.0f} iterations a timestep took "
-                           f"on the GPU; evolution solve and assembly not included")
+        timer = {}
+        rc.run(S, 1, timer=timer)                    # includes the LU factorisations outside the timed loop
+        per = max(timer["loop_seconds"], 1e-3)
+        n = int(max(2, min(50, budget / per)))
+        rc.run(S, n, timer=timer)
+        return dict(value=n / timer["loop_seconds"], unit="timesteps/s", cores=1, host_cores=cores, kind="port",
+                    sample=f"{n} timesteps of the oracle's direct-solve path (reference CPU() recipe: advection "
+                           f"assembly + 2 sparse-LU solves per step, factorisation excluded; numpy + SuperLU, one core) "
+                           f"on {workload}")
+    n = A_host.shape[0]
+    y = np.sin(np.arange(n, dtype=float)) * 1e-3
+    t0 = time.perf_counter()
+    its = 0
+    while time.perf_counter() - t0 < 0.6 * budget:
+        _, st = kc.gmres(A_host, y, M=1 / h ** 3, itmax=40)
+        its += st["niter"]
+    per_gm = (time.perf_counter() - t0) / its
+    # evolution CG and advection assembly on the base mesh of the hierarchy (cost per row / per cell carries over)
+    S = rc.setup("example", model=mesh_model, dt=dt)
+    Ab = (S.M + S.theta("BDF2") * (S.Kh + S.Kv)).tocsr()
+    rhs = S.M @ np.ones(Ab.shape[0])
+    t1 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t1 < 0.1 * budget:
+        _, sc = kc.cg(Ab, rhs, M=1 / Ab.diagonal(), itmax=10)
+        reps += sc["niter"]
+    per_cg_row = (time.perf_counter() - t1) / reps / Ab.shape[0]
+    b0 = np.sin(np.arange(S.orc.sp.nb, dtype=float))
+    u0 = np.cos(np.arange(S.orc.sp.nu, dtype=float))
+    t2 = time.perf_counter()
+    S.orc.advection_rhs(b0, b0, u0, u0, dt, "BDF2")
+    per_cell = (time.perf_counter() - t2) / len(S.orc.topo.cells)
+    nb_big = int(round(Ab.shape[0] * ncell / len(S.orc.topo.cells)))
+    step = per_gm * np.mean(gm_its) + per_cg_row * nb_big * np.mean(cg_its) + per_cell * ncell
+    return dict(value=1.0 / step, unit="timesteps/s", cores=cores, kind="port",
+                sample=f"host Krylov branch of the reference (src/iterative_solvers.jl:58) restated in C + OpenMP on {cores} "
+                       f"cores: {its} GMRES(20) iterations on the {workload} inversion matrix = {per_gm * 1e3:.1f} ms/iteration "
+                       f"x {np.mean(gm_its):.0f} iterations per timestep (the GPU run's count: same algorithm and stopping "
+                       f"rule), + Jacobi-CG {per_cg_row * nb_big * 1e3:.2f} ms/iteration x {np.mean(cg_its):.0f} and the "
+                       f"advection assembly {per_cell * ncell:.2f} s (numpy, per-cell cost measured on the base mesh)")
 
 
 def main():
@@ -131,15 +152,32 @@ def main():
     arch = npg.GPU(int(os.environ.get("NPG_FORCE_DEVICE", local)))     # NPG_FORCE_DEVICE: rehearse N ranks on one GPU
     ctx = arch.ctx
     t_setup = time.time()
-    mesh_model = workloads.bowl_mesh_model(a.workload)
-    if world > 1 or force_dist:
+    channel = a.workload.startswith("channel_basin")
+    if channel:
+        # BASELINE.json configs[4]: "channel_basin_h<h>[_dirichlet]" - scratch/run.jl on the structured-to-tet periodic mesh
+        from nupgcm_amd import channel_basin
+        parts = a.workload.split("_")
+        hh = float(parts[2][1:])
+        mesh_model = channel_basin.channel_basin_model(hh, workloads.CB_ALPHA)
+    else:
+        mesh_model = workloads.bowl_mesh_model(a.workload)
+    if channel:
+        if world > 1:
+            raise SystemExit("the channel-basin workload runs on one GPU in this round")
+        model = workloads.channel_basin_model(arch, mesh_model=mesh_model,
+                                              surface="dirichlet" if a.workload.endswith("dirichlet") else "flux")
+    elif world > 1 or force_dist:
         from nupgcm_amd import distributed
         model = distributed.example_model(arch, mesh_model, dist, dt=a.dt)
     else:
         kw = {} if a.reorth_eta is None else {"reorth_eta": a.reorth_eta}
-        model = workloads.example_model(arch, mesh_model, dt=a.dt, **kw)
+        if a.preconditioner == "multigrid":
+            model = workloads.example_model(arch, a.workload, dt=a.dt, preconditioner="multigrid", **kw)
+        else:
+            model = workloads.example_model(arch, mesh_model, dt=a.dt, **kw)
     d = model.fe_data.dofs
-    npg.invert(model)                                     # examples/bowl_mixing.jl:194
+    if not channel:
+        npg.invert(model)                                 # examples/bowl_mixing.jl:194 (the channel model is built inverted)
     ctx.sync()
     t_setup = time.time() - t_setup
 
@@ -171,7 +209,7 @@ def main():
     N, nnz = A.shape[0], A.nnz
     ws = model.inversion.solver.workspace
     ms_total, launches = 0.0, 0
-    if not a.no_profile_pass:
+    if not a.no_profile_pass and hasattr(ws, "set_profile"):
         ws.set_profile(True)
         npg.run(model, n_steps=1)
         ms_total, launches = ws.get_profile()
@@ -182,7 +220,10 @@ def main():
         avg_ms = ms_total / launches
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
         roofline = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                        traffic=pmc_traffic(a.workload), kernel="k_gmres_arnoldi (Givens prologue + CSR-stream SpMV"
+                        traffic=pmc_traffic(a.workload),
+                        traffic_source=(f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier builder "
+                                        "run on this workload, not measured in this run)"
+                                        if pmc_traffic(a.workload) is not None else None), kernel="k_gmres_arnoldi (Givens prologue + CSR-stream SpMV"
                         + (")" if N >= 8192 else " + fused Gram-Schmidt dots)"),
                         avg_launch_us=avg_ms * 1e3, launches=launches, algorithmic_bytes_per_launch=alg_bytes,
                         cache_resident=bool(alg_bytes < 256 * 2 ** 20))
@@ -209,29 +250,63 @@ def main():
         "value": a.steps / elapsed, "unit": "timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{a.workload}: example parameters of examples/bowl_mixing.jl (eps=0.2, alpha=1/2, "
-                               f"mu_rho=1, N2=2, BDF2 dt={a.dt:g}), full evolve!+invert! timestep loop",
+        "config": {"workload": (f"{a.workload}: production parameters of scratch/run.jl (alpha=1/8, f=y, P1 buoyancy, nu(x) -> "
+                                f"full-stress form, convection + eddy closures, wind, BDF1 with the adaptive CFL step, "
+                                f"GMRES itmax=1000) on the x-periodic structured-to-tet channel-basin mesh; element kernels "
+                                f"{model.evolution.fe.precision}-local / fp64-accumulate, fp64 solves" if channel else
+                                f"{a.workload}: example parameters of examples/bowl_mixing.jl (eps=0.2, alpha=1/2, "
+                                f"mu_rho=1, N2=2, BDF2 dt={a.dt:g}), full evolve!+invert! timestep loop"),
                    "tets": int(model.fe_data.mesh.ncell), "nu": int(d.nu), "np": int(d.np), "nb": int(d.nb),
                    "N_inversion": int(N), "nnz_A": int(nnz), "node_block_storage": bool(getattr(A, "paired", False)),
                    "full_nodes": int(d.n_full), "surface_nodes": int(d.n_surf), "gmres_iterations_per_step": gm_its,
                    "cg_iterations_per_step": cg_its, "gmres_second_gs_passes_per_step": [s[1]["nreorth"] for s in stats],
-                   "gmres_memory": 20, "atol": 1e-6, "rtol": 1e-6,
+                   "inversion_seconds_per_step": [round(s[1]["seconds"], 4) for s in stats],
+                   "gmres_memory": 20, "atol": 1e-6, "rtol": 1e-6, "gmres_itmax": model.inversion.solver.kwargs["itmax"],
+                   "all_solved": all(s[1]["solved"] == 1 for s in stats), "preconditioner": repr(model.inversion.solver.P),
                    "setup_seconds": round(t_setup, 1), "parallelism": f"row-partitioned x{world}" if world > 1 else "1 GPU"},
         "roofline": roofline,
         "spmv_standalone": {"avg_launch_us": spmv_ms * 1e3, "GBps": alg_bytes / (spmv_ms * 1e-3) / 1e9},
     }
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    # ---- the same loop with the multigrid-preconditioned inversion (new work; the headline above stays the reference's
+    # configuration): refined bowl meshes on one GPU
+    if (rank == 0 and world == 1 and not channel and a.preconditioner == "diagonal" and not a.no_multigrid
+            and workloads.BOWL_MESHES[a.workload][1] >= 1):
+        t_mg = time.time()
+        mg = workloads.example_model(arch, a.workload, dt=a.dt, preconditioner="multigrid")
+        npg.invert(mg)
+        ctx.sync()
+        t_mg = time.time() - t_mg
+        npg.run(mg, n_steps=max(a.warmup, 1))
+        ctx.sync()
+        k = max(a.steps, 5)
+        t0 = time.perf_counter()
+        npg.run(mg, n_steps=k)
+        ctx.sync()
+        el = time.perf_counter() - t0
+        st = mg.stats[-k:]
+        out["multigrid"] = {
+            "what": "the same timestep loop with the inversion preconditioned by a geometric multigrid V-cycle behind "
+                    "flexible GMRES(20), same stopping rule (csrc/mg.hip)",
+            "value": k / el, "unit": "timesteps/s", "steps": k, "ms_per_step": 1e3 * el / k,
+            "speedup_vs_headline": (k / el) / out["value"],
+            "fgmres_iterations_per_step": [x[1]["niter"] for x in st], "all_solved": all(x[1]["solved"] == 1 for x in st),
+            "inversion_ms_per_step": [round(1e3 * x[1]["seconds"], 2) for x in st],
+            "preconditioner": repr(mg.inversion.solver.P), "setup_seconds": round(t_mg, 1)}
+        del mg
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not channel:
         big = N > 40000
         A_host = None
+        base_model = mesh_model
         if big:
             # the solver's A may be stored by node blocks; the oracle gets a plain CSR copy assembled afresh
             A_plain = A if not getattr(A, "paired", False) else npg.build_A_inversion(arch, model.fe_data, model.params,
                                                                                       model.forcings.nu)
             A_host = A_plain.to_scipy_csr()
             del A_plain
-        out["cpu_baseline"] = cpu_baseline(a.workload, mesh_model, a.dt, float(np.mean(gm_its)), a.cpu_seconds,
-                                           A_host=A_host,
-                                           h=model.fe_data.mesh.median_edge_length() if big else None)
+            base_model = workloads.bowl_hierarchy_models(a.workload)[0]
+        out["cpu_baseline"] = cpu_baseline(a.workload, base_model, a.dt, gm_its, cg_its, a.cpu_seconds, A_host=A_host,
+                                           h=model.fe_data.mesh.median_edge_length() if big else None,
+                                           ncell=int(model.fe_data.mesh.ncell))
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -920,7 +920,11 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     NPG_HIP(hipMemcpyAsync(ws->C, ws->h_C, sizeof(Snap), hipMemcpyHostToDevice, st));
     NPG_HIP(hipStreamSynchronize(st));      // h_C[0] is reused below as a result slot
 
-    static const int eager = getenv("NPG_GMRES_EAGER") ? atoi(getenv("NPG_GMRES_EAGER")) : 0;
+    // Under rocprofv3's kernel tracer (ROCm 7.2) relaunching the per-cycle hipGraphs segfaults inside hipGraphLaunch, in the
+    // tool library's packet interception (backtrace: profiles/r02_rocprofv3_graph_crash.txt; the same command with eager
+    // launches profiles cleanly) - so a traced process launches eagerly.  rocprofv3 marks its child with these variables.
+    static const int traced = getenv("ROCPROFILER_LIBRARY_CTOR") || getenv("ROCPROF_OUTPUT_PATH") || getenv("ROCP_TOOL_LIBRARIES");
+    static const int eager = getenv("NPG_GMRES_EAGER") ? atoi(getenv("NPG_GMRES_EAGER")) : traced;
     static const int trace = getenv("NPG_GMRES_TRACE") ? atoi(getenv("NPG_GMRES_TRACE")) : 0;
 
     // (re)capture the per-cycle graphs when any baked-in argument changed

@@ -84,3 +84,27 @@ def test_K4_reference_bar(name, fixture, eu_max, eb_max, golden_dir):
     eu = S.orc.l2_sq_u(u, z["u"]) / S.orc.l2_sq_u(z["u"])
     eb = S.orc.l2_sq_b(b, z["b"]) / S.orc.l2_sq_b(z["b"])
     assert eu < eu_max < 1e-3 + 1e-12 and eb < eb_max < 1e-3 + 1e-12
+
+
+def test_c_openmp_krylov_restatement_matches_the_numpy_oracle():
+    """oracle/krylov_c.c (the all-cores CPU baseline of bench.py) takes the same iterates as oracle/krylov_oracle.py"""
+    import os
+    import subprocess
+
+    from oracle import krylov_c as kc
+    from oracle import krylov_oracle as ko
+    subprocess.run(["make", "-C", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")],
+                   check=True, capture_output=True)
+    S = rc.setup("bowl_surface_flux")
+    h, _ = S.orc.precond_h()
+    y = S.B @ S.orc.interpolate_b(S.cfg["b0"]) + S.b0
+    x0 = 1e-3 * np.sin(np.arange(len(y)))
+    x1, s1 = ko.gmres(S.A, y, x0=x0, M=1 / h ** 3, itmax=130)
+    x2, s2 = kc.gmres(S.A, y, x0=x0, M=1 / h ** 3, itmax=130)
+    assert s1["niter"] == s2["niter"] == 130 and not s2["solved"]
+    assert np.allclose(s1["residuals"], s2["residuals"], rtol=1e-9) and np.linalg.norm(x1 - x2) < 1e-12 * np.linalg.norm(x1)
+    A = (S.M + 0.01 * (S.Kh + S.Kv)).tocsr()
+    b = S.M @ np.ones(A.shape[0])
+    x1, s1 = ko.cg(A, b, M=1 / A.diagonal())
+    x2, s2 = kc.cg(A, b, M=1 / A.diagonal())
+    assert s1["niter"] == s2["niter"] and s2["solved"] and np.linalg.norm(x1 - x2) < 1e-12 * np.linalg.norm(x1)

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Parameter sweep of the multigrid-preconditioned inversion on a refined bowl mesh: iterations and milliseconds per solve
+(cold start, reference stopping rule) for V-cycle / smoother settings.  Usage: python tools/mg_sweep.py [workload]"""
+import itertools
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import nupgcm_amd as npg  # noqa: E402
+from nupgcm_amd import workloads  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "bowl3D_h0.02"
+arch = npg.GPU(0)
+t0 = time.time()
+m = workloads.example_model(arch, wl, preconditioner="multigrid")
+prm = m.params
+npg.set_b(m, lambda x: 0.1 * np.exp(-(x[..., 2] + prm.H(x)) / (0.1 * prm.alpha)))
+print(f"{wl}: set-up {time.time() - t0:.1f} s, levels {m.inversion.solver.P.levels}", flush=True)
+s = m.inversion.solver
+P = s.P
+combos = [dict()] + [dict(nu1=a, nu2=b, schur_sweeps=c, coarse_sweeps=d, omega=w)
+                     for (a, b), c, d, w in itertools.product([(1, 1), (1, 2), (2, 2), (0, 2), (0, 3)], [1, 2, 3], [10, 20],
+                                                              [2.5])]
+combos += [dict(omega=w) for w in (2.0, 3.0)] + [dict(coarse_sweeps=c) for c in (5, 40)]
+for kw in combos:
+    P.set_params(**kw)
+    s.x.fill(0.0)
+    npg.invert(m)
+    st = s.workspace.stats
+    print(f"{kw}: solved={st['solved']} its={st['niter']} {1e3 * st['seconds']:.1f} ms  ({1e3 * st['seconds'] / max(st['niter'], 1):.2f} ms/it)",
+          flush=True)
