@@ -1,14 +1,30 @@
-# nuPGCMHIPExt.jl - package extension a nuPGCM maintainer would add next to ext/nuPGCMCUDAExt.jl.
+# nuPGCMHIPExt.jl - the package extension a nuPGCM maintainer adds in place of ext/nuPGCMCUDAExt.jl (load ONE of the two:
+# both define the `GPU()` methods of on_architecture / vector_type).  It binds the C ABI of include/nupgcm_hip.h.
 #
-# NOT executed in this repository's CI (the build image has no Julia); it shows the reference-side binding of the C ABI in
-# include/nupgcm_hip.h.  It adds methods of the existing `GPU` singleton for two new array types, exactly the way
-# ext/nuPGCMCUDAExt.jl:24-33 does for CuArray / CuSparseMatrixCSR (a new Architecture subtype would silently fall into the
-# `lu(A)` branches: src/inversion.jl:42, src/evolution.jl:148,166 test `typeof(arch) == GPU`).
+# STATUS: never executed - the build image has no Julia.  Every method below has a line-for-line twin in
+# tests/test_gpu_julia_mirror.py which drives the SAME entry points in the SAME order with the SAME argument conventions
+# (1-based -> 0-based shifts, CSC input, native-order vectors + host permutations) from reference-shaped inputs, on the GPU.
+#
+# How it hooks in without touching the reference's toolkits (dispatch points, reference file:line):
+#   * array conversion ........ the ten methods of ext/nuPGCMCUDAExt.jl:24-33 for HIPVector / HIPSparseMatrixCSR
+#   * Krylov workspaces ....... src/inversion.jl:84, src/evolution.jl:120 and src/preconditioners.jl:19 call
+#                               `Krylov.GmresWorkspace(N, N, VT; memory)` / `Krylov.CgWorkspace(N, N, VT)` with
+#                               VT = vector_type(arch, T): methods of those two constructors for VT = HIPVector{Float64}
+#                               return the device-resident workspaces of libnupgcm_hip (`workspace.x .= 0` then lowers to
+#                               fill!, defined here)
+#   * iterative_solve! ........ method for IterativeSolverToolkit{<:HIPSparseMatrixCSR} (src/iterative_solvers.jl:31-68):
+#                               one ccall per solve
+#   * invert!(inversion, b) ... method for InversionToolkit{<:HIPSparseMatrixCSR} (src/inversion.jl:101-110): y = B b + b0
+#                               as one copy + one SpMV (no device broadcast machinery needed)
+#   * evolve!(model, ...) ..... method for models whose inversion lives on the HIP device (src/model.jl:213-285): the
+#                               advection assembly + right-hand-side combination of :269-278 - a serial Gridap loop on the
+#                               host in the reference, also in GPU mode - becomes one call of npg_fe_evolution_rhs
 module nuPGCMHIPExt
 
 using nuPGCM
 using SparseArrays, LinearAlgebra
 import Krylov
+import Gridap
 
 const lib = get(ENV, "NUPGCM_HIP_LIB", "libnupgcm_hip.so")
 
@@ -33,7 +49,7 @@ end
 mutable struct HIPVector{T} <: AbstractVector{T}
     h::Ptr{Cvoid}
     n::Int
-    function HIPVector{Float64}(::UndefInitializer, n::Integer)
+    function HIPVector{Float64}(::UndefInitializer, n::Integer)          # npg_vec_create zero-fills
         out = Ref{Ptr{Cvoid}}()
         check(@ccall lib.npg_vec_create(ctx()::Ptr{Cvoid}, n::Int64, out::Ptr{Ptr{Cvoid}})::Cint)
         v = new{Float64}(out[], n)
@@ -41,6 +57,10 @@ mutable struct HIPVector{T} <: AbstractVector{T}
     end
 end
 Base.size(v::HIPVector) = (v.n,)
+Base.similar(v::HIPVector{Float64}) = HIPVector{Float64}(undef, v.n)
+Base.summary(v::HIPVector) = "$(v.n)-element HIPVector{Float64}"
+Base.show(io::IO, ::MIME"text/plain", v::HIPVector) = print(io, summary(v))
+Base.getindex(::HIPVector, ::Int) = error("scalar indexing of a HIPVector is not supported; use on_architecture(CPU(), v)")
 
 mutable struct HIPSparseMatrixCSR{T} <: AbstractSparseMatrix{T, Int32}
     h::Ptr{Cvoid}
@@ -48,6 +68,8 @@ mutable struct HIPSparseMatrixCSR{T} <: AbstractSparseMatrix{T, Int32}
     n::Int
 end
 Base.size(A::HIPSparseMatrixCSR) = (A.m, A.n)
+Base.summary(A::HIPSparseMatrixCSR) = "$(A.m)×$(A.n) HIPSparseMatrixCSR{Float64}"
+Base.show(io::IO, ::MIME"text/plain", A::HIPSparseMatrixCSR) = print(io, summary(A))
 
 # ---- the ten methods of ext/nuPGCMCUDAExt.jl:24-33 ------------------------------------------------------------------------
 function nuPGCM.on_architecture(::GPU, a::Array{Float64})
@@ -63,6 +85,7 @@ end
 nuPGCM.on_architecture(::GPU, v::HIPVector) = v
 function nuPGCM.on_architecture(::GPU, A::SparseMatrixCSC{Float64, Int64})     # CuSparseMatrixCSR(a): CSC -> CSR on upload
     out = Ref{Ptr{Cvoid}}()
+    # drop_zeros = 1: Gridap stores structural zeros (32 % of A_inversion); on_architecture(CPU(), .) still round-trips values
     check(@ccall lib.npg_csr_create_from_csc(ctx()::Ptr{Cvoid}, size(A, 1)::Int64, size(A, 2)::Int64,
                                               (A.colptr .- 1)::Ptr{Int64}, (A.rowval .- 1)::Ptr{Int64},
                                               A.nzval::Ptr{Float64}, 1::Cint, out::Ptr{Ptr{Cvoid}})::Cint)
@@ -86,49 +109,204 @@ function nuPGCM.print_memory_status(::GPU)
     println("GPU memory usage: ", round((t[] - f[]) / 2^30, digits = 3), " GiB / ", round(t[] / 2^30, digits = 3), " GiB")
 end
 
-# ---- what the hot path does with the device objects (SURVEY.md 8b) -----------------------------------------------------
+# ---- what the reference's GPU path does with the device objects (SURVEY.md 8b) --------------------------------------------
 function LinearAlgebra.mul!(y::HIPVector, A::HIPSparseMatrixCSR, x::HIPVector, α::Number = true, β::Number = false)
     check(@ccall lib.npg_spmv(A.h::Ptr{Cvoid}, x.h::Ptr{Cvoid}, y.h::Ptr{Cvoid}, Float64(α)::Float64, Float64(β)::Float64)::Cint)
     return y
 end
+Base.:*(A::HIPSparseMatrixCSR, x::HIPVector) = mul!(HIPVector{Float64}(undef, A.m), A, x)
 LinearAlgebra.dot(x::HIPVector, y::HIPVector) =
     (o = Ref{Float64}(); check(@ccall lib.npg_vec_dot(x.h::Ptr{Cvoid}, y.h::Ptr{Cvoid}, o::Ptr{Float64})::Cint); o[])
 LinearAlgebra.norm(x::HIPVector) =
     (o = Ref{Float64}(); check(@ccall lib.npg_vec_nrm2(x.h::Ptr{Cvoid}, o::Ptr{Float64})::Cint); o[])
 Base.fill!(x::HIPVector, a) = (check(@ccall lib.npg_vec_fill(x.h::Ptr{Cvoid}, Float64(a)::Float64)::Cint); x)
-Base.getindex(x::HIPVector, perm::Vector{Int}) = begin      # solver.x[inv_perm], src/model.jl:282,312
-    a = Vector{Float64}(undef, x.n)
+Base.copyto!(y::HIPVector, x::HIPVector) = (check(@ccall lib.npg_vec_copy(y.h::Ptr{Cvoid}, x.h::Ptr{Cvoid})::Cint); y)
+Base.copy(x::HIPVector) = copyto!(similar(x), x)
+LinearAlgebra.axpby!(a::Number, x::HIPVector, b::Number, y::HIPVector) =          # y = a x + b y
+    (check(@ccall lib.npg_vec_axpby(y.h::Ptr{Cvoid}, Float64(a)::Float64, x.h::Ptr{Cvoid}, Float64(b)::Float64)::Cint); y)
+LinearAlgebra.axpy!(a::Number, x::HIPVector, y::HIPVector) = axpby!(a, x, 1.0, y)
+LinearAlgebra.rmul!(x::HIPVector, a::Number) = axpby!(0.0, x, a, x)
+LinearAlgebra.mul!(y::HIPVector, D::Diagonal{Float64, <:HIPVector}, x::HIPVector) =   # mul!(q, ::Diagonal, w)
+    (check(@ccall lib.npg_vec_mul(y.h::Ptr{Cvoid}, D.diag.h::Ptr{Cvoid}, x.h::Ptr{Cvoid})::Cint); y)
+function Base.getindex(x::HIPVector, perm::Vector{Int})      # solver.x[inv_perm], src/model.jl:282,312 - result on the HOST
+    a = Vector{Float64}(undef, length(perm))
     check(@ccall lib.npg_vec_download_perm(x.h::Ptr{Cvoid}, a::Ptr{Float64}, (perm .- 1)::Ptr{Int64})::Cint)
-    a
+    return a
 end
+nuPGCM.on_architecture(::CPU, a::Vector{Float64}) = a        # ... so that on_architecture(CPU(), x[inv_perm]) is the identity
 
-# ---- iterative_solve!: one ccall per solve instead of Krylov.krylov_solve! (src/iterative_solvers.jl:58) -------------------
+# ---- Krylov workspaces: the constructors the toolkits call, for VT = HIPVector{Float64} -----------------------------------
 struct SolveStats
     solved::Int32; niter::Int32; npass::Int32; status::Int32; nreorth::Int32; nflagged::Int32
     rnorm0::Float64; rnorm::Float64; seconds::Float64
 end
+SolveStats() = SolveStats(0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0)
+Base.getproperty(s::SolveStats, f::Symbol) = f === :timer ? getfield(s, :seconds) : getfield(s, f)   # workspace.stats.timer
+
 mutable struct HIPGmresWorkspace
     h::Ptr{Cvoid}
     x::HIPVector{Float64}       # workspace.x: the toolkit's `x` aliases it (src/iterative_solvers.jl:26-29) => warm start
     stats::SolveStats
 end
+mutable struct HIPCgWorkspace
+    h::Ptr{Cvoid}
+    x::HIPVector{Float64}
+    stats::SolveStats
+end
+function Krylov.GmresWorkspace(m::Integer, n::Integer, ::Type{HIPVector{Float64}}; memory::Integer = 20)
+    out = Ref{Ptr{Cvoid}}()
+    check(@ccall lib.npg_gmres_create(ctx()::Ptr{Cvoid}, n::Int64, memory::Cint, out::Ptr{Ptr{Cvoid}})::Cint)
+    ws = HIPGmresWorkspace(out[], HIPVector{Float64}(undef, n), SolveStats())
+    finalizer(w -> @ccall(lib.npg_gmres_destroy(w.h::Ptr{Cvoid})::Cint), ws)
+end
+function Krylov.CgWorkspace(m::Integer, n::Integer, ::Type{HIPVector{Float64}})
+    out = Ref{Ptr{Cvoid}}()
+    check(@ccall lib.npg_cg_create(ctx()::Ptr{Cvoid}, n::Int64, out::Ptr{Ptr{Cvoid}})::Cint)
+    ws = HIPCgWorkspace(out[], HIPVector{Float64}(undef, n), SolveStats())
+    finalizer(w -> @ccall(lib.npg_cg_destroy(w.h::Ptr{Cvoid})::Cint), ws)
+end
+
+# (kind, scalar, handle) of npg_*_solve's preconditioner arguments for the reference's `P`: Diagonal(1/h^dim * ones(N)) on the
+# inversion (src/inversion.jl:54) -> NPG_PRECOND_SCALAR, Diagonal(1 ./ diag(A)) on the evolution (src/evolution.jl:149,167)
+# -> NPG_PRECOND_DIAG.  Decided by a device reduction (min == max), never by indexing the device vector.
+function precond_args(P::Diagonal{Float64, <:HIPVector})
+    val, flag = Ref{Float64}(), Ref{Cint}()
+    check(@ccall lib.npg_vec_is_constant(P.diag.h::Ptr{Cvoid}, val::Ptr{Float64}, flag::Ptr{Cint})::Cint)
+    return flag[] != 0 ? (Cint(1), val[], C_NULL) : (Cint(2), 0.0, P.diag.h)
+end
+precond_args(::Nothing) = (Cint(0), 0.0, C_NULL)
+
+# ---- iterative_solve!: one ccall per solve instead of Krylov.krylov_solve! (src/iterative_solvers.jl:58) -------------------
 function nuPGCM.iterative_solve!(tk::nuPGCM.IterativeSolverToolkit{<:HIPSparseMatrixCSR})
     ws, kw = tk.workspace, tk.kwargs
+    kind, scalar, dh = precond_args(tk.P)
     st = Ref{SolveStats}()
-    P = tk.P                                          # Diagonal(1/h^dim * ones(N)) on the inversion, Diagonal(1 ./ diag A) on the evolution
-    scalar = allequal(P.diag) ? (1, first(P.diag), C_NULL) : (2, 0.0, P.diag.h)
     if ws isa HIPGmresWorkspace
-        check(@ccall lib.npg_gmres_solve(ws.h::Ptr{Cvoid}, tk.A.h::Ptr{Cvoid}, scalar[1]::Cint, scalar[2]::Float64,
-                                         scalar[3]::Ptr{Cvoid}, tk.y.h::Ptr{Cvoid}, tk.x.h::Ptr{Cvoid},
-                                         kw[:atol]::Float64, kw[:rtol]::Float64, kw[:itmax]::Int64, 0.1::Float64,
+        kw[:restart] || error("restart=false is not supported by the HIP GMRES (the reference uses restart=true)")
+        check(@ccall lib.npg_gmres_solve(ws.h::Ptr{Cvoid}, tk.A.h::Ptr{Cvoid}, kind::Cint, scalar::Float64, dh::Ptr{Cvoid},
+                                         tk.y.h::Ptr{Cvoid}, tk.x.h::Ptr{Cvoid}, Float64(kw[:atol])::Float64,
+                                         Float64(kw[:rtol])::Float64, Int64(kw[:itmax])::Int64, 0.1::Float64,
                                          st::Ptr{SolveStats})::Cint)
     else
-        check(@ccall lib.npg_cg_solve(ws.h::Ptr{Cvoid}, tk.A.h::Ptr{Cvoid}, scalar[1]::Cint, scalar[2]::Float64,
-                                      scalar[3]::Ptr{Cvoid}, tk.y.h::Ptr{Cvoid}, tk.x.h::Ptr{Cvoid}, kw[:atol]::Float64,
-                                      kw[:rtol]::Float64, kw[:itmax]::Int64, st::Ptr{SolveStats})::Cint)
+        check(@ccall lib.npg_cg_solve(ws.h::Ptr{Cvoid}, tk.A.h::Ptr{Cvoid}, kind::Cint, scalar::Float64, dh::Ptr{Cvoid},
+                                      tk.y.h::Ptr{Cvoid}, tk.x.h::Ptr{Cvoid}, Float64(kw[:atol])::Float64,
+                                      Float64(kw[:rtol])::Float64, Int64(kw[:itmax])::Int64, st::Ptr{SolveStats})::Cint)
     end
     ws.stats = st[]
+    @debug "$(tk.label) iterative solve: solved=$(ws.stats.solved == 1), niter=$(ws.stats.niter), time=$(ws.stats.seconds)"
     return tk
+end
+
+# ---- invert!(inversion, b): y = B b + b0 without device broadcasts (src/inversion.jl:101-110) --------------------------------
+function nuPGCM.invert!(inversion::nuPGCM.InversionToolkit{<:HIPSparseMatrixCSR}, b)
+    s = inversion.solver
+    bd = nuPGCM.on_architecture(GPU(), Vector{Float64}(b.free_values))     # B consumes b in native order (src/inversion.jl:38)
+    copyto!(s.y, inversion.b)
+    mul!(s.y, inversion.B, bd, 1.0, 1.0)
+    nuPGCM.iterative_solve!(s)
+    return inversion
+end
+
+# ---- element kernels: npg_fe_* from the tables Gridap holds ------------------------------------------------------------------
+# Filled from Gridap's public accessors; see nupgcm_amd/fe.py + nupgcm_amd/assembly.py for the same tables built without Gridap.
+struct FeDesc
+    ncell::Int64; nq::Int32; nloc_b::Int32
+    grad_lambda::Ptr{Float64}; wdet::Ptr{Float64}; qw::Ptr{Float64}; N2::Ptr{Float64}; dN2::Ptr{Float64}
+    Nb::Ptr{Float64}; dNb::Ptr{Float64}; N1::Ptr{Float64}
+    cell_u::Ptr{Int32}; cell_p::Ptr{Int32}; cell_b::Ptr{Int32}
+    u_diri::Ptr{Float64}; n_u_diri::Int64; b_diri::Ptr{Float64}; n_b_diri::Int64
+    n_inv::Int64; n_b::Int64
+end
+mutable struct HIPFE
+    h::Ptr{Cvoid}
+    keep::Vector{Any}           # host tables stay alive for the duration of npg_fe_create only; kept for debugging
+end
+const FE_CACHE = IdDict{Any, HIPFE}()
+
+"0-based device index of a Gridap dof id: free id k > 0 -> inv_perm[k] - 1 (+ offset); Dirichlet id -k < 0 stays -k, which IS
+the ABI's `-1 - (k - 1)` (include/nupgcm_hip.h: an entry < 0 is Dirichlet value number -1 - entry)"
+devidx(id, inv_perm, off = 0) = id > 0 ? Int32(off + inv_perm[id] - 1) : Int32(id)
+
+function hip_fe(fe_data)
+    get!(FE_CACHE, fe_data) do
+        mesh, spaces, dofs = fe_data.mesh, fe_data.spaces, fe_data.dofs
+        U, P = spaces.X_trial[1], spaces.X_trial[2]
+        B = spaces.B_trial
+        Ω, dΩ = mesh.Ω, mesh.dΩ
+        X = Gridap.Geometry.get_cell_coordinates(Ω)                       # ncell x 4 points (cells sorted by GridapGmsh)
+        nc = length(X)
+        G, wdet = Matrix{Float64}(undef, 12, nc), Vector{Float64}(undef, nc)   # ABI layout [ncell][4][3] = column-major 12 x nc
+        for (c, x) in enumerate(X)
+            J = hcat(collect(Tuple(x[2] - x[1])), collect(Tuple(x[3] - x[1])), collect(Tuple(x[4] - x[1])))
+            Ji = inv(J)                                                   # rows = gradients of the reference coordinates
+            g = vcat(-sum(Ji, dims = 1), Ji)                              # 4 x 3: grad lambda_k
+            G[:, c] = vec(permutedims(g))
+            wdet[c] = abs(det(J))
+        end
+        quad = Gridap.CellData.get_data(Gridap.CellData.get_cell_quadrature(dΩ))[1]   # the one reference rule of Measure(Ω, 4)
+        xq, qw = Gridap.ReferenceFEs.get_coordinates(quad), Gridap.ReferenceFEs.get_weights(quad)
+        lam = [i == 1 ? 1 - sum(Tuple(p)) : Tuple(p)[i - 1] for p in xq, i in 1:4]        # nq x 4 barycentric
+        ea, eb = [1, 1, 2, 1, 2, 3], [2, 3, 3, 4, 4, 4]                   # Gridap's local edge order on a TET
+        nq = length(qw)
+        N2 = hcat(lam .* (2 .* lam .- 1), 4 .* lam[:, ea] .* lam[:, eb])  # nq x 10, nodal P2 = Gridap's (to rounding)
+        dN2 = zeros(nq, 10, 4)
+        for k in 1:4; dN2[:, k, k] = 4 .* lam[:, k] .- 1; end
+        for e in 1:6; dN2[:, 4 + e, ea[e]] = 4 .* lam[:, eb[e]]; dN2[:, 4 + e, eb[e]] = 4 .* lam[:, ea[e]]; end
+        dN1 = zeros(nq, 4, 4); for k in 1:4; dN1[:, k, k] .= 1; end
+        p1b = Gridap.FESpaces.num_free_dofs(B) + Gridap.FESpaces.num_dirichlet_dofs(B) == Gridap.Geometry.num_nodes(mesh.model)
+        Nb, dNb, nlb = p1b ? (lam, dN1, 4) : (N2, dN2, 10)
+        rowmajor(a) = vec(permutedims(a, reverse(1:ndims(a))))            # C layout of the ABI
+        # DoF tables: velocity dofs are node-major with interleaved components (dof = 3 (node - 1) + comp), SURVEY 8c
+        idsu, idsp, idsb = Gridap.FESpaces.get_cell_dof_ids(U), Gridap.FESpaces.get_cell_dof_ids(P), Gridap.FESpaces.get_cell_dof_ids(B)
+        ip, ib, nu = dofs.inv_p_inversion, dofs.inv_p_b, dofs.nu
+        cu = Int32[devidx(idsu[c][l], ip) for l in 1:30, c in 1:nc]       # 30 x nc column-major = [ncell][10][3]
+        cp = Int32[idsp[c][m] > 0 ? Int32(ip[nu + idsp[c][m]] - 1) : Int32(-1) for m in 1:4, c in 1:nc]
+        cb = Int32[devidx(idsb[c][i], ib) for i in 1:nlb, c in 1:nc]
+        ud = Vector{Float64}(Gridap.FESpaces.get_dirichlet_dof_values(U))
+        bd = Vector{Float64}(Gridap.FESpaces.get_dirichlet_dof_values(B))
+        tabs = Any[G, wdet, Vector{Float64}(qw), rowmajor(N2), rowmajor(dN2), rowmajor(Nb), rowmajor(dNb), rowmajor(lam), cu, cp, cb, ud, bd]
+        d = FeDesc(nc, nq, nlb, pointer(G), pointer(wdet), pointer(tabs[3]), pointer(tabs[4]), pointer(tabs[5]), pointer(tabs[6]),
+                   pointer(tabs[7]), pointer(tabs[8]), pointer(cu), pointer(cp), pointer(cb), pointer(ud), length(ud),
+                   pointer(bd), length(bd), dofs.nu + dofs.np, dofs.nb)
+        out = Ref{Ptr{Cvoid}}()
+        GC.@preserve tabs check(@ccall lib.npg_fe_create(ctx()::Ptr{Cvoid}, Ref(d)::Ptr{FeDesc}, out::Ptr{Ptr{Cvoid}})::Cint)
+        fe = HIPFE(out[], tabs)
+        finalizer(x -> @ccall(lib.npg_fe_destroy(x.h::Ptr{Cvoid})::Cint), fe)
+    end
+end
+
+upload_perm(a::Vector{Float64}, perm::Vector{Int}) = begin               # on_architecture(arch, a[perm]) in one call
+    v = HIPVector{Float64}(undef, length(perm))
+    check(@ccall lib.npg_vec_upload_perm(v.h::Ptr{Cvoid}, a::Ptr{Float64}, (perm .- 1)::Ptr{Int64})::Cint)
+    v
+end
+
+# ---- evolve!: src/model.jl:213-285 with :269-278 on the device ---------------------------------------------------------------
+const HIPModel = nuPGCM.Model{GPU, <:Any, <:Any, <:Any, <:nuPGCM.InversionToolkit{<:HIPSparseMatrixCSR}}
+function nuPGCM.evolve!(model::HIPModel, u_prev, b_prev)
+    dofs, ev, ts = model.fe_data.dofs, model.evolution, model.timestepper
+    solver = ev.solver
+    θ = nuPGCM.evolution_parameter(model.params, ts)
+    if model.forcings.conv_param.is_on || ts.adaptive
+        # closures and the LHS refresh stay on the reference's (host) path, src/model.jl:229-261; only array conversions of
+        # this extension are involved.  (npg_fe_update_kappa_convection / npg_fe_assemble_matrix move them to the device too:
+        # see nupgcm_amd/model.py evolve.)
+        invoke(nuPGCM.evolve!, Tuple{nuPGCM.Model, Any, Any}, model, u_prev, b_prev)
+        return model
+    end
+    fe = hip_fe(model.fe_data)
+    # state in the solvers' orderings: [u; p] by p_inversion (the pressure part is not read by the advection form), b by p_b
+    xi(u) = upload_perm(vcat(Vector{Float64}(u.free_values), zeros(dofs.np)), dofs.p_inversion)
+    bv(b) = upload_perm(Vector{Float64}(b.free_values), dofs.p_b)
+    scheme = ts isa nuPGCM.BDF1 ? Cint(1) : Cint(2)
+    check(@ccall lib.npg_fe_evolution_rhs(fe.h::Ptr{Cvoid}, scheme::Cint, ts.Δt[]::Float64, Float64(model.params.N²)::Float64,
+                                          θ::Float64, bv(model.state.b).h::Ptr{Cvoid}, bv(b_prev).h::Ptr{Cvoid},
+                                          xi(model.state.u).h::Ptr{Cvoid}, xi(u_prev).h::Ptr{Cvoid},
+                                          ev.rhs_diff.h::Ptr{Cvoid}, ev.rhs_flux.h::Ptr{Cvoid}, ev.rhsₘ.h::Ptr{Cvoid},
+                                          ev.rhsₕ.h::Ptr{Cvoid}, ev.rhsᵥ.h::Ptr{Cvoid}, solver.y.h::Ptr{Cvoid})::Cint)
+    nuPGCM.iterative_solve!(solver)
+    model.state.b.free_values .= solver.x[dofs.inv_p_b]                  # src/model.jl:282
+    return model
 end
 
 end # module

@@ -74,6 +74,9 @@ int npg_vec_dot(const npg_vec *x, const npg_vec *y, double *out);
 int npg_vec_nrm2(const npg_vec *x, double *out);
 /* max |x_i| and whether any entry is NaN: the blow-up guard's reductions (src/model.jl:149-153) */
 int npg_vec_maxabs(const npg_vec *x, double *out, int *has_nan);
+/* *is_constant = every entry equals *value (min == max).  Lets a binding recognise `Diagonal(s * ones(n))` - the inversion
+ * preconditioner of src/inversion.jl:54 - without indexing a device vector, and pass it as NPG_PRECOND_SCALAR */
+int npg_vec_is_constant(const npg_vec *x, double *value, int *is_constant);
 /* y = sum_k coef[k] * xs[k]   (k < nterms <= 8): the fused broadcasts at src/inversion.jl:104, src/model.jl:278 */
 int npg_vec_lincomb(npg_vec *y, int nterms, const double *coef, const npg_vec *const *xs);
 /* y = d .* x   -- mul!(y, ::Diagonal, x) */

@@ -72,6 +72,7 @@ def _declare(L):
         "npg_vec_upload_perm": [P, VP, VP], "npg_vec_download_perm": [P, VP, VP], "npg_vec_fill": [P, D],
         "npg_vec_copy": [P, P], "npg_vec_axpby": [P, D, P, D], "npg_vec_dot": [P, P, C.POINTER(D)],
         "npg_vec_nrm2": [P, C.POINTER(D)], "npg_vec_maxabs": [P, C.POINTER(D), C.POINTER(C.c_int)],
+        "npg_vec_is_constant": [P, C.POINTER(D), C.POINTER(C.c_int)],
         "npg_vec_lincomb": [P, C.c_int, C.POINTER(D), PP], "npg_vec_mul": [P, P, P],
         "npg_csr_create_from_csc": [P, I64, I64, VP, VP, VP, C.c_int, PP],
         "npg_csr_create": [P, I64, I64, VP, VP, VP, PP], "npg_csr_destroy": [P],

@@ -96,6 +96,28 @@ __global__ void k_maxabs_partial(const double *x, int64_t n, double *part) {
     }
 }
 
+__global__ void k_minmax_partial(const double *x, int64_t n, double *part) {
+    __shared__ double sh[8];
+    double lo = 1e300, hi = -1e300;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = x[i];
+        lo = fmin(lo, v);
+        hi = fmax(hi, v);
+    }
+    lo = -wave_max(-lo);
+    hi = wave_max(hi);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sh[wave] = lo;
+        sh[4 + wave] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = fmin(fmin(sh[0], sh[1]), fmin(sh[2], sh[3]));
+        part[2 * blockIdx.x + 1] = fmax(fmax(sh[4], sh[5]), fmax(sh[6], sh[7]));
+    }
+}
+
 __global__ void k_final_sum(const double *part, int np, double *out) {
     __shared__ double sh[4];
     double s = 0.0;
@@ -352,6 +374,23 @@ NPG_API int npg_vec_nrm2(const npg_vec *x, double *out) {
     int rc = reduce_dot(x->ctx, x->d, x->d, x->n, &s);
     *out = std::sqrt(s);
     return rc;
+}
+
+NPG_API int npg_vec_is_constant(const npg_vec *x, double *value, int *is_constant) {
+    NPG_REQUIRE(x && value && is_constant && x->n > 0, "npg_vec_is_constant: bad argument");
+    npg_ctx *ctx = x->ctx;
+    const int g = grid_for(x->n, 1024);
+    hipLaunchKernelGGL(k_minmax_partial, dim3(g), dim3(kBlock), 0, ctx->stream, x->d, x->n, ctx->d_scratch + 8);
+    NPG_HIP(hipMemcpyAsync(ctx->h_scratch, ctx->d_scratch + 8, 2 * g * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    NPG_HIP(hipStreamSynchronize(ctx->stream));
+    double lo = 1e300, hi = -1e300;
+    for (int i = 0; i < g; ++i) {
+        lo = std::fmin(lo, ctx->h_scratch[2 * i]);
+        hi = std::fmax(hi, ctx->h_scratch[2 * i + 1]);
+    }
+    *value = lo;
+    *is_constant = lo == hi;
+    return NPG_OK;
 }
 
 NPG_API int npg_vec_maxabs(const npg_vec *x, double *out, int *has_nan) {
