@@ -1,11 +1,13 @@
 """State checkpoints and VTK output - mirrors /root/reference/src/IO.jl:1-59 (save_state, set_state_from_file!, save_vtk).
 
-The reference stores {u, p, b, t} (free values in the native Gridap DoF order) with JLD2; no HDF5/JLD2 writer is available
-here, so the same four fields go into a NumPy `.npz` archive - same names, same order, same meaning (the fixtures under
-tests/golden/state_*.npz, extracted from the reference's own .jld2 files, use this layout too and load with
-`set_state_from_file`).  `save_vtk` writes an unstructured-grid `.vtu` (ASCII XML) with quadratic tetrahedra, as
+The reference stores {u, p, b, t} (free values in the native Gridap DoF order) with JLD2, i.e. in an HDF5 file with a 512-byte
+JLD2 header block.  `save_state` writes exactly that layout through libhdf5 (nupgcm_amd/_hdf5.py), and `set_state_from_file`
+reads it - so checkpoints can be exchanged with the reference in both directions (its own test/data/*.jld2 state files load
+directly).  A path ending in `.npz` selects a NumPy archive with the same four names instead (the committed fixtures under
+tests/golden/state_*.npz use it).  `save_vtk` writes an unstructured-grid `.vtu` (ASCII XML) with quadratic tetrahedra, as
 `writevtk(...; order=2)` does: u at the P2 nodes, p (P1, interpolated to the edge mid-points), the full buoyancy N2 z + b
-and the time as field data."""
+and the time as field data (the reference's extra diagnostic cell fields alpha b_z, nu, kappa_v - src/IO.jl:38-52 - are not
+written)."""
 from __future__ import annotations
 
 import numpy as np
@@ -19,14 +21,24 @@ def save_state(model, ofile):
     """save_state(model, ofile) - src/IO.jl:1-10"""
     s = model.state
     t = 0.0 if model.timestepper is None else float(model.timestepper.t)
-    np.savez(ofile, u=s.u, p=s.p, b=s.b, t=t)
-    return ofile
+    ofile = str(ofile)
+    if ofile.endswith(".npz"):
+        np.savez(ofile, u=s.u, p=s.p, b=s.b, t=t)
+    else:
+        from . import _hdf5
+        _hdf5.write_flat(ofile, dict(u=s.u, p=s.p, b=s.b, t=np.float64(t)))     # jldsave(ofile; u, p, b, t)
+    return ofile                                                               # the path actually written
 
 
 def set_state_from_file(model, ifile):
     """set_state_from_file!(model, ifile) - src/IO.jl:12-23.  As in the reference only the current fields and the time are
     restored: a run resumed from a checkpoint starts its time stepper afresh (previous-step copies = current state)."""
-    z = np.load(ifile)
+    ifile = str(ifile)
+    if ifile.endswith(".npz"):
+        z = dict(np.load(ifile))
+    else:
+        from . import _hdf5
+        z = _hdf5.read_flat(ifile, ("u", "p", "b", "t"))                         # jldopen(ifile)["u"] ...
     d = model.fe_data.dofs
     u, p, b = (np.asarray(z[k], dtype=float) for k in ("u", "p", "b"))
     if u.shape != (d.nu,) or p.shape != (d.np,) or b.shape != (d.nb,):

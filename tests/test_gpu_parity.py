@@ -842,8 +842,13 @@ def test_checkpoint_and_vtk(arch, golden_dir, tmp_path):
     import xml.etree.ElementTree as ET
     m = build_model("bowl_surface_flux")
     npg.run(m, n_steps=3)
-    ck = npg.save_state(m, str(tmp_path / "state.npz"))
+    ck = npg.save_state(m, str(tmp_path / "state_0000000000000003.jld2"))        # JLD2 layout (HDF5 + 512-byte header block)
+    assert ck.endswith(".jld2") and os.path.exists(ck) and open(ck, "rb").read(36) == b"HDF5-based Julia Data Format, versio"
+    ck_npz = npg.save_state(m, str(tmp_path / "state.npz"))
     u, p, b, t = m.state.u, m.state.p, m.state.b, m.timestepper.t
+    mz = build_model("bowl_surface_flux")
+    npg.set_state_from_file(mz, ck_npz)
+    assert np.array_equal(mz.state.u, u) and mz.timestepper.t == t
     runs = []
     for _ in range(2):
         m2 = build_model("bowl_surface_flux")
@@ -880,3 +885,19 @@ def test_checkpoint_and_vtk(arch, golden_dir, tmp_path):
     free = m.fe_data.spaces.u_dof >= 0
     assert np.array_equal(uu[free], m.state.u[m.fe_data.spaces.u_dof[free]])
     assert float(root.find("UnstructuredGrid/FieldData/DataArray").text) == m.timestepper.t
+
+
+def test_blow_up_guard(arch):
+    """run! stops with the reference's error when max|u| or max|b| exceeds 1e3 or turns NaN (src/model.jl:148-153); the state
+    it stopped on stays readable"""
+    m = build_model("bowl_surface_flux")
+    npg.set_b(m, lambda x: 1e6 * x[..., 2])                  # |b| > 1e3 after the first evolve!
+    with pytest.raises(npg.BlowUp, match="Blow-up detected"):
+        npg.run(m, n_steps=3)
+    assert m.step_index == 1 and np.abs(m.state.b).max() > 1e3
+    m = build_model("bowl_surface_flux")
+    bad = m.state.b
+    bad[7] = np.nan
+    npg.set_b(m, bad)
+    with pytest.raises(npg.BlowUp):
+        npg.run(m, n_steps=1)

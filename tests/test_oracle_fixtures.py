@@ -108,3 +108,48 @@ def test_c_openmp_krylov_restatement_matches_the_numpy_oracle():
     x1, s1 = ko.cg(A, b, M=1 / A.diagonal())
     x2, s2 = kc.cg(A, b, M=1 / A.diagonal())
     assert s1["niter"] == s2["niter"] and s2["solved"] and np.linalg.norm(x1 - x2) < 1e-12 * np.linalg.norm(x1)
+
+
+def test_jld2_layout_checkpoint_io(tmp_path):
+    """nupgcm_amd._hdf5 writes what `jldsave(ofile; u, p, b, t)` lays out (src/IO.jl:8): user block of 512 bytes with the JLD2
+    header line, Float64 datasets u, p, b and a scalar t - and reads the reference's own state files bit for bit."""
+    import os
+    import subprocess
+
+    from nupgcm_amd import _hdf5
+    p = str(tmp_path / "state.jld2")
+    d = dict(u=np.arange(7.0) / 3, p=np.ones(3), b=np.linspace(0, 1, 4), t=np.float64(2.5))
+    _hdf5.write_flat(p, d)
+    back = _hdf5.read_flat(p, ("u", "p", "b", "t", "absent"))
+    assert set(back) == {"u", "p", "b", "t"} and all(np.array_equal(back[k].ravel(), np.ravel(d[k])) for k in d)
+    raw = open(p, "rb").read(520)
+    assert raw.startswith(b"HDF5-based Julia Data Format, version 0.1.1\x00") and raw[512:516] == b"\x89HDF"
+    if os.path.exists("/opt/conda/bin/h5dump"):
+        hdr = subprocess.run(["/opt/conda/bin/h5dump", "-H", "-B", p], capture_output=True, text=True).stdout
+        assert "USERBLOCK_SIZE 512" in hdr and "SUPERBLOCK_VERSION 2" in hdr
+        assert hdr.count("H5T_IEEE_F64LE") == 4 and "SCALAR" in hdr
+    ref = "/root/reference/test/data/bowl_surface_flux.jld2"
+    if os.path.exists(ref):                       # only in the build container: the file itself does not travel
+        r = _hdf5.read_flat(ref, ("u", "p", "b", "t"))
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_bowl_surface_flux.npz"))
+        assert all(np.array_equal(r[k].ravel(), z[k].ravel()) for k in ("u", "p", "b", "t"))
+
+
+def test_iperm_fixture_of_the_2d_matrix():
+    """test/data/A_bowl_mixing_2D.jld2 also pins `iperm`, the inverse of the reference's RCM p_inversion
+    (test/bowl_mixing_tests.jl:58-63: `A[iperm, iperm]` must reproduce the un-permuted assembly).  The fixture matrix is the
+    UN-permuted one (K1 compares it entry by entry with the oracle's native-order assembly), so what the permutation pins
+    is its own structure: a permutation of 1:N that keeps the velocity and pressure blocks apart
+    (p_inversion = [p_u; nu + p_p], src/dofs.jl:38) and - being an RCM - narrows the band of the permuted velocity block."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "A_bowl_mixing_2D.npz"))
+    iperm = z["iperm"] - 1
+    N = int(z["m"])
+    assert np.array_equal(np.sort(iperm), np.arange(N))
+    A = sp.csc_matrix((z["nzval"], z["rowval"] - 1, z["colptr"] - 1), shape=(N, N)).tocsr()
+    nu = 990                                        # 2-D fixture sizes (SURVEY 8c): nu = 990, np = 108
+    perm = np.argsort(iperm)                        # p_inversion
+    assert set(perm[:nu]) == set(range(nu)) and set(perm[nu:]) == set(range(nu, N))
+    Auu = A[:nu, :nu]
+    band = lambda M: int(np.abs(M.tocoo().row - M.tocoo().col).max())
+    assert band(Auu[perm[:nu]][:, perm[:nu]]) < band(Auu) / 2
