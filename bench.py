@@ -162,10 +162,12 @@ def main():
     else:
         mesh_model = workloads.bowl_mesh_model(a.workload)
     if channel:
-        if world > 1:
-            raise SystemExit("the channel-basin workload runs on one GPU in this round")
-        model = workloads.channel_basin_model(arch, mesh_model=mesh_model,
-                                              surface="dirichlet" if a.workload.endswith("dirichlet") else "flux")
+        surf = "dirichlet" if a.workload.endswith("dirichlet") else "flux"
+        if world > 1 or force_dist:
+            from nupgcm_amd import distributed
+            model = distributed.channel_basin_model(arch, mesh_model, dist, surface=surf)
+        else:
+            model = workloads.channel_basin_model(arch, mesh_model=mesh_model, surface=surf)
     elif world > 1 or force_dist:
         from nupgcm_amd import distributed
         model = distributed.example_model(arch, mesh_model, dist, dt=a.dt)

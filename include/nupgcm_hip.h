@@ -37,6 +37,7 @@ typedef struct npg_cg npg_cg;
 typedef struct npg_fe npg_fe;
 typedef struct npg_halo npg_halo;
 typedef struct npg_precond npg_precond;
+typedef struct npg_index npg_index;
 typedef struct npg_fgmres npg_fgmres;
 
 /* ---- context: replaces the implicit CUDA.jl device/stream (ext/nuPGCMCUDAExt.jl:8-16) ------------------------- */
@@ -116,6 +117,12 @@ int npg_csr_pair_xy(npg_csr *A, int64_t npairs, double rtol, int *paired);
 /* how the matrix is laid out in HBM: number of block nodes, {c, K, C} records (20 bytes each, standing for 4 or 5 CSR
  * entries) and plain CSR entries (12 bytes each).  Plain matrix: 0, 0, nnz. */
 int npg_csr_storage(const npg_csr *A, int64_t *nodes, int64_t *records, int64_t *csr_entries);
+/* dst.val[k] = src.val[map[k]]: a matrix whose entries are a fixed subset / rearrangement of another's - a rank's row block
+ * of a replicated, re-assembled matrix (closure refreshes of K_v and A, src/model.jl:160-170,229-261, when the solve is
+ * distributed).  npg_index = a device-resident int64 index array, every entry checked against `bound` at creation. */
+int npg_index_create(npg_ctx *ctx, int64_t n, const int64_t *host, int64_t bound, npg_index **out);
+int npg_index_destroy(npg_index *ix);
+int npg_csr_gather_values(npg_csr *dst, const npg_csr *src, const npg_index *map);
 /* d[i] = 1 / A[i,i]   -- `Diagonal(1 ./ diag(A))` (src/evolution.jl:149,167; src/model.jl:256) */
 int npg_csr_inv_diag(const npg_csr *A, npg_vec *d);
 /* y = alpha * A x + beta * y   -- mul!(y, A, x) / A*x  (cuSPARSE SpMV in the reference) */

@@ -223,6 +223,24 @@ class DeviceVector:
         return f"{self.n}-element DeviceVector{{Float64}}"
 
 
+class DeviceIndex:
+    """device-resident int64 index array (npg_index): entries are checked against `bound` when it is created"""
+
+    def __init__(self, ctx, host, bound):
+        a = L.as_i64(host)
+        h = C.c_void_p()
+        L.check(L.lib().npg_index_create(ctx.h, a.size, L.ptr(a), int(bound), C.byref(h)))
+        self.h, self.ctx, self.n = h, ctx, a.size
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.lib().npg_index_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 class DeviceCSR:
     """fp64 CSR matrix with int32 column indices in HBM (the reference's CuSparseMatrixCSR{Float64,Int32})."""
 
@@ -320,6 +338,11 @@ class DeviceCSR:
     def combine(self, a, X, b, Y, Z):
         """self = a X + b (Y + Z) on a shared pattern"""
         L.check(L.lib().npg_csr_combine(self.h, float(a), X.h, float(b), Y.h, Z.h))
+        return self
+
+    def gather_values(self, src, index):
+        """self.val[k] = src.val[index[k]] (npg_csr_gather_values): this matrix holds a fixed subset of src's entries"""
+        L.check(L.lib().npg_csr_gather_values(self.h, src.h, index.h))
         return self
 
     def inv_diag(self, out: DeviceVector = None):

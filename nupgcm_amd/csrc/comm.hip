@@ -32,6 +32,17 @@ namespace npg {
         }                                                                                         \
     } while (0)
 
+// inside ncclGroupStart() ... ncclGroupEnd(): close the group before reporting, or the communicator stays in group mode
+#define NPG_NCCL_IN_GROUP(call)                                                                   \
+    do {                                                                                          \
+        ncclResult_t r_ = (call);                                                                 \
+        if (r_ != ncclSuccess) {                                                                  \
+            npg::set_error("%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+            ncclGroupEnd();                                                                       \
+            return NPG_ECOMM;                                                                     \
+        }                                                                                         \
+    } while (0)
+
 // ---- shared-memory loop-back transport ---------------------------------------------------------------------------------
 struct ShmHeader {
     std::atomic<int> arrived;
@@ -235,8 +246,8 @@ NPG_API int npg_comm_allgather_segments(npg_ctx *ctx, const npg_vec *local, int 
     for (int s = 0; s < nseg; ++s) {
         if (seg_len[s] == 0) continue;
         const double *src = seg_rank[s] == ctx->rank ? local->d + seg_local_off[s] : full->d + seg_global_off[s];
-        NPG_NCCL(ncclBroadcast(src, full->d + seg_global_off[s], (size_t)seg_len[s], ncclDouble, seg_rank[s], comm,
-                               ctx->stream));
+        NPG_NCCL_IN_GROUP(ncclBroadcast(src, full->d + seg_global_off[s], (size_t)seg_len[s], ncclDouble, seg_rank[s], comm,
+                                        ctx->stream));
     }
     NPG_NCCL(ncclGroupEnd());
     return NPG_OK;
@@ -306,7 +317,8 @@ int npg::halo_exchange_raw(npg_halo *h, double *x) {
                                    hipMemcpyDeviceToHost, ctx->stream));
         NPG_HIP(hipStreamSynchronize(ctx->stream));
         NPG_SHM_BARRIER(c);
-        for (int p = 0; p < h->npeers; ++p) {
+        bool bad = false;                                   // a mismatch is reported AFTER the closing barrier: every rank
+        for (int p = 0; p < h->npeers; ++p) {               // leaves the collective, none is left spinning
             const int64_t r0 = h->recv_ptr[p], r1 = h->recv_ptr[p + 1];
             if (r1 == r0) continue;
             const int64_t *sd = (const int64_t *)c->slot_of(h->peer[p]);
@@ -317,21 +329,27 @@ int npg::halo_exchange_raw(npg_halo *h, double *x) {
                     so = sd[2 + 3 * q];
                     sc = sd[3 + 3 * q];
                 }
-            NPG_REQUIRE(sc == r1 - r0, "shm transport: rank %d sends %lld values to rank %d, which expects %lld",
-                        h->peer[p], (long long)sc, c->rank, (long long)(r1 - r0));
+            if (sc != r1 - r0) {
+                set_error("shm transport: rank %d sends %lld values to rank %d, which expects %lld", h->peer[p], (long long)sc,
+                          c->rank, (long long)(r1 - r0));
+                bad = true;
+                continue;
+            }
             const char *payload = c->slot_of(h->peer[p]) + (size_t)(1 + 3 * snp) * sizeof(int64_t);
             NPG_HIP(hipMemcpy(x + h->n_owned + r0, payload + (size_t)so * sizeof(double), (size_t)sc * sizeof(double),
                               hipMemcpyHostToDevice));
         }
         NPG_SHM_BARRIER(c);
-        return NPG_OK;
+        return bad ? NPG_ECOMM : NPG_OK;
     }
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     NPG_NCCL(ncclGroupStart());
     for (int p = 0; p < h->npeers; ++p) {
         const int64_t s0 = h->send_ptr[p], s1 = h->send_ptr[p + 1], r0 = h->recv_ptr[p], r1 = h->recv_ptr[p + 1];
-        if (s1 > s0) NPG_NCCL(ncclSend(h->send_buf + s0, (size_t)(s1 - s0), ncclDouble, h->peer[p], comm, ctx->stream));
-        if (r1 > r0) NPG_NCCL(ncclRecv(x + h->n_owned + r0, (size_t)(r1 - r0), ncclDouble, h->peer[p], comm, ctx->stream));
+        if (s1 > s0)
+            NPG_NCCL_IN_GROUP(ncclSend(h->send_buf + s0, (size_t)(s1 - s0), ncclDouble, h->peer[p], comm, ctx->stream));
+        if (r1 > r0)
+            NPG_NCCL_IN_GROUP(ncclRecv(x + h->n_owned + r0, (size_t)(r1 - r0), ncclDouble, h->peer[p], comm, ctx->stream));
     }
     NPG_NCCL(ncclGroupEnd());
     return NPG_OK;

@@ -123,6 +123,18 @@ int build_tiles(npg_csr *A);
 NPG_SHARED int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp);
 struct CsrDev;
 NPG_SHARED CsrDev csr_view(const npg_csr *A);
+// epilogue of the tiled SpMV kernel: y = alpha (A x) + beta c   [c may be y itself; not read when beta == 0]
+//                           and, if z:  z = zc zin + w dg .* y  [zin may be null]
+struct SpmvEpi {
+    double alpha = 1.0, beta = 0.0;
+    const double *c = nullptr;
+    double *y = nullptr;
+    double w = 0.0, zc = 0.0;
+    const double *dg = nullptr, *zin = nullptr;
+    double *z = nullptr;
+};
+int spmv_epi(const npg_csr *A, const double *x, const SpmvEpi &e);
+int spmv_raw(const npg_csr *A, const double *x, double *y, double alpha, double beta);
 // reductions that return a scalar to the host (synchronous)
 int reduce_dot(npg_ctx *ctx, const double *x, const double *y, int64_t n, double *out);
 int reduce_maxabs(npg_ctx *ctx, const double *x, int64_t n, double *out, int *has_nan);

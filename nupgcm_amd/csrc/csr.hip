@@ -79,8 +79,7 @@ constexpr int kSpmvThreads = 512;
 
 template <int L>
 __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv(CsrDev A, const TileDesc *__restrict__ tile_ptr, int ntiles,
-                                                        const double *__restrict__ x, double *__restrict__ y,
-                                                        double alpha, double beta) {
+                                                        const double *__restrict__ x, SpmvEpi e) {
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
     int t = blockIdx.x;
@@ -93,7 +92,14 @@ __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv(CsrDev A, const TileDe
         spmv_tile<kSpmvThreads, L>(A, PlainX{x}, td, tl, sw);
         for (int r = threadIdx.x; r < td.nrows; r += kSpmvThreads) {
             const int row = td.r0 + r;
-            y[row] = (beta == 0.0) ? alpha * sw[r] : alpha * sw[r] + beta * y[row];
+            double v = e.alpha * sw[r];
+            if (e.beta != 0.0) v += e.beta * e.c[row];
+            e.y[row] = v;
+            if (e.z) {                                   // second output: z = zc zin + w dg .* y  (smoother relaxations, mg.hip)
+                double t = e.w * e.dg[row] * v;
+                if (e.zin) t += e.zc * e.zin[row];
+                e.z[row] = t;
+            }
         }
         if (tn >= ntiles) break;
         t = tn;
@@ -105,6 +111,12 @@ __global__ void k_combine(double *out, double a, const double *X, double b, cons
                           int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = a * X[i] + b * (Y[i] + Z[i]);
+}
+
+__global__ void k_gather_values(double *__restrict__ dst, const double *__restrict__ src, const int64_t *__restrict__ idx,
+                                int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[idx[i]];
 }
 
 __global__ void k_inv_diag(const int64_t *rowptr, const int32_t *col, const double *val, double *d, int64_t m) {
@@ -141,10 +153,10 @@ static int upload_csr(npg_ctx *ctx, int64_t m, int64_t n, std::vector<int64_t> &
 }
 
 template <int L>
-static void launch_spmv(const npg_csr *A, const double *x, double *y, double alpha, double beta) {
+static void launch_spmv(const npg_csr *A, const double *x, const SpmvEpi &e) {
     const int grid = std::min<int>(A->ntiles, 3 * A->ctx->num_cu);      // 3 x 38 KiB of LDS per CU
     hipLaunchKernelGGL(k_spmv<L>, dim3(std::max(grid, 1)), dim3(kSpmvThreads), 0, A->ctx->stream, csr_view(A),
-                       A->tile_ptr, A->ntiles, x, y, alpha, beta);
+                       A->tile_ptr, A->ntiles, x, e);
 }
 
 CsrDev csr_view(const npg_csr *A) {
@@ -428,6 +440,49 @@ NPG_API int npg_csr_combine(npg_csr *out, double a, const npg_csr *X, double b, 
     return NPG_OK;
 }
 
+struct npg_index {
+    npg_ctx *ctx = nullptr;
+    int64_t n = 0, bound = 0;
+    int64_t *d = nullptr;
+};
+
+NPG_API int npg_index_create(npg_ctx *ctx, int64_t n, const int64_t *host, int64_t bound, npg_index **out) {
+    NPG_REQUIRE(ctx && out && n >= 0 && (n == 0 || host), "npg_index_create: bad argument");
+    for (int64_t i = 0; i < n; ++i)
+        NPG_REQUIRE(host[i] >= 0 && host[i] < bound, "npg_index_create: entry %lld = %lld outside [0, %lld)", (long long)i,
+                    (long long)host[i], (long long)bound);
+    npg_index *ix = new npg_index();
+    ix->ctx = ctx;
+    ix->n = n;
+    ix->bound = bound;
+    NPG_HIP(hipSetDevice(ctx->device));
+    NPG_HIP(hipMalloc((void **)&ix->d, std::max<size_t>(1, (size_t)n) * sizeof(int64_t)));
+    if (n) NPG_HIP(hipMemcpy(ix->d, host, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+    *out = ix;
+    return NPG_OK;
+}
+
+NPG_API int npg_index_destroy(npg_index *ix) {
+    if (!ix) return NPG_OK;
+    hipStreamSynchronize(ix->ctx->stream);
+    hipFree(ix->d);
+    delete ix;
+    return NPG_OK;
+}
+
+NPG_API int npg_csr_gather_values(npg_csr *dst, const npg_csr *src, const npg_index *map) {
+    NPG_REQUIRE(dst && src && map, "npg_csr_gather_values: NULL argument");
+    NPG_REQUIRE(dst->nnode() == 0 && src->nnode() == 0, "npg_csr_gather_values: node-blocked matrices are not supported");
+    NPG_REQUIRE(map->n == dst->nnz && map->bound == src->nnz,
+                "npg_csr_gather_values: the map has %lld entries into %lld values, the matrices have %lld and %lld",
+                (long long)map->n, (long long)map->bound, (long long)dst->nnz, (long long)src->nnz);
+    const int grid = (int)std::min<int64_t>(2048, (dst->nnz + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_gather_values, dim3(std::max(grid, 1)), dim3(kBlock), 0, dst->ctx->stream, dst->val, src->val,
+                       map->d, dst->nnz);
+    NPG_HIP(hipGetLastError());
+    return NPG_OK;
+}
+
 NPG_API int npg_csr_inv_diag(const npg_csr *A, npg_vec *d) {
     NPG_REQUIRE(A && d && A->m <= A->n && d->n == A->m, "npg_csr_inv_diag: shape mismatch");   // m < n: a rank's row block
     const int grid = (int)std::min<int64_t>(2048, (A->m + kBlock - 1) / kBlock);
@@ -439,15 +494,24 @@ NPG_API int npg_csr_inv_diag(const npg_csr *A, npg_vec *d) {
 
 namespace npg {
 // y[0, m) = alpha A x[0, n) + beta y on raw device pointers (x and y may be windows into larger vectors; they must not overlap)
-int spmv_raw(const npg_csr *A, const double *x, double *y, double alpha, double beta) {
+int spmv_epi(const npg_csr *A, const double *x, const SpmvEpi &e) {
     switch (A->lanes) {
-        case 4: launch_spmv<4>(A, x, y, alpha, beta); break;
-        case 8: launch_spmv<8>(A, x, y, alpha, beta); break;
-        case 16: launch_spmv<16>(A, x, y, alpha, beta); break;
-        default: launch_spmv<32>(A, x, y, alpha, beta); break;
+        case 4: launch_spmv<4>(A, x, e); break;
+        case 8: launch_spmv<8>(A, x, e); break;
+        case 16: launch_spmv<16>(A, x, e); break;
+        default: launch_spmv<32>(A, x, e); break;
     }
     NPG_HIP(hipGetLastError());
     return NPG_OK;
+}
+
+int spmv_raw(const npg_csr *A, const double *x, double *y, double alpha, double beta) {
+    SpmvEpi e{};
+    e.alpha = alpha;
+    e.beta = beta;
+    e.c = y;
+    e.y = y;
+    return spmv_epi(A, x, e);
 }
 }  // namespace npg
 

@@ -23,6 +23,7 @@
 // Diagonal preconditioner puts on the residual (src/inversion.jl:42-54; right preconditioning leaves r the true residual).
 #include <algorithm>
 #include <cmath>
+#include <map>
 
 #include "common.h"
 #include "device_utils.h"
@@ -106,8 +107,6 @@ __global__ void __launch_bounds__(kBlock) k_combine_z(double *__restrict__ x, co
     }
 }
 
-int spmv_raw(const npg_csr *A, const double *x, double *y, double alpha, double beta);   // csr.hip
-
 }  // namespace npg
 
 using namespace npg;
@@ -116,7 +115,8 @@ struct MgLevel {
     const npg_csr *A = nullptr, *G = nullptr, *D = nullptr, *Dinv = nullptr, *S = nullptr, *P = nullptr, *R = nullptr;
     int64_t n = 0, nu = 0, np = 0;
     double *sdinv = nullptr;                         // 1 / diag(S)
-    double *r = nullptr, *t = nullptr, *rhs = nullptr, *dp = nullptr, *res = nullptr, *x = nullptr, *b = nullptr;
+    double *r = nullptr, *t = nullptr, *rhs = nullptr, *dp = nullptr, *dp2 = nullptr, *res = nullptr, *x = nullptr,
+           *b = nullptr;
 };
 
 struct BlockPc {
@@ -138,10 +138,20 @@ struct npg_precond {
     double omega = 2.5, jw = 0.7;
     int sweeps = 3, nu1 = 2, nu2 = 2, coarse = 20;
     std::vector<void *> allocs;
+    // one instantiated hipGraph of the V-cycle per (input, output) address pair: flexible GMRES applies the preconditioner
+    // to the same `memory` basis / Z column pairs in every restart cycle, so a cycle's ~300 launches (most of them
+    // latency-bound coarse-level kernels) are enqueued by one hipGraphLaunch
+    std::map<std::pair<const double *, double *>, hipGraphExec_t> graphs;
+    bool use_graphs = true;
     // block diagonal
     std::vector<BlockPc> blocks;
     int64_t inner_iterations = 0, applications = 0;
 };
+
+static void drop_graphs(npg_precond *pc) {
+    for (auto &kv : pc->graphs) hipGraphExecDestroy(kv.second);
+    pc->graphs.clear();
+}
 
 static inline void axpby(npg_ctx *c, double *y, double a, const double *x, double b, int64_t n) {
     hipLaunchKernelGGL(k_mg_axpby, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, y, a, x, b, n);
@@ -157,6 +167,9 @@ NPG_API int npg_precond_create(npg_ctx *ctx, int kind, int nparts, npg_precond *
     npg_precond *pc = new npg_precond();
     pc->ctx = ctx;
     pc->kind = kind;
+    // relaunching hipGraphs under rocprofv3's kernel tracer crashes the tool (profiles/r02_rocprofv3_graph_crash.txt)
+    const bool traced = getenv("ROCPROFILER_LIBRARY_CTOR") || getenv("ROCPROF_OUTPUT_PATH") || getenv("ROCP_TOOL_LIBRARIES");
+    pc->use_graphs = getenv("NPG_MG_EAGER") ? atoi(getenv("NPG_MG_EAGER")) == 0 : !traced;
     if (kind == NPG_PC_MG) pc->L.resize(nparts); else pc->blocks.resize(nparts);
     *out = pc;
     return NPG_OK;
@@ -165,6 +178,7 @@ NPG_API int npg_precond_create(npg_ctx *ctx, int kind, int nparts, npg_precond *
 NPG_API int npg_precond_destroy(npg_precond *pc) {
     if (!pc) return NPG_OK;
     hipStreamSynchronize(pc->ctx->stream);
+    drop_graphs(pc);
     for (void *p : pc->allocs) hipFree(p);
     for (BlockPc &b : pc->blocks) {
         if (b.cg) npg_cg_destroy(b.cg);
@@ -211,7 +225,7 @@ NPG_API int npg_precond_mg_set_level(npg_precond *pc, int level, const npg_csr *
     sv.ctx = pc->ctx; sv.n = np; sv.d = l.sdinv; sv.owns = false;
     if ((rc = npg_csr_inv_diag(S, &sv))) return rc;
     if ((rc = mg_alloc(pc, &l.r, n)) || (rc = mg_alloc(pc, &l.t, nu)) || (rc = mg_alloc(pc, &l.rhs, np)) ||
-        (rc = mg_alloc(pc, &l.dp, np)) || (rc = mg_alloc(pc, &l.res, np)))
+        (rc = mg_alloc(pc, &l.dp, np)) || (rc = mg_alloc(pc, &l.dp2, np)) || (rc = mg_alloc(pc, &l.res, np)))
         return rc;
     if (level + 1 < (int)pc->L.size())
         if ((rc = mg_alloc(pc, &l.x, n)) || (rc = mg_alloc(pc, &l.b, n))) return rc;
@@ -231,6 +245,7 @@ NPG_API int npg_precond_mg_update_level(npg_precond *pc, int level, const npg_cs
                     Dinv->m == l.nu && Dinv->n == l.nu && S->m == l.np && S->n == l.np,
                 "npg_precond_mg_update_level: shapes differ from the level's");
     NPG_HIP(hipStreamSynchronize(pc->ctx->stream));
+    drop_graphs(pc);
     l.A = A; l.G = G; l.D = D; l.Dinv = Dinv; l.S = S;
     npg_vec sv;
     sv.ctx = pc->ctx; sv.n = l.np; sv.d = l.sdinv; sv.owns = false;
@@ -243,12 +258,15 @@ NPG_API int npg_precond_mg_set_params(npg_precond *pc, double omega, double jaco
     NPG_REQUIRE(omega > 0 && jacobi_weight > 0 && schur_sweeps >= 1 && nu1 >= 0 && nu2 >= 0 && nu1 + nu2 >= 1 &&
                     coarse_sweeps >= 1,
                 "npg_precond_mg_set_params: bad parameter");
+    NPG_HIP(hipStreamSynchronize(pc->ctx->stream));
+    drop_graphs(pc);
     pc->omega = omega; pc->jw = jacobi_weight; pc->sweeps = schur_sweeps;
     pc->nu1 = nu1; pc->nu2 = nu2; pc->coarse = coarse_sweeps;
     return NPG_OK;
 }
 
-// nsteps Braess-Sarazin steps on level l for A x = b
+// nsteps Braess-Sarazin steps on level l for A x = b.  Eight launches per step: the vector updates ride in the epilogues of
+// the SpMV kernels (SpmvEpi) - on the coarse levels, where every kernel is latency-bound, the launch count is the cost.
 static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int nsteps, bool x_is_zero) {
     MgLevel &l = pc->L[lev];
     npg_ctx *c = pc->ctx;
@@ -256,20 +274,36 @@ static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int n
     int rc;
     for (int s = 0; s < nsteps; ++s) {
         const bool zero = x_is_zero && s == 0;
-        axpby(c, l.r, 1.0, b, 0.0, l.n);                                             // r = b - A x
-        if (!zero && (rc = spmv_raw(l.A, x, l.r, -1.0, 1.0))) return rc;
-        if ((rc = spmv_raw(l.Dinv, l.r, l.t, 1.0, 0.0))) return rc;                  // t = Dh^-1 r_u
-        axpby(c, l.rhs, -pc->omega, l.r + nu, 0.0, np);                              // rhs = D t - w r_p
-        if ((rc = spmv_raw(l.D, l.t, l.rhs, 1.0, 1.0))) return rc;
-        daxpby(c, l.dp, pc->jw, l.sdinv, l.rhs, 0.0, np);                            // damped Jacobi on S dp = rhs
-        for (int k = 1; k < pc->sweeps; ++k) {
-            axpby(c, l.res, 1.0, l.rhs, 0.0, np);
-            if ((rc = spmv_raw(l.S, l.dp, l.res, -1.0, 1.0))) return rc;
-            daxpby(c, l.dp, pc->jw, l.sdinv, l.res, 1.0, np);
+        const double *r = l.r;
+        if (zero) {
+            r = b;                                                                   // r = b - A 0
+        } else {
+            SpmvEpi e{};                                                             // r = b - A x
+            e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l.r;
+            if ((rc = spmv_epi(l.A, x, e))) return rc;
         }
-        if ((rc = spmv_raw(l.G, l.dp, l.r, -1.0, 1.0))) return rc;                   // r_u -= G dp
-        if ((rc = spmv_raw(l.Dinv, l.r, x, 1.0 / pc->omega, zero ? 0.0 : 1.0))) return rc;   // x_u += Dh^-1 r_u / w
-        axpby(c, x + nu, 1.0, l.dp, zero ? 0.0 : 1.0, np);                           // x_p += dp
+        if ((rc = spmv_raw(l.Dinv, r, l.t, 1.0, 0.0))) return rc;                    // t = Dh^-1 r_u
+        double *dp = l.dp, *dq = l.dp2;
+        {
+            SpmvEpi e{};                                                             // rhs = D t - w r_p ; dp = jw rhs / diag S
+            e.alpha = 1.0; e.beta = -pc->omega; e.c = r + nu; e.y = l.rhs;
+            e.w = pc->jw; e.dg = l.sdinv; e.z = dp;
+            if ((rc = spmv_epi(l.D, l.t, e))) return rc;
+        }
+        for (int k = 1; k < pc->sweeps; ++k) {                                       // damped Jacobi on S dp = rhs
+            SpmvEpi e{};                                                             // res = rhs - S dp ; dq = dp + jw res / diag S
+            e.alpha = -1.0; e.beta = 1.0; e.c = l.rhs; e.y = l.res;
+            e.w = pc->jw; e.dg = l.sdinv; e.zin = dp; e.zc = 1.0; e.z = dq;
+            if ((rc = spmv_epi(l.S, dp, e))) return rc;
+            std::swap(dp, dq);
+        }
+        {
+            SpmvEpi e{};                                                             // t = r_u - G dp   (t is free again)
+            e.alpha = -1.0; e.beta = 1.0; e.c = r; e.y = l.t;
+            if ((rc = spmv_epi(l.G, dp, e))) return rc;
+        }
+        if ((rc = spmv_raw(l.Dinv, l.t, x, 1.0 / pc->omega, zero ? 0.0 : 1.0))) return rc;   // x_u += Dh^-1 t / w
+        axpby(c, x + nu, 1.0, dp, zero ? 0.0 : 1.0, np);                             // x_p += dp
     }
     return NPG_OK;
 }
@@ -277,12 +311,12 @@ static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int n
 static int mg_vcycle(npg_precond *pc, int lev, double *x, const double *b) {
     if (lev == 0) return mg_smooth(pc, 0, x, b, pc->coarse, true);
     MgLevel &l = pc->L[lev], &lc = pc->L[lev - 1];
-    npg_ctx *c = pc->ctx;
     int rc;
     if (pc->nu1 > 0) {
         if ((rc = mg_smooth(pc, lev, x, b, pc->nu1, true))) return rc;
-        axpby(c, l.r, 1.0, b, 0.0, l.n);
-        if ((rc = spmv_raw(l.A, x, l.r, -1.0, 1.0))) return rc;
+        SpmvEpi e{};
+        e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l.r;
+        if ((rc = spmv_epi(l.A, x, e))) return rc;
         if ((rc = spmv_raw(l.R, l.r, lc.b, 1.0, 0.0))) return rc;
     } else {
         if ((rc = spmv_raw(l.R, b, lc.b, 1.0, 0.0))) return rc;
@@ -312,7 +346,26 @@ static int precond_apply_raw(npg_precond *pc, const double *r, double *z) {
     ++pc->applications;
     if (pc->kind == NPG_PC_MG) {
         NPG_REQUIRE(pc->L.back().A, "npg_precond_apply: multigrid levels are not all set");
-        return mg_vcycle(pc, (int)pc->L.size() - 1, z, r);
+        const int top = (int)pc->L.size() - 1;
+        if (!pc->use_graphs) return mg_vcycle(pc, top, z, r);
+        hipStream_t st = pc->ctx->stream;
+        auto key = std::make_pair(r, z);
+        auto it = pc->graphs.find(key);
+        if (it == pc->graphs.end()) {
+            if (pc->graphs.size() >= 64) drop_graphs(pc);                  // a caller that keeps changing buffers
+            hipGraph_t g = nullptr;
+            NPG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int rcv = mg_vcycle(pc, top, z, r);
+            const hipError_t ec = hipStreamEndCapture(st, &g);
+            if (rcv) return rcv;
+            NPG_HIP(ec);
+            hipGraphExec_t ex = nullptr;
+            NPG_HIP(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+            hipGraphDestroy(g);
+            it = pc->graphs.emplace(key, ex).first;
+        }
+        NPG_HIP(hipGraphLaunch(it->second, st));
+        return NPG_OK;
     }
     for (BlockPc &b : pc->blocks) {
         NPG_REQUIRE(b.A, "npg_precond_apply: a block has not been set");
@@ -415,8 +468,11 @@ NPG_API int npg_fgmres_solve(npg_fgmres *ws, const npg_csr *A, npg_precond *pc, 
     int rc;
     double *V = ws->V, *Z = ws->Z;
     // r0 = y - A x
-    axpby(c, V, 1.0, y->d, 0.0, n);
-    if ((rc = spmv_raw(A, x->d, V, -1.0, 1.0))) return rc;
+    {
+        SpmvEpi e{};
+        e.alpha = -1.0; e.beta = 1.0; e.c = y->d; e.y = V;
+        if ((rc = spmv_epi(A, x->d, e))) return rc;
+    }
     double dd;
     if ((rc = reduce_dot(c, V, V, n, &dd))) return rc;
     double beta = std::sqrt(dd);
@@ -495,8 +551,11 @@ NPG_API int npg_fgmres_solve(npg_fgmres *ws, const npg_csr *A, npg_precond *pc, 
         for (int i = 0; i < k; ++i) cf.y[i] = yk[i];
         if (k > 0) hipLaunchKernelGGL(k_combine_z, dim3(grid), dim3(kBlock), 0, st, x->d, Z, ld, k, cf, n);
         // true residual: the next pass starts from it, and a pass that met the estimate is confirmed by it
-        axpby(c, V, 1.0, y->d, 0.0, n);
-        if ((rc = spmv_raw(A, x->d, V, -1.0, 1.0))) return rc;
+        {
+            SpmvEpi e{};
+            e.alpha = -1.0; e.beta = 1.0; e.c = y->d; e.y = V;
+            if ((rc = spmv_epi(A, x->d, e))) return rc;
+        }
         if ((rc = reduce_dot(c, V, V, n, &dd))) return rc;
         beta = std::sqrt(dd);
         stats->rnorm = scale * beta;

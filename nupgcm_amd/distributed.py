@@ -84,10 +84,17 @@ class RowPartition:
         return [(r, 0, int(self.b_bounds[r]), int(self.b_bounds[r + 1] - self.b_bounds[r])) for r in range(self.nranks)]
 
 
-def local_block(A, owned, owner):
+def local_block(A, owned, owner, with_map=False):
     """Rows `owned` (ascending global ids) of the square global CSR matrix A, renumbered [owned | ghosts].
-    Returns (A_loc, ghosts) with ghosts sorted by (owner rank, global id)."""
+    Returns (A_loc, ghosts) with ghosts sorted by (owner rank, global id); with_map: also the position of every local entry
+    in A's value array (A_loc.data == A.data[map]) - what npg_csr_gather_values needs to refresh the block from a
+    re-assembled global matrix."""
     A = sp.csr_matrix(A)
+    if with_map:
+        A_loc, ghosts = local_block(A, owned, owner)
+        tag = sp.csr_matrix((np.arange(1, A.nnz + 1, dtype=np.float64), A.indices, A.indptr), shape=A.shape)
+        T_loc, _ = local_block(tag, owned, owner)                 # same pattern, same ordering of the entries
+        return A_loc, ghosts, np.rint(T_loc.data).astype(np.int64) - 1
     R = A[owned]
     cols = np.unique(R.indices)
     is_owned = np.zeros(A.shape[1], dtype=bool)
@@ -190,8 +197,7 @@ def distribute_model(model, dist, block_nodes=None):
     from .iterative_solvers import CgWorkspace, Diagonal, GmresWorkspace
     arch, ctx = model.arch, model.arch.ctx
     rank, world = dist.get_rank(), dist.get_world_size()
-    if model.forcings.conv_param.is_on or model.forcings.eddy_param.is_on:
-        raise NotImplementedError("distributed runs do not re-assemble coefficient-dependent matrices yet")
+    closures = model.forcings.conv_param.is_on or model.forcings.eddy_param.is_on
     # RCCL bootstrap: rank 0's unique id travels over the launcher's process group
     ids = [comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(ids, src=0)
@@ -201,19 +207,22 @@ def distribute_model(model, dist, block_nodes=None):
     model.partition = part
     if block_nodes is None:
         block_nodes = d.nu + d.np >= 100000
-    block_nodes = block_nodes and not callable(model.forcings.nu)
+    block_nodes = block_nodes and not callable(model.forcings.nu) and not model.forcings.eddy_param.is_on
+
+    from .architectures import DeviceIndex
 
     def make(A_dev, owned, owner):
-        A_loc, ghosts = local_block(A_dev.to_scipy_csr(), owned, owner)
+        A_loc, ghosts, amap = local_block(A_dev.to_scipy_csr(), owned, owner, with_map=True)
         allg = [None] * world
         dist.all_gather_object(allg, ghosts)
         plan = halo_plan(rank, owned, owner, allg)
-        return A_loc, Halo(ctx, len(owned), len(ghosts), plan)
+        return A_loc, Halo(ctx, len(owned), len(ghosts), plan), amap
 
     # ---- inversion -------------------------------------------------------------------------------------------------
     inv, s = model.inversion, model.inversion.solver
     owned = part.inv_owned(rank)
-    A_loc, halo = make(s.A, owned, part.inv_owner())
+    A_loc, halo, a_map = make(s.A, owned, part.inv_owner())
+    A_full = s.A
     B_loc = sp.csr_matrix(inv.B.to_scipy_csr()[owned])
     b0_loc = inv.b.to_host()[owned]
     x_full = s.x
@@ -228,25 +237,34 @@ def distribute_model(model, dist, block_nodes=None):
     inv.solver = DistributedSolverToolkit(A_loc_dev, Diagonal(scalar=s.P.scalar, n=len(owned)),
                                           DeviceVector(ctx, len(owned)), ws, s.kwargs, s.label, x_full, halo,
                                           part.inv_segments())
+    if closures:
+        # the closures re-assemble the GLOBAL matrices (every rank runs the element kernels on the replicated state); a
+        # rank's block is a fixed subset of their entries and follows by one gather (src/model.jl:160-170,229-261)
+        inv.solver.A_full, inv.solver.A_map = A_full, DeviceIndex(ctx, a_map, A_full.nnz)
     # ---- evolution -------------------------------------------------------------------------------------------------
     ev, se = model.evolution, model.evolution.solver
     bo = part.b_owned(rank)
-    Ae_loc, halo_b = make(se.A, bo, part.b_owner())
-    lut = None
+    Ae_loc, halo_b, b_map = make(se.A, bo, part.b_owner())
 
     def loc(Mdev):
-        nonlocal lut
         Ml, gh = local_block(Mdev.to_scipy_csr(), bo, part.b_owner())
         return DeviceCSR.from_scipy(ctx, Ml)
 
-    # M, Kh, Kv share A_evo's pattern, hence its ghost set and column numbering
+    # M, Kh, Kv share A_evo's pattern, hence its ghost set, column numbering and value map
+    Kv_full = ev.Kv
     ev.M, ev.Kh, ev.Kv = loc(ev.M), loc(ev.Kh), loc(ev.Kv)
+    if closures:
+        ev.Kv_full, ev.Kv_map = Kv_full, DeviceIndex(ctx, b_map, Kv_full.nnz)
     wsb = CgWorkspace(ctx, len(bo))
     L.check(L.lib().npg_cg_set_halo(wsb.h, halo_b.h))
     A_dev = DeviceCSR.from_scipy(ctx, Ae_loc)
     P = Diagonal(A_dev.inv_diag(DeviceVector(ctx, len(bo))))
     ev.solver = DistributedSolverToolkit(A_dev, P, se.y, wsb, se.kwargs, se.label, se.x, halo_b, part.b_segments(),
                                          y_range=(int(part.b_bounds[rank]), len(bo)))
+    # a model that already holds a state (set_b!, invert! before distributing): the solvers' own slices follow it
+    inv.solver.load_owned_from_full()
+    ev.solver.load_owned_from_full()
+    model._prev = None
     torch.cuda.synchronize()
     return model
 
@@ -256,3 +274,11 @@ def example_model(arch, mesh_model, dist, dt=1e-3, block_nodes=None, **kw):
     # the global matrix stays plain CSR (it is downloaded and cut into row blocks); the local blocks get the node records
     return distribute_model(workloads.example_model(arch, mesh_model, dt=dt, block_nodes=False, **kw), dist,
                             block_nodes=block_nodes)
+
+
+def channel_basin_model(arch, mesh_model, dist, **kw):
+    """BASELINE configs[4] distributed: scratch/run.jl on the x-periodic channel-basin mesh (the periodic seam shows up as
+    one more neighbour in the halo plan - a rank's off-rank columns are whatever its rows reference), closures refreshed
+    through the replicated global matrices."""
+    from . import workloads
+    return distribute_model(workloads.channel_basin_model(arch, mesh_model=mesh_model, **kw), dist, block_nodes=False)

@@ -105,7 +105,11 @@ def evolve(model: Model, x_inv_prev: DeviceVector, b_prev: DeviceVector):
     if frc.conv_param.is_on:
         cp = frc.conv_param
         fe.update_kappa_convection(cp.kappa_c, cp.N2min, prm.alpha, prm.N2, model.b_vec)       # src/model.jl:229-232
-        fe.assemble(L.NPG_MAT_KV, ev.Kv, lift=ev.rhs_v)                                        # src/model.jl:235
+        if hasattr(ev, "Kv_full"):        # distributed: assemble the replicated matrix, gather this rank's row block
+            fe.assemble(L.NPG_MAT_KV, ev.Kv_full, lift=ev.rhs_v)
+            ev.Kv.gather_values(ev.Kv_full, ev.Kv_map)
+        else:
+            fe.assemble(L.NPG_MAT_KV, ev.Kv, lift=ev.rhs_v)                                    # src/model.jl:235
         fe.rhs_diff(prm.N2, ev.rhs_diff)                                                       # src/model.jl:237
     if frc.conv_param.is_on or ts.adaptive:
         collect_evolution_LHS_into(solver.A, solver.P, prm, ts, ev.M, ev.Kh, ev.Kv)            # src/model.jl:251-261
@@ -152,7 +156,12 @@ def run(model: Model, n_info=10, n_save=float("inf"), n_plot=float("inf"), advec
         if frc.eddy_param.is_on and advection and i % 10 == 0:                                  # src/model.jl:160-170
             ep = frc.eddy_param
             fe.update_nu_eddy(ep.N2min, prm.alpha, prm.N2, b)
-            build_A_inversion(model.arch, model.fe_data, prm, None, A=model.inversion.solver.A)
+            sol = model.inversion.solver
+            if hasattr(sol, "A_full"):    # distributed: re-assemble the replicated matrix, gather this rank's row block
+                build_A_inversion(model.arch, model.fe_data, prm, None, A=sol.A_full)
+                sol.A.gather_values(sol.A_full, sol.A_map)
+            else:
+                build_A_inversion(model.arch, model.fe_data, prm, None, A=sol.A)
             if hasattr(model.inversion.solver.P, "refresh"):         # an operator-dependent preconditioner follows A
                 model.inversion.solver.P.refresh(model.inversion.solver.A)
         model.stats.append((model.evolution.solver.workspace.stats, model.inversion.solver.workspace.stats))

@@ -21,8 +21,14 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     arch = npg.GPU(int(os.environ.get("NPG_FORCE_DEVICE", 0)))
     ctx = arch.ctx
-    mm = workloads.bowl_mesh_model("bowl3D_h0.1")
-    m = distributed.example_model(arch, mm, dist, block_nodes=block_nodes)
+    channel = len(sys.argv) > 3 and sys.argv[3] == "channel"
+    if channel:
+        from nupgcm_amd import channel_basin
+        mm = channel_basin.channel_basin_model(0.0625, workloads.CB_ALPHA)
+        m = distributed.channel_basin_model(arch, mm, dist, element_precision="fp64")
+    else:
+        mm = workloads.bowl_mesh_model("bowl3D_h0.1")
+        m = distributed.example_model(arch, mm, dist, block_nodes=block_nodes)
     # distributed SpMV: owned rows of A x for a known global x
     s = m.inversion.solver
     part = m.partition
@@ -34,10 +40,12 @@ def main():
     s.halo.exchange(x_loc)
     y_loc = s.A.mul(x_loc).to_host()
     ghosts = x_loc.to_host()[len(owned):]
-    npg.invert(m)
+    if not channel:
+        npg.invert(m)
     npg.run(m, n_steps=nsteps)
     ctx.sync()
-    np.savez(f"{out}.rank{rank}.npz", storage=np.array(s.A.storage()), owned=owned, y_loc=y_loc, n_ghost=len(ghosts), u=m.state.u, p=m.state.p,
+    peers = np.asarray(s.halo._keep["peers"])
+    np.savez(f"{out}.rank{rank}.npz", peers=peers, dt=m.timestepper.dt, storage=np.array(s.A.storage()), owned=owned, y_loc=y_loc, n_ghost=len(ghosts), u=m.state.u, p=m.state.p,
              b=m.state.b, gm=[st[1]["niter"] for st in m.stats], cg=[st[0]["niter"] for st in m.stats],
              solved=[bool(st[1]["solved"]) and bool(st[0]["solved"]) for st in m.stats])
     dist.barrier()

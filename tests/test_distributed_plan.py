@@ -152,3 +152,36 @@ def test_partition_boundaries_on_node_starts():
             nf, ns = part.local_nodes(r)
             assert 3 * nf + 2 * ns <= part.u_bounds[r + 1] - part.u_bounds[r]
         assert np.array_equal(np.sort(np.concatenate([part.inv_owned(r) for r in range(world)])), np.arange(nu + 300))
+
+
+def test_periodic_mesh_plan_and_value_map():
+    """The channel-basin mesh (BASELINE configs[4]): the partition of its RCM-ordered inversion system, the halo plan and the
+    entry map that refreshes a rank's row block from a re-assembled global matrix (npg_csr_gather_values).  The periodic
+    seam needs no special case - a rank's ghosts are whatever columns its rows reference - but it shows: some rank's
+    neighbour set is not just {rank - 1, rank + 1}."""
+    from nupgcm_amd import channel_basin, workloads
+    fed = workloads.channel_basin_fe_data(channel_basin.channel_basin_model(0.1, 1 / 8, dz=0.04), "flux")
+    rp, ci, shape = fed.pattern_A(structural=True)
+    rng = np.random.default_rng(5)
+    A = sp.csr_matrix((rng.standard_normal(len(ci)), ci, rp), shape=shape)
+    d = fed.dofs
+    world = 4
+    part = D.RowPartition(d.nu, d.np, d.nb, world, d.n_full, d.n_surf)
+    owner = part.inv_owner()
+    blocks = [D.local_block(A, part.inv_owned(r), owner, with_map=True) for r in range(world)]
+    ghosts = [b[1] for b in blocks]
+    x = np.cos(np.arange(A.shape[0], dtype=float))
+    A2 = sp.csr_matrix((rng.standard_normal(len(ci)), ci, rp), shape=shape)     # "re-assembled": same pattern, new values
+    peers = []
+    for r in range(world):
+        owned = part.inv_owned(r)
+        A_loc, gh, amap = blocks[r]
+        assert np.array_equal(A_loc.data, A.data[amap])                         # the map reproduces the block ...
+        A_new = sp.csr_matrix((A2.data[amap], A_loc.indices, A_loc.indptr), shape=A_loc.shape)
+        x_loc = np.concatenate([x[owned], x[gh]])
+        assert np.allclose(A_new @ x_loc, (A2 @ x)[owned], rtol=1e-13, atol=1e-13)      # ... and refreshes it
+        plan = D.halo_plan(r, owned, owner, ghosts)
+        assert plan["recv_ptr"][-1] == len(gh)
+        peers.append(set(int(q) for q in plan["peers"]))
+    assert all(r in peers[q] for r in range(world) for q in peers[r])            # the plan is symmetric
+    assert any(p - {r - 1, r + 1} for r, p in enumerate(peers))                  # the seam (and the pressure rows) reach further

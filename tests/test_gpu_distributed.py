@@ -67,3 +67,33 @@ def test_multi_rank_rehearsal(serial, world, blocks, tmp_path):
     assert np.all(np.abs(z["gm"] - ref_gm) <= 0.1 * ref_gm + 20), (z["gm"], ref_gm)
     assert rel(z["b"], ref.state.b) < 1e-6
     assert rel(z["u"], ref.state.u) < 1e-3 and rel(z["p"], ref.state.p) < 1e-3
+
+
+def test_channel_basin_closures_and_periodic_seam_distributed(tmp_path):
+    """BASELINE configs[4] on 3 ranks (rehearsal transport): the x-periodic mesh, P1 buoyancy, full-stress A, BDF1 with the CFL
+    step, the convection closure every step and the eddy closure's re-assembly of A at step 10 - each re-assembled as the
+    replicated global matrix and gathered into the rank's row block - against the single-GPU run of the same model."""
+    from nupgcm_amd import channel_basin
+    world, nsteps = 3, 11
+    arch = npg.GPU()
+    mm = channel_basin.channel_basin_model(0.0625, workloads.CB_ALPHA)
+    ref = workloads.channel_basin_model(arch, mesh_model=mm, element_precision="fp64")
+    npg.run(ref, n_steps=nsteps)
+    out = str(tmp_path / "cb")
+    env = dict(os.environ, NPG_COMM_TRANSPORT="shm", NPG_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_rehearsal_worker.py"), out, str(nsteps),
+           "channel"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ranks = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
+    for z in ranks[1:]:
+        assert np.array_equal(z["b"], ranks[0]["b"]) and np.array_equal(z["u"], ranks[0]["u"]) and z["dt"] == ranks[0]["dt"]
+    z = ranks[0]
+    assert list(z["gm"]) == [1000] * nsteps                       # run.jl's itmax ends every inversion, on every rank count
+    assert abs(z["dt"] - ref.timestepper.dt) < 1e-3 * ref.timestepper.dt
+    assert rel(z["b"], ref.state.b) < 1e-3 and rel(z["u"], ref.state.u) < 1e-2, (rel(z["b"], ref.state.b), rel(z["u"], ref.state.u))
+    # the periodic seam: with contiguous RCM row blocks on a non-periodic mesh the middle rank of three talks to its two
+    # neighbours; here some rank also holds columns across the seam
+    assert max(len(zz["peers"]) for zz in ranks) == 2 and all(len(zz["peers"]) >= 1 for zz in ranks)

@@ -21,10 +21,10 @@ npg.set_b(m, lambda x: 0.1 * np.exp(-(x[..., 2] + prm.H(x)) / (0.1 * prm.alpha))
 print(f"{wl}: set-up {time.time() - t0:.1f} s, levels {m.inversion.solver.P.levels}", flush=True)
 s = m.inversion.solver
 P = s.P
-combos = [dict()] + [dict(nu1=a, nu2=b, schur_sweeps=c, coarse_sweeps=d, omega=w)
-                     for (a, b), c, d, w in itertools.product([(1, 1), (1, 2), (2, 2), (0, 2), (0, 3)], [1, 2, 3], [10, 20],
-                                                              [2.5])]
-combos += [dict(omega=w) for w in (2.0, 3.0)] + [dict(coarse_sweeps=c) for c in (5, 40)]
+combos = [dict()] + [dict(coarse_sweeps=c) for c in (30, 40, 60)] + [dict(omega=w) for w in (2.0, 2.2, 2.8, 3.2)] + \
+    [dict(jacobi_weight=w) for w in (0.5, 0.85, 1.0)] + [dict(schur_sweeps=4), dict(schur_sweeps=5, coarse_sweeps=40),
+                                                        dict(nu1=2, nu2=3), dict(nu1=3, nu2=3), dict(nu1=3, nu2=3, coarse_sweeps=40)]
+s.kwargs["itmax"] = 150
 for kw in combos:
     P.set_params(**kw)
     s.x.fill(0.0)
