@@ -205,6 +205,9 @@ int npg_precond_mg_update_level(npg_precond *pc, int level, const npg_csr *A, co
  * steps (2, 2), coarse_sweeps: smoothing steps that stand in for the coarsest-level solve (20). */
 int npg_precond_mg_set_params(npg_precond *pc, double omega, double jacobi_weight, int schur_sweeps, int nu1, int nu2,
                               int coarse_sweeps);
+/* gamma = 1: V-cycle (default); gamma = 2: W-cycle - every level's coarse problem is visited twice, which keeps the
+ * convergence independent of the number of levels where the V-cycle's degrades (4 levels: DESIGN.md section 4.5) */
+int npg_precond_mg_set_cycle(npg_precond *pc, int gamma);
 /* z = M^-1 r (one application: one V-cycle / one round of inner CG solves) */
 int npg_precond_apply(npg_precond *pc, const npg_vec *r, npg_vec *z);
 int npg_precond_counters(npg_precond *pc, int64_t *applications, int64_t *inner_iterations);

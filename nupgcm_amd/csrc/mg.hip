@@ -136,7 +136,7 @@ struct npg_precond {
     // multigrid
     std::vector<MgLevel> L;
     double omega = 2.5, jw = 0.7;
-    int sweeps = 3, nu1 = 2, nu2 = 2, coarse = 20;
+    int sweeps = 3, nu1 = 2, nu2 = 2, coarse = 20, gamma = 1;
     std::vector<void *> allocs;
     // one instantiated hipGraph of the V-cycle per (input, output) address pair: flexible GMRES applies the preconditioner
     // to the same `memory` basis / Z column pairs in every restart cycle, so a cycle's ~300 launches (most of them
@@ -265,6 +265,14 @@ NPG_API int npg_precond_mg_set_params(npg_precond *pc, double omega, double jaco
     return NPG_OK;
 }
 
+NPG_API int npg_precond_mg_set_cycle(npg_precond *pc, int gamma) {
+    NPG_REQUIRE(pc && pc->kind == NPG_PC_MG && (gamma == 1 || gamma == 2), "npg_precond_mg_set_cycle: gamma must be 1 (V) or 2 (W)");
+    NPG_HIP(hipStreamSynchronize(pc->ctx->stream));
+    drop_graphs(pc);
+    pc->gamma = gamma;
+    return NPG_OK;
+}
+
 // nsteps Braess-Sarazin steps on level l for A x = b.  Eight launches per step: the vector updates ride in the epilogues of
 // the SpMV kernels (SpmvEpi) - on the coarse levels, where every kernel is latency-bound, the launch count is the cost.
 static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int nsteps, bool x_is_zero) {
@@ -308,23 +316,29 @@ static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int n
     return NPG_OK;
 }
 
-static int mg_vcycle(npg_precond *pc, int lev, double *x, const double *b) {
-    if (lev == 0) return mg_smooth(pc, 0, x, b, pc->coarse, true);
+// One multigrid cycle on level `lev` for A x = b: gamma = 1 is the V-cycle, gamma = 2 the W-cycle (the coarse problem of
+// every level is visited gamma times, the second visit continuing from the first one's result).
+static int mg_cycle(npg_precond *pc, int lev, double *x, const double *b, bool x_is_zero) {
+    if (lev == 0) return mg_smooth(pc, 0, x, b, pc->coarse, x_is_zero);
     MgLevel &l = pc->L[lev], &lc = pc->L[lev - 1];
     int rc;
-    if (pc->nu1 > 0) {
-        if ((rc = mg_smooth(pc, lev, x, b, pc->nu1, true))) return rc;
+    if (pc->nu1 > 0 && (rc = mg_smooth(pc, lev, x, b, pc->nu1, x_is_zero))) return rc;
+    const bool still_zero = x_is_zero && pc->nu1 == 0;
+    if (still_zero) {
+        if ((rc = spmv_raw(l.R, b, lc.b, 1.0, 0.0))) return rc;
+    } else {
         SpmvEpi e{};
         e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l.r;
         if ((rc = spmv_epi(l.A, x, e))) return rc;
         if ((rc = spmv_raw(l.R, l.r, lc.b, 1.0, 0.0))) return rc;
-    } else {
-        if ((rc = spmv_raw(l.R, b, lc.b, 1.0, 0.0))) return rc;
     }
-    if ((rc = mg_vcycle(pc, lev - 1, lc.x, lc.b))) return rc;
-    if ((rc = spmv_raw(l.P, lc.x, x, 1.0, pc->nu1 > 0 ? 1.0 : 0.0))) return rc;
+    for (int g = 0; g < pc->gamma; ++g)
+        if ((rc = mg_cycle(pc, lev - 1, lc.x, lc.b, g == 0))) return rc;
+    if ((rc = spmv_raw(l.P, lc.x, x, 1.0, still_zero ? 0.0 : 1.0))) return rc;
     return mg_smooth(pc, lev, x, b, pc->nu2, false);
 }
+
+static int mg_vcycle(npg_precond *pc, int lev, double *x, const double *b) { return mg_cycle(pc, lev, x, b, true); }
 
 NPG_API int npg_precond_blockdiag_set(npg_precond *pc, int k, int64_t offset, const npg_csr *A, const npg_vec *jacobi,
                                       int64_t itmax, double atol, double rtol) {

@@ -210,9 +210,22 @@ def distribute_model(model, dist, block_nodes=None):
     block_nodes = block_nodes and not callable(model.forcings.nu) and not model.forcings.eddy_param.is_on
 
     from .architectures import DeviceIndex
+    fed = model.fe_data
+    full_stress = callable(model.forcings.nu) or model.forcings.eddy_param.is_on
 
-    def make(A_dev, owned, owner):
-        A_loc, ghosts, amap = local_block(A_dev.to_scipy_csr(), owned, owner, with_map=True)
+    def make(pattern, A_dev, owned, owner):
+        """This rank's row block of a replicated device matrix WITHOUT moving values through the host: the block's pattern,
+        ghost list and entry map come from the global sparsity pattern (host index arrays only), the values from one
+        device gather out of the matrix every rank assembled with the element kernels."""
+        rp, ci, shape = pattern
+        tags = sp.csr_matrix((np.arange(1, len(ci) + 1, dtype=np.float64), ci, rp), shape=shape)
+        T_loc, ghosts = local_block(tags, owned, owner) if shape[0] == shape[1] else (sp.csr_matrix(tags[owned]), None)
+        T_loc.sort_indices()
+        amap = DeviceIndex(ctx, np.rint(T_loc.data).astype(np.int64) - 1, A_dev.nnz)
+        A_loc = DeviceCSR.from_pattern(ctx, T_loc.shape[0], T_loc.shape[1], T_loc.indptr, T_loc.indices)
+        A_loc.gather_values(A_dev, amap)
+        if ghosts is None:
+            return A_loc, None, amap
         allg = [None] * world
         dist.all_gather_object(allg, ghosts)
         plan = halo_plan(rank, owned, owner, allg)
@@ -221,16 +234,17 @@ def distribute_model(model, dist, block_nodes=None):
     # ---- inversion -------------------------------------------------------------------------------------------------
     inv, s = model.inversion, model.inversion.solver
     owned = part.inv_owned(rank)
-    A_loc, halo, a_map = make(s.A, owned, part.inv_owner())
+    if s.A.storage()[0]:
+        raise ValueError("distribute_model: build the model with block_nodes=False (the global matrix is cut into row blocks)")
     A_full = s.A
-    B_loc = sp.csr_matrix(inv.B.to_scipy_csr()[owned])
+    A_loc_dev, halo, a_map = make(fed.pattern_A(structural=full_stress), A_full, owned, part.inv_owner())
+    B_loc_dev, _, _ = make(fed.pattern_B(), inv.B, owned, None)
     b0_loc = inv.b.to_host()[owned]
     x_full = s.x
     ws = GmresWorkspace(ctx, len(owned), memory=s.workspace.memory)
     L.check(L.lib().npg_gmres_set_halo(ws.h, halo.h))
-    inv.B = DeviceCSR.from_scipy(ctx, B_loc)
+    inv.B = B_loc_dev
     inv.b = DeviceVector.from_host(ctx, b0_loc)
-    A_loc_dev = DeviceCSR.from_scipy(ctx, A_loc)
     if block_nodes:
         # owned nodes lead the local numbering in the global order [full | surface]; couplings to ghosts stay CSR
         A_loc_dev.block_nodes(*part.local_nodes(rank))
@@ -240,24 +254,24 @@ def distribute_model(model, dist, block_nodes=None):
     if closures:
         # the closures re-assemble the GLOBAL matrices (every rank runs the element kernels on the replicated state); a
         # rank's block is a fixed subset of their entries and follows by one gather (src/model.jl:160-170,229-261)
-        inv.solver.A_full, inv.solver.A_map = A_full, DeviceIndex(ctx, a_map, A_full.nnz)
+        inv.solver.A_full, inv.solver.A_map = A_full, a_map
     # ---- evolution -------------------------------------------------------------------------------------------------
     ev, se = model.evolution, model.evolution.solver
     bo = part.b_owned(rank)
-    Ae_loc, halo_b, b_map = make(se.A, bo, part.b_owner())
+    pat_b = fed.pattern_b()
+    A_dev, halo_b, b_map = make(pat_b, se.A, bo, part.b_owner())
+    # M, Kh, Kv share A_evo's pattern, hence its ghost set, column numbering and entry map
+    Kv_full = ev.Kv
 
     def loc(Mdev):
-        Ml, gh = local_block(Mdev.to_scipy_csr(), bo, part.b_owner())
-        return DeviceCSR.from_scipy(ctx, Ml)
+        Ml = A_dev.clone()
+        return Ml.gather_values(Mdev, b_map)
 
-    # M, Kh, Kv share A_evo's pattern, hence its ghost set, column numbering and value map
-    Kv_full = ev.Kv
     ev.M, ev.Kh, ev.Kv = loc(ev.M), loc(ev.Kh), loc(ev.Kv)
     if closures:
-        ev.Kv_full, ev.Kv_map = Kv_full, DeviceIndex(ctx, b_map, Kv_full.nnz)
+        ev.Kv_full, ev.Kv_map = Kv_full, b_map
     wsb = CgWorkspace(ctx, len(bo))
     L.check(L.lib().npg_cg_set_halo(wsb.h, halo_b.h))
-    A_dev = DeviceCSR.from_scipy(ctx, Ae_loc)
     P = Diagonal(A_dev.inv_diag(DeviceVector(ctx, len(bo))))
     ev.solver = DistributedSolverToolkit(A_dev, P, se.y, wsb, se.kwargs, se.label, se.x, halo_b, part.b_segments(),
                                          y_range=(int(part.b_bounds[rank]), len(bo)))
@@ -271,7 +285,7 @@ def distribute_model(model, dist, block_nodes=None):
 
 def example_model(arch, mesh_model, dist, dt=1e-3, block_nodes=None, **kw):
     from . import workloads
-    # the global matrix stays plain CSR (it is downloaded and cut into row blocks); the local blocks get the node records
+    # the global matrix stays plain CSR (row blocks are gathered out of it on the device); the local blocks get the node records
     return distribute_model(workloads.example_model(arch, mesh_model, dt=dt, block_nodes=False, **kw), dist,
                             block_nodes=block_nodes)
 

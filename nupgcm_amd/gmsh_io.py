@@ -35,6 +35,8 @@ class GmshModel:
     # node of n (n itself when it has none).  GridapGmsh glues the vertices of paired nodes in the grid topology; cells keep
     # their own node coordinates.  None = not periodic.
     periodic: np.ndarray = None
+    # set by refine.refine_once: for every cell of the PARENT mesh the diagonal (0, 1, 2) its inner octahedron was cut along
+    child_variant: np.ndarray = None
 
     def tag_mask(self, names) -> int:
         m = 0

@@ -105,7 +105,10 @@ def nodal_interpolation(mesh_c: Mesh, mesh_f: Mesh):
     if ncf != 8 * mesh_c.ncell:
         raise ValueError("nodal_interpolation: the fine mesh is not a uniform red refinement of the coarse one")
     par, kid = np.arange(ncf) // 8, np.arange(ncf) % 8
-    lam = refine.CHILD_BARY[kid]                                     # (ncf, 4 fine verts, 4 coarse verts), model order
+    variant = getattr(mesh_f.model, "child_variant", None)
+    if variant is None or len(variant) != mesh_c.ncell:
+        raise ValueError("nodal_interpolation: the fine mesh does not carry refine_once's child_variant of this coarse mesh")
+    lam = refine.CHILD_BARY[np.asarray(variant, dtype=np.int64)[par], kid]   # (ncf, 4 fine verts, 4 coarse verts), model order
     fm = mesh_f.vertex_of[np.asarray(mesh_f.model.cells, dtype=np.int64)]
     lam = np.take_along_axis(lam, np.argsort(fm, axis=1, kind="stable")[:, :, None], axis=1)
     cm = mesh_c.vertex_of[np.asarray(mesh_c.model.cells, dtype=np.int64)][par]
@@ -179,7 +182,7 @@ class MultigridPreconditioner(GeneralPreconditioner):
     solver's matrix (it may be stored by node blocks); the coarser operators are re-discretised on their own meshes."""
 
     def __init__(self, arch, params, forcings, hierarchy, A_fine: DeviceCSR = None, omega=2.5, jacobi_weight=0.7,
-                 schur_sweeps=3, nu1=2, nu2=2, coarse_sweeps=20, block_nodes=None):
+                 schur_sweeps=3, nu1=2, nu2=2, coarse_sweeps=20, block_nodes=None, cycle="V"):
         """A function-valued nu (full-stress form) is re-discretised on every level like a constant one.  With the eddy
         closure on, `refresh(A)` (called by run! after each re-assembly of A, src/model.jl:160-170) rebuilds the FINEST level's
         smoother from the new matrix; the coarser levels keep the operators of the set-up viscosity - a preconditioner need
@@ -210,7 +213,7 @@ class MultigridPreconditioner(GeneralPreconditioner):
                                                      None if Pd is None else Pd.h, None if Rd is None else Rd.h))
             self.levels.append(dict(n=d.nu + d.np, nu=nu, S_nnz=S.nnz))
             prev = fed
-        self.set_params(omega, jacobi_weight, schur_sweeps, nu1, nu2, coarse_sweeps)
+        self.set_params(omega, jacobi_weight, schur_sweeps, nu1, nu2, coarse_sweeps, cycle)
 
     @staticmethod
     def _blocks(A: DeviceCSR, d):
@@ -231,11 +234,12 @@ class MultigridPreconditioner(GeneralPreconditioner):
         self._keep += dev                       # the old handles stay alive until the preconditioner goes (they are small)
         return self
 
-    def set_params(self, omega=2.5, jacobi_weight=0.7, schur_sweeps=3, nu1=2, nu2=2, coarse_sweeps=20):
+    def set_params(self, omega=2.5, jacobi_weight=0.7, schur_sweeps=3, nu1=2, nu2=2, coarse_sweeps=20, cycle="V"):
         L.check(L.lib().npg_precond_mg_set_params(self.h, float(omega), float(jacobi_weight), int(schur_sweeps), int(nu1),
                                                   int(nu2), int(coarse_sweeps)))
+        L.check(L.lib().npg_precond_mg_set_cycle(self.h, {"V": 1, "W": 2}[cycle]))
         self.params = dict(omega=omega, jacobi_weight=jacobi_weight, schur_sweeps=schur_sweeps, nu1=nu1, nu2=nu2,
-                           coarse_sweeps=coarse_sweeps)
+                           coarse_sweeps=coarse_sweeps, cycle=cycle)
 
     def __repr__(self):
         return f"MultigridPreconditioner({[lv['n'] for lv in self.levels]}, {self.params})"

@@ -16,17 +16,24 @@ _E = np.array([[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]])
 
 
 # The eight children of refine_once in terms of the parent's vertices (model order): child k's vertex v is the midpoint of
-# parent vertices CHILD_VERTS[k][v] (a vertex itself when both coincide).  CHILD_BARY[k, v, :] are its barycentric
-# coordinates in the parent - what nupgcm_amd.multigrid needs to interpolate between the levels of a refinement hierarchy.
+# parent vertices CHILD_VERTS[d][k][v] (a vertex itself when both coincide).  The four corner children are the same for every
+# parent; the inner octahedron is cut along one of its three diagonals d = 0: m01-m23, 1: m02-m13, 2: m03-m12 - the SHORTEST
+# one (in the parent's straight geometry), the standard choice that keeps the children's shape from degrading (a fixed
+# diagonal brings the worst cell of the bowl meshes from 0.126 to 0.036 of a regular tetrahedron's volume / longest-edge^3,
+# the shortest one keeps 0.126 on every level).  CHILD_BARY[d, k, v, :] are the barycentric coordinates of child vertices in
+# the parent - what nupgcm_amd.multigrid needs to interpolate between the levels of a refinement hierarchy.
 _M01, _M02, _M03, _M12, _M13, _M23 = (0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)
-CHILD_VERTS = (((0, 0), _M01, _M02, _M03), (_M01, (1, 1), _M12, _M13), (_M02, _M12, (2, 2), _M23),
-               (_M03, _M13, _M23, (3, 3)), (_M01, _M02, _M03, _M13), (_M01, _M02, _M12, _M13),
-               (_M02, _M03, _M13, _M23), (_M02, _M12, _M13, _M23))
-CHILD_BARY = np.zeros((8, 4, 4))
-for _k, _kid in enumerate(CHILD_VERTS):
-    for _v, (_a, _b) in enumerate(_kid):
-        CHILD_BARY[_k, _v, _a] += 0.5
-        CHILD_BARY[_k, _v, _b] += 0.5
+_CORNERS = (((0, 0), _M01, _M02, _M03), (_M01, (1, 1), _M12, _M13), (_M02, _M12, (2, 2), _M23), (_M03, _M13, _M23, (3, 3)))
+_INNER = (((_M01, _M23, _M02, _M03), (_M01, _M23, _M03, _M13), (_M01, _M23, _M13, _M12), (_M01, _M23, _M12, _M02)),
+          ((_M02, _M13, _M01, _M03), (_M02, _M13, _M03, _M23), (_M02, _M13, _M23, _M12), (_M02, _M13, _M12, _M01)),
+          ((_M03, _M12, _M01, _M02), (_M03, _M12, _M02, _M23), (_M03, _M12, _M23, _M13), (_M03, _M12, _M13, _M01)))
+CHILD_VERTS = tuple(_CORNERS + _INNER[d] for d in range(3))
+CHILD_BARY = np.zeros((3, 8, 4, 4))
+for _d in range(3):
+    for _k, _kid in enumerate(CHILD_VERTS[_d]):
+        for _v, (_a, _b) in enumerate(_kid):
+            CHILD_BARY[_d, _k, _v, _a] += 0.5
+            CHILD_BARY[_d, _k, _v, _b] += 0.5
 
 
 def _mid_ids(nv, a, b):
@@ -44,11 +51,18 @@ def refine_once(model: GmshModel, project=None) -> GmshModel:
     uniq, inv = np.unique(keys.ravel(), return_inverse=True)
     mid = (nv + inv).reshape(-1, 6)                                            # m01 m02 m03 m12 m13 m23
     coords = np.vstack([model.coords, 0.5 * (model.coords[uniq // nv] + model.coords[uniq % nv])])
-    v0, v1, v2, v3 = cells.T
-    m01, m02, m03, m12, m13, m23 = mid.T
-    kids = [(v0, m01, m02, m03), (m01, v1, m12, m13), (m02, m12, v2, m23), (m03, m13, m23, v3),
-            (m01, m02, m03, m13), (m01, m02, m12, m13), (m02, m03, m13, m23), (m02, m12, m13, m23)]
-    new_cells = np.stack([np.stack(k, axis=1) for k in kids], axis=1).reshape(-1, 4)
+    # the inner octahedron of every parent is cut along its shortest diagonal (ties: the first)
+    d3 = np.stack([np.linalg.norm(coords[mid[:, a]] - coords[mid[:, b]], axis=1) for a, b in ((0, 5), (1, 4), (2, 3))], axis=1)
+    variant = np.argmin(d3, axis=1).astype(np.int8)
+    node = np.concatenate([cells, mid], axis=1)                 # columns 0-3: vertices, 4-9: m01 m02 m03 m12 m13 m23
+    col = {(0, 0): 0, (1, 1): 1, (2, 2): 2, (3, 3): 3, _M01: 4, _M02: 5, _M03: 6, _M12: 7, _M13: 8, _M23: 9}
+    new_cells = np.empty((len(cells), 8, 4), dtype=np.int64)
+    for d in range(3):
+        sel = variant == d
+        for k, kid in enumerate(CHILD_VERTS[d]):
+            for v, pair in enumerate(kid):
+                new_cells[sel, k, v] = node[sel, col[pair]]
+    new_cells = new_cells.reshape(-1, 4)
 
     def lookup(a, b):
         pos = np.searchsorted(uniq, _mid_ids(nv, a, b))
@@ -79,6 +93,7 @@ def refine_once(model: GmshModel, project=None) -> GmshModel:
     else:
         new_rid, new_rph = rid, rph
     out = GmshModel(3, coords, node_phys, new_cells, new_fac, new_fph, new_rid, new_rph, list(model.phys_names))
+    out.child_variant = variant                                 # per PARENT cell: which diagonal its inner children share
     if project is not None:
         out.coords = project(out)
     return out

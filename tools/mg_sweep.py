@@ -21,14 +21,16 @@ npg.set_b(m, lambda x: 0.1 * np.exp(-(x[..., 2] + prm.H(x)) / (0.1 * prm.alpha))
 print(f"{wl}: set-up {time.time() - t0:.1f} s, levels {m.inversion.solver.P.levels}", flush=True)
 s = m.inversion.solver
 P = s.P
-combos = [dict()] + [dict(coarse_sweeps=c) for c in (30, 40, 60)] + [dict(omega=w) for w in (2.0, 2.2, 2.8, 3.2)] + \
-    [dict(jacobi_weight=w) for w in (0.5, 0.85, 1.0)] + [dict(schur_sweeps=4), dict(schur_sweeps=5, coarse_sweeps=40),
-                                                        dict(nu1=2, nu2=3), dict(nu1=3, nu2=3), dict(nu1=3, nu2=3, coarse_sweeps=40)]
-s.kwargs["itmax"] = 150
+import json
+combos = json.loads(sys.argv[2]) if len(sys.argv) > 2 else [dict()]
+s.kwargs["itmax"] = int(sys.argv[3]) if len(sys.argv) > 3 else 150
 for kw in combos:
     P.set_params(**kw)
     s.x.fill(0.0)
     npg.invert(m)
     st = s.workspace.stats
-    print(f"{kw}: solved={st['solved']} its={st['niter']} {1e3 * st['seconds']:.1f} ms  ({1e3 * st['seconds'] / max(st['niter'], 1):.2f} ms/it)",
-          flush=True)
+    h = s.workspace.history()
+    rate = (h[-1] / h[0]) ** (1.0 / max(len(h) - 1, 1))
+    print("   history every 10:", " ".join(f"{v / h[0]:.1e}" for v in h[::10]), flush=True)
+    print(f"{kw}: solved={st['solved']} its={st['niter']} {1e3 * st['seconds']:.1f} ms  ({1e3 * st['seconds'] / max(st['niter'], 1):.2f} ms/it)"
+          f"  residual x{h[-1] / h[0]:.2e}, mean factor per iteration {rate:.3f}", flush=True)
