@@ -93,6 +93,16 @@ def refine_once(model: GmshModel, project=None) -> GmshModel:
     else:
         new_rid, new_rph = rid, rph
     out = GmshModel(3, coords, node_phys, new_cells, new_fac, new_fph, new_rid, new_rph, list(model.phys_names))
+    if model.periodic is not None:
+        # the image of an edge of the paired face is an edge of the master face (the two faces carry the same triangulation):
+        # its midpoint is the image of that edge's midpoint; every other new node is its own master
+        per = np.asarray(model.periodic, dtype=np.int64)
+        ea, eb = uniq // nv, uniq % nv
+        ma, mb = per[ea], per[eb]
+        mkey = np.minimum(ma, mb) * nv + np.maximum(ma, mb)
+        pos = np.minimum(np.searchsorted(uniq, mkey), len(uniq) - 1)
+        paired = (ma != ea) & (mb != eb) & (uniq[pos] == mkey)
+        out.periodic = np.concatenate([per, np.where(paired, nv + pos, nv + np.arange(len(uniq)))])
     out.child_variant = variant                                 # per PARENT cell: which diagonal its inner children share
     if project is not None:
         out.coords = project(out)
@@ -121,6 +131,31 @@ def bowl_projector(alpha):
         x[coast, 2] = 0.0
         x[surf, 2] = 0.0
         x[bot, 2] = -alpha * (1.0 - x[bot, 0] ** 2 - x[bot, 1] ** 2)
+        return x
+
+    return project
+
+
+def channel_basin_projector(alpha):
+    """Put new boundary nodes of a refined channel-basin mesh (nupgcm_amd.channel_basin) back on the geometry of
+    /root/reference/scratch/run.jl:54-97: bottom z = -H(x, y) (the vertical wall at y = -L/2 keeps its nodes), surface and
+    coast z = 0, the coast of the northern end on its circle.  H is x-periodic, so paired nodes stay a period apart."""
+    from .channel_basin import L_DOMAIN, W_DOMAIN, depth
+
+    def project(m: GmshModel):
+        x = m.coords.copy()
+        bit = {n: 1 << i for i, n in enumerate(m.phys_names)}
+        ph = np.asarray(m.node_phys)
+        coast = (ph & bit.get("coastline", 0)) != 0
+        surf = ((ph & bit.get("surface", 0)) != 0) & ~coast
+        wall = np.abs(x[:, 1] + L_DOMAIN / 2) < 1e-12
+        bot = ((ph & bit.get("bottom", 0)) != 0) & ~coast & ~wall
+        x[coast | surf, 2] = 0.0
+        yc, r0 = L_DOMAIN / 2 - W_DOMAIN / 2, W_DOMAIN / 2
+        arc = coast & (x[:, 1] > yc + 1e-12)
+        d = x[arc, :2] - np.array([W_DOMAIN / 2, yc])
+        x[arc, :2] = np.array([W_DOMAIN / 2, yc]) + d * (r0 / np.linalg.norm(d, axis=1))[:, None]
+        x[bot, 2] = -depth(x[bot, 0], x[bot, 1], alpha)
         return x
 
     return project

@@ -134,14 +134,29 @@ def channel_basin_fe_data(mesh_model, surface="flux"):
     return FEData(mesh, spaces)
 
 
+def channel_basin_hierarchy_models(h, levels, dz=None):
+    """[coarse, ..., fine] channel-basin meshes: the generated mesh of spacing h 2^levels and its red refinements, boundary
+    nodes projected back onto the depth profile; the finest has spacing h"""
+    ms = [channel_basin.channel_basin_model(h * 2 ** levels, CB_ALPHA, None if dz is None else dz * 2 ** levels)]
+    for _ in range(levels):
+        ms.append(refine.refine_once(ms[-1], refine.channel_basin_projector(CB_ALPHA)))
+    return ms
+
+
 def channel_basin_model(arch, h=None, dz=None, mesh_model=None, surface="flux", itmax=1000, CFL_factor=0.8,
-                        element_precision="fp32", conv=None, eddy_N2min=None, atol=1e-6, rtol=1e-6, **inv_kw):
+                        element_precision="fp32", conv=None, eddy_N2min=None, atol=1e-6, rtol=1e-6, levels=0, **inv_kw):
     """The model of scratch/run.jl:146-172 on the structured-to-tet channel-basin mesh (nupgcm_amd.channel_basin): BDF1 with
     the adaptive CFL step, itmax = 1000 for the inversion (:155), initial buoyancy (:169), inverted once (:171).
     element_precision: "fp32" = configs[4]'s mixed mode (fp32 element-local arithmetic, fp64 accumulation and solves).
     conv / eddy_N2min override the closure strengths (tests on coarse meshes)."""
-    mm = mesh_model if mesh_model is not None else channel_basin.channel_basin_model(h, CB_ALPHA, dz)
-    fed = channel_basin_fe_data(mm, surface)
+    hier = None
+    if levels > 0:
+        hier = [channel_basin_fe_data(m, surface) for m in channel_basin_hierarchy_models(h, levels, dz)]
+        fed = hier[-1]
+        inv_kw = dict(inv_kw, hierarchy=hier, preconditioner="multigrid")
+    else:
+        mm = mesh_model if mesh_model is not None else channel_basin.channel_basin_model(h, CB_ALPHA, dz)
+        fed = channel_basin_fe_data(mm, surface)
     prm, frc, _, _, dt, b0 = channel_basin_parameters(surface)
     if conv is not None:
         frc.conv_param = conv
@@ -149,7 +164,8 @@ def channel_basin_model(arch, h=None, dz=None, mesh_model=None, surface="flux", 
         frc.eddy_param = EddyParameterization(f=frc.eddy_param.f, N2min=eddy_N2min, is_on=True)
     ts = BDF1(t_start=0.0, t_stop=prm.mu_rho / prm.eps ** 2, dt=dt, adaptive=True, CFL_factor=CFL_factor)
     from .inversion import device_fe
-    device_fe(arch, fed).set_precision(element_precision)
+    for f in (hier or [fed]):
+        device_fe(arch, f).set_precision(element_precision)
     if inv_kw.get("preconditioner") == "multigrid" and "hierarchy" not in inv_kw:
         inv_kw["hierarchy"] = [fed]             # no refinement hierarchy: the smoother alone preconditions
     inv = InversionToolkit(arch, fed, prm, frc, itmax=itmax, atol=atol, rtol=rtol, **inv_kw)

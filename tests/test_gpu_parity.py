@@ -783,7 +783,7 @@ def test_full_size_properties(arch):
     assert N == 2150791
     A_csr = npg.build_A_inversion(arch, fed, prm, frc.nu)                  # plain CSR
     A_blk = npg.build_A_inversion(arch, fed, prm, frc.nu)
-    assert A_blk.block_nodes(d.n_full, d.n_surf) and A_csr.nnz == A_blk.nnz == 126707207
+    assert A_blk.block_nodes(d.n_full, d.n_surf) and A_csr.nnz == A_blk.nnz == 126821881
     nodes, rec, ent = A_blk.storage()
     assert nodes == d.n_full + d.n_surf and ent + 4 * rec <= A_csr.nnz <= ent + 5 * rec
     rng = np.random.default_rng(0)
