@@ -166,6 +166,10 @@ def main():
         if world > 1 or force_dist:
             from nupgcm_amd import distributed
             model = distributed.channel_basin_model(arch, mesh_model, dist, surface=surf)
+        elif a.preconditioner == "multigrid":
+            # converged inversions instead of run.jl's 1000-iteration cap: V-cycle over a 3-level refinement hierarchy whose
+            # finest mesh has the requested spacing
+            model = workloads.channel_basin_model(arch, h=hh, levels=2, surface=surf, itmax=0)
         else:
             model = workloads.channel_basin_model(arch, mesh_model=mesh_model, surface=surf)
     elif world > 1 or force_dist:
