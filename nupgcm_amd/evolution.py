@@ -39,7 +39,11 @@ def build_rhs_flux(arch, params, forcings, fe_data):
 class EvolutionToolkit:
     """src/evolution.jl:1-17: {arch, M, Kh, Kv, rhs_diff, rhs_flux, rhs_M, rhs_h, rhs_v, solver}"""
 
-    def __init__(self, arch, fe_data, params, forcings, ts, atol=1e-6, rtol=1e-6, itmax=0, history=True, verbose=False):
+    def __init__(self, arch, fe_data, params, forcings, ts, atol=1e-6, rtol=1e-6, itmax=0, history=True, verbose=False,
+                 first_step_lhs="bdf1"):
+        """first_step_lhs: "bdf1" = the current source (the first step of any run uses a BDF1 left-hand side,
+        src/evolution.jl:110-111); "bdf2" = the timestepper's own LHS from the start - what the reference's exact state
+        fixture test/data/bowl_surface_flux.jld2 (written by an older revision) encodes."""
         if not isinstance(arch, GPU):
             raise TypeError("nupgcm_amd implements the GPU() architecture only (no CPU fallback)")
         self.arch, self.fe_data, self.params, self.forcings = arch, fe_data, params, forcings
@@ -55,7 +59,7 @@ class EvolutionToolkit:
         self.rhs_diff = fe.rhs_diff(params.N2, DeviceVector(ctx, nb))
         self.rhs_flux = build_rhs_flux(arch, params, forcings, fe_data)
         # LHS for the first step: always a BDF1 matrix (src/evolution.jl:110-111)
-        ts1 = BDF1(t_start=ts.t_start, t_stop=ts.t_stop, dt=ts.dt)
+        ts1 = BDF1(t_start=ts.t_start, t_stop=ts.t_stop, dt=ts.dt) if first_step_lhs == "bdf1" else ts
         A = fe.new_matrix("b")
         P = Diagonal(DeviceVector(ctx, nb))
         collect_evolution_LHS_into(A, P, params, ts1, self.M, self.Kh, self.Kv)
