@@ -183,6 +183,7 @@ int64_t npg_cg_history(npg_cg *ws, double *buf, int64_t cap);
 #define NPG_PC_BLOCKDIAG 1   /* BlockDiagonalPreconditioner([Block(CgPreconditioner(A_k, Diagonal), indices_k)...])
                                 (src/preconditioners.jl:53-125): nparts blocks                                        */
 #define NPG_PC_MG 2          /* geometric multigrid V-cycle on the saddle-point system (new work): nparts levels      */
+#define NPG_PC_DENSE 3       /* explicit dense inverse in HBM (new work; small systems, <= 65 536 unknowns): nparts = 1 */
 int npg_precond_create(npg_ctx *ctx, int kind, int nparts, npg_precond **out);
 int npg_precond_destroy(npg_precond *pc);
 /* Block k acts on x[offset, offset + n_k): CG on A_k with M = Diagonal(jacobi) (ldiv = false), itmax / atol / rtol as given
@@ -208,6 +209,14 @@ int npg_precond_mg_set_params(npg_precond *pc, double omega, double jacobi_weigh
 /* gamma = 1: V-cycle (default); gamma = 2: W-cycle - every level's coarse problem is visited twice, which keeps the
  * convergence independent of the number of levels where the V-cycle's degrades (4 levels: DESIGN.md section 4.5) */
 int npg_precond_mg_set_cycle(npg_precond *pc, int gamma);
+/* NPG_PC_DENSE: A^-1 as n^2 doubles in HBM (2 GB at 16 k unknowns, 8 GB at 31 k: what 288 GB buy) - densified, factorised
+ * and inverted once by rocSOLVER (getrf + getri, set-up), applied per solve by a hand-written split-column GEMV at HBM speed.
+ * For the reference's small meshes, where the scalar-preconditioned GMRES is bound by kernel latency (19 us x 600 iterations),
+ * this is the device counterpart of its CPU() path's `lu(A)` + `ldiv!` (src/inversion.jl:55-58, src/iterative_solvers.jl:42-47);
+ * behind flexible GMRES it needs 1-2 iterations.  A must be plain CSR.  Call again to follow a re-assembled A. */
+int npg_precond_dense_set(npg_precond *pc, const npg_csr *A);
+/* multigrid: solve the coarsest level with its dense inverse instead of smoothing steps (on != 0) */
+int npg_precond_mg_set_coarse_dense(npg_precond *pc, int on);
 /* z = M^-1 r (one application: one V-cycle / one round of inner CG solves) */
 int npg_precond_apply(npg_precond *pc, const npg_vec *r, npg_vec *z);
 int npg_precond_counters(npg_precond *pc, int64_t *applications, int64_t *inner_iterations);

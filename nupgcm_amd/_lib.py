@@ -93,7 +93,8 @@ def _declare(L):
         "npg_precond_mg_set_level": [P, C.c_int, P, I64, P, P, P, P, P, P],
         "npg_precond_mg_update_level": [P, C.c_int, P, P, P, P, P],
         "npg_precond_mg_set_params": [P, D, D, C.c_int, C.c_int, C.c_int, C.c_int],
-        "npg_precond_mg_set_cycle": [P, C.c_int],
+        "npg_precond_mg_set_cycle": [P, C.c_int], "npg_precond_dense_set": [P, P],
+        "npg_precond_mg_set_coarse_dense": [P, C.c_int],
         "npg_precond_apply": [P, P, P], "npg_precond_counters": [P, C.POINTER(I64), C.POINTER(I64)],
         "npg_fgmres_create": [P, I64, C.c_int, PP], "npg_fgmres_destroy": [P],
         "npg_fgmres_solve": [P, P, P, P, P, D, D, D, I64, C.POINTER(SolveStats)],
@@ -150,7 +151,7 @@ def as_i32(a):
 
 
 NPG_PRECOND_NONE, NPG_PRECOND_SCALAR, NPG_PRECOND_DIAG = 0, 1, 2
-NPG_PC_BLOCKDIAG, NPG_PC_MG = 1, 2
+NPG_PC_BLOCKDIAG, NPG_PC_MG, NPG_PC_DENSE = 1, 2, 3
 NPG_BDF1, NPG_BDF2 = 1, 2
 NPG_FE_FP64, NPG_FE_FP32 = 0, 1
 NPG_MAT_M, NPG_MAT_KH, NPG_MAT_KV, NPG_MAT_A, NPG_MAT_B = 1, 2, 3, 4, 5

@@ -21,6 +21,8 @@
 // an iteration costs a V-cycle, i.e. milliseconds on the meshes where this is used, so the host drives the loop).  The
 // stopping rule is the reference's: scale * ||r|| <= atol + rtol * scale * ||r0|| with scale = 1/h^dim, the factor its
 // Diagonal preconditioner puts on the residual (src/inversion.jl:42-54; right preconditioning leaves r the true residual).
+#include <rocsolver/rocsolver.h>
+
 #include <algorithm>
 #include <cmath>
 #include <map>
@@ -94,6 +96,50 @@ __global__ void __launch_bounds__(kBlock) k_sum_partials(const double *__restric
     if (threadIdx.x < nvals) out[threadIdx.x] = res[threadIdx.x];
 }
 
+// ---- explicit dense inverse (NPG_PC_DENSE) ----------------------------------------------------------------------------------
+// dA (column-major n x n, zero-filled) <- CSR
+__global__ void k_densify(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
+                          int64_t n, double *__restrict__ dA) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
+        for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) dA[r + (int64_t)col[k] * n] = val[k];
+}
+
+// part[s][i] = sum over the s-th chunk of columns j of M[i + j n] x[j]: thread = row i, consecutive lanes read consecutive
+// doubles of one column (coalesced), eight columns in flight per thread; blockIdx.y = chunk
+constexpr int kGemvChunkCols = 512;
+__global__ void __launch_bounds__(kBlock) k_dense_gemv_part(const double *__restrict__ M, int64_t n,
+                                                            const double *__restrict__ x, double *__restrict__ part) {
+    __shared__ double xs[kGemvChunkCols];
+    const int64_t j0 = (int64_t)blockIdx.y * kGemvChunkCols;
+    const int nj = (int)min((int64_t)kGemvChunkCols, n - j0);
+    for (int j = threadIdx.x; j < nj; j += kBlock) xs[j] = x[j0 + j];
+    __syncthreads();
+    const int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double *__restrict__ Mi = M + i + j0 * n;
+    double acc = 0.0;
+    int j = 0;
+    for (; j + 8 <= nj; j += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(Mi + (int64_t)(j + u) * n);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u] * xs[j + u];
+    }
+    for (; j < nj; ++j) acc += Mi[(int64_t)j * n] * xs[j];
+    part[(int64_t)blockIdx.y * n + i] = acc;
+}
+
+// z = a (sum_s part[s]) + b z   (fixed order)
+__global__ void __launch_bounds__(kBlock) k_dense_gemv_sum(const double *__restrict__ part, int nsplit, int64_t n, double a,
+                                                           double b, double *__restrict__ z) {
+    const int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < nsplit; ++k) s += part[(int64_t)k * n + i];
+    z[i] = (b == 0.0) ? a * s : a * s + b * z[i];
+}
+
 // x += sum_c y[c] Z_c
 struct Coefs {
     double y[kMaxMem];
@@ -129,10 +175,18 @@ struct BlockPc {
     double atol = 0.0, rtol = 0.0;
 };
 
+struct DenseInv {
+    int64_t n = 0;
+    double *M = nullptr;       // A^-1, column-major
+    double *part = nullptr;    // [nsplit][n] partial products
+    int nsplit = 0;
+};
+
 struct npg_precond {
     npg_ctx *ctx = nullptr;
     int kind = 0;
     int64_t n = 0;
+    DenseInv dense;            // NPG_PC_DENSE, or the multigrid's exact coarsest-level solve
     // multigrid
     std::vector<MgLevel> L;
     double omega = 2.5, jw = 0.7;
@@ -162,7 +216,8 @@ static inline void daxpby(npg_ctx *c, double *y, double w, const double *d, cons
 
 NPG_API int npg_precond_create(npg_ctx *ctx, int kind, int nparts, npg_precond **out) {
     NPG_REQUIRE(ctx && out, "npg_precond_create: NULL argument");
-    NPG_REQUIRE(kind == NPG_PC_MG || kind == NPG_PC_BLOCKDIAG, "npg_precond_create: unknown kind %d", kind);
+    NPG_REQUIRE(kind == NPG_PC_MG || kind == NPG_PC_BLOCKDIAG || kind == NPG_PC_DENSE, "npg_precond_create: unknown kind %d",
+                kind);
     NPG_REQUIRE(nparts >= 1 && nparts <= 16, "npg_precond_create: need 1..16 levels / blocks");
     npg_precond *pc = new npg_precond();
     pc->ctx = ctx;
@@ -170,7 +225,8 @@ NPG_API int npg_precond_create(npg_ctx *ctx, int kind, int nparts, npg_precond *
     // relaunching hipGraphs under rocprofv3's kernel tracer crashes the tool (profiles/r02_rocprofv3_graph_crash.txt)
     const bool traced = getenv("ROCPROFILER_LIBRARY_CTOR") || getenv("ROCPROF_OUTPUT_PATH") || getenv("ROCP_TOOL_LIBRARIES");
     pc->use_graphs = getenv("NPG_MG_EAGER") ? atoi(getenv("NPG_MG_EAGER")) == 0 : !traced;
-    if (kind == NPG_PC_MG) pc->L.resize(nparts); else pc->blocks.resize(nparts);
+    if (kind == NPG_PC_MG) pc->L.resize(nparts);
+    if (kind == NPG_PC_BLOCKDIAG) pc->blocks.resize(nparts);
     *out = pc;
     return NPG_OK;
 }
@@ -179,6 +235,8 @@ NPG_API int npg_precond_destroy(npg_precond *pc) {
     if (!pc) return NPG_OK;
     hipStreamSynchronize(pc->ctx->stream);
     drop_graphs(pc);
+    if (pc->dense.M) hipFree(pc->dense.M);
+    if (pc->dense.part) hipFree(pc->dense.part);
     for (void *p : pc->allocs) hipFree(p);
     for (BlockPc &b : pc->blocks) {
         if (b.cg) npg_cg_destroy(b.cg);
@@ -187,6 +245,80 @@ NPG_API int npg_precond_destroy(npg_precond *pc) {
     }
     delete pc;
     return NPG_OK;
+}
+
+// z = a A^-1 r + b z
+static int dense_apply(npg_precond *pc, const double *r, double *z, double a, double b) {
+    const DenseInv &d = pc->dense;
+    hipStream_t st = pc->ctx->stream;
+    const int gx = (int)((d.n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_dense_gemv_part, dim3(gx, d.nsplit), dim3(kBlock), 0, st, d.M, d.n, r, d.part);
+    hipLaunchKernelGGL(k_dense_gemv_sum, dim3(gx), dim3(kBlock), 0, st, d.part, d.nsplit, d.n, a, b, z);
+    NPG_HIP(hipGetLastError());
+    return NPG_OK;
+}
+
+// A^-1 of a plain-CSR matrix as a dense fp64 array in HBM: densify, LU with partial pivoting and inversion by rocSOLVER
+// (set-up; n^2 doubles - 2 GB at 16 k unknowns, 8 GB at 31 k), applied per solve by the hand-written GEMV above
+static int dense_build(npg_precond *pc, const npg_csr *A) {
+    NPG_REQUIRE(A && A->m == A->n && A->nnode() == 0, "dense inverse: a square plain-CSR matrix is required");
+    const int64_t n = A->m;
+    NPG_REQUIRE(n > 0 && n <= 65536, "dense inverse: %lld unknowns (limit 65 536: n^2 doubles must fit in HBM with room to spare)",
+                (long long)n);
+    hipStream_t st = pc->ctx->stream;
+    DenseInv &d = pc->dense;
+    if (d.M) { hipFree(d.M); hipFree(d.part); d.M = d.part = nullptr; }
+    d.n = n;
+    d.nsplit = (int)((n + kGemvChunkCols - 1) / kGemvChunkCols);
+    NPG_HIP(hipMalloc((void **)&d.M, (size_t)n * n * sizeof(double)));
+    NPG_HIP(hipMalloc((void **)&d.part, (size_t)d.nsplit * n * sizeof(double)));
+    NPG_HIP(hipMemsetAsync(d.M, 0, (size_t)n * n * sizeof(double), st));
+    hipLaunchKernelGGL(k_densify, dim3(grid_for(n)), dim3(kBlock), 0, st, A->rowptr, A->col, A->val, n, d.M);
+    NPG_HIP(hipGetLastError());
+    rocblas_handle h = nullptr;
+    NPG_REQUIRE(rocblas_create_handle(&h) == rocblas_status_success, "dense inverse: rocblas_create_handle failed");
+    rocblas_set_stream(h, st);
+    rocblas_int *ipiv = nullptr, *info = nullptr;
+    NPG_HIP(hipMalloc((void **)&ipiv, (size_t)n * sizeof(rocblas_int)));
+    NPG_HIP(hipMalloc((void **)&info, sizeof(rocblas_int)));
+    rocblas_status s1 = rocsolver_dgetrf(h, (rocblas_int)n, (rocblas_int)n, d.M, (rocblas_int)n, ipiv, info);
+    rocblas_int i1 = -1, i2 = -1;
+    NPG_HIP(hipMemcpyAsync(&i1, info, sizeof i1, hipMemcpyDeviceToHost, st));
+    NPG_HIP(hipStreamSynchronize(st));
+    rocblas_status s2 = rocblas_status_success;
+    if (s1 == rocblas_status_success && i1 == 0) {
+        s2 = rocsolver_dgetri(h, (rocblas_int)n, d.M, (rocblas_int)n, ipiv, info);
+        NPG_HIP(hipMemcpyAsync(&i2, info, sizeof i2, hipMemcpyDeviceToHost, st));
+        NPG_HIP(hipStreamSynchronize(st));
+    }
+    hipFree(ipiv);
+    hipFree(info);
+    rocblas_destroy_handle(h);
+    NPG_REQUIRE(s1 == rocblas_status_success && i1 == 0 && s2 == rocblas_status_success && i2 == 0,
+                "dense inverse: rocSOLVER getrf/getri failed (status %d/%d, info %d/%d: the matrix is singular to working "
+                "precision, or out of memory)", (int)s1, (int)s2, (int)i1, (int)i2);
+    return NPG_OK;
+}
+
+NPG_API int npg_precond_dense_set(npg_precond *pc, const npg_csr *A) {
+    NPG_REQUIRE(pc && pc->kind == NPG_PC_DENSE, "npg_precond_dense_set: not a dense-inverse preconditioner");
+    int rc = dense_build(pc, A);
+    if (rc) return rc;
+    pc->n = A->m;
+    return NPG_OK;
+}
+
+// the multigrid's coarsest level solved exactly by its explicit inverse instead of `coarse_sweeps` smoothing steps; call
+// again after npg_precond_mg_update_level(level 0) to rebuild it
+NPG_API int npg_precond_mg_set_coarse_dense(npg_precond *pc, int on) {
+    NPG_REQUIRE(pc && pc->kind == NPG_PC_MG && !pc->L.empty() && pc->L[0].A, "npg_precond_mg_set_coarse_dense: level 0 is not set");
+    NPG_HIP(hipStreamSynchronize(pc->ctx->stream));
+    drop_graphs(pc);
+    if (!on) {
+        if (pc->dense.M) { hipFree(pc->dense.M); hipFree(pc->dense.part); pc->dense = DenseInv{}; }
+        return NPG_OK;
+    }
+    return dense_build(pc, pc->L[0].A);
 }
 
 static int mg_alloc(npg_precond *pc, double **p, int64_t n) {
@@ -319,9 +451,17 @@ static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int n
 // One multigrid cycle on level `lev` for A x = b: gamma = 1 is the V-cycle, gamma = 2 the W-cycle (the coarse problem of
 // every level is visited gamma times, the second visit continuing from the first one's result).
 static int mg_cycle(npg_precond *pc, int lev, double *x, const double *b, bool x_is_zero) {
+    int rc;
+    if (lev == 0 && pc->dense.M) {                                   // exact coarsest-level solve
+        if (x_is_zero) return dense_apply(pc, b, x, 1.0, 0.0);
+        MgLevel &l0 = pc->L[0];
+        SpmvEpi e{};
+        e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l0.r;
+        if ((rc = spmv_epi(l0.A, x, e))) return rc;
+        return dense_apply(pc, l0.r, x, 1.0, 1.0);
+    }
     if (lev == 0) return mg_smooth(pc, 0, x, b, pc->coarse, x_is_zero);
     MgLevel &l = pc->L[lev], &lc = pc->L[lev - 1];
-    int rc;
     if (pc->nu1 > 0 && (rc = mg_smooth(pc, lev, x, b, pc->nu1, x_is_zero))) return rc;
     const bool still_zero = x_is_zero && pc->nu1 == 0;
     if (still_zero) {
@@ -358,6 +498,10 @@ NPG_API int npg_precond_blockdiag_set(npg_precond *pc, int k, int64_t offset, co
 
 static int precond_apply_raw(npg_precond *pc, const double *r, double *z) {
     ++pc->applications;
+    if (pc->kind == NPG_PC_DENSE) {
+        NPG_REQUIRE(pc->dense.M, "npg_precond_apply: the dense inverse has not been set");
+        return dense_apply(pc, r, z, 1.0, 0.0);
+    }
     if (pc->kind == NPG_PC_MG) {
         NPG_REQUIRE(pc->L.back().A, "npg_precond_apply: multigrid levels are not all set");
         const int top = (int)pc->L.size() - 1;

@@ -75,8 +75,9 @@ class InversionToolkit:
                  reorth_eta=0.1, block_nodes=None, preconditioner="diagonal", hierarchy=None, precond_kw=None):
         """preconditioner: "diagonal" = the reference's GPU choice Diagonal(1/h^dim) (src/inversion.jl:42-54, default);
         "block_diagonal" = its experimental BlockDiagonalPreconditioner (src/inversion.jl:60, src/preconditioners.jl:53-93);
-        "multigrid" = MultigridPreconditioner over `hierarchy` (FEData coarse ... fine, the last one being fe_data).  The last
-        two are inexact operators: the workspace is then a flexible GMRES(memory) with the same stopping rule."""
+        "multigrid" = MultigridPreconditioner over `hierarchy` (FEData coarse ... fine, the last one being fe_data);
+        "dense_inverse" = the explicit inverse in HBM (small meshes).  These
+        are general operators: the workspace is then a flexible GMRES(memory) with the same stopping rule."""
         if not isinstance(arch, GPU):
             raise TypeError("nupgcm_amd implements the GPU() architecture only (no CPU fallback)")
         if not restart:
@@ -108,6 +109,8 @@ class InversionToolkit:
                     if not hierarchy or hierarchy[-1] is not fe_data:
                         raise ValueError("preconditioner='multigrid' needs hierarchy=[FEData coarse, ..., fe_data]")
                     P = mgm.MultigridPreconditioner(arch, params, forcings, hierarchy, A_fine=A, **(precond_kw or {}))
+                elif preconditioner == "dense_inverse":
+                    P = mgm.DenseInversePreconditioner(arch, A)
                 elif preconditioner == "block_diagonal":
                     P = mgm.BlockDiagonalPreconditioner(arch, params, fe_data, A, **(precond_kw or {}))
                 else:

@@ -92,6 +92,24 @@ class BlockDiagonalPreconditioner(GeneralPreconditioner):
                                                       float(atol), float(rtol)))
 
 
+class DenseInversePreconditioner(GeneralPreconditioner):
+    """P = A^-1 held explicitly in HBM (n^2 doubles) - npg_precond_dense_set.  For the reference's own small meshes (16 k /
+    31 k unknowns: 2 / 8 GB), where the Krylov path is bound by kernel latency; the device counterpart of the CPU() path's
+    `lu(A)` + `ldiv!` (src/inversion.jl:55-58).  `refresh(A)` follows a re-assembled matrix (eddy closure)."""
+
+    def __init__(self, arch, A: DeviceCSR):
+        super().__init__(arch.ctx, L.NPG_PC_DENSE, 1)
+        self.refresh(A)
+
+    def refresh(self, A: DeviceCSR):
+        L.check(L.lib().npg_precond_dense_set(self.h, A.h))
+        self.n = A.shape[0]
+        return self
+
+    def __repr__(self):
+        return f"DenseInversePreconditioner(n={self.n}, {8 * self.n ** 2 / 2 ** 30:.1f} GiB)"
+
+
 # ---- multigrid -----------------------------------------------------------------------------------------------------------------
 def _p2_shape(lam):
     return np.concatenate([lam * (2 * lam - 1), 4 * lam[..., _TET_EDGE_A] * lam[..., _TET_EDGE_B]], axis=-1)
@@ -182,8 +200,10 @@ class MultigridPreconditioner(GeneralPreconditioner):
     solver's matrix (it may be stored by node blocks); the coarser operators are re-discretised on their own meshes."""
 
     def __init__(self, arch, params, forcings, hierarchy, A_fine: DeviceCSR = None, omega=2.5, jacobi_weight=0.7,
-                 schur_sweeps=3, nu1=2, nu2=2, coarse_sweeps=20, block_nodes=None, cycle="V"):
-        """A function-valued nu (full-stress form) is re-discretised on every level like a constant one.  With the eddy
+                 schur_sweeps=3, nu1=2, nu2=2, coarse_sweeps=20, block_nodes=None, cycle="V", coarse_dense=None):
+        """coarse_dense: solve the coarsest level exactly with its dense inverse (DenseInversePreconditioner's machinery)
+        instead of `coarse_sweeps` smoothing steps; None = whenever a hierarchy's coarsest level has <= 40 000 unknowns
+        (<= 12 GiB; measured at 2.15 M unknowns: 19 instead of 32 iterations for a cold solve, 88 instead of 128 ms).  A function-valued nu (full-stress form) is re-discretised on every level like a constant one.  With the eddy
         closure on, `refresh(A)` (called by run! after each re-assembly of A, src/model.jl:160-170) rebuilds the FINEST level's
         smoother from the new matrix; the coarser levels keep the operators of the set-up viscosity - a preconditioner need
         not be exact, the Krylov method corrects for it."""
@@ -214,6 +234,11 @@ class MultigridPreconditioner(GeneralPreconditioner):
             self.levels.append(dict(n=d.nu + d.np, nu=nu, S_nnz=S.nnz))
             prev = fed
         self.set_params(omega, jacobi_weight, schur_sweeps, nu1, nu2, coarse_sweeps, cycle)
+        if coarse_dense is None:
+            coarse_dense = len(hierarchy) > 1 and self.levels[0]["n"] <= 40000
+        if coarse_dense:
+            L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, 1))
+        self.coarse_dense = bool(coarse_dense)
 
     @staticmethod
     def _blocks(A: DeviceCSR, d):
@@ -242,7 +267,8 @@ class MultigridPreconditioner(GeneralPreconditioner):
                            coarse_sweeps=coarse_sweeps, cycle=cycle)
 
     def __repr__(self):
-        return f"MultigridPreconditioner({[lv['n'] for lv in self.levels]}, {self.params})"
+        return (f"MultigridPreconditioner({[lv['n'] for lv in self.levels]}, {self.params}, "
+                f"coarsest level: {'dense inverse' if self.coarse_dense else 'smoothing steps'})")
 
 
 class FgmresWorkspace:

@@ -76,6 +76,8 @@ def example_model(arch, label_or_model, dt=1e-3, t_stop=1e9, preconditioner="dia
     else:
         mm = bowl_mesh_model(label_or_model) if isinstance(label_or_model, str) else label_or_model
         fed = example_fe_data(mm)
+        if preconditioner == "dense_inverse":
+            inv_kw = dict(inv_kw, block_nodes=False)                 # the dense inverse is built from the plain CSR matrix
     ts = BDF2(t_start=0.0, t_stop=t_stop, dt=dt)
     inv = InversionToolkit(arch, fed, prm, frc, preconditioner=preconditioner, **inv_kw)
     evo = EvolutionToolkit(arch, fed, prm, frc, ts)

@@ -57,7 +57,7 @@ def two_level(arch):
     hier = [workloads.example_fe_data(m) for m in workloads.bowl_hierarchy_models("bowl3D_h0.05")]
     A = npg.build_A_inversion(arch, hier[-1], prm, frc.nu)
     As = A.to_scipy_csr()
-    P = mgm.MultigridPreconditioner(arch, prm, frc, hier, A_fine=A, block_nodes=False)
+    P = mgm.MultigridPreconditioner(arch, prm, frc, hier, A_fine=A, block_nodes=False, coarse_dense=False)
     return prm, frc, hier, A, As, P
 
 
@@ -209,3 +209,49 @@ def test_block_diagonal_preconditioner_of_the_reference(arch):
     assert rel(x[:d.nu], xd[:d.nu]) < 1e-5
     apps, inner = inv.solver.P.counters()
     assert apps == st["niter"] and inner > apps
+
+
+def test_dense_inverse_preconditioner_on_the_reference_meshes(arch):
+    """P = A^-1 explicit in HBM (NPG_PC_DENSE) on bowl3D h = 0.1: one application IS the direct solve (checked against the
+    fixture-pinned oracle's sparse LU), flexible GMRES needs <= 3 iterations at any tolerance, and the 5-step timestep loop
+    lands on the oracle's direct-solve trajectory."""
+    prm, frc = workloads.example_parameters()
+    fed = workloads.example_fe_data(workloads.bowl_mesh_model("bowl3D_h0.1"))
+    S = rc.setup("example")
+    d, ctx = fed.dofs, arch.ctx
+    A = npg.build_A_inversion(arch, fed, prm, frc.nu)
+    P = npg.DenseInversePreconditioner(arch, A)
+    n = A.shape[0]
+    r = np.cos(np.arange(n) * 0.23)
+    z = P.apply(npg.DeviceVector.from_host(ctx, r), npg.DeviceVector(ctx, n)).to_host()
+    zd = spla.splu(sp.csc_matrix(S.A)).solve(r[d.inv_p_inversion])          # oracle: native order
+    assert rel(z[d.inv_p_inversion], zd) < 1e-8, rel(z[d.inv_p_inversion], zd)
+    m = workloads.example_model(arch, "bowl3D_h0.1", preconditioner="dense_inverse", atol=1e-12, rtol=1e-12)
+    m.evolution.solver.kwargs.update(atol=1e-13, rtol=1e-13)
+    npg.invert(m)
+    npg.run(m, n_steps=5)
+    assert all(st[1]["solved"] == 1 and st[1]["niter"] <= 3 for st in m.stats), [st[1] for st in m.stats]
+    u, p, b = rc.run(S, 5, solver="direct", invert_first=True)
+    assert rel(m.state.b, b) < 1e-9 and rel(m.state.u, u) < 1e-7 and rel(m.state.p, p) < 1e-7, \
+        (rel(m.state.b, b), rel(m.state.u, u), rel(m.state.p, p))
+    with pytest.raises(npg._lib.DeviceError):                                    # node-blocked matrices are refused
+        Ab = npg.build_A_inversion(arch, fed, prm, frc.nu)
+        Ab.block_nodes(d.n_full, d.n_surf)
+        npg.DenseInversePreconditioner(arch, Ab)
+
+
+def test_multigrid_with_exact_coarse_solve(arch, two_level):
+    """coarse_dense: the coarsest level solved by its dense inverse; the V-cycle then equals the restatement with an exact
+    coarse solve, and the iteration count drops to the two-grid optimum"""
+    prm, frc, hier, A, As, P = two_level
+    n = As.shape[0]
+    P2 = mgm.MultigridPreconditioner(arch, prm, frc, hier, A_fine=A, block_nodes=False, coarse_dense=True)
+    levels = _host_levels(arch, prm, frc, hier)
+    lu0 = spla.splu(sp.csc_matrix(levels[0].A))
+    r = np.sin(np.arange(n) * 0.37) + 0.1
+    z = P2.apply(npg.DeviceVector.from_host(arch.ctx, r), npg.DeviceVector(arch.ctx, n)).to_host()
+    l = levels[1]
+    x = mo.smooth(l, np.zeros(n), r, 2, 2.5, 0.7, 3)
+    x = x + l.P @ lu0.solve(l.P.T @ (r - l.A @ x))
+    zr = mo.smooth(l, x, r, 2, 2.5, 0.7, 3)
+    assert rel(z, zr) < 1e-8, rel(z, zr)
