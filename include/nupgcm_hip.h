@@ -123,6 +123,13 @@ int npg_csr_storage(const npg_csr *A, int64_t *nodes, int64_t *records, int64_t 
 int npg_index_create(npg_ctx *ctx, int64_t n, const int64_t *host, int64_t bound, npg_index **out);
 int npg_index_destroy(npg_index *ix);
 int npg_csr_gather_values(npg_csr *dst, const npg_csr *src, const npg_index *map);
+/* Device-side pieces of the multigrid set-up / refresh (csrc/mg.hip), all on FIXED patterns supplied by the host:
+ * Dinv <- inverse of the node-block diagonal of A[0:nu, 0:nu] (3 x 3 blocks for the first n_full nodes, 2 x 2 for the next
+ * n_surf, 1 x 1 for the rest; Dinv's pattern holds exactly these blocks), and S <- D Dinv G (products outside S's pattern
+ * are an error).  With npg_csr_gather_values for G = A[u, p] and D = A[p, u] a re-assembled A (eddy closure) refreshes a
+ * level's smoother without leaving the device. */
+int npg_csr_node_block_inverse(npg_csr *Dinv, const npg_csr *A, int64_t n_full, int64_t n_surf);
+int npg_csr_triple_product(npg_csr *S, const npg_csr *D, const npg_csr *Dinv, const npg_csr *G);
 /* d[i] = 1 / A[i,i]   -- `Diagonal(1 ./ diag(A))` (src/evolution.jl:149,167; src/model.jl:256) */
 int npg_csr_inv_diag(const npg_csr *A, npg_vec *d);
 /* y = alpha * A x + beta * y   -- mul!(y, A, x) / A*x  (cuSPARSE SpMV in the reference) */

@@ -440,6 +440,91 @@ NPG_API int npg_csr_combine(npg_csr *out, double a, const npg_csr *X, double b, 
     return NPG_OK;
 }
 
+// ---- device-side pieces of the multigrid set-up (mg.hip): node-block inverse and S = D Dinv G on fixed patterns --------------
+__device__ __forceinline__ double csr_entry(const int64_t *rowptr, const int32_t *col, const double *val, int64_t row, int32_t c) {
+    int64_t lo = rowptr[row], hi = rowptr[row + 1] - 1;
+    while (lo <= hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const int32_t v = col[mid];
+        if (v == c) return val[mid];
+        if (v < c) lo = mid + 1; else hi = mid - 1;
+    }
+    return 0.0;
+}
+
+// Dinv = inverse of the node-block diagonal of A[0:nu, 0:nu]: 3 x 3 blocks for the first n_full nodes, 2 x 2 for the next
+// n_surf, 1 x 1 for the rest.  Dinv's pattern holds exactly those blocks (sorted rows), so entry (r, c) of node block q sits
+// at rowptr[r] + (c - first(q)).  One thread per node.
+__global__ void k_node_block_inverse(const int64_t *__restrict__ arp, const int32_t *__restrict__ acol,
+                                     const double *__restrict__ aval, int64_t n_full, int64_t n_surf, int64_t nu,
+                                     const int64_t *__restrict__ drp, double *__restrict__ dval) {
+    const int64_t nnode = n_full + n_surf + (nu - 3 * n_full - 2 * n_surf);
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nnode; q += (int64_t)gridDim.x * blockDim.x) {
+        int sz;
+        int64_t r0;
+        if (q < n_full) { sz = 3; r0 = 3 * q; }
+        else if (q < n_full + n_surf) { sz = 2; r0 = 3 * n_full + 2 * (q - n_full); }
+        else { sz = 1; r0 = 3 * n_full + 2 * n_surf + (q - n_full - n_surf); }
+        double a[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        for (int i = 0; i < sz; ++i)
+            for (int j = 0; j < sz; ++j) a[i][j] = csr_entry(arp, acol, aval, r0 + i, (int32_t)(r0 + j));
+        double inv[3][3];
+        if (sz == 1) {
+            inv[0][0] = 1.0 / a[0][0];
+        } else if (sz == 2) {
+            const double det = a[0][0] * a[1][1] - a[0][1] * a[1][0];
+            inv[0][0] = a[1][1] / det; inv[0][1] = -a[0][1] / det;
+            inv[1][0] = -a[1][0] / det; inv[1][1] = a[0][0] / det;
+        } else {
+            const double c00 = a[1][1] * a[2][2] - a[1][2] * a[2][1], c01 = a[1][2] * a[2][0] - a[1][0] * a[2][2],
+                         c02 = a[1][0] * a[2][1] - a[1][1] * a[2][0];
+            const double det = a[0][0] * c00 + a[0][1] * c01 + a[0][2] * c02;
+            inv[0][0] = c00 / det; inv[1][0] = c01 / det; inv[2][0] = c02 / det;
+            inv[0][1] = (a[0][2] * a[2][1] - a[0][1] * a[2][2]) / det;
+            inv[1][1] = (a[0][0] * a[2][2] - a[0][2] * a[2][0]) / det;
+            inv[2][1] = (a[0][1] * a[2][0] - a[0][0] * a[2][1]) / det;
+            inv[0][2] = (a[0][1] * a[1][2] - a[0][2] * a[1][1]) / det;
+            inv[1][2] = (a[0][2] * a[1][0] - a[0][0] * a[1][2]) / det;
+            inv[2][2] = (a[0][0] * a[1][1] - a[0][1] * a[1][0]) / det;
+        }
+        for (int i = 0; i < sz; ++i)
+            for (int j = 0; j < sz; ++j) dval[drp[r0 + i] + j] = inv[i][j];
+    }
+}
+
+// S = D Dinv G into S's fixed pattern: one thread per row, the row's slots found by binary search; products outside the
+// pattern are counted in *missing
+__global__ void k_triple_product(const int64_t *__restrict__ drp, const int32_t *__restrict__ dcol, const double *__restrict__ dval,
+                                 const int64_t *__restrict__ irp, const int32_t *__restrict__ icol, const double *__restrict__ ival,
+                                 const int64_t *__restrict__ grp, const int32_t *__restrict__ gcol, const double *__restrict__ gval,
+                                 int64_t m, const int64_t *__restrict__ srp, const int32_t *__restrict__ scol,
+                                 double *__restrict__ sval, int *missing) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s0 = srp[i], s1 = srp[i + 1];
+        for (int64_t k = s0; k < s1; ++k) sval[k] = 0.0;
+        for (int64_t kd = drp[i]; kd < drp[i + 1]; ++kd) {
+            const int32_t a = dcol[kd];
+            const double dv = dval[kd];
+            for (int64_t ki = irp[a]; ki < irp[a + 1]; ++ki) {
+                const int32_t b = icol[ki];
+                const double w = dv * ival[ki];
+                for (int64_t kg = grp[b]; kg < grp[b + 1]; ++kg) {
+                    const int32_t j = gcol[kg];
+                    int64_t lo = s0, hi = s1 - 1, slot = -1;
+                    while (lo <= hi) {
+                        const int64_t mid = (lo + hi) >> 1;
+                        const int32_t v = scol[mid];
+                        if (v == j) { slot = mid; break; }
+                        if (v < j) lo = mid + 1; else hi = mid - 1;
+                    }
+                    if (slot >= 0) sval[slot] += w * gval[kg];
+                    else atomicAdd(missing, 1);
+                }
+            }
+        }
+    }
+}
+
 struct npg_index {
     npg_ctx *ctx = nullptr;
     int64_t n = 0, bound = 0;
@@ -480,6 +565,42 @@ NPG_API int npg_csr_gather_values(npg_csr *dst, const npg_csr *src, const npg_in
     hipLaunchKernelGGL(k_gather_values, dim3(std::max(grid, 1)), dim3(kBlock), 0, dst->ctx->stream, dst->val, src->val,
                        map->d, dst->nnz);
     NPG_HIP(hipGetLastError());
+    return NPG_OK;
+}
+
+NPG_API int npg_csr_node_block_inverse(npg_csr *Dinv, const npg_csr *A, int64_t n_full, int64_t n_surf) {
+    NPG_REQUIRE(Dinv && A && n_full >= 0 && n_surf >= 0, "npg_csr_node_block_inverse: bad argument");
+    NPG_REQUIRE(A->nnode() == 0 && Dinv->nnode() == 0, "npg_csr_node_block_inverse: node-blocked matrices are not supported");
+    const int64_t nu = Dinv->m;
+    NPG_REQUIRE(Dinv->n == nu && A->m >= nu && A->n >= nu && 3 * n_full + 2 * n_surf <= nu,
+                "npg_csr_node_block_inverse: Dinv must be nu x nu with nu <= size(A) and 3 n_full + 2 n_surf <= nu");
+    NPG_REQUIRE(Dinv->nnz == 9 * n_full + 4 * n_surf + (nu - 3 * n_full - 2 * n_surf),
+                "npg_csr_node_block_inverse: Dinv's pattern must hold exactly the node blocks (%lld entries expected, %lld found)",
+                (long long)(9 * n_full + 4 * n_surf + (nu - 3 * n_full - 2 * n_surf)), (long long)Dinv->nnz);
+    const int64_t nnode = n_full + n_surf + (nu - 3 * n_full - 2 * n_surf);
+    const int grid = (int)std::min<int64_t>(2048, (nnode + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_node_block_inverse, dim3(std::max(grid, 1)), dim3(kBlock), 0, A->ctx->stream, A->rowptr, A->col, A->val,
+                       n_full, n_surf, nu, Dinv->rowptr, Dinv->val);
+    NPG_HIP(hipGetLastError());
+    return NPG_OK;
+}
+
+NPG_API int npg_csr_triple_product(npg_csr *S, const npg_csr *D, const npg_csr *Dinv, const npg_csr *G) {
+    NPG_REQUIRE(S && D && Dinv && G, "npg_csr_triple_product: NULL argument");
+    NPG_REQUIRE(S->nnode() == 0 && D->nnode() == 0 && Dinv->nnode() == 0 && G->nnode() == 0,
+                "npg_csr_triple_product: node-blocked matrices are not supported");
+    NPG_REQUIRE(D->n == Dinv->m && Dinv->n == G->m && S->m == D->m && S->n == G->n, "npg_csr_triple_product: shapes do not chain");
+    npg_ctx *ctx = S->ctx;
+    int *missing = reinterpret_cast<int *>(ctx->d_scratch);
+    NPG_HIP(hipMemsetAsync(missing, 0, sizeof(int), ctx->stream));
+    const int grid = (int)std::min<int64_t>(4096, (S->m + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_triple_product, dim3(std::max(grid, 1)), dim3(kBlock), 0, ctx->stream, D->rowptr, D->col, D->val,
+                       Dinv->rowptr, Dinv->col, Dinv->val, G->rowptr, G->col, G->val, S->m, S->rowptr, S->col, S->val, missing);
+    NPG_HIP(hipGetLastError());
+    int miss = 0;
+    NPG_HIP(hipMemcpyAsync(&miss, missing, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    NPG_HIP(hipStreamSynchronize(ctx->stream));
+    NPG_REQUIRE(miss == 0, "npg_csr_triple_product: %d products fall outside S's pattern", miss);
     return NPG_OK;
 }
 

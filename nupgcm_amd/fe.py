@@ -407,7 +407,22 @@ class FEData:
                             u_pos=u_pos, p_pos=p_pos, b_pos=b_pos)
 
     # ---- sparsity patterns, in device (permuted) numbering, rows sorted -----------------------------------------
+    def _cached(self, key, build):
+        cache = self.__dict__.setdefault("_pattern_cache", {})
+        if key not in cache:
+            cache[key] = build()
+        return cache[key]
+
     def pattern_A(self, structural=False):
+        return self._cached(("A", bool(structural)), lambda: self._pattern_A(structural))
+
+    def pattern_B(self, structural=False):
+        return self._cached(("B", bool(structural)), lambda: self._pattern_B(structural))
+
+    def pattern_b(self):
+        return self._cached(("b",), self._pattern_b)
+
+    def _pattern_A(self, structural=False):
         """Pattern of A_inversion.  structural=False: the numerically non-zero pattern of the constant-nu (Laplacian)
         form - same-component friction, (x,y) Coriolis pairs, u-p and p-u couplings.  structural=True: all nine component
         pairs, as Gridap stores them and as the full-stress form (function-valued nu) needs."""
@@ -423,7 +438,7 @@ class FEData:
             P = P + up + up.T
         return _finish_pattern(P)
 
-    def pattern_B(self, structural=False):
+    def _pattern_B(self, structural=False):
         m, t, d = self.mesh, self.tables, self.dofs
         N = d.nu + d.np
         nbn = self.spaces.nb_nodes
@@ -433,7 +448,7 @@ class FEData:
         P = sum(_selector(t.u_pos[:, a], N).T @ Adj @ Sb for a in comps)
         return _finish_pattern(P)
 
-    def pattern_b(self):
+    def _pattern_b(self):
         Sb = _selector(self.tables.b_pos, self.dofs.nb)
         return _finish_pattern(Sb.T @ self.dofs.adjb @ Sb)
 

@@ -163,7 +163,7 @@ def run(model: Model, n_info=10, n_save=float("inf"), n_plot=float("inf"), advec
             else:
                 build_A_inversion(model.arch, model.fe_data, prm, None, A=sol.A)
             if hasattr(model.inversion.solver.P, "refresh"):         # an operator-dependent preconditioner follows A
-                model.inversion.solver.P.refresh(model.inversion.solver.A)
+                model.inversion.solver.P.refresh(model.inversion.solver.A, model)
         model.stats.append((model.evolution.solver.workspace.stats, model.inversion.solver.workspace.stats))
         if i % n_info == 0 and log is not None:
             t1 = time.time()

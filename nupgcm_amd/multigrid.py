@@ -6,8 +6,10 @@ friction-only velocity block, pressure mass matrix / (alpha^2 eps^2)).  `Multigr
 are built from (nupgcm_amd.refine), with a node-block Braess-Sarazin smoother - see csrc/mg.hip.  Both are applied by
 libnupgcm_hip.so; this module only prepares their operators at set-up time:
 
-  * per level: FEData (own RCM / node-block ordering), the level's A assembled by the device kernels, its blocks
-    G = A[u, p], D = A[p, u], the inverse Dinv of the node-block diagonal of A[u, u] and S = D Dinv G (host scipy, set-up only),
+  * per level: FEData (own RCM / node-block ordering), the level's A assembled by the device kernels, and the FIXED patterns
+    (host index work on the global sparsity pattern) of its blocks G = A[u, p], D = A[p, u], of the inverse Dinv of the
+    node-block diagonal of A[u, u] and of S = D Dinv G - the values are computed on the device (gathers, node-block inverse,
+    fixed-pattern triple product), at set-up and again whenever the eddy closure re-assembles A,
   * between levels: P2 (velocity) and P1 (pressure) nodal interpolation from the parent cell of every fine node, composed with
     both levels' device orderings; the pressure of every level is pinned at its own last vertex (src/dofs.jl:57), so the
     interpolated coarse pressure is shifted by its value there (constants are in the null space of the gradient block).
@@ -101,7 +103,7 @@ class DenseInversePreconditioner(GeneralPreconditioner):
         super().__init__(arch.ctx, L.NPG_PC_DENSE, 1)
         self.refresh(A)
 
-    def refresh(self, A: DeviceCSR):
+    def refresh(self, A: DeviceCSR, model=None):
         L.check(L.lib().npg_precond_dense_set(self.h, A.h))
         self.n = A.shape[0]
         return self
@@ -194,22 +196,85 @@ def node_block_inverse(F, n_full, n_surf):
     return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nu, nu))
 
 
+def _node_block_pattern(nu, n_full, n_surf):
+    """CSR pattern (rowptr, col) of the node-block diagonal: 3 x 3 / 2 x 2 / 1 x 1 blocks in the node-block DoF order"""
+    r3, r2 = 3 * n_full, 3 * n_full + 2 * n_surf
+    size = np.concatenate([np.full(r3, 3), np.full(r2 - r3, 2), np.ones(nu - r2, dtype=np.int64)]).astype(np.int64)
+    rp = np.zeros(nu + 1, dtype=np.int64)
+    np.cumsum(size, out=rp[1:])
+    first = np.concatenate([3 * (np.arange(r3) // 3), r3 + 2 * (np.arange(r2 - r3) // 2), np.arange(r2, nu)])
+    col = np.repeat(first, size) + (np.arange(rp[-1]) - np.repeat(rp[:-1], size))
+    return rp, col.astype(np.int32)
+
+
+class _LevelOperators:
+    """The smoother's operators of one level on FIXED patterns, (re)computed on the device from the level's plain-CSR A:
+    G = A[u, p] and D = A[p, u] by entry gathers, Dinv by the node-block inverse kernel, S = D Dinv G by the fixed-pattern
+    triple product.  The host only ever touches index arrays (the global sparsity pattern), at set-up."""
+
+    def __init__(self, ctx, fed, pattern):
+        from .architectures import DeviceIndex
+        d = fed.dofs
+        nu, n = d.nu, d.nu + d.np
+        rp, ci, shape = pattern
+        nnz = len(ci)
+        tags = sp.csr_matrix((np.arange(1, nnz + 1, dtype=np.float64), ci, rp), shape=shape)
+        Gt, Dt = sp.csr_matrix(tags[:nu, nu:]), sp.csr_matrix(tags[nu:, :nu])
+        Gt.sort_indices(); Dt.sort_indices()
+        self.nu, self.n_full, self.n_surf = nu, d.n_full, d.n_surf
+        self.G = DeviceCSR.from_pattern(ctx, nu, n - nu, Gt.indptr, Gt.indices)
+        self.D = DeviceCSR.from_pattern(ctx, n - nu, nu, Dt.indptr, Dt.indices)
+        self.mapG = DeviceIndex(ctx, np.rint(Gt.data).astype(np.int64) - 1, nnz)
+        self.mapD = DeviceIndex(ctx, np.rint(Dt.data).astype(np.int64) - 1, nnz)
+        irp, icol = _node_block_pattern(nu, d.n_full, d.n_surf)
+        self.Dinv = DeviceCSR.from_pattern(ctx, nu, nu, irp, icol)
+        one = lambda M: sp.csr_matrix((np.ones(M.nnz, dtype=np.float32), M.indices, M.indptr), shape=M.shape)
+        Ip = sp.csr_matrix((np.ones(len(icol), dtype=np.float32), icol, irp), shape=(nu, nu))
+        Sp = sp.csr_matrix(one(Dt) @ Ip @ one(Gt))
+        Sp.sort_indices()
+        self.S = DeviceCSR.from_pattern(ctx, n - nu, n - nu, Sp.indptr, Sp.indices)
+
+    def update(self, A: DeviceCSR):
+        self.G.gather_values(A, self.mapG)
+        self.D.gather_values(A, self.mapD)
+        L.check(L.lib().npg_csr_node_block_inverse(self.Dinv.h, A.h, int(self.n_full), int(self.n_surf)))
+        L.check(L.lib().npg_csr_triple_product(self.S.h, self.D.h, self.Dinv.h, self.G.h))
+        return self
+
+
+def injection(mesh_c: Mesh, mesh_f: Mesh, p1):
+    """fine node index of every coarse node (P1: vertices, P2: vertices + edge nodes): the coarse nodes are a subset of the
+    fine ones - read off the rows of the nodal interpolation that hold a single unit entry"""
+    P2, P1 = nodal_interpolation(mesh_c, mesh_f)
+    P = sp.csr_matrix(P1 if p1 else P2)
+    single = np.nonzero((np.diff(P.indptr) == 1))[0]
+    rows = single[np.abs(P.data[P.indptr[single]] - 1.0) < 1e-12]
+    inj = np.full(P.shape[1], -1, dtype=np.int64)
+    inj[P.indices[P.indptr[rows]]] = rows
+    if (inj < 0).any():
+        raise ValueError("injection: a coarse node has no coinciding fine node")
+    return inj
+
+
 class MultigridPreconditioner(GeneralPreconditioner):
     """MultigridPreconditioner(arch, params, forcings, hierarchy): hierarchy = [FEData coarse, ..., FEData fine], each the
-    red refinement of the one before (workloads.bowl_hierarchy); the last one is the model's own fe_data.  `A_fine` is the
-    solver's matrix (it may be stored by node blocks); the coarser operators are re-discretised on their own meshes."""
+    red refinement of the one before (workloads.bowl_hierarchy_models / channel_basin_hierarchy_models); the last one is the
+    model's own fe_data.  `A_fine` is the solver's matrix (it may be stored by node blocks); the coarser operators are
+    re-discretised on their own meshes."""
 
     def __init__(self, arch, params, forcings, hierarchy, A_fine: DeviceCSR = None, omega=2.5, jacobi_weight=0.7,
                  schur_sweeps=3, nu1=2, nu2=2, coarse_sweeps=20, block_nodes=None, cycle="V", coarse_dense=None):
         """coarse_dense: solve the coarsest level exactly with its dense inverse (DenseInversePreconditioner's machinery)
         instead of `coarse_sweeps` smoothing steps; None = whenever a hierarchy's coarsest level has <= 40 000 unknowns
-        (<= 12 GiB; measured at 2.15 M unknowns: 19 instead of 32 iterations for a cold solve, 88 instead of 128 ms).  A function-valued nu (full-stress form) is re-discretised on every level like a constant one.  With the eddy
-        closure on, `refresh(A)` (called by run! after each re-assembly of A, src/model.jl:160-170) rebuilds the FINEST level's
-        smoother from the new matrix; the coarser levels keep the operators of the set-up viscosity - a preconditioner need
-        not be exact, the Krylov method corrects for it."""
+        (<= 12 GiB; measured at 2.15 M unknowns: 19 instead of 32 iterations for a cold solve, 88 instead of 128 ms).
+        A function-valued nu (full-stress form) is re-discretised on every level like a constant one.  With the eddy closure
+        on, `refresh(A, model)` (called by run! after each re-assembly of A, src/model.jl:160-170) re-assembles EVERY level
+        with the new viscosity (the buoyancy is injected into the coarser meshes) and recomputes the smoothers' operators
+        on the device."""
         super().__init__(arch.ctx, L.NPG_PC_MG, len(hierarchy))
         ctx = arch.ctx
-        self.levels = []
+        self.arch, self.prm, self.frc, self.hierarchy = arch, params, forcings, hierarchy
+        self.levels, self.ops, self.A = [], [], []
         self._top = hierarchy[-1]
         full = callable(forcings.nu) or forcings.eddy_param.is_on
         prev = None
@@ -217,21 +282,22 @@ class MultigridPreconditioner(GeneralPreconditioner):
             d = fed.dofs
             top = lev == len(hierarchy) - 1
             A = build_A_inversion(arch, fed, params, forcings.nu, structural=full)   # plain CSR, [u; p] device order
-            G, D, Dinv, S = self._blocks(A, d)
+            ops = _LevelOperators(ctx, fed, fed.pattern_A(structural=full)).update(A)
             nu = d.nu
             if top and A_fine is not None:
                 A = A_fine
             elif not full and (block_nodes if block_nodes is not None else A.shape[0] >= 100000):
                 A.block_nodes(d.n_full, d.n_surf)
-            dev = [A] + [DeviceCSR.from_scipy(ctx, M) for M in (G, D, Dinv, S)]
             Pd = Rd = None
             if prev is not None:
                 P = prolongation(prev, fed)
                 Pd, Rd = DeviceCSR.from_scipy(ctx, P), DeviceCSR.from_scipy(ctx, sp.csr_matrix(P.T))
-            self._keep += dev + [Pd, Rd]
-            L.check(L.lib().npg_precond_mg_set_level(self.h, lev, dev[0].h, int(nu), dev[1].h, dev[2].h, dev[3].h, dev[4].h,
+            self._keep += [Pd, Rd]
+            self.ops.append(ops)
+            self.A.append(A)
+            L.check(L.lib().npg_precond_mg_set_level(self.h, lev, A.h, int(nu), ops.G.h, ops.D.h, ops.Dinv.h, ops.S.h,
                                                      None if Pd is None else Pd.h, None if Rd is None else Rd.h))
-            self.levels.append(dict(n=d.nu + d.np, nu=nu, S_nnz=S.nnz))
+            self.levels.append(dict(n=d.nu + d.np, nu=nu, S_nnz=ops.S.nnz))
             prev = fed
         self.set_params(omega, jacobi_weight, schur_sweeps, nu1, nu2, coarse_sweeps, cycle)
         if coarse_dense is None:
@@ -239,24 +305,37 @@ class MultigridPreconditioner(GeneralPreconditioner):
         if coarse_dense:
             L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, 1))
         self.coarse_dense = bool(coarse_dense)
+        self._inj = None
 
-    @staticmethod
-    def _blocks(A: DeviceCSR, d):
-        """G = A[u, p], D = A[p, u], Dinv = (node-block diagonal of A[u, u])^-1, S = D Dinv G from a plain-CSR device matrix"""
-        As = A.to_scipy_csr()
-        nu = d.nu
-        G, D = sp.csr_matrix(As[:nu, nu:]), sp.csr_matrix(As[nu:, :nu])
-        Dinv = node_block_inverse(As[:nu, :nu], d.n_full, d.n_surf)
-        S = sp.csr_matrix(D @ Dinv @ G)
-        S.sort_indices()
-        return G, D, Dinv, S
+    def _update_level(self, lev, A):
+        ops = self.ops[lev].update(A)
+        L.check(L.lib().npg_precond_mg_update_level(self.h, lev, A.h, ops.G.h, ops.D.h, ops.Dinv.h, ops.S.h))
 
-    def refresh(self, A: DeviceCSR):
-        """the solver's matrix has been re-assembled (eddy closure): rebuild the finest level's smoother from it"""
+    def refresh(self, A: DeviceCSR, model=None):
+        """the solver's matrix has been re-assembled (eddy closure): recompute the finest level's smoother from it and,
+        given the model, re-assemble the coarser levels with the eddy viscosity of the injected buoyancy"""
         top = len(self.levels) - 1
-        dev = [A] + [DeviceCSR.from_scipy(self.ctx, M) for M in self._blocks(A, self._top.dofs)]
-        L.check(L.lib().npg_precond_mg_update_level(self.h, top, *(m.h for m in dev)))
-        self._keep += dev                       # the old handles stay alive until the preconditioner goes (they are small)
+        self.A[top] = A
+        self._update_level(top, A)
+        ep = self.frc.eddy_param
+        if model is None or top == 0 or not ep.is_on:
+            return self
+        if self._inj is None:
+            p1 = self._top.spaces.b_order == 1
+            self._inj = [injection(self.hierarchy[k].mesh, self.hierarchy[k + 1].mesh, p1) for k in range(top)]
+        s_f = self._top.spaces
+        nodal = np.where(s_f.b_dof >= 0, model.state.b[np.maximum(s_f.b_dof, 0)], s_f.b_diri_val)   # fine nodal values
+        for lev in range(top - 1, -1, -1):
+            fed = self.hierarchy[lev]
+            nodal = nodal[self._inj[lev]]
+            s = fed.spaces
+            fe = device_fe(self.arch, fed)
+            bl = DeviceVector.from_host(self.ctx, nodal[s.b_dof >= 0], fed.dofs.p_b)
+            fe.update_nu_eddy(ep.N2min, self.prm.alpha, self.prm.N2, bl)
+            build_A_inversion(self.arch, fed, self.prm, None, A=self.A[lev])
+            self._update_level(lev, self.A[lev])
+        if self.coarse_dense:
+            L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, 1))
         return self
 
     def set_params(self, omega=2.5, jacobi_weight=0.7, schur_sweeps=3, nu1=2, nu2=2, coarse_sweeps=20, cycle="V"):
