@@ -245,8 +245,15 @@ class _LevelOperators:
 def injection(mesh_c: Mesh, mesh_f: Mesh, p1):
     """fine node index of every coarse node (P1: vertices, P2: vertices + edge nodes): the coarse nodes are a subset of the
     fine ones - read off the rows of the nodal interpolation that hold a single unit entry"""
-    P2, P1 = nodal_interpolation(mesh_c, mesh_f)
-    P = sp.csr_matrix(P1 if p1 else P2)
+    if p1:
+        # vertices: refine_once keeps the coarse nodes' ids, so coarse vertex t (master node g) is fine vertex vertex_of_f[g]
+        masters_c = np.full(mesh_c.nv, -1, dtype=np.int64)
+        geo = np.arange(len(mesh_c.vertex_of))
+        own = np.asarray(getattr(mesh_c.model, "periodic", None) if mesh_c.periodic else geo) == geo
+        masters_c[mesh_c.vertex_of[geo[own]]] = geo[own]
+        return mesh_f.vertex_of[masters_c]
+    P2, _ = nodal_interpolation(mesh_c, mesh_f)
+    P = sp.csr_matrix(P2)
     single = np.nonzero((np.diff(P.indptr) == 1))[0]
     rows = single[np.abs(P.data[P.indptr[single]] - 1.0) < 1e-12]
     inj = np.full(P.shape[1], -1, dtype=np.int64)
@@ -306,6 +313,9 @@ class MultigridPreconditioner(GeneralPreconditioner):
             L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, 1))
         self.coarse_dense = bool(coarse_dense)
         self._inj = None
+        if forcings.eddy_param.is_on and len(hierarchy) > 1:      # what refresh() needs, computed at set-up
+            p1 = self._top.spaces.b_order == 1
+            self._inj = [injection(hierarchy[k].mesh, hierarchy[k + 1].mesh, p1) for k in range(len(hierarchy) - 1)]
 
     def _update_level(self, lev, A):
         ops = self.ops[lev].update(A)
