@@ -221,8 +221,11 @@ int npg_precond_mg_set_cycle(npg_precond *pc, int gamma);
  * For the reference's small meshes, where the scalar-preconditioned GMRES is bound by kernel latency (19 us x 600 iterations),
  * this is the device counterpart of its CPU() path's `lu(A)` + `ldiv!` (src/inversion.jl:55-58, src/iterative_solvers.jl:42-47);
  * behind flexible GMRES it needs 1-2 iterations.  A must be plain CSR.  Call again to follow a re-assembled A. */
-int npg_precond_dense_set(npg_precond *pc, const npg_csr *A);
-/* multigrid: solve the coarsest level with its dense inverse instead of smoothing steps (on != 0) */
+int npg_precond_dense_set(npg_precond *pc, const npg_csr *A, int fp32_storage);
+/* fp32_storage != 0 keeps the inverse rounded to fp32 (half the bytes per application; products still accumulate in fp64):
+ * one application then carries ~1e-7 relative error and flexible GMRES takes 2-3 iterations at tight tolerances.
+ * multigrid: solve the coarsest level with its dense inverse instead of smoothing steps; on = 1: fp64 storage, on = 2: fp32
+ * (a coarse-grid correction inside a preconditioner does not need more), on = 0: back to smoothing steps */
 int npg_precond_mg_set_coarse_dense(npg_precond *pc, int on);
 /* z = M^-1 r (one application: one V-cycle / one round of inner CG solves) */
 int npg_precond_apply(npg_precond *pc, const npg_vec *r, npg_vec *z);

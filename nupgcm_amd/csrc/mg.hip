@@ -107,7 +107,8 @@ __global__ void k_densify(const int64_t *__restrict__ rowptr, const int32_t *__r
 // part[s][i] = sum over the s-th chunk of columns j of M[i + j n] x[j]: thread = row i, consecutive lanes read consecutive
 // doubles of one column (coalesced), eight columns in flight per thread; blockIdx.y = chunk
 constexpr int kGemvChunkCols = 512;
-__global__ void __launch_bounds__(kBlock) k_dense_gemv_part(const double *__restrict__ M, int64_t n,
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_dense_gemv_part(const T *__restrict__ M, int64_t n,
                                                             const double *__restrict__ x, double *__restrict__ part) {
     __shared__ double xs[kGemvChunkCols];
     const int64_t j0 = (int64_t)blockIdx.y * kGemvChunkCols;
@@ -116,17 +117,17 @@ __global__ void __launch_bounds__(kBlock) k_dense_gemv_part(const double *__rest
     __syncthreads();
     const int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x;
     if (i >= n) return;
-    const double *__restrict__ Mi = M + i + j0 * n;
+    const T *__restrict__ Mi = M + i + j0 * n;
     double acc = 0.0;
     int j = 0;
     for (; j + 8 <= nj; j += 8) {
-        double v[8];
+        T v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(Mi + (int64_t)(j + u) * n);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u] * xs[j + u];
+        for (int u = 0; u < 8; ++u) acc += (double)v[u] * xs[j + u];
     }
-    for (; j < nj; ++j) acc += Mi[(int64_t)j * n] * xs[j];
+    for (; j < nj; ++j) acc += (double)Mi[(int64_t)j * n] * xs[j];
     part[(int64_t)blockIdx.y * n + i] = acc;
 }
 
@@ -138,6 +139,11 @@ __global__ void __launch_bounds__(kBlock) k_dense_gemv_sum(const double *__restr
     double s = 0.0;
     for (int k = 0; k < nsplit; ++k) s += part[(int64_t)k * n + i];
     z[i] = (b == 0.0) ? a * s : a * s + b * z[i];
+}
+
+__global__ void k_to_float(const double *__restrict__ src, float *__restrict__ dst, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (float)src[i];
 }
 
 // x += sum_c y[c] Z_c
@@ -177,10 +183,18 @@ struct BlockPc {
 
 struct DenseInv {
     int64_t n = 0;
-    double *M = nullptr;       // A^-1, column-major
+    double *M = nullptr;       // A^-1, column-major (fp64 storage) ...
+    float *Mf = nullptr;       // ... or rounded to fp32 (half the bytes per application; a preconditioner may be inexact)
     double *part = nullptr;    // [nsplit][n] partial products
     int nsplit = 0;
 };
+
+static void dense_free(DenseInv &d) {
+    if (d.M) hipFree(d.M);
+    if (d.Mf) hipFree(d.Mf);
+    if (d.part) hipFree(d.part);
+    d = DenseInv{};
+}
 
 struct npg_precond {
     npg_ctx *ctx = nullptr;
@@ -235,8 +249,7 @@ NPG_API int npg_precond_destroy(npg_precond *pc) {
     if (!pc) return NPG_OK;
     hipStreamSynchronize(pc->ctx->stream);
     drop_graphs(pc);
-    if (pc->dense.M) hipFree(pc->dense.M);
-    if (pc->dense.part) hipFree(pc->dense.part);
+    dense_free(pc->dense);
     for (void *p : pc->allocs) hipFree(p);
     for (BlockPc &b : pc->blocks) {
         if (b.cg) npg_cg_destroy(b.cg);
@@ -252,7 +265,10 @@ static int dense_apply(npg_precond *pc, const double *r, double *z, double a, do
     const DenseInv &d = pc->dense;
     hipStream_t st = pc->ctx->stream;
     const int gx = (int)((d.n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_dense_gemv_part, dim3(gx, d.nsplit), dim3(kBlock), 0, st, d.M, d.n, r, d.part);
+    if (d.Mf)
+        hipLaunchKernelGGL(k_dense_gemv_part<float>, dim3(gx, d.nsplit), dim3(kBlock), 0, st, d.Mf, d.n, r, d.part);
+    else
+        hipLaunchKernelGGL(k_dense_gemv_part<double>, dim3(gx, d.nsplit), dim3(kBlock), 0, st, d.M, d.n, r, d.part);
     hipLaunchKernelGGL(k_dense_gemv_sum, dim3(gx), dim3(kBlock), 0, st, d.part, d.nsplit, d.n, a, b, z);
     NPG_HIP(hipGetLastError());
     return NPG_OK;
@@ -260,14 +276,14 @@ static int dense_apply(npg_precond *pc, const double *r, double *z, double a, do
 
 // A^-1 of a plain-CSR matrix as a dense fp64 array in HBM: densify, LU with partial pivoting and inversion by rocSOLVER
 // (set-up; n^2 doubles - 2 GB at 16 k unknowns, 8 GB at 31 k), applied per solve by the hand-written GEMV above
-static int dense_build(npg_precond *pc, const npg_csr *A) {
+static int dense_build(npg_precond *pc, const npg_csr *A, bool fp32) {
     NPG_REQUIRE(A && A->m == A->n && A->nnode() == 0, "dense inverse: a square plain-CSR matrix is required");
     const int64_t n = A->m;
     NPG_REQUIRE(n > 0 && n <= 65536, "dense inverse: %lld unknowns (limit 65 536: n^2 doubles must fit in HBM with room to spare)",
                 (long long)n);
     hipStream_t st = pc->ctx->stream;
     DenseInv &d = pc->dense;
-    if (d.M) { hipFree(d.M); hipFree(d.part); d.M = d.part = nullptr; }
+    dense_free(d);
     d.n = n;
     d.nsplit = (int)((n + kGemvChunkCols - 1) / kGemvChunkCols);
     NPG_HIP(hipMalloc((void **)&d.M, (size_t)n * n * sizeof(double)));
@@ -297,12 +313,20 @@ static int dense_build(npg_precond *pc, const npg_csr *A) {
     NPG_REQUIRE(s1 == rocblas_status_success && i1 == 0 && s2 == rocblas_status_success && i2 == 0,
                 "dense inverse: rocSOLVER getrf/getri failed (status %d/%d, info %d/%d: the matrix is singular to working "
                 "precision, or out of memory)", (int)s1, (int)s2, (int)i1, (int)i2);
+    if (fp32) {
+        NPG_HIP(hipMalloc((void **)&d.Mf, (size_t)n * n * sizeof(float)));
+        hipLaunchKernelGGL(k_to_float, dim3(4096), dim3(kBlock), 0, st, d.M, d.Mf, n * n);
+        NPG_HIP(hipGetLastError());
+        NPG_HIP(hipStreamSynchronize(st));
+        NPG_HIP(hipFree(d.M));
+        d.M = nullptr;
+    }
     return NPG_OK;
 }
 
-NPG_API int npg_precond_dense_set(npg_precond *pc, const npg_csr *A) {
+NPG_API int npg_precond_dense_set(npg_precond *pc, const npg_csr *A, int fp32_storage) {
     NPG_REQUIRE(pc && pc->kind == NPG_PC_DENSE, "npg_precond_dense_set: not a dense-inverse preconditioner");
-    int rc = dense_build(pc, A);
+    int rc = dense_build(pc, A, fp32_storage != 0);
     if (rc) return rc;
     pc->n = A->m;
     return NPG_OK;
@@ -315,10 +339,10 @@ NPG_API int npg_precond_mg_set_coarse_dense(npg_precond *pc, int on) {
     NPG_HIP(hipStreamSynchronize(pc->ctx->stream));
     drop_graphs(pc);
     if (!on) {
-        if (pc->dense.M) { hipFree(pc->dense.M); hipFree(pc->dense.part); pc->dense = DenseInv{}; }
+        dense_free(pc->dense);
         return NPG_OK;
     }
-    return dense_build(pc, pc->L[0].A);
+    return dense_build(pc, pc->L[0].A, on == 2);
 }
 
 static int mg_alloc(npg_precond *pc, double **p, int64_t n) {
@@ -452,7 +476,7 @@ static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int n
 // every level is visited gamma times, the second visit continuing from the first one's result).
 static int mg_cycle(npg_precond *pc, int lev, double *x, const double *b, bool x_is_zero) {
     int rc;
-    if (lev == 0 && pc->dense.M) {                                   // exact coarsest-level solve
+    if (lev == 0 && (pc->dense.M || pc->dense.Mf)) {                 // direct coarsest-level solve
         if (x_is_zero) return dense_apply(pc, b, x, 1.0, 0.0);
         MgLevel &l0 = pc->L[0];
         SpmvEpi e{};
@@ -499,7 +523,7 @@ NPG_API int npg_precond_blockdiag_set(npg_precond *pc, int k, int64_t offset, co
 static int precond_apply_raw(npg_precond *pc, const double *r, double *z) {
     ++pc->applications;
     if (pc->kind == NPG_PC_DENSE) {
-        NPG_REQUIRE(pc->dense.M, "npg_precond_apply: the dense inverse has not been set");
+        NPG_REQUIRE(pc->dense.M || pc->dense.Mf, "npg_precond_apply: the dense inverse has not been set");
         return dense_apply(pc, r, z, 1.0, 0.0);
     }
     if (pc->kind == NPG_PC_MG) {

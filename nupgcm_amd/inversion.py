@@ -110,7 +110,7 @@ class InversionToolkit:
                         raise ValueError("preconditioner='multigrid' needs hierarchy=[FEData coarse, ..., fe_data]")
                     P = mgm.MultigridPreconditioner(arch, params, forcings, hierarchy, A_fine=A, **(precond_kw or {}))
                 elif preconditioner == "dense_inverse":
-                    P = mgm.DenseInversePreconditioner(arch, A)
+                    P = mgm.DenseInversePreconditioner(arch, A, **(precond_kw or {}))
                 elif preconditioner == "block_diagonal":
                     P = mgm.BlockDiagonalPreconditioner(arch, params, fe_data, A, **(precond_kw or {}))
                 else:

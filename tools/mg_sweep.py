@@ -27,7 +27,7 @@ s.kwargs["itmax"] = int(sys.argv[3]) if len(sys.argv) > 3 else 150
 from nupgcm_amd import _lib as L  # noqa: E402
 for kw in combos:
     kw = dict(kw)
-    L.check(L.lib().npg_precond_mg_set_coarse_dense(P.h, int(bool(kw.pop("coarse_dense", False)))))
+    L.check(L.lib().npg_precond_mg_set_coarse_dense(P.h, int(kw.pop("coarse_dense", 0))))
     P.set_params(**kw)
     s.x.fill(0.0)
     npg.invert(m)
