@@ -564,6 +564,8 @@ static int precond_apply_raw(npg_precond *pc, const double *r, double *z) {
 
 NPG_API int npg_precond_apply(npg_precond *pc, const npg_vec *r, npg_vec *z) {
     NPG_REQUIRE(pc && r && z, "npg_precond_apply: NULL argument");
+    NPG_REQUIRE(pc->kind != NPG_PC_MG || pc->L.back().A, "npg_precond_apply: multigrid levels are not all set");
+    NPG_REQUIRE(pc->kind != NPG_PC_DENSE || pc->dense.M || pc->dense.Mf, "npg_precond_apply: the dense inverse has not been set");
     NPG_REQUIRE(r->n == pc->n && z->n == pc->n && r->d != z->d, "npg_precond_apply: vectors must have %lld entries and not alias",
                 (long long)pc->n);
     return precond_apply_raw(pc, r->d, z->d);

@@ -258,3 +258,55 @@ def test_multigrid_with_exact_coarse_solve(arch, two_level):
         assert rel(z, zr) < bar, (mode, rel(z, zr))
         if mode == "fp32":
             assert rel(z, zr) > 1e-10                            # the fp32 copy is really what ran
+
+
+def test_preconditioner_abi_argument_errors(arch):
+    """the round-2 entry points validate on the host like the rest of the ABI: wrong shapes, wrong order of set-up calls, index
+    maps out of range, node-block patterns that do not match - status code + message, never a device fault"""
+    import ctypes as C
+
+    from nupgcm_amd import _lib as L
+    from nupgcm_amd.architectures import DeviceIndex
+    ctx = arch.ctx
+    lib = L.lib()
+    I = npg.on_architecture(arch, sp.csr_matrix(sp.eye(12)))
+    pc = C.c_void_p()
+    assert lib.npg_precond_create(ctx.h, 7, 1, C.byref(pc)) != 0 and b"unknown kind" in lib.npg_last_error()
+    assert lib.npg_precond_create(ctx.h, L.NPG_PC_MG, 0, C.byref(pc)) != 0
+    P = mgm.GeneralPreconditioner(ctx, L.NPG_PC_MG, 2)
+    r, z = npg.DeviceVector(ctx, 12), npg.DeviceVector(ctx, 12)
+    with pytest.raises(L.DeviceError, match="not all set"):
+        P.apply(r, z)
+    G = npg.on_architecture(arch, sp.csr_matrix(np.ones((8, 4))))
+    D = npg.on_architecture(arch, sp.csr_matrix(np.ones((4, 8))))
+    Di = npg.on_architecture(arch, sp.csr_matrix(sp.eye(8)))
+    S = npg.on_architecture(arch, sp.csr_matrix(sp.eye(4)))
+    # level 1 before level 0; transfer operators at level 0; block shapes that do not add up
+    assert lib.npg_precond_mg_set_level(P.h, 1, I.h, 8, G.h, D.h, Di.h, S.h, I.h, I.h) != 0
+    assert lib.npg_precond_mg_set_level(P.h, 0, I.h, 8, G.h, D.h, Di.h, S.h, I.h, I.h) != 0
+    assert lib.npg_precond_mg_set_level(P.h, 0, I.h, 7, G.h, D.h, Di.h, S.h, None, None) != 0
+    assert lib.npg_precond_mg_set_level(P.h, 0, I.h, 8, G.h, D.h, Di.h, S.h, None, None) == 0
+    assert lib.npg_precond_mg_set_level(P.h, 0, I.h, 8, G.h, D.h, Di.h, S.h, None, None) != 0      # already set
+    assert lib.npg_precond_mg_set_params(P.h, -1.0, 0.7, 3, 2, 2, 20) != 0
+    assert lib.npg_precond_mg_set_cycle(P.h, 3) != 0
+    ws = npg.FgmresWorkspace(ctx, 12)
+    with pytest.raises(L.DeviceError):
+        ws.solve(I, npg.DeviceVector(ctx, 11), ws.x, None)                                        # short right-hand side
+    with pytest.raises(L.DeviceError):
+        npg.FgmresWorkspace(ctx, 12, memory=40)
+    Pd = mgm.GeneralPreconditioner(ctx, L.NPG_PC_DENSE, 1)
+    with pytest.raises(L.DeviceError, match="has not been set"):
+        Pd.apply(r, z)
+    assert lib.npg_precond_dense_set(Pd.h, G.h, 0) != 0                                           # not square
+    sing = npg.on_architecture(arch, sp.csr_matrix(np.array([[1.0, 2.0], [2.0, 4.0]])))
+    assert lib.npg_precond_dense_set(Pd.h, sing.h, 0) != 0 and b"singular" in lib.npg_last_error()
+    # fixed-pattern helpers
+    with pytest.raises(L.DeviceError, match="outside"):
+        DeviceIndex(ctx, np.array([0, 5, 99]), 12)
+    with pytest.raises(L.DeviceError):
+        I.gather_values(G, DeviceIndex(ctx, np.zeros(12, dtype=np.int64), 32).__class__(ctx, np.zeros(3, dtype=np.int64), 32))
+    with pytest.raises(L.DeviceError, match="node blocks"):
+        L.check(lib.npg_csr_node_block_inverse(I.h, I.h, 2, 1))            # I holds 12 entries, the blocks would need 28
+    with pytest.raises(L.DeviceError, match="outside S"):
+        L.check(lib.npg_csr_triple_product(S.h, D.h, Di.h, G.h))           # D Dinv G is full, S's pattern is diagonal
+    lib.npg_precond_destroy(pc) if pc else None
