@@ -62,6 +62,9 @@ class Model:
         self.b_vec = evolution.solver.x if evolution is not None else DeviceVector(ctx, fe_data.dofs.nb)
         self.state = State(self)
         self.step_index = 1
+        # True: run! starts each inversion from the extrapolation 2 x_{n-1} - x_{n-2} of the last two solutions instead of
+        # x_{n-1} alone (the reference's warm start); off by default = the reference's recipe
+        self.extrapolate_guess = False
         self.stats = []
         self._prev = None
         self._u_view = inversion.solver.x.view(0, fe_data.dofs.nu)     # x[1:nu] = u (p_inversion = [p_u; nu + p_p])
@@ -144,6 +147,10 @@ def run(model: Model, n_info=10, n_save=float("inf"), n_plot=float("inf"), advec
         pv["x_curr"].copy_from(inv_x)                                                           # src/model.jl:140-141
         pv["b_curr"].copy_from(b)
         evolve(model, pv["x_prev"], pv["b_prev"])                                               # src/model.jl:144
+        if getattr(model, "extrapolate_guess", False) and i > 1:
+            # initial guess 2 x_{n-1} - x_{n-2} instead of the reference's x_{n-1} (x aliases workspace.x,
+            # src/iterative_solvers.jl:26-29): changes the result only within the solver tolerance
+            inv_x.axpby(-1.0, pv["x_prev"], 2.0)
         invert(model)                                                                           # src/model.jl:145
         update_t(ts)
         # blow-up guard (src/model.jl:149-153): device reductions over [u; p] and b

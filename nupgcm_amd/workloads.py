@@ -81,7 +81,10 @@ def example_model(arch, label_or_model, dt=1e-3, t_stop=1e9, preconditioner="dia
     ts = BDF2(t_start=0.0, t_stop=t_stop, dt=dt)
     inv = InversionToolkit(arch, fed, prm, frc, preconditioner=preconditioner, **inv_kw)
     evo = EvolutionToolkit(arch, fed, prm, frc, ts)
-    return Model(arch, prm, frc, fed, inv, evo, ts)
+    model = Model(arch, prm, frc, fed, inv, evo, ts)
+    # with a real preconditioner an iteration is worth saving: start each inversion from 2 x_{n-1} - x_{n-2} (model.run)
+    model.extrapolate_guess = preconditioner == "multigrid"
+    return model
 
 
 # ---- BASELINE.json configs[4]: the channel-basin production configuration (scratch/run.jl) -------------------------------
@@ -173,6 +176,7 @@ def channel_basin_model(arch, h=None, dz=None, mesh_model=None, surface="flux", 
     inv = InversionToolkit(arch, fed, prm, frc, itmax=itmax, atol=atol, rtol=rtol, **inv_kw)
     evo = EvolutionToolkit(arch, fed, prm, frc, ts, atol=atol, rtol=rtol)
     model = Model(arch, prm, frc, fed, inv, evo, ts)
+    model.extrapolate_guess = inv_kw.get("preconditioner") == "multigrid"
     set_b(model, b0)
     invert(model)
     return model
