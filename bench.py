@@ -300,9 +300,9 @@ def main():
         npg.invert(mg)
         ctx.sync()
         t_mg = time.time() - t_mg
-        npg.run(mg, n_steps=max(a.warmup, 1))
+        npg.run(mg, n_steps=max(a.warmup, 3))            # the extrapolated initial guess needs two steps of history to settle
         ctx.sync()
-        k = max(a.steps, 5)
+        k = max(a.steps, 10)
         t0 = time.perf_counter()
         npg.run(mg, n_steps=k)
         ctx.sync()
