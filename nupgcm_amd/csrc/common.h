@@ -120,7 +120,7 @@ int allreduce_sum_device(npg_ctx *ctx, double *buf, int n);
 int ensure_stage(npg_ctx *ctx, size_t doubles);
 int build_tiles(npg_csr *A);
 // tile boundaries (consecutive whole rows, at most tile_slots LDS product slots) for any tile size: tuning harness
-NPG_SHARED int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp);
+NPG_SHARED int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp, int max_rows = kTileRows);
 struct CsrDev;
 NPG_SHARED CsrDev csr_view(const npg_csr *A);
 // epilogue of the tiled SpMV kernel: y = alpha (A x) + beta c   [c may be y itself; not read when beta == 0]

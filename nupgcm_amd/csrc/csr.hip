@@ -8,7 +8,7 @@ namespace npg {
 
 // Row tiles for the CSR-stream kernels: consecutive whole rows, at most kTileNnz stored entries and kTileRows rows per
 // tile; small matrices get about one tile per CU.  A row longer than kTileNnz becomes a tile of its own.
-int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp) {
+int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp, int max_rows) {
     const int64_t m = A->m;
     const int64_t *rp = A->h_rowptr.data();
     const int64_t *pp = A->nnode() ? A->h_prow.data() : nullptr;
@@ -16,7 +16,7 @@ int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp) 
     auto node = [&](int64_t r) { return r < nf3 ? r / 3 : A->nfull + (r - nf3) / 2; };      // r starts a node
     const int64_t slots_total = rp[m] + (pp ? 3 * pp[A->nfull] + 2 * (pp[A->nnode()] - pp[A->nfull]) : 0);
     int64_t target = slots_total / (int64_t)A->ctx->num_cu;
-    target = std::max<int64_t>(1024, std::min<int64_t>(tile_slots, target)); // >= 1 tile per CU on small matrices
+    target = std::min<int64_t>(tile_slots, std::max<int64_t>(1024, target)); // >= 1 tile per CU on small matrices
     // LDS product slots of rows [a, b): their CSR entries + one per component per record (a, b on node boundaries of
     // one kind inside the block rows)
     auto slots = [&](int64_t a, int64_t b) {
@@ -31,7 +31,7 @@ int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp) 
         const bool inblk = r < nbr;
         const int64_t step = !inblk ? 1 : (r < nf3 ? 3 : 2), lim = !inblk ? m : (r < nf3 ? nf3 : nbr);
         int64_t r1 = r + step;
-        while (r1 < lim && r1 + step - r <= kTileRows && slots(r, r1 + step) <= target) r1 += step;
+        while (r1 < lim && r1 + step - r <= max_rows && slots(r, r1 + step) <= target) r1 += step;
         NPG_REQUIRE(!inblk || slots(r, r1) <= tile_slots, "build_tiles: the rows of one node do not fit one tile");
         tp.push_back((int32_t)r1);
         r = r1;

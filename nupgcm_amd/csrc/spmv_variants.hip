@@ -6,6 +6,7 @@
 
 #include "common.h"
 #include "spmv_device.h"
+#include "spmv_pack.h"
 
 namespace npg {
 
@@ -542,6 +543,569 @@ static int run_wide2(const npg_csr *A, const double *x, double *y, int bpc, int 
     return NPG_OK;
 }
 
+// ---- tile-packed blobs + LDS-DMA pipelined tiles (spmv_pack.h) ---------------------------------------------------------
+// a cycle stamp the compiler keeps in place relative to memory operations
+__device__ __forceinline__ unsigned long long stamp_here() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+
+template <int NT, int L, int TNNZ, int TROWS, int WPE, bool NTL, bool PERM>
+__global__ void __launch_bounds__(NT, WPE) k_spmv_pack(CsrDev A, const char *__restrict__ blob,
+                                                       const PackDesc *__restrict__ tiles, int ntiles,
+                                                       const double *__restrict__ x, double *__restrict__ y,
+                                                       unsigned long long *acc) {
+    constexpr int BUFB = pack_buf_bytes(TNNZ, TROWS, PERM);
+    static_assert(2 * BUFB + 8 * TROWS <= 65536, "LDS-DMA addresses its destination through 16 bits of M0");
+    __shared__ __attribute__((aligned(16))) char buf[2][BUFB];
+    __shared__ double sw[TROWS];
+    unsigned long long a[5] = {0, 0, 0, 0, 0}, c0, c1, c2, c3, c4, c5;
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    int tn = t + gridDim.x;
+    PackDesc td = tiles[t];
+    PackDesc nd = td;
+    if (tn < ntiles) nd = tiles[tn];
+    pack_issue<NT, NTL, PERM>(blob, td, buf[0]);
+    int b = 0;
+    while (true) {
+        const int tnn = tn + gridDim.x;
+        PackDesc nnd = nd;
+        if (tnn < ntiles) nnd = tiles[tnn];                       // scalar load, in flight during this tile
+        if (acc) c0 = stamp_here();
+        wait_vm0_barrier();                                       // A
+        if (acc) c1 = stamp_here();
+        if (td.flags & 4) {
+            pack_long_row<NT>(A, PlainX{x}, td, buf[b], sw);
+            if (tn < ntiles) pack_issue<NT, NTL, PERM>(blob, nd, buf[b ^ 1]);
+        } else {
+            pack_products<NT, PlainX, TNNZ, PERM>(A, PlainX{x}, td, buf[b]);       // B, C
+            if (acc) c2 = stamp_here();
+            if (tn < ntiles) pack_issue<NT, NTL, PERM>(blob, nd, buf[b ^ 1]);      // D
+            if (acc) c3 = stamp_here();
+            pack_sums<NT, L, PERM>(td, buf[b], sw);                     // E
+        }
+        if (acc) c4 = stamp_here();
+        wait_lds_barrier();                                       // F
+        for (int r = threadIdx.x; r < td.nrows; r += NT) y[td.r0 + r] = sw[r];
+        if (acc) {
+            c5 = stamp_here();
+            a[0] += c1 - c0;
+            a[1] += c2 - c1;
+            a[2] += c3 - c2;
+            a[3] += c4 - c3;
+            a[4] += c5 - c4;
+        }
+        if (tn >= ntiles) break;
+        t = tn;
+        tn = tnn;
+        td = nd;
+        nd = nnd;
+        b ^= 1;
+    }
+    if (acc && threadIdx.x == 0)
+        for (int i = 0; i < 5; ++i) atomicAdd(acc + i, a[i]);
+}
+
+
+// three LDS buffers: tile t is multiplied and summed while tile t+1's x values are in flight to registers and tile t+2's
+// blob is in flight to LDS
+template <int NT, int L, int TNNZ, int TROWS, int WPE, bool NTL>
+__global__ void __launch_bounds__(NT, WPE) k_spmv_pack3(CsrDev A, const char *__restrict__ blob,
+                                                        const PackDesc *__restrict__ tiles, int ntiles,
+                                                        const double *__restrict__ x, double *__restrict__ y,
+                                                        unsigned long long *acc) {
+    constexpr int BUFB = pack_buf_bytes(TNNZ, TROWS);
+    static_assert(3 * BUFB + 8 * TROWS <= 65536, "LDS-DMA addresses its destination through 16 bits of M0");
+    __shared__ __attribute__((aligned(16))) char buf[3][BUFB];
+    __shared__ double sw[TROWS];
+    unsigned long long a[5] = {0, 0, 0, 0, 0}, c0, c1, c2, c3, c4, c5;
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    const int stride = gridDim.x;
+    PackDesc td = tiles[t], nd = td, nnd = td;
+    if (t + stride < ntiles) nd = tiles[t + stride];
+    if (t + 2 * stride < ntiles) nnd = tiles[t + 2 * stride];
+    pack_issue<NT, NTL>(blob, td, buf[0]);
+    if (t + stride < ntiles) pack_issue<NT, NTL>(blob, nd, buf[1]);
+    wait_vm0_barrier();
+    PackX<NT, TNNZ> G;
+    pack_gather<NT, PlainX, TNNZ>(A, PlainX{x}, td, buf[0], G);
+    int b = 0;
+    while (true) {
+        const int b1 = b == 2 ? 0 : b + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+        PackDesc n3 = nnd;
+        if (t + 3 * stride < ntiles) n3 = tiles[t + 3 * stride];      // scalar load, in flight during this tile
+        if (acc) c0 = stamp_here();
+        wait_vm0_barrier();                                       // A: x values of tile t here, blob of tile t+1 landed
+        if (acc) c1 = stamp_here();
+        pack_multiply<NT, TNNZ>(td, buf[b], G);
+        if (t + stride < ntiles) pack_gather<NT, PlainX, TNNZ>(A, PlainX{x}, nd, buf[b1], G);
+        wait_lds_barrier();                                       // C
+        if (acc) c2 = stamp_here();
+        if (t + 2 * stride < ntiles) pack_issue<NT, NTL>(blob, nnd, buf[b2]);      // D
+        if (acc) c3 = stamp_here();
+        pack_sums<NT, L>(td, buf[b], sw);                         // E
+        if (acc) c4 = stamp_here();
+        wait_lds_barrier();                                       // F
+        for (int r = threadIdx.x; r < td.nrows; r += NT) y[td.r0 + r] = sw[r];
+        if (acc) {
+            c5 = stamp_here();
+            a[0] += c1 - c0;
+            a[1] += c2 - c1;
+            a[2] += c3 - c2;
+            a[3] += c4 - c3;
+            a[4] += c5 - c4;
+        }
+        t += stride;
+        if (t >= ntiles) break;
+        td = nd;
+        nd = nnd;
+        nnd = n3;
+        b = b1;
+    }
+    if (acc && threadIdx.x == 0)
+        for (int i = 0; i < 5; ++i) atomicAdd(acc + i, a[i]);
+}
+
+// one workgroup per tile: the tile's pieces of the CSR / record arrays -> its blob
+template <bool PERM>
+__global__ void __launch_bounds__(256) k_pack_tiles(CsrDev A, const PackDesc *__restrict__ tiles, int ntiles,
+                                                    char *__restrict__ blob, const uint16_t *__restrict__ pdst,
+                                                    const uint16_t *__restrict__ cdst) {
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const PackDesc pd = tiles[t];
+        if (pd.flags & 4) continue;
+        const bool blk = pd.flags & 1;
+        const PackGeo g = pack_geo<PERM>(pd.nrows, pd.nnode, pd.npe, pd.n, blk);
+        int32_t *I = reinterpret_cast<int32_t *>(blob + pd.off16 * 16);
+        uint16_t *PD = reinterpret_cast<uint16_t *>(I) + 2 * g.i_pdst, *CD = reinterpret_cast<uint16_t *>(I) + 2 * g.i_cdst;
+        double *D = reinterpret_cast<double *>(blob + pd.off16 * 16 + 4 * g.nints);
+        const int64_t base = A.rowptr[pd.r0];
+        const int q0 = blk ? node_of_row(A, pd.r0) : 0;
+        const int64_t pbase = blk ? A.prow[q0] : 0;
+        for (int r = threadIdx.x; r <= pd.nrows; r += blockDim.x) I[r] = 2 * g.npeA + (int32_t)(A.rowptr[pd.r0 + r] - base);
+        if (blk)
+            for (int q = threadIdx.x; q <= pd.nnode; q += blockDim.x) I[g.i_prp + q] = (int32_t)(A.prow[q0 + q] - pbase);
+        for (int e = threadIdx.x; e < pd.npe; e += blockDim.x) {
+            I[g.i_pcol + e] = A.pcol[pbase + e];
+            const double2 kc = A.pkc[pbase + e];
+            D[e] = kc.x;
+            D[g.npeA + e] = kc.y;
+            if (PERM) PD[e] = pdst[pbase + e];
+        }
+        for (int k = threadIdx.x; k < pd.n; k += blockDim.x) {
+            I[g.i_col + k] = A.col[base + k];
+            D[2 * g.npeA + k] = A.val[base + k];
+            if (PERM) CD[k] = cdst[base + k];
+        }
+    }
+}
+
+struct PackTiles {
+    PackDesc *d = nullptr;
+    char *blob = nullptr;
+    int n = 0;
+    size_t bytes = 0;
+};
+static std::map<std::pair<const void *, std::pair<int, int>>, PackTiles> g_packs;
+
+static int sorted_streams(const npg_csr *A, const std::vector<std::pair<int64_t, int>> &rec, const std::vector<std::pair<int64_t, int>> &ent,
+                          CsrDev *Av, uint16_t **pdst_out, uint16_t **cdst_out);
+
+template <int NT, int L, int TNNZ, int TROWS, int WPE, bool NTL, bool PERM = false, int DEPTH = 2>
+static int run_pack(const npg_csr *A, const double *x, double *y, int bpc, int reps, double *ms) {
+    npg_ctx *ctx = A->ctx;
+    auto key = std::make_pair((const void *)A, std::make_pair(TNNZ + (PERM ? 1 : 0), TROWS));
+    CsrDev Av = csr_view(A);
+    if (!g_packs.count(key)) {
+        std::vector<int32_t> tp;
+        int rc = tile_boundaries(A, TNNZ, tp, TROWS);
+        if (rc) return rc;
+        const int64_t *rp = A->h_rowptr.data();
+        const int64_t nf3 = 3 * (int64_t)A->nfull, nbr = A->block_rows();
+        auto node = [&](int64_t r) { return r < nf3 ? r / 3 : A->nfull + (r - nf3) / 2; };
+        std::vector<PackDesc> td(tp.size() - 1);
+        int64_t off16 = 0;
+        int nlong = 0;
+        for (size_t t = 0; t + 1 < tp.size(); ++t) {
+            const int64_t r0 = tp[t], r1 = tp[t + 1];
+            PackDesc &q = td[t];
+            q.off16 = off16;
+            q.r0 = (int32_t)r0;
+            q.nrows = (int32_t)(r1 - r0);
+            q.n = (int32_t)(rp[r1] - rp[r0]);
+            q.npe = 0;
+            q.nnode = 0;
+            q.flags = 0;
+            if (r0 < nbr) {
+                q.flags = 1 | (r0 < nf3 ? 2 : 0);
+                q.nnode = (int32_t)(node(r1) - node(r0));
+                q.npe = (int32_t)(A->h_prow[node(r1)] - A->h_prow[node(r0)]);
+            }
+            const PackGeo g = pack_geo<PERM>(q.nrows, q.nnode, q.npe, q.n, q.flags & 1);
+            if (4 * g.nints + 8 * (g.ndbl + ((q.flags & 2) ? g.npeA : 0)) > pack_buf_bytes(TNNZ, TROWS, PERM)) {
+                NPG_REQUIRE(q.nrows == 1 && !(q.flags & 1), "run_pack: a tile does not fit its LDS buffer");
+                q.flags = 4;
+                ++nlong;
+                continue;
+            }
+            off16 += (4 * (int64_t)g.nints + 8 * (int64_t)g.ndbl) / 16;
+        }
+        PackTiles v;
+        v.n = (int)td.size();
+        v.bytes = (size_t)off16 * 16;
+        NPG_HIP(hipMalloc((void **)&v.d, td.size() * sizeof(PackDesc)));
+        NPG_HIP(hipMemcpy(v.d, td.data(), td.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
+        NPG_HIP(hipMalloc((void **)&v.blob, v.bytes + 64));
+        NPG_HIP(hipMemsetAsync(v.blob, 0, v.bytes + 64, ctx->stream));
+        uint16_t *pdst = nullptr, *cdst = nullptr;
+        CsrDev Ap = Av;
+        if (PERM) {
+            std::vector<std::pair<int64_t, int>> rec, ent;      // (start, count) of every tile's record / CSR stream
+            for (const PackDesc &q : td) {
+                const int64_t q0 = (q.flags & 1) ? node(q.r0) : 0;
+                rec.emplace_back((q.flags & 1) ? A->h_prow[q0] : 0, (q.flags & 4) ? 0 : q.npe);
+                ent.emplace_back(rp[q.r0], (q.flags & 4) ? 0 : q.n);
+            }
+            rc = sorted_streams(A, rec, ent, &Ap, &pdst, &cdst);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_pack_tiles<PERM>, dim3(std::min(v.n, 4096)), dim3(256), 0, ctx->stream, Ap, v.d, v.n, v.blob, pdst,
+                           cdst);
+        NPG_HIP(hipStreamSynchronize(ctx->stream));
+        fprintf(stderr, "  packed %d tiles (<= %d slots, <= %d rows; %d long rows left in CSR): %.1f MB\n", v.n, TNNZ, TROWS, nlong,
+                v.bytes / 1e6);
+        g_packs[key] = v;
+    }
+    const PackTiles t = g_packs[key];
+    const int grid = std::max(1, std::min(t.n, bpc * ctx->num_cu));
+    auto go = [&](unsigned long long *acc) {
+        if constexpr (DEPTH == 3)
+            hipLaunchKernelGGL((k_spmv_pack3<NT, L, TNNZ, TROWS, WPE, NTL>), dim3(grid), dim3(NT), 0, ctx->stream, Av, t.blob,
+                               t.d, t.n, x, y, acc);
+        else
+            hipLaunchKernelGGL((k_spmv_pack<NT, L, TNNZ, TROWS, WPE, NTL, PERM>), dim3(grid), dim3(NT), 0, ctx->stream, Av, t.blob,
+                               t.d, t.n, x, y, acc);
+    };
+    if (getenv("NPG_DMA_PHASES")) {
+        unsigned long long *acc, h[5];
+        NPG_HIP(hipMalloc((void **)&acc, sizeof h));
+        NPG_HIP(hipMemset(acc, 0, sizeof h));
+        go(acc);
+        NPG_HIP(hipStreamSynchronize(ctx->stream));
+        NPG_HIP(hipMemcpy(h, acc, sizeof h, hipMemcpyDeviceToHost));
+        NPG_HIP(hipFree(acc));
+        fprintf(stderr, "  cycles per tile (%d tiles): A wait %.0f | B+C gather %.0f | D issue %.0f | E sums %.0f | F out %.0f\n", t.n,
+                (double)h[0] / t.n, (double)h[1] / t.n, (double)h[2] / t.n, (double)h[3] / t.n, (double)h[4] / t.n);
+    }
+    for (int i = 0; i < 2; ++i) go(nullptr);
+    NPG_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; ++i) go(nullptr);
+    NPG_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    NPG_HIP(hipEventSynchronize(ctx->ev1));
+    float f = 0.f;
+    NPG_HIP(hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    *ms = f / reps;
+    return NPG_OK;
+}
+
+// ---- column-sorted tiles (experiment): inside every tile the record stream and the CSR stream are sorted by column, and
+// every entry carries the product slot it belongs to (uint16), so that adjacent lanes gather adjacent (or the same)
+// components of x: the vector L1 (94 % busy in k_spmv, 83 % of its tag lookups are gathers: profiles/r02_spmv_pmc.txt)
+// sees a quarter of the cache lines per gather instruction.  Products land in the same LDS slots as in spmv_tile, so
+// the segmented sums - and the result, bit for bit - are unchanged.
+struct PermDev {
+    const uint16_t *pdst, *cdst;      // product slot (tile-local record index / CSR entry index) of a stream position
+};
+
+template <int NT, int L, class XF, int TNNZ = kTileNnz, int U2 = 4>
+__device__ __forceinline__ void spmv_tile_perm(const CsrDev &A, const PermDev &P, const XF x, const TileDesc &td,
+                                               TileLdsT<TNNZ> &t, double *__restrict__ out) {
+    const int r0 = td.r0, nrows = td.nrows, r1 = r0 + nrows;
+    const int64_t base = td.base;
+    const int n = td.n;
+    const bool blk = r0 < block_rows(A);
+    const bool full = r0 < 3 * A.nfull;
+    const int ncomp = full ? 3 : 2;
+    const int npe = td.npe;
+    const int64_t pbase = td.pbase;
+    int nnode = 0, q0 = 0;
+    if (blk) {
+        q0 = node_of_row(A, r0);
+        nnode = node_of_row(A, r1) - q0;
+    }
+    const int64_t abase = base & ~1LL;
+    const int off = (int)(base - abase);
+    const int total = n + off;
+    const int slot0 = blk ? ncomp * npe : 0;
+    for (int r = threadIdx.x; r <= nrows; r += NT) t.rp[r] = (int32_t)(A.rowptr[r0 + r] - base) + off + slot0;
+    if (blk)
+        for (int q = threadIdx.x; q <= nnode; q += NT) t.prp[q] = (int32_t)(A.prow[q0 + q] - pbase);
+    constexpr int UP = U2 > 3 ? 3 : U2;
+    for (int e0 = threadIdx.x; e0 < npe; e0 += UP * NT) {
+        int32_t c[UP];
+        int d[UP];
+        double2 kc[UP], xx[UP];
+        double zz[UP];
+#pragma unroll
+        for (int u = 0; u < UP; ++u) {
+            const int e = e0 + u * NT;
+            if (e < npe) {
+                c[u] = __builtin_nontemporal_load(A.pcol + pbase + e);
+                d[u] = __builtin_nontemporal_load(P.pdst + pbase + e);
+                const double *p = reinterpret_cast<const double *>(A.pkc + pbase + e);
+                kc[u].x = __builtin_nontemporal_load(p);
+                kc[u].y = __builtin_nontemporal_load(p + 1);
+            } else {
+                c[u] = 0;
+                d[u] = 0;
+                kc[u] = make_double2(0.0, 0.0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UP; ++u) {
+            const int cf = c[u] < A.nfull ? c[u] : A.nfull;
+            const int xo = 2 * c[u] + cf;
+            xx[u] = x.two(xo);
+            zz[u] = (full && c[u] < A.nfull) ? x.third(xo + 2) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UP; ++u) {
+            const int e = e0 + u * NT;
+            if (e < npe) {
+                t.prod[d[u]] = kc[u].x * xx[u].x + kc[u].y * xx[u].y;
+                t.prod[npe + d[u]] = kc[u].x * xx[u].y - kc[u].y * xx[u].x;
+                if (full) t.prod[2 * npe + d[u]] = kc[u].x * zz[u];
+            }
+        }
+    }
+    for (int k0 = 2 * threadIdx.x; k0 < total; k0 += 2 * NT * U2) {
+        int2 c[U2];
+        int d0[U2], d1[U2];
+        double2 v[U2];
+        double xa[U2], xb[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const int k = k0 + u * 2 * NT;
+            if (k < total && abase + k + 1 < A.nnz) {
+                const long long cc = __builtin_nontemporal_load(reinterpret_cast<const long long *>(A.col + abase + k));
+                c[u] = make_int2((int)(cc & 0xffffffffLL), (int)(cc >> 32));
+                const unsigned dd = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(P.cdst + abase + k));
+                d0[u] = (int)(dd & 0xffffu);
+                d1[u] = (int)(dd >> 16);
+                v[u].x = __builtin_nontemporal_load(A.val + abase + k);
+                v[u].y = __builtin_nontemporal_load(A.val + abase + k + 1);
+            } else if (k < total && abase + k < A.nnz) {
+                c[u] = make_int2(A.col[abase + k], 0);
+                d0[u] = P.cdst[abase + k];
+                d1[u] = 0;
+                v[u] = make_double2(A.val[abase + k], 0.0);
+            } else {
+                c[u] = make_int2(0, 0);
+                d0[u] = d1[u] = 0;
+                v[u] = make_double2(0.0, 0.0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            xa[u] = x(c[u].x);
+            xb[u] = x(c[u].y);
+        }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const int k = k0 + u * 2 * NT;
+            // (an entry in front of the tile's first one belongs to the previous tile: its slot is a pad)
+            if (k < total) t.prod[slot0 + (k >= off ? off + d0[u] : 0)] = (k >= off) ? v[u].x * xa[u] : 0.0;
+            if (k + 1 < total) t.prod[slot0 + off + d1[u]] = v[u].y * xb[u];
+        }
+    }
+    __syncthreads();
+    const int g = threadIdx.x / L, l = threadIdx.x % L;
+    for (int r = g; r < nrows; r += NT / L) {
+        double s = 0.0;
+        const int e = t.rp[r + 1];
+        for (int k = t.rp[r] + 2 * l; k < e; k += 2 * L) {
+            const double a = t.prod[k], b = t.prod[k + 1];
+            s += a + (k + 1 < e ? b : 0.0);
+        }
+        if (blk) {
+            const int q = (r * (full ? 21846 : 32768)) >> 16;
+            const int pb = (r - q * ncomp) * npe, pe = pb + t.prp[q + 1];
+            for (int k = pb + t.prp[q] + 2 * l; k < pe; k += 2 * L) {
+                const double a = t.prod[k], b = t.prod[k + 1];
+                s += a + (k + 1 < pe ? b : 0.0);
+            }
+        }
+        s = group_sum_dpp<L>(s);
+        if (l == 0) out[r] = s;
+    }
+    __syncthreads();
+}
+
+template <int L>
+__global__ void __launch_bounds__(512, 6) k_spmv_perm(CsrDev A, PermDev P, const TileDesc *__restrict__ tile_ptr, int ntiles,
+                                                      const double *__restrict__ x, double *__restrict__ y) {
+    __shared__ TileLds tl;
+    __shared__ double sw[kTileRows];
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    TileDesc td = tile_ptr[t];
+    while (true) {
+        const int tn = t + gridDim.x;
+        TileDesc nd = td;
+        if (tn < ntiles) nd = tile_ptr[tn];
+        spmv_tile_perm<512, L>(A, P, PlainX{x}, td, tl, sw);
+        for (int r = threadIdx.x; r < td.nrows; r += 512) y[td.r0 + r] = sw[r];
+        if (tn >= ntiles) break;
+        t = tn;
+        td = nd;
+    }
+}
+
+struct PermMat {
+    int32_t *pcol = nullptr, *col = nullptr;
+    double *pkc = nullptr, *val = nullptr;
+    uint16_t *pdst = nullptr, *cdst = nullptr;
+};
+static std::map<const void *, PermMat> g_perm;
+
+static int run_perm(const npg_csr *A, const double *x, double *y, int bpc, int reps, double *ms, bool sorted) {
+    npg_ctx *ctx = A->ctx;
+    auto key = (const void *)((const char *)A + (sorted ? 1 : 0));
+    if (!g_perm.count(key)) {
+        NPG_HIP(hipStreamSynchronize(ctx->stream));
+        const int64_t nrec = A->nnode() ? A->h_prow[A->nnode()] : 0, nz = A->rnnz;
+        std::vector<TileDesc> td((size_t)A->ntiles);
+        NPG_HIP(hipMemcpy(td.data(), A->tile_ptr, td.size() * sizeof(TileDesc), hipMemcpyDeviceToHost));
+        std::vector<int32_t> pcol((size_t)nrec), col((size_t)nz);
+        std::vector<double> pkc((size_t)2 * nrec), val((size_t)nz);
+        if (nrec) {
+            NPG_HIP(hipMemcpy(pcol.data(), A->pcol, pcol.size() * 4, hipMemcpyDeviceToHost));
+            NPG_HIP(hipMemcpy(pkc.data(), A->pkc, pkc.size() * 8, hipMemcpyDeviceToHost));
+        }
+        NPG_HIP(hipMemcpy(col.data(), A->col, col.size() * 4, hipMemcpyDeviceToHost));
+        NPG_HIP(hipMemcpy(val.data(), A->val, val.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<int32_t> pcol2(pcol.size()), col2(col.size());
+        std::vector<double> pkc2(pkc.size()), val2(val.size());
+        std::vector<uint16_t> pdst(pcol.size() + 8), cdst(col.size() + 8);
+        std::vector<int> idx;
+        for (const TileDesc &q : td) {
+            idx.resize((size_t)q.npe);
+            for (int e = 0; e < q.npe; ++e) idx[e] = e;
+            if (sorted) std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return pcol[q.pbase + a] < pcol[q.pbase + b]; });
+            for (int e = 0; e < q.npe; ++e) {
+                pcol2[q.pbase + e] = pcol[q.pbase + idx[e]];
+                pkc2[2 * (q.pbase + e)] = pkc[2 * (q.pbase + idx[e])];
+                pkc2[2 * (q.pbase + e) + 1] = pkc[2 * (q.pbase + idx[e]) + 1];
+                pdst[q.pbase + e] = (uint16_t)idx[e];
+            }
+            idx.resize((size_t)q.n);
+            for (int k = 0; k < q.n; ++k) idx[k] = k;
+            if (sorted) std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return col[q.base + a] < col[q.base + b]; });
+            for (int k = 0; k < q.n; ++k) {
+                col2[q.base + k] = col[q.base + idx[k]];
+                val2[q.base + k] = val[q.base + idx[k]];
+                cdst[q.base + k] = (uint16_t)idx[k];
+            }
+        }
+        PermMat m;
+        auto up = [&](auto **d, const auto &h) {
+            NPG_HIP(hipMalloc((void **)d, std::max<size_t>(16, h.size() * sizeof(h[0]) + 16)));
+            if (!h.empty()) NPG_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(h[0]), hipMemcpyHostToDevice));
+            return 0;
+        };
+        if (up(&m.pcol, pcol2) || up(&m.col, col2) || up(&m.pkc, pkc2) || up(&m.val, val2) || up(&m.pdst, pdst) ||
+            up(&m.cdst, cdst))
+            return NPG_EHIP;
+        g_perm[key] = m;
+    }
+    const PermMat m = g_perm[key];
+    CsrDev Av = csr_view(A);
+    Av.pcol = m.pcol;
+    Av.col = m.col;
+    Av.pkc = reinterpret_cast<const double2 *>(m.pkc);
+    Av.val = m.val;
+    const PermDev P{m.pdst, m.cdst};
+    const int grid = std::max(1, std::min<int>(A->ntiles, bpc * ctx->num_cu));
+    auto go = [&]() {
+        hipLaunchKernelGGL(k_spmv_perm<8>, dim3(grid), dim3(512), 0, ctx->stream, Av, P, A->tile_ptr, A->ntiles, x, y);
+    };
+    for (int i = 0; i < 2; ++i) go();
+    NPG_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; ++i) go();
+    NPG_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    NPG_HIP(hipEventSynchronize(ctx->ev1));
+    float f = 0.f;
+    NPG_HIP(hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    *ms = f / reps;
+    return NPG_OK;
+}
+
+// every tile's record stream and CSR stream sorted by column; *Av gets the permuted arrays, pdst / cdst the tile-local
+// index every stream position came from (= its product slot)
+static int sorted_streams(const npg_csr *A, const std::vector<std::pair<int64_t, int>> &rec, const std::vector<std::pair<int64_t, int>> &ent,
+                          CsrDev *Av, uint16_t **pdst_out, uint16_t **cdst_out) {
+    npg_ctx *ctx = A->ctx;
+    NPG_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t nrec = A->nnode() ? A->h_prow[A->nnode()] : 0, nz = A->rnnz;
+    std::vector<int32_t> pcol((size_t)nrec), col((size_t)nz);
+    std::vector<double> pkc((size_t)2 * nrec), val((size_t)nz);
+    if (nrec) {
+        NPG_HIP(hipMemcpy(pcol.data(), A->pcol, pcol.size() * 4, hipMemcpyDeviceToHost));
+        NPG_HIP(hipMemcpy(pkc.data(), A->pkc, pkc.size() * 8, hipMemcpyDeviceToHost));
+    }
+    NPG_HIP(hipMemcpy(col.data(), A->col, col.size() * 4, hipMemcpyDeviceToHost));
+    NPG_HIP(hipMemcpy(val.data(), A->val, val.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<int32_t> pcol2(pcol), col2(col);
+    std::vector<double> pkc2(pkc), val2(val);
+    std::vector<uint16_t> pdst(pcol.size() + 8), cdst(col.size() + 8);
+    std::vector<int> idx;
+    for (size_t t = 0; t < rec.size(); ++t) {
+        const int64_t pb = rec[t].first, b = ent[t].first;
+        const int npe = rec[t].second, n = ent[t].second;
+        idx.resize((size_t)npe);
+        for (int e = 0; e < npe; ++e) idx[e] = e;
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return pcol[pb + a] < pcol[pb + c]; });
+        for (int e = 0; e < npe; ++e) {
+            pcol2[pb + e] = pcol[pb + idx[e]];
+            pkc2[2 * (pb + e)] = pkc[2 * (pb + idx[e])];
+            pkc2[2 * (pb + e) + 1] = pkc[2 * (pb + idx[e]) + 1];
+            pdst[pb + e] = (uint16_t)idx[e];
+        }
+        idx.resize((size_t)n);
+        for (int k = 0; k < n; ++k) idx[k] = k;
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return col[b + a] < col[b + c]; });
+        for (int k = 0; k < n; ++k) {
+            col2[b + k] = col[b + idx[k]];
+            val2[b + k] = val[b + idx[k]];
+            cdst[b + k] = (uint16_t)idx[k];
+        }
+    }
+    int32_t *dpcol, *dcol;
+    double *dpkc, *dval;
+    NPG_HIP(hipMalloc((void **)&dpcol, pcol2.size() * 4 + 16));
+    NPG_HIP(hipMalloc((void **)&dcol, col2.size() * 4 + 16));
+    NPG_HIP(hipMalloc((void **)&dpkc, pkc2.size() * 8 + 16));
+    NPG_HIP(hipMalloc((void **)&dval, val2.size() * 8 + 16));
+    NPG_HIP(hipMalloc((void **)pdst_out, pdst.size() * 2 + 16));
+    NPG_HIP(hipMalloc((void **)cdst_out, cdst.size() * 2 + 16));
+    if (nrec) {
+        NPG_HIP(hipMemcpy(dpcol, pcol2.data(), pcol2.size() * 4, hipMemcpyHostToDevice));
+        NPG_HIP(hipMemcpy(dpkc, pkc2.data(), pkc2.size() * 8, hipMemcpyHostToDevice));
+    }
+    NPG_HIP(hipMemcpy(dcol, col2.data(), col2.size() * 4, hipMemcpyHostToDevice));
+    NPG_HIP(hipMemcpy(dval, val2.data(), val2.size() * 8, hipMemcpyHostToDevice));
+    NPG_HIP(hipMemcpy(*pdst_out, pdst.data(), pdst.size() * 2, hipMemcpyHostToDevice));
+    NPG_HIP(hipMemcpy(*cdst_out, cdst.data(), cdst.size() * 2, hipMemcpyHostToDevice));
+    Av->pcol = dpcol;
+    Av->col = dcol;
+    Av->pkc = reinterpret_cast<const double2 *>(dpkc);
+    Av->val = dval;
+    return NPG_OK;
+}
+
 }  // namespace npg
 
 using namespace npg;
@@ -586,6 +1150,24 @@ NPG_API int npg_spmv_variant(const npg_csr *A, const npg_vec *x, npg_vec *y, int
         case 43: return run_prod<512, 4800, 4, 6, false, 3>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 44: return run_prod<512, 4800, 4, 6, false, 0>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 45: return run_prod<512, 4800, 4, 6, false, 1>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 60: return run_pack<512, 8, 2048, 128, 6, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 61: return run_pack<512, 8, 2048, 128, 6, false>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 62: return run_pack<512, 8, 2560, 160, 4, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 66: return run_pack<64, 8, 256, 16, 6, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 67: return run_pack<64, 8, 384, 24, 4, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 68: return run_pack<128, 8, 512, 32, 6, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 69: return run_pack<64, 8, 512, 32, 3, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 63: return run_pack<256, 8, 1024, 64, 6, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 64: return run_pack<1024, 8, 2560, 160, 4, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 65: return run_pack<256, 8, 2048, 128, 3, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 72: return run_pack<512, 8, 1792, 128, 6, true, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 73: return run_pack<256, 8, 896, 64, 6, true, true>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 74: return run_pack<512, 8, 1792, 128, 6, true, false>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 75: return run_pack<512, 8, 1280, 96, 6, true, false, 3>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 76: return run_pack<256, 8, 640, 48, 6, true, false, 3>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 77: return run_pack<512, 8, 1664, 128, 4, true, false, 3>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 70: return run_perm(A, x->d, y->d, blocks_per_cu, reps, ms, true);
+        case 71: return run_perm(A, x->d, y->d, blocks_per_cu, reps, ms, false);
         case 0: return run_var<512, 4096, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 1: return run_var<512, 4096, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 2: return run_var<1024, 8192, 8>(A, x->d, y->d, blocks_per_cu, reps, ms);

@@ -42,11 +42,28 @@ names = {0: "NT512 T4096 U4", 1: "NT512 T4096 U8", 2: "NT1024 T8192 U8", 3: "NT2
          50: "wide NT512 T5824 UP4 UC3 (2 WG/CU)", 51: "wide NT512 T8192 UP6 UC4", 52: "wide NT512 T9216 UP6 UC4",
          53: "wide NT512 T8192 UP6 UC3", 54: "wide NT1024 T9216 UP3 UC2",
          43: "T4800: gathers from an LDS stage filled per tile (diagnostic)", 44: "T4800 product",
-         45: "T4800 gathers removed (diagnostic)"}
+         45: "T4800 gathers removed (diagnostic)",
+         60: "packed NT512 T2048 nt (3 WG/CU)", 61: "packed NT512 T2048 (3 WG/CU)", 62: "packed NT512 T2560 nt (2 WG/CU)",
+         63: "packed NT256 T1024 nt (6 WG/CU)", 64: "packed NT1024 T2560 nt (1 WG/CU)",
+         65: "packed NT256 T2048 nt (3 WG/CU)", 66: "packed wave tiles NT64 T256", 67: "packed wave tiles NT64 T384",
+         68: "packed NT128 T512", 69: "packed wave tiles NT64 T512",
+         70: "product tiles, column-sorted + slot index", 71: "product tiles, slot index only (unsorted)",
+         72: "packed + column-sorted NT512 T1792", 73: "packed + column-sorted NT256 T896", 74: "packed NT512 T1792",
+         75: "packed, gathers a tile ahead NT512 T1280 (3 WG/CU)", 76: "packed, gathers a tile ahead NT256 T640 (6 WG/CU)",
+         77: "packed, gathers a tile ahead NT512 T1664 (2-3 WG/CU)"}
 print(f"{wl}: N={N} nnz={nnz} algorithmic bytes={alg / 1e6:.1f} MB")
+import time
+for _ in range(3):
+    A.mul(x, y)
+arch.ctx.sync()
+t0 = time.perf_counter()
+for _ in range(50):
+    A.mul(x, y)
+arch.ctx.sync()
+print(f"product k_spmv (A.mul, wall over 50 calls): {(time.perf_counter() - t0) / 50 * 1e6:8.1f} us")
 vs = [int(a) for a in sys.argv[3].split(',')] if len(sys.argv) > 3 else range(16)
 for v in vs:
-    for bpc in (2, 3, 4, 5, 6, 8):
+    for bpc in [int(b) for b in os.environ.get('BPC', '2,3,4,5,6,8').split(',')]:
         ms = C.c_double()
         y.fill(0.0)
         rc = fn(A.h, x.h, y.h, v, bpc, reps, C.byref(ms))
