@@ -59,6 +59,21 @@ struct ShmComm {
     char *slot_of(int r) const { return base + 4096 + (size_t)r * slot; }
 };
 
+// NPG_COMM_SELFTEST=1: a ONE-rank RCCL communicator goes through every RCCL call site (all-reduce, broadcast, grouped
+// send/recv to itself) instead of the single-rank shortcuts, so that the product transport can be exercised on a
+// one-GPU box (tests/test_gpu_rccl_selftest.py).  Never set in production.
+static bool selftest() {
+    static const bool on = [] {
+        const char *t = getenv("NPG_COMM_SELFTEST");
+        return t && atoi(t) != 0;
+    }();
+    return on;
+}
+static bool single_rank_shortcut(const npg_ctx *ctx) {
+    if (!ctx->comm && !ctx->shm) return true;
+    return ctx->nranks == 1 && !(selftest() && ctx->comm);
+}
+
 static bool use_shm() {
     const char *t = getenv("NPG_COMM_TRANSPORT");
     return t && strcmp(t, "shm") == 0;
@@ -182,7 +197,7 @@ NPG_API int npg_comm_init(npg_ctx *ctx, const void *id128, int rank, int nranks)
 
 NPG_API int npg_comm_allreduce_sum(npg_ctx *ctx, double *host_inout, int n) {
     NPG_REQUIRE(ctx && host_inout && n > 0 && (size_t)n <= ctx->scratch_doubles, "npg_comm_allreduce_sum: bad argument");
-    if (ctx->nranks == 1 || (!ctx->comm && !ctx->shm)) return NPG_OK;
+    if (single_rank_shortcut(ctx)) return NPG_OK;
     NPG_HIP(hipMemcpyAsync(ctx->d_scratch, host_inout, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (ctx->shm) {
         int rc = shm_allreduce(ctx, ctx->d_scratch, n);
@@ -209,7 +224,7 @@ NPG_API int npg_comm_allgather_segments(npg_ctx *ctx, const npg_vec *local, int 
             NPG_REQUIRE(seg_local_off[s] >= 0 && seg_local_off[s] + seg_len[s] <= local->n,
                         "npg_comm_allgather_segments: local segment %d out of range", s);
     }
-    if (ctx->nranks == 1 || (!ctx->comm && !ctx->shm)) {
+    if (single_rank_shortcut(ctx)) {
         for (int s = 0; s < nseg; ++s)
             NPG_HIP(hipMemcpyAsync(full->d + seg_global_off[s], local->d + seg_local_off[s],
                                    (size_t)seg_len[s] * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -268,7 +283,7 @@ NPG_API int npg_halo_create(npg_ctx *ctx, int64_t n_owned, int64_t n_ghost, int 
         h->recv_ptr.assign(recv_ptr, recv_ptr + npeers + 1);
         NPG_REQUIRE(h->recv_ptr[npeers] == n_ghost, "npg_halo_create: recv_ptr must cover the ghost segment exactly");
         for (int p = 0; p < npeers; ++p)
-            NPG_REQUIRE(peer_rank[p] >= 0 && peer_rank[p] < ctx->nranks && peer_rank[p] != ctx->rank,
+            NPG_REQUIRE(peer_rank[p] >= 0 && peer_rank[p] < ctx->nranks && (peer_rank[p] != ctx->rank || selftest()),
                         "npg_halo_create: bad peer rank %d", peer_rank[p]);
         const int64_t ns = h->send_ptr[npeers];
         for (int64_t k = 0; k < ns; ++k)
@@ -356,7 +371,7 @@ int npg::halo_exchange_raw(npg_halo *h, double *x) {
 }
 
 int npg::allreduce_sum_device(npg_ctx *ctx, double *buf, int n) {
-    if (ctx->nranks == 1 || (!ctx->comm && !ctx->shm)) return NPG_OK;
+    if (single_rank_shortcut(ctx)) return NPG_OK;
     if (ctx->shm) return shm_allreduce(ctx, buf, n);
     NPG_NCCL(ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
     return NPG_OK;

@@ -1,0 +1,107 @@
+"""RCCL call sites on ONE GPU (launched by tests/test_gpu_rccl_selftest.py with NPG_COMM_SELFTEST=1).
+
+RCCL refuses two ranks on one device, so the multi-rank rehearsals use the shared-memory loop-back transport and the
+product transport's call sites never ran on a development box.  A ONE-rank RCCL communicator does run them: with
+NPG_COMM_SELFTEST=1 csrc/comm.hip skips its single-rank shortcuts and allows a halo plan whose peer is the rank itself,
+so ncclCommInitRank, ncclAllReduce, grouped ncclSend/ncclRecv, ncclBroadcast and the distributed GMRES / CG cycles built
+on them execute on hardware and are checked against the serial solvers."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import nupgcm_amd as npg                                          # noqa: E402
+from nupgcm_amd import _lib as L                                  # noqa: E402
+from nupgcm_amd import distributed                                # noqa: E402
+from nupgcm_amd.architectures import comm_unique_id               # noqa: E402
+
+
+def main():
+    assert os.environ.get("NPG_COMM_SELFTEST") == "1" and os.environ.get("NPG_COMM_TRANSPORT", "") != "shm"
+    arch = npg.GPU(0)
+    ctx = arch.ctx
+    ctx.comm_init(comm_unique_id(), 0, 1)                        # ncclGetUniqueId + ncclCommInitRank
+    rng = np.random.default_rng(5)
+
+    # ncclAllReduce (one rank: the sum is the input)
+    v = rng.standard_normal(31)
+    assert np.array_equal(ctx.allreduce_sum(v), v)
+
+    # grouped ncclSend / ncclRecv: the rank is its own neighbour
+    n, S = 3000, np.arange(2936, 3000)[::-1].copy()
+    plan = dict(peers=np.array([0], np.int32), send_ptr=np.array([0, len(S)], np.int64), send_idx=S.astype(np.int32),
+                recv_ptr=np.array([0, len(S)], np.int64))
+    halo = distributed.Halo(ctx, n, len(S), plan)
+    xh = np.concatenate([rng.standard_normal(n), np.zeros(len(S))])
+    x = npg.DeviceVector.from_host(ctx, xh)
+    halo.exchange(x)
+    ctx.sync()
+    assert np.array_equal(x.to_host()[n:], xh[S])
+
+    # ncclBroadcast per segment (the all-gather of the owned slices)
+    loc = npg.DeviceVector.from_host(ctx, rng.standard_normal(500))
+    full = npg.DeviceVector(ctx, 800)
+    full.fill(0.0)
+    distributed.allgather_segments(ctx, loc, [(0, 0, 100, 200), (0, 200, 400, 300)], full)
+    ctx.sync()
+    f, lh = full.to_host(), loc.to_host()
+    assert np.array_equal(f[100:300], lh[:200]) and np.array_equal(f[400:700], lh[200:500]) and not f[:100].any()
+
+    # distributed GMRES: the columns in S are served from the ghost segment, which the halo exchange fills with x[S]
+    M = sp.random(n, n, density=8.0 / n, random_state=3, format="csr") + sp.diags(np.linspace(4.0, 9.0, n))
+    M = sp.csr_matrix(M)
+    Mc = M.tocsc()
+    own = Mc.copy()
+    own[:, S] = 0
+    own.eliminate_zeros()
+    A_loc = sp.hstack([own.tocsr(), Mc[:, S].tocsr()], format="csr")
+    A_loc.sort_indices()
+    A_ser = npg.DeviceCSR.from_scipy(ctx, M)
+    A_dis = npg.DeviceCSR.from_scipy(ctx, A_loc)
+    rhs = rng.standard_normal(n)
+    y = npg.DeviceVector.from_host(ctx, rhs)
+    P = npg.Diagonal(diag=npg.DeviceVector.from_host(ctx, 1.0 / M.diagonal()))
+    ws0 = npg.GmresWorkspace(ctx, n, memory=20)
+    x0 = npg.DeviceVector(ctx, n)
+    x0.fill(0.0)
+    st0 = ws0.solve(A_ser, y, x0, P, atol=1e-12, rtol=1e-10, itmax=400, reorth_eta=0.0)
+    ws1 = npg.GmresWorkspace(ctx, n, memory=20)
+    L.check(L.lib().npg_gmres_set_halo(ws1.h, halo.h))
+    x1 = npg.DeviceVector(ctx, n + len(S))
+    x1.fill(0.0)
+    st1 = ws1.solve(A_dis, y, x1, P, atol=1e-12, rtol=1e-10, itmax=400)
+    ctx.sync()
+    xs, xd = x0.to_host(), x1.to_host()[:n]
+    assert st0["solved"] and st1["solved"], (st0, st1)
+    res = np.linalg.norm(M @ xd - rhs) / np.linalg.norm(rhs)
+    assert res < 1e-8, res
+    assert np.linalg.norm(xd - xs) <= 1e-8 * np.linalg.norm(xs)
+    assert abs(st1["niter"] - st0["niter"]) <= 2, (st0["niter"], st1["niter"])
+
+    # distributed CG on an SPD matrix through the same halo
+    Sy = sp.csr_matrix(M + M.T + sp.diags(np.full(n, 20.0)))
+    Sc = Sy.tocsc()
+    own = Sc.copy()
+    own[:, S] = 0
+    own.eliminate_zeros()
+    B_loc = sp.hstack([own.tocsr(), Sc[:, S].tocsr()], format="csr")
+    B_loc.sort_indices()
+    B_dis = npg.DeviceCSR.from_scipy(ctx, B_loc)
+    Pc = npg.Diagonal(diag=npg.DeviceVector.from_host(ctx, 1.0 / Sy.diagonal()))
+    cg = npg.CgWorkspace(ctx, n)
+    L.check(L.lib().npg_cg_set_halo(cg.h, halo.h))
+    x2 = npg.DeviceVector(ctx, n + len(S))
+    x2.fill(0.0)
+    st2 = cg.solve(B_dis, y, x2, Pc, atol=1e-12, rtol=1e-10, itmax=400)
+    ctx.sync()
+    xc = x2.to_host()[:n]
+    assert st2["solved"], st2
+    assert np.linalg.norm(Sy @ xc - rhs) <= 1e-8 * np.linalg.norm(rhs)
+    print(f"RCCL self-test OK: gmres {st0['niter']} / {st1['niter']} iterations (serial / through RCCL), cg {st2['niter']}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Per-iteration cost of the distributed GMRES cycle's RCCL calls on ONE GPU: a one-rank communicator in self-test mode
+(NPG_COMM_SELFTEST=1, see tests/rccl_selftest_worker.py) against the serial cycle on the same matrix.
+Usage: NPG_COMM_SELFTEST=1 python tools/rccl_cycle_cost.py [n]"""
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import nupgcm_amd as npg                                          # noqa: E402
+from nupgcm_amd import _lib as L, distributed                     # noqa: E402
+from nupgcm_amd.architectures import comm_unique_id               # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+arch = npg.GPU(0)
+ctx = arch.ctx
+ctx.comm_init(comm_unique_id(), 0, 1)
+rng = np.random.default_rng(5)
+S = np.arange(n - 256, n)[::-1].copy()
+plan = dict(peers=np.array([0], np.int32), send_ptr=np.array([0, len(S)], np.int64), send_idx=S.astype(np.int32),
+            recv_ptr=np.array([0, len(S)], np.int64))
+halo = distributed.Halo(ctx, n, len(S), plan)
+# slowly converging: a shifted 1-D Laplacian-like band + random couplings
+M = sp.diags([-1.0, 2.0005, -1.0], [-1, 0, 1], shape=(n, n), format="csr") + 1e-3 * sp.random(n, n, density=4.0 / n, random_state=1)
+M = sp.csr_matrix(M)
+Mc = M.tocsc()
+own = sp.lil_matrix(Mc)
+own[:, S] = 0
+own = sp.csr_matrix(own)
+own.eliminate_zeros()
+A_loc = sp.hstack([own, Mc[:, S].tocsr()], format="csr")
+A_loc.sort_indices()
+A_ser, A_dis = npg.DeviceCSR.from_scipy(ctx, M), npg.DeviceCSR.from_scipy(ctx, A_loc)
+y = npg.DeviceVector.from_host(ctx, rng.standard_normal(n))
+P = npg.Diagonal(diag=npg.DeviceVector.from_host(ctx, 1.0 / M.diagonal()))
+for label, A, nx, dist_ in (("serial (hipGraph cycles)", A_ser, n, False), ("through RCCL, one-rank communicator", A_dis, n + len(S), True)):
+    ws = npg.GmresWorkspace(ctx, n, memory=20)
+    if dist_:
+        L.check(L.lib().npg_gmres_set_halo(ws.h, halo.h))
+    for rep in range(2):
+        x = npg.DeviceVector(ctx, nx)
+        x.fill(0.0)
+        ctx.sync()
+        t0 = time.perf_counter()
+        st = ws.solve(A, y, x, P, atol=1e-30, rtol=1e-14, itmax=2000)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+    print(f"{label:40s}: {st['niter']} iterations, {dt / st['niter'] * 1e6:7.1f} us per iteration")
