@@ -343,6 +343,12 @@ int npg_halo_exchange(npg_halo *h, npg_vec *x_with_ghosts);
  * n_owned x (n_owned + n_ghost) row block, y with n_owned and x with n_owned + n_ghost entries, exchange the interface
  * before every SpMV and all-reduce the inner products (two 32-double messages per GMRES iteration). */
 int npg_gmres_set_halo(npg_gmres *ws, npg_halo *h);
+/* Distributed cycles (new work, no reference counterpart).  overlap (default 1): the split cycle (>= 8192 rows per rank)
+ * runs the tiles of the row block that read no ghost column while the halo exchange of the Arnoldi vector is in flight
+ * on the plan's own stream, the others behind it; 0 exchanges first.  graph (default 0): replay the cycle - RCCL calls
+ * included - from a hipGraph instead of launching it eagerly (RCCL transport only; exercised on a one-rank communicator
+ * so far).  Same iterates in every combination (tests/rccl_selftest_worker.py). */
+int npg_gmres_set_dist_options(npg_gmres *ws, int overlap, int graph);
 int npg_cg_set_halo(npg_cg *ws, npg_halo *h);
 
 #ifdef __cplusplus

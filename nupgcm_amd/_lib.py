@@ -110,7 +110,7 @@ def _declare(L):
         "npg_comm_allreduce_sum": [P, C.POINTER(D), C.c_int],
         "npg_comm_allgather_segments": [P, P, C.c_int, VP, VP, VP, VP, P],
         "npg_halo_create": [P, I64, I64, C.c_int, VP, VP, VP, VP, PP], "npg_halo_destroy": [P],
-        "npg_halo_exchange": [P, P], "npg_gmres_set_halo": [P, P], "npg_cg_set_halo": [P, P],
+        "npg_halo_exchange": [P, P], "npg_gmres_set_halo": [P, P], "npg_gmres_set_dist_options": [P, C.c_int, C.c_int], "npg_cg_set_halo": [P, P],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

@@ -302,18 +302,55 @@ NPG_API int npg_halo_destroy(npg_halo *h) {
     hipStreamSynchronize(h->ctx->stream);
     if (h->send_idx) hipFree(h->send_idx);
     if (h->send_buf) hipFree(h->send_buf);
+    if (h->cstream) {
+        hipStreamSynchronize(h->cstream);
+        hipEventDestroy(h->ev_ready);
+        hipEventDestroy(h->ev_done);
+        hipStreamDestroy(h->cstream);
+    }
     delete h;
     return NPG_OK;
 }
 
-int npg::halo_exchange_raw(npg_halo *h, double *x) {
+static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st);
+
+int npg::halo_exchange_raw(npg_halo *h, double *x) { return halo_exchange_on(h, x, h->ctx->stream); }
+
+int npg::halo_exchange_async(npg_halo *h, double *x) {
+    npg_ctx *ctx = h->ctx;
+    if (h->npeers == 0 && !ctx->shm) return NPG_OK;
+    h->pending_x = x;
+    if (ctx->shm) return NPG_OK;          // host-driven loop-back transport: the exchange happens in halo_exchange_wait()
+    if (!h->cstream) {
+        NPG_HIP(hipSetDevice(ctx->device));
+        NPG_HIP(hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking));
+        NPG_HIP(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+        NPG_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+    }
+    NPG_HIP(hipEventRecord(h->ev_ready, ctx->stream));
+    NPG_HIP(hipStreamWaitEvent(h->cstream, h->ev_ready, 0));
+    int rc = halo_exchange_on(h, x, h->cstream);
+    if (rc != NPG_OK) return rc;
+    NPG_HIP(hipEventRecord(h->ev_done, h->cstream));
+    return NPG_OK;
+}
+
+int npg::halo_exchange_wait(npg_halo *h) {
+    npg_ctx *ctx = h->ctx;
+    if (h->npeers == 0 && !ctx->shm) return NPG_OK;
+    if (ctx->shm) return halo_exchange_on(h, h->pending_x, ctx->stream);
+    NPG_HIP(hipStreamWaitEvent(ctx->stream, h->ev_done, 0));
+    return NPG_OK;
+}
+
+static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st) {
     npg_ctx *ctx = h->ctx;
     if (h->npeers == 0 && !ctx->shm) return NPG_OK;
     NPG_REQUIRE(ctx->comm || ctx->shm, "halo exchange: communicator not initialised");
     const int64_t ns = h->npeers ? h->send_ptr[h->npeers] : 0;
     if (ns > 0) {
         const int grid = (int)std::min<int64_t>(1024, (ns + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(k_pack, dim3(grid), dim3(kBlock), 0, ctx->stream, x, h->send_idx, ns, h->send_buf);
+        hipLaunchKernelGGL(k_pack, dim3(grid), dim3(kBlock), 0, st, x, h->send_idx, ns, h->send_buf);
     }
     if (ctx->shm) {
         // slot = [npeers, {peer, offset, count} x npeers | packed send buffer]; a receiver looks its own entry up
@@ -362,9 +399,9 @@ int npg::halo_exchange_raw(npg_halo *h, double *x) {
     for (int p = 0; p < h->npeers; ++p) {
         const int64_t s0 = h->send_ptr[p], s1 = h->send_ptr[p + 1], r0 = h->recv_ptr[p], r1 = h->recv_ptr[p + 1];
         if (s1 > s0)
-            NPG_NCCL_IN_GROUP(ncclSend(h->send_buf + s0, (size_t)(s1 - s0), ncclDouble, h->peer[p], comm, ctx->stream));
+            NPG_NCCL_IN_GROUP(ncclSend(h->send_buf + s0, (size_t)(s1 - s0), ncclDouble, h->peer[p], comm, st));
         if (r1 > r0)
-            NPG_NCCL_IN_GROUP(ncclRecv(x + h->n_owned + r0, (size_t)(r1 - r0), ncclDouble, h->peer[p], comm, ctx->stream));
+            NPG_NCCL_IN_GROUP(ncclRecv(x + h->n_owned + r0, (size_t)(r1 - r0), ncclDouble, h->peer[p], comm, st));
     }
     NPG_NCCL(ncclGroupEnd());
     return NPG_OK;

@@ -87,6 +87,8 @@ struct npg_csr {
     // nnz-balanced row tiles for the tiled SpMV kernels (device + host copy)
     npg::TileDesc *tile_ptr = nullptr; // device, ntiles descriptors
     int32_t ntiles = 0;
+    int32_t ntiles_interior = 0; // row block of a distributed matrix (n > m: columns [owned | ghosts]): the first
+                                 // ntiles_interior descriptors are tiles without ghost columns (= ntiles otherwise)
     int32_t lanes = 16;          // lanes per row chosen from the mean row length
     std::vector<int64_t> h_rowptr;
     // node-block part (npg_csr_block_nodes, spmv_device.h): the rows of the first nfull (x, y, z) nodes and of the nsurf
@@ -111,11 +113,20 @@ struct npg_halo {
     std::vector<int64_t> send_ptr, recv_ptr;
     int32_t *send_idx = nullptr;   // device
     double *send_buf = nullptr;    // device
+    // overlapped exchange (halo_exchange_async): its own stream and the two events that order it against the compute stream
+    hipStream_t cstream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    double *pending_x = nullptr;   // vector of the exchange begun by halo_exchange_async()
 };
 
 namespace npg {
 // enqueue the exchange of x's ghost segment / an in-place sum over ranks of n doubles on the context's stream
 int halo_exchange_raw(npg_halo *h, double *x);
+// The same exchange beside the compute stream: it starts once everything enqueued on the context's stream so far has
+// finished (x's owned entries are final) and runs on the plan's own stream; halo_exchange_wait() makes the context's
+// stream wait for the ghost segment.  Kernels enqueued between the two calls must not touch x's ghost segment.
+int halo_exchange_async(npg_halo *h, double *x);
+int halo_exchange_wait(npg_halo *h);
 int allreduce_sum_device(npg_ctx *ctx, double *buf, int n);
 int ensure_stage(npg_ctx *ctx, size_t doubles);
 int build_tiles(npg_csr *A);

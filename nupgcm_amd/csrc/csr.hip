@@ -39,6 +39,17 @@ int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp, 
     return NPG_OK;
 }
 
+// flag[t] != 0: tile t reads a column >= first_ghost (one 64-thread workgroup per tile)
+__global__ void k_tile_ghost_flags(const TileDesc *__restrict__ td, int ntiles, const int32_t *__restrict__ col,
+                                   int32_t first_ghost, int32_t *__restrict__ flag) {
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const TileDesc q = td[t];
+        int f = 0;
+        for (int k = threadIdx.x; k < q.n; k += blockDim.x) f |= col[q.base + k] >= first_ghost;
+        if (f) flag[t] = 1;
+    }
+}
+
 int build_tiles(npg_csr *A) {
     std::vector<int32_t> tp;
     int rc = tile_boundaries(A, kTileNnz, tp);
@@ -72,6 +83,28 @@ int build_tiles(npg_csr *A) {
     if (A->tile_ptr) NPG_HIP(hipFree(A->tile_ptr));
     NPG_HIP(hipMalloc((void **)&A->tile_ptr, std::max<size_t>(1, td.size()) * sizeof(TileDesc)));
     NPG_HIP(hipMemcpy(A->tile_ptr, td.data(), td.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    A->ntiles_interior = A->ntiles;
+    if (A->n > A->m && A->ntiles > 0 && A->rnnz > 0) {
+        // row block of a distributed matrix: tiles that read no ghost column come first, so that a solver can run them
+        // while the halo exchange is in flight (record columns are owned nodes by construction: only the CSR part counts)
+        int32_t *dflag;
+        std::vector<int32_t> flag((size_t)A->ntiles, 0);
+        NPG_HIP(hipMalloc((void **)&dflag, flag.size() * sizeof(int32_t)));
+        NPG_HIP(hipMemsetAsync(dflag, 0, flag.size() * sizeof(int32_t), A->ctx->stream));
+        hipLaunchKernelGGL(k_tile_ghost_flags, dim3(std::min<int>(A->ntiles, 4096)), dim3(64), 0, A->ctx->stream, A->tile_ptr,
+                           A->ntiles, A->col, (int32_t)A->m, dflag);
+        NPG_HIP(hipMemcpyAsync(flag.data(), dflag, flag.size() * sizeof(int32_t), hipMemcpyDeviceToHost, A->ctx->stream));
+        NPG_HIP(hipStreamSynchronize(A->ctx->stream));
+        NPG_HIP(hipFree(dflag));
+        std::vector<TileDesc> ord;
+        ord.reserve(td.size());
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int t = 0; t < A->ntiles; ++t)
+                if ((flag[t] != 0) == (pass == 1)) ord.push_back(td[t]);
+            if (pass == 0) A->ntiles_interior = (int32_t)ord.size();
+        }
+        NPG_HIP(hipMemcpy(A->tile_ptr, ord.data(), ord.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    }
     return NPG_OK;
 }
 

@@ -61,6 +61,7 @@ struct GDev {
     CsrDev A;
     const TileDesc *tile_ptr;
     int ntiles, n, mem;
+    int nt_int;           // tiles [0, nt_int) read no ghost column (distributed row blocks; = ntiles otherwise)
     int pkind;
     double pscalar;
     const double *pdiag;
@@ -291,8 +292,11 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_residual(GDev d) {
 
 // ---- K1 ---------------------------------------------------------------------------------------------------------------
 // (the fused form serves small, latency-bound systems: it may take 128 registers, two workgroups per CU)
+// Tiles [t0, t1).  The distributed split cycle launches it twice per step - the tiles without ghost columns while the halo
+// exchange is in flight, the others behind it; the prologue is a pure function of state neither launch changes, so
+// running it twice writes the same values twice.
 template <int L, bool FUSED>
-__global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, int j) {
+__global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, int j, int t0, int t1) {
     __shared__ KShared sh;
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
@@ -333,10 +337,10 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
     const bool ro = sh.reorth != 0;
     const double h2k = (ro && k < j) ? sh.h2[k] : 0.0;
     double acc = 0.0;
-    TileDesc nd = d.tile_ptr[blockIdx.x < (unsigned)d.ntiles ? blockIdx.x : 0];
-    for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
+    TileDesc nd = d.tile_ptr[t0 + (int)blockIdx.x < t1 ? t0 + (int)blockIdx.x : 0];
+    for (int t = t0 + blockIdx.x; t < t1; t += gridDim.x) {
         const TileDesc td = nd;
-        if (t + (int)gridDim.x < d.ntiles) nd = d.tile_ptr[t + gridDim.x];      // in flight during this tile
+        if (t + (int)gridDim.x < t1) nd = d.tile_ptr[t + gridDim.x];      // in flight during this tile
         const int r0 = td.r0, r1 = td.r0 + td.nrows;
         // split mode: this thread's row of wt for the epilogue, fetched now so that its latency hides behind the tile
         // (a tile has at most kTileRows <= kKB rows: one row per thread)
@@ -655,6 +659,8 @@ struct npg_gmres {
     bool explicit_norm = false;   // distributed: a solve met cancellation in the Pythagorean norm
     bool safe_mode = false;       // one GPU: a solve in fast mode met a column that was due a second Gram-Schmidt pass
     int split_mode = -1;
+    int halo_overlap = 1;         // distributed split cycle: interior tiles beside the halo exchange (npg_gmres_set_dist_options)
+    int dist_graph = 0;           // distributed cycles replayed from a hipGraph that holds the RCCL calls (opt-in)
     std::vector<hipEvent_t> pev;
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
@@ -694,16 +700,40 @@ template <int L>
 static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gmres *ws, bool dist) {
     int rc = NPG_OK;
     const bool fold = dist;
+    // distributed split cycle: the tiles that read no ghost column run while the exchange of wt's ghost segment is in
+    // flight on the plan's own stream (NPG_HALO_OVERLAP=0: exchange first, one launch)
+    static const bool overlap_env = !getenv("NPG_HALO_OVERLAP") || atoi(getenv("NPG_HALO_OVERLAP")) != 0;
+    const bool overlap = dist && d.split && overlap_env && ws->halo_overlap && d.nt_int > 0 && d.nt_int < d.ntiles;
+    const int maxg = ws ? std::min(kMaxG, 3 * ws->ctx->num_cu) : kMaxG;
+    if (dist && getenv("NPG_HALO_OVERLAP_VERBOSE")) {
+        static int last = -1;
+        const int now = (overlap ? 2 : 0) + (d.split ? 1 : 0);
+        if (now != last && (last = now, true))
+            fprintf(stderr, "halo overlap %s: %d interior / %d boundary tiles per Arnoldi step (split %d)\n", overlap ? "on" : "off",
+                    d.nt_int, d.ntiles - d.nt_int, d.split);
+    }
     for (int j = 0; j < d.mem; ++j) {
-        if (dist && (rc = halo_exchange_raw(ws->halo, d.wt))) return rc;
-        if (pev) hipEventRecord(pev[2 * j], st);
-        if (d.split) {
-            hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(d.G1), dim3(kKB), 0, st, d, j);
+        if (overlap) {
+            if ((rc = halo_exchange_async(ws->halo, d.wt))) return rc;
+            if (pev) hipEventRecord(pev[2 * j], st);
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(std::max(1, std::min(d.nt_int, maxg))), dim3(kKB), 0, st, d, j,
+                               0, d.nt_int);
+            if ((rc = halo_exchange_wait(ws->halo))) return rc;
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(std::max(1, std::min(d.ntiles - d.nt_int, maxg))), dim3(kKB), 0,
+                               st, d, j, d.nt_int, d.ntiles);
             if (pev) hipEventRecord(pev[2 * j + 1], st);
             launch_rows_kernel(d, j, st, false);
         } else {
-            hipLaunchKernelGGL((k_gmres_arnoldi<L, true>), dim3(d.G1), dim3(kKB), 0, st, d, j);
+        if (dist && (rc = halo_exchange_raw(ws->halo, d.wt))) return rc;
+        if (pev) hipEventRecord(pev[2 * j], st);
+        if (d.split) {
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(d.G1), dim3(kKB), 0, st, d, j, 0, d.ntiles);
             if (pev) hipEventRecord(pev[2 * j + 1], st);
+            launch_rows_kernel(d, j, st, false);
+        } else {
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, true>), dim3(d.G1), dim3(kKB), 0, st, d, j, 0, d.ntiles);
+            if (pev) hipEventRecord(pev[2 * j + 1], st);
+        }
         }
         if (fold && (rc = fold_rows(ws, d.P1, d.GP1, 0, st, dist))) return rc;
         if (d.split)
@@ -846,6 +876,7 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     d.A = csr_view(A);
     d.tile_ptr = A->tile_ptr;
     d.ntiles = A->ntiles;
+    d.nt_int = A->ntiles_interior;
     d.n = (int)ws->n;
     d.mem = ws->mem;
     d.pkind = precond_kind;
@@ -927,16 +958,26 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     static const int eager = getenv("NPG_GMRES_EAGER") ? atoi(getenv("NPG_GMRES_EAGER")) : traced;
     static const int trace = getenv("NPG_GMRES_TRACE") ? atoi(getenv("NPG_GMRES_TRACE")) : 0;
 
+    // Distributed cycles are launched eagerly unless asked otherwise: RCCL calls can be captured (the exchange stream
+    // forks from and joins the captured stream through the plan's events), but a captured collective has only been run on
+    // a one-rank communicator so far (tests/rccl_selftest_worker.py) - NPG_DIST_GRAPH=1 / npg_gmres_set_dist_options opt in.
+    static const int dist_graph_env = getenv("NPG_DIST_GRAPH") ? atoi(getenv("NPG_DIST_GRAPH")) : 0;
+    const bool graph_dist = dist && (ws->dist_graph || dist_graph_env) && ws->ctx->comm && !ws->ctx->shm;
     // (re)capture the per-cycle graphs when any baked-in argument changed
-    if (!dist && !eager && !ws->profile && (!ws->have_graph || memcmp(&ws->key, &d, sizeof(GDev)) != 0)) {
+    if ((!dist || graph_dist) && !eager && !ws->profile && (!ws->have_graph || memcmp(&ws->key, &d, sizeof(GDev)) != 0)) {
         for (int k = 0; k < 2; ++k) {
             if (ws->exec[k]) hipGraphExecDestroy(ws->exec[k]);
             if (ws->graph[k]) hipGraphDestroy(ws->graph[k]);
             ws->exec[k] = nullptr;
             ws->graph[k] = nullptr;
             NPG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            int rcg = launch_cycle(d, A->lanes, st, nullptr, ws, false);
-            if (rcg) return rcg;
+            int rcg = launch_cycle(d, A->lanes, st, nullptr, ws, dist != nullptr);
+            if (rcg) {
+                hipGraph_t broken = nullptr;
+                hipStreamEndCapture(st, &broken);
+                if (broken) hipGraphDestroy(broken);
+                return rcg;
+            }
             NPG_HIP(hipMemcpyAsync(ws->h_C + k, ws->C, sizeof(Snap), hipMemcpyDeviceToHost, st));
             NPG_HIP(hipStreamEndCapture(st, &ws->graph[k]));
             NPG_HIP(hipGraphInstantiate(&ws->exec[k], ws->graph[k], nullptr, nullptr, 0));
@@ -962,7 +1003,7 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     int64_t n_launch = 0;
     auto enqueue_cycle = [&](int slot) -> int {
         const auto l0 = std::chrono::steady_clock::now();
-        if (eager || dist) {
+        if (eager || (dist && !graph_dist)) {
             int rcc = launch_cycle(d, A->lanes, st, nullptr, ws, dist != nullptr);
             if (rcc) return rcc;
             NPG_HIP(hipMemcpyAsync(ws->h_C + slot, ws->C, sizeof(Snap), hipMemcpyDeviceToHost, st));
@@ -1068,6 +1109,14 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
         stats->rnorm = last.rnorm;
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
+    return NPG_OK;
+}
+
+NPG_API int npg_gmres_set_dist_options(npg_gmres *ws, int overlap, int graph) {
+    NPG_REQUIRE(ws, "npg_gmres_set_dist_options: NULL workspace");
+    ws->halo_overlap = overlap ? 1 : 0;
+    ws->dist_graph = graph ? 1 : 0;
+    ws->have_graph = false;
     return NPG_OK;
 }
 

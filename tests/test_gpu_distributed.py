@@ -36,17 +36,24 @@ def serial():
     return m, y
 
 
-@pytest.mark.parametrize("world,blocks", [(2, False), (3, False), (3, True), (4, True)])
-def test_multi_rank_rehearsal(serial, world, blocks, tmp_path):
+@pytest.mark.parametrize("world,blocks,split", [(2, False, False), (3, False, False), (3, True, False), (4, True, False),
+                                                (3, True, True)])
+def test_multi_rank_rehearsal(serial, world, blocks, split, tmp_path):
+    """split: force the split GMRES cycle that rank blocks of >= 8192 rows use - its Arnoldi step runs the tiles without
+    ghost columns before the halo exchange has completed and the others behind it (gmres.hip, launch_cycle_L)."""
     ref, y = serial
     out = str(tmp_path / "dist")
     env = dict(os.environ, NPG_COMM_TRANSPORT="shm", NPG_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
                OMP_NUM_THREADS="2")
+    if split:
+        env.update(NPG_GMRES_SPLIT="1", NPG_HALO_OVERLAP_VERBOSE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_rehearsal_worker.py"), out, "3",
            "blocks" if blocks else "csr"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    if split:
+        assert "halo overlap on" in r.stderr, r.stderr[-2000:]
     ranks = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
     # every row owned exactly once, and A x assembled from the ranks' owned rows equals the serial product
     owned = np.concatenate([z["owned"] for z in ranks])

@@ -14,7 +14,7 @@ import nupgcm_amd as npg                                          # noqa: E402
 from nupgcm_amd import _lib as L, distributed                     # noqa: E402
 from nupgcm_amd.architectures import comm_unique_id               # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+n = min(int(sys.argv[1]) if len(sys.argv) > 1 else 20000, 100000)      # a latency probe: small systems only
 arch = npg.GPU(0)
 ctx = arch.ctx
 ctx.comm_init(comm_unique_id(), 0, 1)
@@ -27,19 +27,22 @@ halo = distributed.Halo(ctx, n, len(S), plan)
 M = sp.diags([-1.0, 2.0005, -1.0], [-1, 0, 1], shape=(n, n), format="csr") + 1e-3 * sp.random(n, n, density=4.0 / n, random_state=1)
 M = sp.csr_matrix(M)
 Mc = M.tocsc()
-own = sp.lil_matrix(Mc)
-own[:, S] = 0
-own = sp.csr_matrix(own)
+keep = np.ones(n)
+keep[S] = 0.0
+own = sp.csr_matrix(M @ sp.diags(keep))
 own.eliminate_zeros()
 A_loc = sp.hstack([own, Mc[:, S].tocsr()], format="csr")
 A_loc.sort_indices()
 A_ser, A_dis = npg.DeviceCSR.from_scipy(ctx, M), npg.DeviceCSR.from_scipy(ctx, A_loc)
 y = npg.DeviceVector.from_host(ctx, rng.standard_normal(n))
 P = npg.Diagonal(diag=npg.DeviceVector.from_host(ctx, 1.0 / M.diagonal()))
-for label, A, nx, dist_ in (("serial (hipGraph cycles)", A_ser, n, False), ("through RCCL, one-rank communicator", A_dis, n + len(S), True)):
+for label, A, nx, dist_, graph in (("serial (hipGraph cycles)", A_ser, n, False, 0),
+                                   ("through RCCL, one-rank communicator, eager launches", A_dis, n + len(S), True, 0),
+                                   ("through RCCL, one-rank communicator, hipGraph replay", A_dis, n + len(S), True, 1)):
     ws = npg.GmresWorkspace(ctx, n, memory=20)
     if dist_:
         L.check(L.lib().npg_gmres_set_halo(ws.h, halo.h))
+        L.check(L.lib().npg_gmres_set_dist_options(ws.h, 1, graph))
     for rep in range(2):
         x = npg.DeviceVector(ctx, nx)
         x.fill(0.0)
@@ -48,4 +51,4 @@ for label, A, nx, dist_ in (("serial (hipGraph cycles)", A_ser, n, False), ("thr
         st = ws.solve(A, y, x, P, atol=1e-30, rtol=1e-14, itmax=2000)
         ctx.sync()
         dt = time.perf_counter() - t0
-    print(f"{label:40s}: {st['niter']} iterations, {dt / st['niter'] * 1e6:7.1f} us per iteration")
+    print(f"{label:56s}: {st['niter']} iterations, {dt / st['niter'] * 1e6:7.1f} us per iteration")
