@@ -446,6 +446,7 @@ NPG_API int npg_csr_clone(const npg_csr *A, npg_csr **out) {
     B->col = A->col;
     B->tile_ptr = A->tile_ptr;
     B->ntiles = A->ntiles;
+    B->ntiles_interior = A->ntiles_interior;
     B->lanes = A->lanes;
     B->owns_pattern = false;
     B->h_rowptr = A->h_rowptr;
