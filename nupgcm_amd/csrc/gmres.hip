@@ -705,6 +705,8 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
     static const bool overlap_env = !getenv("NPG_HALO_OVERLAP") || atoi(getenv("NPG_HALO_OVERLAP")) != 0;
     const bool overlap = dist && d.split && overlap_env && ws->halo_overlap && d.nt_int > 0 && d.nt_int < d.ntiles;
     const int maxg = ws ? std::min(kMaxG, 3 * ws->ctx->num_cu) : kMaxG;
+    static const int reserve_env = getenv("NPG_HALO_RESERVE_CUS") ? atoi(getenv("NPG_HALO_RESERVE_CUS")) : 4;
+    const int reserve = std::max(0, std::min(reserve_env, maxg / 6));
     if (dist && getenv("NPG_HALO_OVERLAP_VERBOSE")) {
         static int last = -1;
         const int now = (overlap ? 2 : 0) + (d.split ? 1 : 0);
@@ -716,8 +718,10 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
         if (overlap) {
             if ((rc = halo_exchange_async(ws->halo, d.wt))) return rc;
             if (pev) hipEventRecord(pev[2 * j], st);
-            hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(std::max(1, std::min(d.nt_int, maxg))), dim3(kKB), 0, st, d, j,
-                               0, d.nt_int);
+            // the interior launch leaves a few CUs free: its workgroups are persistent (they hold their CU until the last tile),
+            // and RCCL's send/recv kernels could otherwise not start before they are all done
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(std::max(1, std::min(d.nt_int, maxg - 3 * reserve))), dim3(kKB), 0,
+                               st, d, j, 0, d.nt_int);
             if ((rc = halo_exchange_wait(ws->halo))) return rc;
             hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(std::max(1, std::min(d.ntiles - d.nt_int, maxg))), dim3(kKB), 0,
                                st, d, j, d.nt_int, d.ntiles);
