@@ -1106,6 +1106,208 @@ static int sorted_streams(const npg_csr *A, const std::vector<std::pair<int64_t,
     return NPG_OK;
 }
 
+// ---- CU-local tile queues (experiment): the workgroups resident on ONE CU take ADJACENT tiles from that CU's own
+// contiguous chunk of the tile sequence, so that they share their x window in the CU's 32 KiB L1 and a workgroup's next
+// tile reuses most of the lines of its last one.  (Round-robin dealing gives a CU three unrelated windows of ~19 KiB.)
+// A workgroup finds its CU from HW_ID / XCC_ID, the first one to arrive on a CU claims the next chunk; chunks are
+// balanced by stored bytes; a workgroup whose chunk is empty steals from the following chunks (every wave reaches the
+// exit: the queues only ever advance).
+struct CuQueues {
+    int *tab;          // [2048] physical CU key -> chunk + 1 (0: not claimed yet)
+    int *nclaimed;     // chunks claimed so far
+    int *next;         // [nchunk] next tile of the chunk
+    const int *end;    // [nchunk] end of the chunk
+    int nchunk;
+};
+
+__device__ __forceinline__ int my_cu_key() {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);       // HW_REG_HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);      // HW_REG_XCC_ID
+    return (int)(((xcc & 7u) << 8) | ((hw >> 8) & 0xffu));                          // XCC, SE, SH, CU
+}
+
+template <int L>
+__global__ void __launch_bounds__(512, 6) k_spmv_cuq(CsrDev A, const TileDesc *__restrict__ tile_ptr, int ntiles, CuQueues Q,
+                                                     const double *__restrict__ x, double *__restrict__ y) {
+    __shared__ TileLds tl;
+    __shared__ double sw[kTileRows];
+    __shared__ int s_chunk, s_tile;
+    if (threadIdx.x == 0) {
+        const int key = my_cu_key();
+        int c = atomicAdd(&Q.tab[key], 0);
+        if (c == 0) {
+            if (atomicCAS(&Q.tab[key], 0, -1) == 0) {
+                c = atomicAdd(Q.nclaimed, 1) % Q.nchunk + 1;
+                atomicExch(&Q.tab[key], c);
+            } else {
+                while ((c = atomicAdd(&Q.tab[key], 0)) <= 0) __builtin_amdgcn_s_sleep(2);
+            }
+        } else if (c < 0) {
+            while ((c = atomicAdd(&Q.tab[key], 0)) <= 0) __builtin_amdgcn_s_sleep(2);
+        }
+        s_chunk = c - 1;
+    }
+    __syncthreads();
+    const int home = s_chunk;
+    auto claim = [&]() {          // thread 0: next tile for this workgroup, -1 when every queue is empty
+        for (int k = 0; k < Q.nchunk; ++k) {
+            const int c = home + k < Q.nchunk ? home + k : home + k - Q.nchunk;
+            if (atomicAdd(&Q.next[c], 0) >= Q.end[c]) continue;
+            const int t = atomicAdd(&Q.next[c], 1);
+            if (t < Q.end[c]) return t;
+        }
+        return -1;
+    };
+    __shared__ TileDesc s_td;
+    if (threadIdx.x == 0) {
+        s_tile = claim();
+        if (s_tile >= 0) s_td = tile_ptr[s_tile];
+    }
+    __syncthreads();
+    int t = s_tile;
+    while (t >= 0) {
+        const TileDesc td = s_td;
+        __syncthreads();                       // everyone has read s_tile / s_td
+        if (threadIdx.x == 0) {                // the next tile and its descriptor, fetched while this one is worked on
+            s_tile = claim();
+            if (s_tile >= 0) s_td = tile_ptr[s_tile];
+        }
+        spmv_tile<512, L>(A, PlainX{x}, td, tl, sw);
+        for (int r = threadIdx.x; r < td.nrows; r += 512) y[td.r0 + r] = sw[r];
+        __syncthreads();
+        t = s_tile;
+    }
+}
+
+__global__ void k_cuq_reset(CuQueues Q, const int *__restrict__ begin) {
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) Q.tab[i] = 0;
+    for (int i = threadIdx.x; i < Q.nchunk; i += blockDim.x) Q.next[i] = begin[i];
+    if (threadIdx.x == 0) *Q.nclaimed = 0;
+}
+
+static int run_cuq(const npg_csr *A, const double *x, double *y, int bpc, int reps, double *ms) {
+    npg_ctx *ctx = A->ctx;
+    static std::map<const void *, std::pair<CuQueues, int *>> cache;
+    if (!cache.count(A)) {
+        std::vector<TileDesc> td((size_t)A->ntiles);
+        NPG_HIP(hipMemcpy(td.data(), A->tile_ptr, td.size() * sizeof(TileDesc), hipMemcpyDeviceToHost));
+        const int nchunk = ctx->num_cu;
+        std::vector<double> cum(td.size() + 1, 0.0);
+        for (size_t t = 0; t < td.size(); ++t) cum[t + 1] = cum[t] + 20.0 * td[t].npe + 12.0 * td[t].n + 12.0 * td[t].nrows;
+        std::vector<int> begin(nchunk), end(nchunk);
+        int t0 = 0;
+        for (int c = 0; c < nchunk; ++c) {
+            const double target = cum.back() * (c + 1) / nchunk;
+            int t1 = t0;
+            while (t1 < (int)td.size() && cum[t1 + 1] <= target + 1e-9) ++t1;
+            if (c == nchunk - 1) t1 = (int)td.size();
+            begin[c] = t0;
+            end[c] = t1;
+            t0 = t1;
+        }
+        CuQueues Q;
+        int *dbegin, *dend;
+        NPG_HIP(hipMalloc((void **)&Q.tab, 2048 * sizeof(int)));
+        NPG_HIP(hipMalloc((void **)&Q.nclaimed, sizeof(int)));
+        NPG_HIP(hipMalloc((void **)&Q.next, nchunk * sizeof(int)));
+        NPG_HIP(hipMalloc((void **)&dend, nchunk * sizeof(int)));
+        NPG_HIP(hipMalloc((void **)&dbegin, nchunk * sizeof(int)));
+        NPG_HIP(hipMemcpy(dend, end.data(), nchunk * sizeof(int), hipMemcpyHostToDevice));
+        NPG_HIP(hipMemcpy(dbegin, begin.data(), nchunk * sizeof(int), hipMemcpyHostToDevice));
+        Q.end = dend;
+        Q.nchunk = nchunk;
+        cache[A] = std::make_pair(Q, dbegin);
+    }
+    const CuQueues Q = cache[A].first;
+    const int *dbegin = cache[A].second;
+    const int grid = std::max(1, std::min<int>(A->ntiles, bpc * ctx->num_cu));
+    const CsrDev Av = csr_view(A);
+    auto go = [&]() {
+        hipLaunchKernelGGL(k_cuq_reset, dim3(1), dim3(256), 0, ctx->stream, Q, dbegin);
+        hipLaunchKernelGGL(k_spmv_cuq<8>, dim3(grid), dim3(512), 0, ctx->stream, Av, A->tile_ptr, A->ntiles, Q, x, y);
+    };
+    for (int i = 0; i < 2; ++i) go();
+    NPG_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; ++i) go();
+    NPG_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    NPG_HIP(hipEventSynchronize(ctx->ev1));
+    float f = 0.f;
+    NPG_HIP(hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    *ms = f / reps;
+    return NPG_OK;
+}
+
+// the same idea with the global order kept: at step k the whole chip works on tiles [768 k, 768 (k + 1)) as it does
+// with round-robin dealing (one moving window over the matrix), but the three workgroups of a CU take three ADJACENT
+// tiles of it.  Needs exactly 3 workgroups on each of the CUs (grid = 3 x CUs, 51 KB of LDS each).
+template <int L>
+__global__ void __launch_bounds__(512, 6) k_spmv_cuadj(CsrDev A, const TileDesc *__restrict__ tile_ptr, int ntiles, CuQueues Q,
+                                                       const double *__restrict__ x, double *__restrict__ y) {
+    __shared__ TileLds tl;
+    __shared__ double sw[kTileRows];
+    __shared__ int s_lane;
+    if (threadIdx.x == 0) {
+        const int key = my_cu_key();
+        int c = atomicAdd(&Q.tab[key], 0);
+        if (c == 0 && atomicCAS(&Q.tab[key], 0, -1) == 0) {
+            c = atomicAdd(Q.nclaimed, 1) + 1;
+            atomicExch(&Q.tab[key], c);
+        } else {
+            while ((c = atomicAdd(&Q.tab[key], 0)) <= 0) __builtin_amdgcn_s_sleep(2);
+        }
+        const int slot = atomicAdd(&Q.next[c - 1], 1);          // arrival order on this CU
+        s_lane = (slot < 3 && c - 1 < Q.nchunk) ? 3 * (c - 1) + slot : -1;
+    }
+    __syncthreads();
+    const int lane = s_lane, stride = 3 * Q.nchunk;
+    if (lane < 0) return;
+    int t = lane;
+    if (t >= ntiles) return;
+    TileDesc td = tile_ptr[t];
+    while (true) {
+        const int tn = t + stride;
+        TileDesc nd = td;
+        if (tn < ntiles) nd = tile_ptr[tn];
+        spmv_tile<512, L>(A, PlainX{x}, td, tl, sw);
+        for (int r = threadIdx.x; r < td.nrows; r += 512) y[td.r0 + r] = sw[r];
+        if (tn >= ntiles) break;
+        t = tn;
+        td = nd;
+    }
+}
+
+__global__ void k_cuadj_reset(CuQueues Q) {
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) Q.tab[i] = 0;
+    for (int i = threadIdx.x; i < Q.nchunk; i += blockDim.x) Q.next[i] = 0;
+    if (threadIdx.x == 0) *Q.nclaimed = 0;
+}
+
+static int run_cuadj(const npg_csr *A, const double *x, double *y, int reps, double *ms) {
+    npg_ctx *ctx = A->ctx;
+    static CuQueues Q{};
+    if (!Q.tab) {
+        NPG_HIP(hipMalloc((void **)&Q.tab, 2048 * sizeof(int)));
+        NPG_HIP(hipMalloc((void **)&Q.nclaimed, sizeof(int)));
+        NPG_HIP(hipMalloc((void **)&Q.next, 2048 * sizeof(int)));
+        Q.end = nullptr;
+        Q.nchunk = ctx->num_cu;
+    }
+    const CsrDev Av = csr_view(A);
+    auto go = [&]() {
+        hipLaunchKernelGGL(k_cuadj_reset, dim3(1), dim3(256), 0, ctx->stream, Q);
+        hipLaunchKernelGGL(k_spmv_cuadj<8>, dim3(3 * ctx->num_cu), dim3(512), 0, ctx->stream, Av, A->tile_ptr, A->ntiles, Q, x, y);
+    };
+    for (int i = 0; i < 2; ++i) go();
+    NPG_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; ++i) go();
+    NPG_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    NPG_HIP(hipEventSynchronize(ctx->ev1));
+    float f = 0.f;
+    NPG_HIP(hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    *ms = f / reps;
+    return NPG_OK;
+}
+
 }  // namespace npg
 
 using namespace npg;
@@ -1166,6 +1368,8 @@ NPG_API int npg_spmv_variant(const npg_csr *A, const npg_vec *x, npg_vec *y, int
         case 75: return run_pack<512, 8, 1280, 96, 6, true, false, 3>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 76: return run_pack<256, 8, 640, 48, 6, true, false, 3>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 77: return run_pack<512, 8, 1664, 128, 4, true, false, 3>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 81: return run_cuadj(A, x->d, y->d, reps, ms);
+        case 80: return run_cuq(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 70: return run_perm(A, x->d, y->d, blocks_per_cu, reps, ms, true);
         case 71: return run_perm(A, x->d, y->d, blocks_per_cu, reps, ms, false);
         case 0: return run_var<512, 4096, 4>(A, x->d, y->d, blocks_per_cu, reps, ms);

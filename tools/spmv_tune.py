@@ -50,7 +50,9 @@ names = {0: "NT512 T4096 U4", 1: "NT512 T4096 U8", 2: "NT1024 T8192 U8", 3: "NT2
          70: "product tiles, column-sorted + slot index", 71: "product tiles, slot index only (unsorted)",
          72: "packed + column-sorted NT512 T1792", 73: "packed + column-sorted NT256 T896", 74: "packed NT512 T1792",
          75: "packed, gathers a tile ahead NT512 T1280 (3 WG/CU)", 76: "packed, gathers a tile ahead NT256 T640 (6 WG/CU)",
-         77: "packed, gathers a tile ahead NT512 T1664 (2-3 WG/CU)"}
+         77: "packed, gathers a tile ahead NT512 T1664 (2-3 WG/CU)",
+         80: "product tiles, CU-local tile queues (adjacent tiles per CU)",
+         81: "product tiles, the 3 workgroups of a CU on adjacent tiles, global order kept"}
 print(f"{wl}: N={N} nnz={nnz} algorithmic bytes={alg / 1e6:.1f} MB")
 import time
 for _ in range(3):
