@@ -1308,6 +1308,57 @@ static int run_cuadj(const npg_csr *A, const double *x, double *y, int reps, dou
     return NPG_OK;
 }
 
+// ---- diagnostic: the same gather instructions on a SMALL window of x (column index wrapped): prices the gathers' cache
+// misses apart from their instructions (results are meaningless)
+template <int MASK>
+struct WrapX {
+    const double *x;
+    __device__ __forceinline__ double operator()(int c) const { return x[c & MASK]; }
+    __device__ __forceinline__ double2 two(int i) const {
+        double2 r;
+        __builtin_memcpy(&r, x + (i & MASK & ~1), sizeof r);
+        return r;
+    }
+    __device__ __forceinline__ double third(int i) const { return x[i & MASK]; }
+};
+
+template <int L, class XF>
+__global__ void __launch_bounds__(512, 6) k_spmv_xf(CsrDev A, const TileDesc *__restrict__ tile_ptr, int ntiles,
+                                                    const double *__restrict__ x, double *__restrict__ y) {
+    __shared__ TileLds tl;
+    __shared__ double sw[kTileRows];
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    TileDesc td = tile_ptr[t];
+    while (true) {
+        const int tn = t + gridDim.x;
+        TileDesc nd = td;
+        if (tn < ntiles) nd = tile_ptr[tn];
+        spmv_tile<512, L>(A, XF{x}, td, tl, sw);
+        for (int r = threadIdx.x; r < td.nrows; r += 512) y[td.r0 + r] = sw[r];
+        if (tn >= ntiles) break;
+        t = tn;
+        td = nd;
+    }
+}
+
+template <class XF>
+static int run_xf(const npg_csr *A, const double *x, double *y, int bpc, int reps, double *ms) {
+    npg_ctx *ctx = A->ctx;
+    const int grid = std::max(1, std::min<int>(A->ntiles, bpc * ctx->num_cu));
+    const CsrDev Av = csr_view(A);
+    auto go = [&]() { hipLaunchKernelGGL((k_spmv_xf<8, XF>), dim3(grid), dim3(512), 0, ctx->stream, Av, A->tile_ptr, A->ntiles, x, y); };
+    for (int i = 0; i < 2; ++i) go();
+    NPG_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; ++i) go();
+    NPG_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    NPG_HIP(hipEventSynchronize(ctx->ev1));
+    float f = 0.f;
+    NPG_HIP(hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    *ms = f / reps;
+    return NPG_OK;
+}
+
 }  // namespace npg
 
 using namespace npg;
@@ -1368,6 +1419,10 @@ NPG_API int npg_spmv_variant(const npg_csr *A, const npg_vec *x, npg_vec *y, int
         case 75: return run_pack<512, 8, 1280, 96, 6, true, false, 3>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 76: return run_pack<256, 8, 640, 48, 6, true, false, 3>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 77: return run_pack<512, 8, 1664, 128, 4, true, false, 3>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 82: return run_xf<PlainX>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 83: return run_xf<WrapX<2047>>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 84: return run_xf<WrapX<32767>>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 85: return run_xf<WrapX<524287>>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 81: return run_cuadj(A, x->d, y->d, reps, ms);
         case 80: return run_cuq(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 70: return run_perm(A, x->d, y->d, blocks_per_cu, reps, ms, true);

@@ -52,7 +52,9 @@ names = {0: "NT512 T4096 U4", 1: "NT512 T4096 U8", 2: "NT1024 T8192 U8", 3: "NT2
          75: "packed, gathers a tile ahead NT512 T1280 (3 WG/CU)", 76: "packed, gathers a tile ahead NT256 T640 (6 WG/CU)",
          77: "packed, gathers a tile ahead NT512 T1664 (2-3 WG/CU)",
          80: "product tiles, CU-local tile queues (adjacent tiles per CU)",
-         81: "product tiles, the 3 workgroups of a CU on adjacent tiles, global order kept"}
+         81: "product tiles, the 3 workgroups of a CU on adjacent tiles, global order kept",
+         82: "product kernel rebuilt in the harness (reference for 83-85)", 83: "gathers wrapped into 16 KB of x (all L1 hits; diagnostic)",
+         84: "gathers wrapped into 256 KB of x (L2 hits; diagnostic)", 85: "gathers wrapped into 4 MB of x (diagnostic)"}
 print(f"{wl}: N={N} nnz={nnz} algorithmic bytes={alg / 1e6:.1f} MB")
 import time
 for _ in range(3):
