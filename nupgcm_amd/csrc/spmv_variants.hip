@@ -1359,6 +1359,350 @@ static int run_xf(const npg_csr *A, const double *x, double *y, int bpc, int rep
     return NPG_OK;
 }
 
+// ---- diagnostic: the gathers served by LDS reads from a (fake) x window instead of the texture path: what an x window
+// staged in LDS could buy at most (results are meaningless; the window is never filled)
+struct LdsX {
+    const double *w;          // LDS
+    __device__ __forceinline__ double operator()(int c) const { return w[c & 511]; }
+    __device__ __forceinline__ double2 two(int i) const { return make_double2(w[i & 511], w[(i + 1) & 511]); }
+    __device__ __forceinline__ double third(int i) const { return w[i & 511]; }
+};
+
+template <int L, int TNNZ, int MODE>
+__global__ void __launch_bounds__(512, 6) k_spmv_ldsx(CsrDev A, const int32_t *__restrict__ tile_ptr, int ntiles,
+                                                      const double *__restrict__ x, double *__restrict__ y) {
+    __shared__ TileLdsT<TNNZ> tl;
+    __shared__ double sw[kTileRows];
+    __shared__ double xw[512];
+    xw[threadIdx.x] = x[threadIdx.x];
+    __syncthreads();
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int r0 = tile_ptr[t], r1 = tile_ptr[t + 1];
+        if (MODE == 0)
+            spmv_tile<512, L, PlainX, TNNZ, 4>(A, PlainX{x}, r0, r1, tl, sw);
+        else if (MODE == 1)
+            spmv_tile<512, L, LdsX, TNNZ, 4>(A, LdsX{xw}, r0, r1, tl, sw);
+        else
+            spmv_tile<512, L, FakeX, TNNZ, 4>(A, FakeX{x}, r0, r1, tl, sw);
+        for (int r = threadIdx.x; r < r1 - r0; r += 512) y[r0 + r] = sw[r];
+    }
+}
+
+template <int MODE>
+static int run_ldsx(const npg_csr *A, const double *x, double *y, int bpc, int reps, double *ms) {
+    constexpr int TNNZ = 5120;
+    auto key = std::make_pair((const void *)A, TNNZ);
+    if (!g_ptiles.count(key)) {
+        std::vector<int32_t> tp;
+        int rc = tile_boundaries(A, TNNZ, tp);
+        if (rc) return rc;
+        VarTiles v;
+        v.n = (int)tp.size() - 1;
+        NPG_HIP(hipMalloc((void **)&v.d, tp.size() * sizeof(int32_t)));
+        NPG_HIP(hipMemcpy(v.d, tp.data(), tp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        g_ptiles[key] = v;
+    }
+    const VarTiles t = g_ptiles[key];
+    npg_ctx *ctx = A->ctx;
+    const int grid = std::max(1, std::min(t.n, bpc * ctx->num_cu));
+    const CsrDev Av = csr_view(A);
+    auto go = [&]() { hipLaunchKernelGGL((k_spmv_ldsx<8, TNNZ, MODE>), dim3(grid), dim3(512), 0, ctx->stream, Av, t.d, t.n, x, y); };
+    for (int i = 0; i < 2; ++i) go();
+    NPG_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; ++i) go();
+    NPG_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    NPG_HIP(hipEventSynchronize(ctx->ev1));
+    float f = 0.f;
+    NPG_HIP(hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    *ms = f / reps;
+    return NPG_OK;
+}
+
+// ---- x windows in LDS (experiment): diagnostic 87 says gathers served by LDS reads cost a sixth of gathers on the
+// texture path.  Per tile up to 16 contiguous index ranges of x (<= WIN doubles in total; 88 % of the gather accesses of
+// A_inversion on bowl3D h = 0.02 at 3072-slot tiles, counted on the host) are copied into LDS by coalesced loads, and the
+// tile's column indices are rewritten at build time: bit 31 set = offset into the window (bit 30: the node has a z
+// component), else the global index as before.
+constexpr int kWin = 2560, kWinRanges = 16, kWinTile = 3072;
+struct WinRange {
+    int32_t lo;            // first index of x
+    uint16_t len, off;     // length, offset into the window
+};
+
+template <int NT, int L, int TNNZ, int U2 = 4>
+__device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const double *__restrict__ x, const WinRange *__restrict__ wr,
+                                              const TileDesc &td, TileLdsT<TNNZ> &t, double *__restrict__ xw,
+                                              double *__restrict__ out) {
+    const int r0 = td.r0, nrows = td.nrows, r1 = r0 + nrows;
+    const int64_t base = td.base;
+    const int n = td.n;
+    const bool blk = r0 < block_rows(A);
+    const bool full = r0 < 3 * A.nfull;
+    const int ncomp = full ? 3 : 2;
+    const int npe = td.npe;
+    const int64_t pbase = td.pbase;
+    int nnode = 0, q0 = 0;
+    if (blk) {
+        q0 = node_of_row(A, r0);
+        nnode = node_of_row(A, r1) - q0;
+    }
+    const int64_t abase = base & ~1LL;
+    const int off = (int)(base - abase);
+    const int total = n + off;
+    const int slot0 = blk ? ncomp * npe : 0;
+    for (int r = threadIdx.x; r <= nrows; r += NT) t.rp[r] = (int32_t)(A.rowptr[r0 + r] - base) + off + slot0;
+    if (blk)
+        for (int q = threadIdx.x; q <= nnode; q += NT) t.prp[q] = (int32_t)(A.prow[q0 + q] - pbase);
+    // ---- the record stream's loads first (they do not need the window), then the window
+    constexpr int UP = (TNNZ / 2 + NT - 1) / NT;      // (x, y)-node tiles: two slots per record
+    int32_t c[UP];
+    double2 kc[UP];
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+        const int e = threadIdx.x + u * NT;
+        if (e < npe) {
+            c[u] = __builtin_nontemporal_load(A.pcol + pbase + e);
+            const double *p = reinterpret_cast<const double *>(A.pkc + pbase + e);
+            kc[u].x = __builtin_nontemporal_load(p);
+            kc[u].y = __builtin_nontemporal_load(p + 1);
+        } else {
+            c[u] = 0;
+            kc[u] = make_double2(0.0, 0.0);
+        }
+    }
+    {
+        const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
+        if (g < kWinRanges) {
+            const WinRange w = wr[g];
+            for (int i = l; i < w.len; i += 32) xw[w.off + i] = x[w.lo + i];
+        }
+    }
+    __syncthreads();
+    {
+        double2 xx[UP];
+        double zz[UP];
+#pragma unroll
+        for (int u = 0; u < UP; ++u) {
+            if (c[u] < 0) {
+                const int o = c[u] & 0xffff;
+                xx[u] = make_double2(xw[o], xw[o + 1]);
+                zz[u] = (c[u] & 0x40000000) ? xw[o + 2] : 0.0;
+            } else {
+                const int cf = c[u] < A.nfull ? c[u] : A.nfull;
+                const int xo = 2 * c[u] + cf;
+                double2 r;
+                __builtin_memcpy(&r, x + xo, sizeof r);
+                xx[u] = r;
+                zz[u] = (full && c[u] < A.nfull) ? x[xo + 2] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UP; ++u) {
+            const int e = threadIdx.x + u * NT;
+            if (e < npe) {
+                t.prod[e] = kc[u].x * xx[u].x + kc[u].y * xx[u].y;
+                t.prod[npe + e] = kc[u].x * xx[u].y - kc[u].y * xx[u].x;
+                if (full) t.prod[2 * npe + e] = kc[u].x * zz[u];
+            }
+        }
+    }
+    for (int k0 = 2 * threadIdx.x; k0 < total; k0 += 2 * NT * U2) {
+        int2 cc[U2];
+        double2 v[U2];
+        double xa[U2], xb[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const int k = k0 + u * 2 * NT;
+            if (k < total && abase + k + 1 < A.nnz) {
+                const long long q = __builtin_nontemporal_load(reinterpret_cast<const long long *>(A.col + abase + k));
+                cc[u] = make_int2((int)(q & 0xffffffffLL), (int)(q >> 32));
+                v[u].x = __builtin_nontemporal_load(A.val + abase + k);
+                v[u].y = __builtin_nontemporal_load(A.val + abase + k + 1);
+            } else if (k < total && abase + k < A.nnz) {
+                cc[u] = make_int2(A.col[abase + k], 0);
+                v[u] = make_double2(A.val[abase + k], 0.0);
+            } else {
+                cc[u] = make_int2(0, 0);
+                v[u] = make_double2(0.0, 0.0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const int k = k0 + u * 2 * NT;
+            // (the entry in front of the tile's first one belongs to the previous tile: its index is that tile's)
+            xa[u] = (k >= off) ? (cc[u].x < 0 ? xw[cc[u].x & 0xffff] : x[cc[u].x]) : 0.0;
+            xb[u] = cc[u].y < 0 ? xw[cc[u].y & 0xffff] : x[cc[u].y];
+        }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const int k = k0 + u * 2 * NT;
+            if (k < total) t.prod[slot0 + k] = (k >= off) ? v[u].x * xa[u] : 0.0;
+            if (k + 1 < total) t.prod[slot0 + k + 1] = v[u].y * xb[u];
+        }
+    }
+    __syncthreads();
+    const int g = threadIdx.x / L, l = threadIdx.x % L;
+    for (int r = g; r < nrows; r += NT / L) {
+        double s = 0.0;
+        const int e = t.rp[r + 1];
+        for (int k = t.rp[r] + 2 * l; k < e; k += 2 * L) {
+            const double a = t.prod[k], b = t.prod[k + 1];
+            s += a + (k + 1 < e ? b : 0.0);
+        }
+        if (blk) {
+            const int q = (r * (full ? 21846 : 32768)) >> 16;
+            const int pb = (r - q * ncomp) * npe, pe = pb + t.prp[q + 1];
+            for (int k = pb + t.prp[q] + 2 * l; k < pe; k += 2 * L) {
+                const double a = t.prod[k], b = t.prod[k + 1];
+                s += a + (k + 1 < pe ? b : 0.0);
+            }
+        }
+        s = group_sum_dpp<L>(s);
+        if (l == 0) out[r] = s;
+    }
+    __syncthreads();
+}
+
+template <int L>
+__global__ void __launch_bounds__(512, 6) k_spmv_win(CsrDev A, const WinRange *__restrict__ wr, const TileDesc *__restrict__ tile_ptr,
+                                                     int ntiles, const double *__restrict__ x, double *__restrict__ y) {
+    __shared__ TileLdsT<kWinTile> tl;
+    __shared__ double sw[kTileRows];
+    __shared__ double xw[kWin + 2];
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    TileDesc td = tile_ptr[t];
+    while (true) {
+        const int tn = t + gridDim.x;
+        TileDesc nd = td;
+        if (tn < ntiles) nd = tile_ptr[tn];
+        spmv_tile_win<512, L, kWinTile>(A, x, wr + (size_t)t * kWinRanges, td, tl, xw, sw);
+        for (int r = threadIdx.x; r < td.nrows; r += 512) y[td.r0 + r] = sw[r];
+        if (tn >= ntiles) break;
+        t = tn;
+        td = nd;
+    }
+}
+
+struct WinMat {
+    int32_t *pcol = nullptr, *col = nullptr;
+    WinRange *wr = nullptr;
+    TileDesc *td = nullptr;
+    int ntiles = 0;
+};
+
+static int run_win(const npg_csr *A, const double *x, double *y, int bpc, int reps, double *ms, bool windows) {
+    npg_ctx *ctx = A->ctx;
+    static std::map<std::pair<const void *, bool>, WinMat> cache;
+    auto key = std::make_pair((const void *)A, windows);
+    if (!cache.count(key)) {
+        NPG_HIP(hipStreamSynchronize(ctx->stream));
+        std::vector<int32_t> tp;
+        int rc = tile_boundaries(A, kWinTile, tp);
+        if (rc) return rc;
+        const int64_t *rp = A->h_rowptr.data();
+        const int64_t nfull = A->nfull, nf3 = 3 * nfull, nbr = A->block_rows();
+        auto node = [&](int64_t r) { return r < nf3 ? r / 3 : nfull + (r - nf3) / 2; };
+        auto first = [&](int64_t c) { return c < nfull ? 3 * c : nf3 + 2 * (c - nfull); };
+        const int nt = (int)tp.size() - 1;
+        std::vector<TileDesc> td((size_t)nt);
+        const int64_t nrec = A->nnode() ? A->h_prow[A->nnode()] : 0, nz = A->rnnz;
+        std::vector<int32_t> pcol((size_t)nrec), col((size_t)nz);
+        if (nrec) NPG_HIP(hipMemcpy(pcol.data(), A->pcol, pcol.size() * 4, hipMemcpyDeviceToHost));
+        NPG_HIP(hipMemcpy(col.data(), A->col, col.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<WinRange> wr((size_t)nt * kWinRanges, WinRange{0, 0, 0});
+        double lanes_all = 0, lanes_win = 0, staged = 0;
+        std::vector<std::pair<int64_t, int>> need;      // (index of x, lanes)
+        for (int t = 0; t < nt; ++t) {
+            const int64_t r0 = tp[t], r1 = tp[t + 1];
+            TileDesc &q = td[t];
+            q.r0 = (int32_t)r0;
+            q.nrows = (int32_t)(r1 - r0);
+            q.base = rp[r0];
+            q.n = (int32_t)(rp[r1] - rp[r0]);
+            q.pbase = 0;
+            q.npe = 0;
+            if (r0 < nbr) {
+                q.pbase = A->h_prow[node(r0)];
+                q.npe = (int32_t)(A->h_prow[node(r1)] - q.pbase);
+            }
+            if (!windows) continue;
+            need.clear();
+            for (int e = 0; e < q.npe; ++e) need.emplace_back(first(pcol[q.pbase + e]), 2);
+            for (int k = 0; k < q.n; ++k) need.emplace_back(col[q.base + k], 1);
+            std::sort(need.begin(), need.end());
+            // clusters of needed indices (gap <= 64), whole nodes
+            struct Cl { int64_t lo, hi; double w; };
+            std::vector<Cl> cl;
+            for (auto &pr : need) {
+                const int64_t i0 = pr.first, i1 = i0 + (pr.second == 2 ? (i0 < nf3 ? 3 : 2) : 1);
+                if (!cl.empty() && i0 <= cl.back().hi + 64) {
+                    cl.back().hi = std::max(cl.back().hi, i1);
+                    cl.back().w += pr.second;
+                } else
+                    cl.push_back(Cl{i0, i1, (double)pr.second});
+                lanes_all += pr.second;
+            }
+            std::sort(cl.begin(), cl.end(), [](const Cl &a, const Cl &b) { return a.w > b.w; });
+            int used = 0, nr = 0;
+            std::vector<Cl> sel;
+            for (auto &c : cl) {
+                const int len = (int)(c.hi - c.lo) + ((c.hi - c.lo) & 1);
+                if (nr >= kWinRanges || used + len > kWin) continue;
+                wr[(size_t)t * kWinRanges + nr] = WinRange{(int32_t)c.lo, (uint16_t)(c.hi - c.lo), (uint16_t)used};
+                sel.push_back(Cl{c.lo, c.hi, (double)used});
+                used += len;
+                ++nr;
+                lanes_win += c.w;
+            }
+            staged += used;
+            auto lookup = [&](int64_t i) -> int {
+                for (auto &c : sel)
+                    if (i >= c.lo && i < c.hi) return (int)c.w + (int)(i - c.lo);
+                return -1;
+            };
+            for (int e = 0; e < q.npe; ++e) {
+                const int64_t cn = pcol[q.pbase + e];
+                const int o = lookup(first(cn));
+                if (o >= 0) pcol[q.pbase + e] = (int32_t)(0x80000000u | (cn < nfull ? 0x40000000u : 0u) | (unsigned)o);
+            }
+            for (int k = 0; k < q.n; ++k) {
+                const int o = lookup(col[q.base + k]);
+                if (o >= 0) col[q.base + k] = (int32_t)(0x80000000u | (unsigned)o);
+            }
+        }
+        if (windows)
+            fprintf(stderr, "  x windows: %d tiles of <= %d slots, %.1f %% of the gather accesses inside, %.0f doubles staged per tile\n", nt,
+                    kWinTile, 100.0 * lanes_win / lanes_all, staged / nt);
+        WinMat m;
+        m.ntiles = nt;
+        NPG_HIP(hipMalloc((void **)&m.pcol, pcol.size() * 4 + 16));
+        NPG_HIP(hipMalloc((void **)&m.col, col.size() * 4 + 16));
+        NPG_HIP(hipMalloc((void **)&m.wr, wr.size() * sizeof(WinRange)));
+        NPG_HIP(hipMalloc((void **)&m.td, td.size() * sizeof(TileDesc)));
+        if (nrec) NPG_HIP(hipMemcpy(m.pcol, pcol.data(), pcol.size() * 4, hipMemcpyHostToDevice));
+        NPG_HIP(hipMemcpy(m.col, col.data(), col.size() * 4, hipMemcpyHostToDevice));
+        NPG_HIP(hipMemcpy(m.wr, wr.data(), wr.size() * sizeof(WinRange), hipMemcpyHostToDevice));
+        NPG_HIP(hipMemcpy(m.td, td.data(), td.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+        cache[key] = m;
+    }
+    const WinMat m = cache[key];
+    CsrDev Av = csr_view(A);
+    Av.pcol = m.pcol;
+    Av.col = m.col;
+    const int grid = std::max(1, std::min<int>(m.ntiles, bpc * ctx->num_cu));
+    auto go = [&]() { hipLaunchKernelGGL(k_spmv_win<8>, dim3(grid), dim3(512), 0, ctx->stream, Av, m.wr, m.td, m.ntiles, x, y); };
+    for (int i = 0; i < 2; ++i) go();
+    NPG_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; ++i) go();
+    NPG_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    NPG_HIP(hipEventSynchronize(ctx->ev1));
+    float f = 0.f;
+    NPG_HIP(hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    *ms = f / reps;
+    return NPG_OK;
+}
+
 }  // namespace npg
 
 using namespace npg;
@@ -1423,6 +1767,11 @@ NPG_API int npg_spmv_variant(const npg_csr *A, const npg_vec *x, npg_vec *y, int
         case 83: return run_xf<WrapX<2047>>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 84: return run_xf<WrapX<32767>>(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 85: return run_xf<WrapX<524287>>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 86: return run_ldsx<0>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 87: return run_ldsx<1>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 88: return run_ldsx<2>(A, x->d, y->d, blocks_per_cu, reps, ms);
+        case 90: return run_win(A, x->d, y->d, blocks_per_cu, reps, ms, true);
+        case 91: return run_win(A, x->d, y->d, blocks_per_cu, reps, ms, false);
         case 81: return run_cuadj(A, x->d, y->d, reps, ms);
         case 80: return run_cuq(A, x->d, y->d, blocks_per_cu, reps, ms);
         case 70: return run_perm(A, x->d, y->d, blocks_per_cu, reps, ms, true);

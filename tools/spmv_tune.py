@@ -54,7 +54,10 @@ names = {0: "NT512 T4096 U4", 1: "NT512 T4096 U8", 2: "NT1024 T8192 U8", 3: "NT2
          80: "product tiles, CU-local tile queues (adjacent tiles per CU)",
          81: "product tiles, the 3 workgroups of a CU on adjacent tiles, global order kept",
          82: "product kernel rebuilt in the harness (reference for 83-85)", 83: "gathers wrapped into 16 KB of x (all L1 hits; diagnostic)",
-         84: "gathers wrapped into 256 KB of x (L2 hits; diagnostic)", 85: "gathers wrapped into 4 MB of x (diagnostic)"}
+         84: "gathers wrapped into 256 KB of x (L2 hits; diagnostic)", 85: "gathers wrapped into 4 MB of x (diagnostic)",
+         86: "T5120 tiles, gathers from global (reference for 87, 88)", 87: "T5120 tiles, gathers served by LDS reads (diagnostic)",
+         88: "T5120 tiles, gathers replaced by arithmetic (diagnostic)",
+         90: "x windows in LDS, T3072 tiles", 91: "same kernel, no windows (all gathers global)"}
 print(f"{wl}: N={N} nnz={nnz} algorithmic bytes={alg / 1e6:.1f} MB")
 import time
 for _ in range(3):
