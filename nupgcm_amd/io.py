@@ -76,10 +76,50 @@ def _nodal_fields(model):
     return u, p, b_full
 
 
+def _nodal_closure_fields(model, b_full):
+    """alpha*b_z, nu, kappa_v at the P2 nodes (src/IO.jl:31-42).  The reference hands Gridap cell fields, which writevtk
+    evaluates cell by cell; here the cell-wise values at a node (d/dz of the P2 interpolant of b_full through the cell's own
+    geometry) are averaged over the cells sharing it, and the closures (src/inputs.jl:87-91, 130-137) or the forcing
+    functions are evaluated on that."""
+    from .fe import _TET_EDGE_A, _TET_EDGE_B, p2_tables
+    m, prm, frc = model.fe_data.mesh, model.params, model.forcings
+    lam = np.vstack([np.eye(4), 0.5 * (np.eye(4)[_TET_EDGE_A] + np.eye(4)[_TET_EDGE_B])])     # the 10 nodes of a cell
+    _, dN = p2_tables(lam, _TET_EDGE_A, _TET_EDGE_B)                 # (10 points, 10 basis, 4 barycentric)
+    X = m.geo_coords[m.cell_geo]                                     # (nc, 4, 3)
+    J = np.concatenate([np.ones((len(X), 4, 1)), X], axis=2)         # lambda = J^-T [1; x]: rows of inv(J) give grad lambda
+    G = np.linalg.inv(J)[:, 1:, :]                                   # (nc, 3, 4): d lambda_k / d x_i
+    bc = b_full[m.cell_nodes]                                        # (nc, 10)
+    dlam = np.einsum("qak,ca->cqk", dN, bc)                          # d b / d lambda_k at the cell's nodes
+    bz = np.einsum("cqk,ck->cq", dlam, G[:, 2, :])                   # d b / d z
+    acc = np.zeros(m.nn)
+    cnt = np.zeros(m.nn)
+    np.add.at(acc, m.cell_nodes.ravel(), bz.ravel())
+    np.add.at(cnt, m.cell_nodes.ravel(), 1.0)
+    abz = prm.alpha * acc / np.maximum(cnt, 1.0)
+    x = m.node_coords
+
+    def ev(fn):
+        return np.asarray(fn(x), dtype=float) * np.ones(m.nn) if callable(fn) else np.full(m.nn, float(fn))
+
+    ep, cp = frc.eddy_param, frc.conv_param
+    if ep.is_on:
+        f = ev(ep.f)
+        v = f * (f / np.sqrt(ep.N2min ** 2 + abz * abz))
+        nu = np.logaddexp(10.0 * 1.0, 10.0 * v) / 10.0               # smoothing = 10, nu_min = 1 (src/inputs.jl:130)
+    else:
+        nu = ev(frc.nu)
+    kv = ev(frc.kappa_v)
+    if cp.is_on:
+        kv = kv + cp.kappa_c * (1.0 + np.tanh(-abz / cp.N2min)) / 2.0
+    return abz, nu, kv
+
+
 def save_vtk(model, ofile):
-    """save_vtk(model; ofile) - src/IO.jl:25-59 with order = 2 (quadratic tetrahedra), fields u, p, b = N2 z + b', t."""
+    """save_vtk(model; ofile) - src/IO.jl:25-59 with order = 2 (quadratic tetrahedra): fields u, p, b = N2 z + b',
+    alpha*b_z, nu, kappa_v and t."""
     m = model.fe_data.mesh
     u, p, b = _nodal_fields(model)
+    abz, nu, kv = _nodal_closure_fields(model, b)
     t = 0.0 if model.timestepper is None else float(model.timestepper.t)
     conn = m.cell_nodes[:, _VTK_P2]
     nc = len(conn)
@@ -103,5 +143,8 @@ def save_vtk(model, ofile):
                 + "\n</DataArray>\n")
         f.write('<DataArray type="Float64" Name="p" format="ascii">\n' + arr(p.reshape(-1, 1), "%.17g") + "\n</DataArray>\n")
         f.write('<DataArray type="Float64" Name="b" format="ascii">\n' + arr(b.reshape(-1, 1), "%.17g") + "\n</DataArray>\n")
+        for name, a in (("alpha*b_z", abz), ("nu", nu), ("kappa_v", kv)):
+            f.write(f'<DataArray type="Float64" Name="{name}" format="ascii">\n' + arr(a.reshape(-1, 1), "%.17g")
+                    + "\n</DataArray>\n")
         f.write("</PointData>\n</Piece>\n</UnstructuredGrid>\n</VTKFile>\n")
     return ofile

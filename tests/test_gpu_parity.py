@@ -903,6 +903,11 @@ def test_checkpoint_and_vtk(arch, golden_dir, tmp_path):
     free = m.fe_data.spaces.u_dof >= 0
     assert np.array_equal(uu[free], m.state.u[m.fe_data.spaces.u_dof[free]])
     assert float(root.find("UnstructuredGrid/FieldData/DataArray").text) == m.timestepper.t
+    # the reference's derived fields (src/IO.jl:31-57)
+    assert {"alpha*b_z", "nu", "kappa_v"} <= set(arrays)
+    for name in ("alpha*b_z", "nu", "kappa_v"):
+        a = np.array(arrays[name].text.split(), dtype=float)
+        assert a.shape == (mesh.nn,) and np.isfinite(a).all()
 
 
 def test_blow_up_guard(arch):
