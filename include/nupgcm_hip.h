@@ -216,6 +216,10 @@ int npg_precond_mg_set_params(npg_precond *pc, double omega, double jacobi_weigh
 /* gamma = 1: V-cycle (default); gamma = 2: W-cycle - every level's coarse problem is visited twice, which keeps the
  * convergence independent of the number of levels where the V-cycle's degrades (4 levels: DESIGN.md section 4.5) */
 int npg_precond_mg_set_cycle(npg_precond *pc, int gamma);
+/* Mixed precision inside the cycle: its SpMVs read fp32 copies of the level operators' values (8 instead of 12 bytes per
+ * CSR entry, 12 instead of 20 per node record); vectors, products, sums and the outer flexible GMRES (with its own fp64
+ * SpMV) stay fp64.  npg_precond_mg_update_level rebuilds the copies. */
+int npg_precond_mg_set_mixed(npg_precond *pc, int on);
 /* NPG_PC_DENSE: A^-1 as n^2 doubles in HBM (2 GB at 16 k unknowns, 8 GB at 31 k: what 288 GB buy) - densified, factorised
  * and inverted once by rocSOLVER (getrf + getri, set-up), applied per solve by a hand-written split-column GEMV at HBM speed.
  * For the reference's small meshes, where the scalar-preconditioned GMRES is bound by kernel latency (19 us x 600 iterations),

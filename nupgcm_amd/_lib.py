@@ -94,7 +94,7 @@ def _declare(L):
         "npg_precond_mg_set_level": [P, C.c_int, P, I64, P, P, P, P, P, P],
         "npg_precond_mg_update_level": [P, C.c_int, P, P, P, P, P],
         "npg_precond_mg_set_params": [P, D, D, C.c_int, C.c_int, C.c_int, C.c_int],
-        "npg_precond_mg_set_cycle": [P, C.c_int], "npg_precond_dense_set": [P, P, C.c_int],
+        "npg_precond_mg_set_cycle": [P, C.c_int], "npg_precond_mg_set_mixed": [P, C.c_int], "npg_precond_dense_set": [P, P, C.c_int],
         "npg_precond_mg_set_coarse_dense": [P, C.c_int],
         "npg_precond_apply": [P, P, P], "npg_precond_counters": [P, C.POINTER(I64), C.POINTER(I64)],
         "npg_fgmres_create": [P, I64, C.c_int, PP], "npg_fgmres_destroy": [P],

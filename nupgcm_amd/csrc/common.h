@@ -100,6 +100,9 @@ struct npg_csr {
     int32_t *pcol = nullptr;     // device, column node of a record
     double *pkc = nullptr;       // device, {K, C} per record
     std::vector<int64_t> h_prow;
+    // optional fp32 copies of the values (csr_refresh_fp32): read instead of val / pkc by SpMVs that ask for them
+    // (SpmvEpi::f32 - the multigrid preconditioner's; results are still accumulated and returned in fp64)
+    float *val32 = nullptr, *pkc32 = nullptr;
     int64_t nnode() const { return (int64_t)nfull + nsurf; }
     int64_t block_rows() const { return 3 * (int64_t)nfull + 2 * (int64_t)nsurf; }
 };
@@ -143,9 +146,12 @@ struct SpmvEpi {
     double w = 0.0, zc = 0.0;
     const double *dg = nullptr, *zin = nullptr;
     double *z = nullptr;
+    int f32 = 0;                 // read the matrix's fp32 value copies when it has them
 };
 int spmv_epi(const npg_csr *A, const double *x, const SpmvEpi &e);
-int spmv_raw(const npg_csr *A, const double *x, double *y, double alpha, double beta);
+int spmv_raw(const npg_csr *A, const double *x, double *y, double alpha, double beta, int f32 = 0);
+// (re)build the fp32 copies of A's values from val / pkc (enqueued on the context's stream)
+int csr_refresh_fp32(const npg_csr *A);
 // reductions that return a scalar to the host (synchronous)
 int reduce_dot(npg_ctx *ctx, const double *x, const double *y, int64_t n, double *out);
 int reduce_maxabs(npg_ctx *ctx, const double *x, int64_t n, double *out, int *has_nan);

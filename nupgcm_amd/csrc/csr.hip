@@ -110,7 +110,7 @@ int build_tiles(npg_csr *A) {
 
 constexpr int kSpmvThreads = 512;
 
-template <int L>
+template <int L, bool F32>
 __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv(CsrDev A, const TileDesc *__restrict__ tile_ptr, int ntiles,
                                                         const double *__restrict__ x, SpmvEpi e) {
     __shared__ TileLds tl;
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv(CsrDev A, const TileDe
         const int tn = t + gridDim.x;
         TileDesc nd = td;
         if (tn < ntiles) nd = tile_ptr[tn];              // in flight during this tile
-        spmv_tile<kSpmvThreads, L>(A, PlainX{x}, td, tl, sw);
+        spmv_tile<kSpmvThreads, L, PlainX, kTileNnz, 4, NoProf, F32>(A, PlainX{x}, td, tl, sw);
         for (int r = threadIdx.x; r < td.nrows; r += kSpmvThreads) {
             const int row = td.r0 + r;
             double v = e.alpha * sw[r];
@@ -188,8 +188,33 @@ static int upload_csr(npg_ctx *ctx, int64_t m, int64_t n, std::vector<int64_t> &
 template <int L>
 static void launch_spmv(const npg_csr *A, const double *x, const SpmvEpi &e) {
     const int grid = std::min<int>(A->ntiles, 3 * A->ctx->num_cu);      // 3 x 38 KiB of LDS per CU
-    hipLaunchKernelGGL(k_spmv<L>, dim3(std::max(grid, 1)), dim3(kSpmvThreads), 0, A->ctx->stream, csr_view(A),
-                       A->tile_ptr, A->ntiles, x, e);
+    if (e.f32 && A->val32 && (A->nnode() == 0 || A->pkc32))
+        hipLaunchKernelGGL((k_spmv<L, true>), dim3(std::max(grid, 1)), dim3(kSpmvThreads), 0, A->ctx->stream, csr_view(A),
+                           A->tile_ptr, A->ntiles, x, e);
+    else
+        hipLaunchKernelGGL((k_spmv<L, false>), dim3(std::max(grid, 1)), dim3(kSpmvThreads), 0, A->ctx->stream, csr_view(A),
+                           A->tile_ptr, A->ntiles, x, e);
+}
+
+__global__ void k_to_float32(const double *__restrict__ src, float *__restrict__ dst, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (float)src[i];
+}
+
+int csr_refresh_fp32(const npg_csr *Ac) {
+    npg_csr *A = const_cast<npg_csr *>(Ac);       // the copies are a cache of val / pkc, not part of the matrix's value
+    NPG_HIP(hipSetDevice(A->ctx->device));
+    const int64_t nz = A->rnnz, nrec = A->nnode() ? A->h_prow[A->nnode()] : 0;
+    if (!A->val32) NPG_HIP(hipMalloc((void **)&A->val32, std::max<size_t>(4, (size_t)nz + 2) * sizeof(float)));
+    if (nz)
+        hipLaunchKernelGGL(k_to_float32, dim3((unsigned)std::min<int64_t>(4096, (nz + 255) / 256)), dim3(256), 0, A->ctx->stream,
+                           A->val, A->val32, nz);
+    if (nrec) {
+        if (!A->pkc32) NPG_HIP(hipMalloc((void **)&A->pkc32, (size_t)2 * nrec * sizeof(float)));
+        hipLaunchKernelGGL(k_to_float32, dim3((unsigned)std::min<int64_t>(4096, (2 * nrec + 255) / 256)), dim3(256), 0,
+                           A->ctx->stream, A->pkc, A->pkc32, 2 * nrec);
+    }
+    return NPG_OK;
 }
 
 CsrDev csr_view(const npg_csr *A) {
@@ -203,6 +228,8 @@ CsrDev csr_view(const npg_csr *A) {
     v.pkc = reinterpret_cast<const double2 *>(A->pkc);
     v.nfull = A->nfull;
     v.nsurf = A->nsurf;
+    v.val32 = A->val32;
+    v.pkc32 = reinterpret_cast<const float2 *>(A->pkc32);
     return v;
 }
 
@@ -384,6 +411,8 @@ NPG_API int npg_csr_destroy(npg_csr *A) {
     if (A->prow) hipFree(A->prow);
     if (A->pcol) hipFree(A->pcol);
     if (A->pkc) hipFree(A->pkc);
+    if (A->val32) hipFree(A->val32);
+    if (A->pkc32) hipFree(A->pkc32);
     delete A;
     return NPG_OK;
 }
@@ -660,12 +689,13 @@ int spmv_epi(const npg_csr *A, const double *x, const SpmvEpi &e) {
     return NPG_OK;
 }
 
-int spmv_raw(const npg_csr *A, const double *x, double *y, double alpha, double beta) {
+int spmv_raw(const npg_csr *A, const double *x, double *y, double alpha, double beta, int f32) {
     SpmvEpi e{};
     e.alpha = alpha;
     e.beta = beta;
     e.c = y;
     e.y = y;
+    e.f32 = f32;
     return spmv_epi(A, x, e);
 }
 }  // namespace npg

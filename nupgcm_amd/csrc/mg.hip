@@ -205,6 +205,7 @@ struct npg_precond {
     std::vector<MgLevel> L;
     double omega = 2.5, jw = 0.7;
     int sweeps = 3, nu1 = 2, nu2 = 2, coarse = 20, gamma = 1;
+    int mixed = 0;             // the cycle's SpMVs read fp32 copies of the level matrices' values (npg_precond_mg_set_mixed)
     std::vector<void *> allocs;
     // one instantiated hipGraph of the V-cycle per (input, output) address pair: flexible GMRES applies the preconditioner
     // to the same `memory` basis / Z column pairs in every restart cycle, so a cycle's ~300 launches (most of them
@@ -345,6 +346,14 @@ NPG_API int npg_precond_mg_set_coarse_dense(npg_precond *pc, int on) {
     return dense_build(pc, pc->L[0].A, on == 2);
 }
 
+// fp32 copies of one level's operators (mixed mode)
+static int mg_refresh_fp32(const MgLevel &l) {
+    int rc;
+    for (const npg_csr *M : {l.A, l.G, l.D, l.Dinv, l.S, l.P, l.R})
+        if (M && (rc = csr_refresh_fp32(M))) return rc;
+    return NPG_OK;
+}
+
 static int mg_alloc(npg_precond *pc, double **p, int64_t n) {
     NPG_HIP(hipMalloc((void **)p, std::max<size_t>(1, (size_t)n) * sizeof(double)));
     pc->allocs.push_back(*p);
@@ -386,6 +395,7 @@ NPG_API int npg_precond_mg_set_level(npg_precond *pc, int level, const npg_csr *
     if (level + 1 < (int)pc->L.size())
         if ((rc = mg_alloc(pc, &l.x, n)) || (rc = mg_alloc(pc, &l.b, n))) return rc;
     pc->n = n;      // the finest level set so far
+    if (pc->mixed && (rc = mg_refresh_fp32(l))) return rc;
     return NPG_OK;
 }
 
@@ -405,7 +415,26 @@ NPG_API int npg_precond_mg_update_level(npg_precond *pc, int level, const npg_cs
     l.A = A; l.G = G; l.D = D; l.Dinv = Dinv; l.S = S;
     npg_vec sv;
     sv.ctx = pc->ctx; sv.n = l.np; sv.d = l.sdinv; sv.owns = false;
-    return npg_csr_inv_diag(S, &sv);
+    int rc = npg_csr_inv_diag(S, &sv);
+    if (rc) return rc;
+    return pc->mixed ? mg_refresh_fp32(l) : NPG_OK;
+}
+
+// Mixed precision: the cycle's SpMVs read fp32 copies of the level operators' values (8 instead of 12 bytes per entry, 12
+// instead of 20 per node record); vectors, products and sums stay fp64, and so does the outer flexible GMRES with its
+// own SpMV - a preconditioner may be inexact.  The copies are rebuilt by npg_precond_mg_update_level.
+NPG_API int npg_precond_mg_set_mixed(npg_precond *pc, int on) {
+    NPG_REQUIRE(pc && pc->kind == NPG_PC_MG, "npg_precond_mg_set_mixed: not a multigrid preconditioner");
+    NPG_HIP(hipStreamSynchronize(pc->ctx->stream));
+    drop_graphs(pc);
+    pc->mixed = on ? 1 : 0;
+    if (pc->mixed)
+        for (const MgLevel &l : pc->L)
+            if (l.A) {
+                int rc = mg_refresh_fp32(l);
+                if (rc) return rc;
+            }
+    return NPG_OK;
 }
 
 NPG_API int npg_precond_mg_set_params(npg_precond *pc, double omega, double jacobi_weight, int schur_sweeps, int nu1,
@@ -443,30 +472,30 @@ static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int n
             r = b;                                                                   // r = b - A 0
         } else {
             SpmvEpi e{};                                                             // r = b - A x
-            e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l.r;
+            e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l.r; e.f32 = pc->mixed;
             if ((rc = spmv_epi(l.A, x, e))) return rc;
         }
-        if ((rc = spmv_raw(l.Dinv, r, l.t, 1.0, 0.0))) return rc;                    // t = Dh^-1 r_u
+        if ((rc = spmv_raw(l.Dinv, r, l.t, 1.0, 0.0, pc->mixed))) return rc;         // t = Dh^-1 r_u
         double *dp = l.dp, *dq = l.dp2;
         {
             SpmvEpi e{};                                                             // rhs = D t - w r_p ; dp = jw rhs / diag S
             e.alpha = 1.0; e.beta = -pc->omega; e.c = r + nu; e.y = l.rhs;
-            e.w = pc->jw; e.dg = l.sdinv; e.z = dp;
+            e.w = pc->jw; e.dg = l.sdinv; e.z = dp; e.f32 = pc->mixed;
             if ((rc = spmv_epi(l.D, l.t, e))) return rc;
         }
         for (int k = 1; k < pc->sweeps; ++k) {                                       // damped Jacobi on S dp = rhs
             SpmvEpi e{};                                                             // res = rhs - S dp ; dq = dp + jw res / diag S
             e.alpha = -1.0; e.beta = 1.0; e.c = l.rhs; e.y = l.res;
-            e.w = pc->jw; e.dg = l.sdinv; e.zin = dp; e.zc = 1.0; e.z = dq;
+            e.w = pc->jw; e.dg = l.sdinv; e.zin = dp; e.zc = 1.0; e.z = dq; e.f32 = pc->mixed;
             if ((rc = spmv_epi(l.S, dp, e))) return rc;
             std::swap(dp, dq);
         }
         {
             SpmvEpi e{};                                                             // t = r_u - G dp   (t is free again)
-            e.alpha = -1.0; e.beta = 1.0; e.c = r; e.y = l.t;
+            e.alpha = -1.0; e.beta = 1.0; e.c = r; e.y = l.t; e.f32 = pc->mixed;
             if ((rc = spmv_epi(l.G, dp, e))) return rc;
         }
-        if ((rc = spmv_raw(l.Dinv, l.t, x, 1.0 / pc->omega, zero ? 0.0 : 1.0))) return rc;   // x_u += Dh^-1 t / w
+        if ((rc = spmv_raw(l.Dinv, l.t, x, 1.0 / pc->omega, zero ? 0.0 : 1.0, pc->mixed))) return rc;   // x_u += Dh^-1 t / w
         axpby(c, x + nu, 1.0, dp, zero ? 0.0 : 1.0, np);                             // x_p += dp
     }
     return NPG_OK;
@@ -480,7 +509,7 @@ static int mg_cycle(npg_precond *pc, int lev, double *x, const double *b, bool x
         if (x_is_zero) return dense_apply(pc, b, x, 1.0, 0.0);
         MgLevel &l0 = pc->L[0];
         SpmvEpi e{};
-        e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l0.r;
+        e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l0.r; e.f32 = pc->mixed;
         if ((rc = spmv_epi(l0.A, x, e))) return rc;
         return dense_apply(pc, l0.r, x, 1.0, 1.0);
     }
@@ -489,16 +518,16 @@ static int mg_cycle(npg_precond *pc, int lev, double *x, const double *b, bool x
     if (pc->nu1 > 0 && (rc = mg_smooth(pc, lev, x, b, pc->nu1, x_is_zero))) return rc;
     const bool still_zero = x_is_zero && pc->nu1 == 0;
     if (still_zero) {
-        if ((rc = spmv_raw(l.R, b, lc.b, 1.0, 0.0))) return rc;
+        if ((rc = spmv_raw(l.R, b, lc.b, 1.0, 0.0, pc->mixed))) return rc;
     } else {
         SpmvEpi e{};
-        e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l.r;
+        e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l.r; e.f32 = pc->mixed;
         if ((rc = spmv_epi(l.A, x, e))) return rc;
-        if ((rc = spmv_raw(l.R, l.r, lc.b, 1.0, 0.0))) return rc;
+        if ((rc = spmv_raw(l.R, l.r, lc.b, 1.0, 0.0, pc->mixed))) return rc;
     }
     for (int g = 0; g < pc->gamma; ++g)
         if ((rc = mg_cycle(pc, lev - 1, lc.x, lc.b, g == 0))) return rc;
-    if ((rc = spmv_raw(l.P, lc.x, x, 1.0, still_zero ? 0.0 : 1.0))) return rc;
+    if ((rc = spmv_raw(l.P, lc.x, x, 1.0, still_zero ? 0.0 : 1.0, pc->mixed))) return rc;
     return mg_smooth(pc, lev, x, b, pc->nu2, false);
 }
 

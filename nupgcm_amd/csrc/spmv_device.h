@@ -48,6 +48,8 @@ struct CsrDev {
     const int32_t *pcol;      // column node c
     const double2 *pkc;       // {K, C}: A[x_q,x_c] = A[y_q,y_c] = A[z_q,z_c] = K ; A[x_q,y_c] = C ; A[y_q,x_c] = -C
     int nfull, nsurf;         // nodes with (x, y, z) rows / with (x, y) rows; block rows = 3 nfull + 2 nsurf
+    const float *val32;       // fp32 copies of val / pkc (tile functions instantiated with F32 read these; null otherwise)
+    const float2 *pkc32;
 };
 
 __device__ __forceinline__ int block_rows(const CsrDev &A) { return 3 * A.nfull + 2 * A.nsurf; }
@@ -86,7 +88,9 @@ using TileLds = TileLdsT<kTileNnz>;
 // Phase 1 + 2 for one tile of rows [r0, r1).  On return (after the trailing barrier) out[r - r0] holds (A x)[r].
 // NT = threads in the workgroup, L = lanes per row, U2 = independent entry pairs per lane and trip.
 // Inside the block rows a tile holds whole nodes of one kind (full or surface).
-template <int NT, int L, class XF, int TNNZ = kTileNnz, int U2 = 4, class PROF = NoProf>
+// F32: the matrix values come from the fp32 copies (8 instead of 12 bytes per CSR entry, 12 instead of 20 per record);
+// products and sums stay fp64.
+template <int NT, int L, class XF, int TNNZ = kTileNnz, int U2 = 4, class PROF = NoProf, bool F32 = false>
 __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const TileDesc &td, TileLdsT<TNNZ> &t,
                                           double *__restrict__ out, PROF prof = PROF()) {
     const int r0 = td.r0, nrows = td.nrows, r1 = r0 + nrows;
@@ -122,9 +126,15 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
                 const int e = e0 + u * NT;
                 if (e < npe) {
                     c[u] = __builtin_nontemporal_load(A.pcol + pbase + e);
-                    const double *p = reinterpret_cast<const double *>(A.pkc + pbase + e);
-                    kc[u].x = __builtin_nontemporal_load(p);
-                    kc[u].y = __builtin_nontemporal_load(p + 1);
+                    if (F32) {
+                        const float *p = reinterpret_cast<const float *>(A.pkc32 + pbase + e);
+                        kc[u].x = (double)__builtin_nontemporal_load(p);
+                        kc[u].y = (double)__builtin_nontemporal_load(p + 1);
+                    } else {
+                        const double *p = reinterpret_cast<const double *>(A.pkc + pbase + e);
+                        kc[u].x = __builtin_nontemporal_load(p);
+                        kc[u].y = __builtin_nontemporal_load(p + 1);
+                    }
                 } else {
                     c[u] = 0;
                     kc[u] = make_double2(0.0, 0.0);
@@ -158,11 +168,16 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
                 if (k < total && abase + k + 1 < A.nnz) {
                     const long long cc = __builtin_nontemporal_load(reinterpret_cast<const long long *>(A.col + abase + k));
                     c[u] = make_int2((int)(cc & 0xffffffffLL), (int)(cc >> 32));
-                    v[u].x = __builtin_nontemporal_load(A.val + abase + k);
-                    v[u].y = __builtin_nontemporal_load(A.val + abase + k + 1);
+                    if (F32) {
+                        v[u].x = (double)__builtin_nontemporal_load(A.val32 + abase + k);
+                        v[u].y = (double)__builtin_nontemporal_load(A.val32 + abase + k + 1);
+                    } else {
+                        v[u].x = __builtin_nontemporal_load(A.val + abase + k);
+                        v[u].y = __builtin_nontemporal_load(A.val + abase + k + 1);
+                    }
                 } else if (k < total && abase + k < A.nnz) {
                     c[u] = make_int2(A.col[abase + k], 0);
-                    v[u] = make_double2(A.val[abase + k], 0.0);
+                    v[u] = make_double2(F32 ? (double)A.val32[abase + k] : A.val[abase + k], 0.0);
                 } else {
                     c[u] = make_int2(0, 0);
                     v[u] = make_double2(0.0, 0.0);
@@ -209,7 +224,7 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
     } else {
         // one very long (plain CSR) row: the whole workgroup strides over it, tree-reduce through LDS
         double s = 0.0;
-        for (int k = threadIdx.x; k < n; k += NT) s += A.val[base + k] * x(A.col[base + k]);
+        for (int k = threadIdx.x; k < n; k += NT) s += (F32 ? (double)A.val32[base + k] : A.val[base + k]) * x(A.col[base + k]);
         s = wave_sum(s);
         __syncthreads();
         if ((threadIdx.x & 63) == 0) t.prod[threadIdx.x >> 6] = s;

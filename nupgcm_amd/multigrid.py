@@ -272,8 +272,11 @@ class MultigridPreconditioner(GeneralPreconditioner):
     re-discretised on their own meshes."""
 
     def __init__(self, arch, params, forcings, hierarchy, A_fine: DeviceCSR = None, omega=2.5, jacobi_weight=0.7,
-                 schur_sweeps=3, nu1=2, nu2=2, coarse_sweeps=20, block_nodes=None, cycle="V", coarse_dense=None):
-        """coarse_dense: solve the coarsest level exactly with its dense inverse (DenseInversePreconditioner's machinery)
+                 schur_sweeps=3, nu1=2, nu2=2, coarse_sweeps=20, block_nodes=None, cycle="V", coarse_dense=None,
+                 mixed=False):
+        """mixed: the cycle's SpMVs read fp32 copies of the level operators' values (npg_precond_mg_set_mixed); vectors,
+        sums and the outer flexible GMRES stay fp64.
+        coarse_dense: solve the coarsest level exactly with its dense inverse (DenseInversePreconditioner's machinery)
         instead of `coarse_sweeps` smoothing steps; None = whenever a hierarchy's coarsest level has <= 40 000 unknowns
         (<= 12 GiB; measured at 2.15 M unknowns: 19 instead of 32 iterations for a cold solve, 88 instead of 128 ms).
         A function-valued nu (full-stress form) is re-discretised on every level like a constant one.  With the eddy closure
@@ -317,6 +320,9 @@ class MultigridPreconditioner(GeneralPreconditioner):
         if self._dense_mode:
             L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, self._dense_mode))
         self.coarse_dense = bool(coarse_dense)
+        self.mixed = bool(mixed)
+        if self.mixed:
+            L.check(L.lib().npg_precond_mg_set_mixed(self.h, 1))
         self._inj = None
         if forcings.eddy_param.is_on and len(hierarchy) > 1:      # what refresh() needs, computed at set-up
             p1 = self._top.spaces.b_order == 1
@@ -362,7 +368,8 @@ class MultigridPreconditioner(GeneralPreconditioner):
 
     def __repr__(self):
         return (f"MultigridPreconditioner({[lv['n'] for lv in self.levels]}, {self.params}, "
-                f"coarsest level: {'dense inverse' if self.coarse_dense else 'smoothing steps'})")
+                f"coarsest level: {'dense inverse' if self.coarse_dense else 'smoothing steps'}"
+                f"{', fp32 operator values inside the cycle' if self.mixed else ''})")
 
 
 class FgmresWorkspace:

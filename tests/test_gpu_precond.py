@@ -260,6 +260,36 @@ def test_multigrid_with_exact_coarse_solve(arch, two_level):
             assert rel(z, zr) > 1e-10                            # the fp32 copy is really what ran
 
 
+def test_multigrid_with_fp32_operator_values(arch, two_level):
+    """mixed=True: the cycle's SpMVs read fp32 copies of the level operators (plain CSR and node-block storage); one
+    application agrees with the fp64 cycle to fp32 rounding (and differs from it: the copies are what ran), the outer
+    flexible GMRES - fp64 throughout - takes the same number of iterations to the same tolerance."""
+    prm, frc, hier, A, As, P = two_level
+    n = As.shape[0]
+    ctx = arch.ctx
+    r = np.sin(np.arange(n) * 0.37) + 0.1
+    z64 = P.apply(npg.DeviceVector.from_host(ctx, r), npg.DeviceVector(ctx, n)).to_host()
+    fed = hier[-1]
+    y = npg.build_B_inversion(arch, fed, prm).to_scipy_csr() @ fed.spaces.interpolate_b(
+        lambda x: 0.1 * np.exp(-(x[..., 2] + prm.H(x)) / (0.1 * prm.alpha)))[fed.dofs.p_b]
+    scale = 1.0 / fed.mesh.median_edge_length() ** 3
+    ws = npg.FgmresWorkspace(ctx, n)
+    x0 = npg.DeviceVector(ctx, n)
+    st0 = ws.solve(A, npg.DeviceVector.from_host(ctx, y), x0, P, atol=1e-6, rtol=1e-6, scale=scale)
+    for blocks in (False, True):
+        Ab = A
+        if blocks:
+            Ab = npg.build_A_inversion(arch, fed, prm, frc.nu)
+            assert Ab.block_nodes(fed.dofs.n_full, fed.dofs.n_surf)
+        Pm = mgm.MultigridPreconditioner(arch, prm, frc, hier, A_fine=Ab, block_nodes=False, coarse_dense=False, mixed=True)
+        z32 = Pm.apply(npg.DeviceVector.from_host(ctx, r), npg.DeviceVector(ctx, n)).to_host()
+        assert 1e-12 < rel(z32, z64) < 1e-5, rel(z32, z64)
+        x1 = npg.DeviceVector(ctx, n)
+        st1 = ws.solve(Ab, npg.DeviceVector.from_host(ctx, y), x1, Pm, atol=1e-6, rtol=1e-6, scale=scale)
+        assert st1["solved"] == 1 and abs(st1["niter"] - st0["niter"]) <= 1, (st0, st1)
+        assert scale * np.linalg.norm(y - As @ x1.to_host()) <= 1.001 * (1e-6 + 1e-6 * scale * np.linalg.norm(y))
+
+
 def test_preconditioner_abi_argument_errors(arch):
     """the round-2 entry points validate on the host like the rest of the ABI: wrong shapes, wrong order of set-up calls, index
     maps out of range, node-block patterns that do not match - status code + message, never a device fault"""

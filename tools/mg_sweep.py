@@ -28,6 +28,8 @@ from nupgcm_amd import _lib as L  # noqa: E402
 for kw in combos:
     kw = dict(kw)
     L.check(L.lib().npg_precond_mg_set_coarse_dense(P.h, int(kw.pop("coarse_dense", 0))))
+    mixed = int(kw.pop("mixed", 0))
+    L.check(L.lib().npg_precond_mg_set_mixed(P.h, mixed))
     P.set_params(**kw)
     s.x.fill(0.0)
     npg.invert(m)
@@ -35,5 +37,6 @@ for kw in combos:
     h = s.workspace.history()
     rate = (h[-1] / h[0]) ** (1.0 / max(len(h) - 1, 1))
     print("   history every 10:", " ".join(f"{v / h[0]:.1e}" for v in h[::10]), flush=True)
+    kw["mixed"] = mixed
     print(f"{kw}: solved={st['solved']} its={st['niter']} {1e3 * st['seconds']:.1f} ms  ({1e3 * st['seconds'] / max(st['niter'], 1):.2f} ms/it)"
           f"  residual x{h[-1] / h[0]:.2e}, mean factor per iteration {rate:.3f}", flush=True)
