@@ -103,6 +103,9 @@ struct npg_csr {
     // optional fp32 copies of the values (csr_refresh_fp32): read instead of val / pkc by SpMVs that ask for them
     // (SpmvEpi::f32 - the multigrid preconditioner's; results are still accumulated and returned in fp64)
     float *val32 = nullptr, *pkc32 = nullptr;
+    // bumped whenever a pointer or count that kernels (and hence captured hipGraphs) bake in changes: build_tiles,
+    // npg_csr_block_nodes, the first csr_refresh_fp32.  Holders of captured graphs compare it (mg.hip).
+    uint64_t gen = 0;
     int64_t nnode() const { return (int64_t)nfull + nsurf; }
     int64_t block_rows() const { return 3 * (int64_t)nfull + 2 * (int64_t)nsurf; }
 };

@@ -1,4 +1,9 @@
 // Context, device vectors and the BLAS-1 / broadcast entry points of the C ABI.
+#include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include <cmath>
 
 #include "common.h"
@@ -159,8 +164,53 @@ using namespace npg;
 // ---- context ----------------------------------------------------------------------------------------------------------
 NPG_API const char *npg_last_error(void) { return g_err; }
 
+// NPG_SEGV_BACKTRACE=1 (diagnostics; used to symbolise the rocprofv3 hipGraphLaunch fault): on SIGSEGV
+// print the faulting address, the mapping that holds / ends at it and every frame with its module and offset, then exit.
+static void maps_line(const void *addr) {
+    FILE *f = fopen("/proc/self/maps", "r");
+    if (!f) return;
+    char line[512];
+    while (fgets(line, sizeof line, f)) {
+        unsigned long lo, hi;
+        if (sscanf(line, "%lx-%lx", &lo, &hi) == 2 && (unsigned long)addr >= lo && (unsigned long)addr < hi) {
+            fprintf(stderr, "      maps: %s", line);
+            break;
+        }
+    }
+    fclose(f);
+}
+static void on_segv(int, siginfo_t *si, void *) {
+    fprintf(stderr, "\n*** [npg] SIGSEGV at address %p\n    mappings below / at the faulting address:\n", si->si_addr);
+    maps_line((const char *)si->si_addr - 1);
+    maps_line(si->si_addr);
+    void *fr[64];
+    const int n = backtrace(fr, 64);
+    for (int i = 0; i < n; ++i) {
+        Dl_info di;
+        if (dladdr(fr[i], &di) && di.dli_fname)
+            fprintf(stderr, "  #%d %p  %s + 0x%lx  (%s)\n", i, fr[i], di.dli_fname,
+                    (unsigned long)((char *)fr[i] - (char *)di.dli_fbase), di.dli_sname ? di.dli_sname : "?");
+        else
+            fprintf(stderr, "  #%d %p  ?\n", i, fr[i]);
+    }
+    _exit(139);
+}
+static void maybe_install_segv_handler() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const char *t = getenv("NPG_SEGV_BACKTRACE");
+    if (!t || atoi(t) == 0) return;
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_sigaction = on_segv;
+    sa.sa_flags = SA_SIGINFO;
+    sigaction(SIGSEGV, &sa, nullptr);
+}
+
 NPG_API int npg_ctx_create(int device, npg_ctx **out) {
     NPG_REQUIRE(out != nullptr, "npg_ctx_create: out is NULL");
+    maybe_install_segv_handler();
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
         set_error("npg_ctx_create: no HIP device visible - libnupgcm_hip has no CPU fallback");

@@ -81,6 +81,7 @@ int build_tiles(npg_csr *A) {
         }
     }
     if (A->tile_ptr) NPG_HIP(hipFree(A->tile_ptr));
+    A->gen++;
     NPG_HIP(hipMalloc((void **)&A->tile_ptr, std::max<size_t>(1, td.size()) * sizeof(TileDesc)));
     NPG_HIP(hipMemcpy(A->tile_ptr, td.data(), td.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
     A->ntiles_interior = A->ntiles;
@@ -205,7 +206,10 @@ int csr_refresh_fp32(const npg_csr *Ac) {
     npg_csr *A = const_cast<npg_csr *>(Ac);       // the copies are a cache of val / pkc, not part of the matrix's value
     NPG_HIP(hipSetDevice(A->ctx->device));
     const int64_t nz = A->rnnz, nrec = A->nnode() ? A->h_prow[A->nnode()] : 0;
-    if (!A->val32) NPG_HIP(hipMalloc((void **)&A->val32, std::max<size_t>(4, (size_t)nz + 2) * sizeof(float)));
+    if (!A->val32) {
+        NPG_HIP(hipMalloc((void **)&A->val32, std::max<size_t>(4, (size_t)nz + 2) * sizeof(float)));
+        A->gen++;
+    }
     if (nz)
         hipLaunchKernelGGL(k_to_float32, dim3((unsigned)std::min<int64_t>(4096, (nz + 255) / 256)), dim3(256), 0, A->ctx->stream,
                            A->val, A->val32, nz);

@@ -37,8 +37,8 @@ static inline int grid_for(int64_t n, int cap = 2048) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
 }
 
-// y = a x + b y (b == 0: y is not read)
-__global__ void k_mg_axpby(double *__restrict__ y, double a, const double *__restrict__ x, double b, int64_t n) {
+// y = a x + b y (b == 0: y is not read).  x may BE y (in-place scaling by flexible GMRES): no __restrict__ here.
+__global__ void k_mg_axpby(double *y, double a, const double *x, double b, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
 }
@@ -211,6 +211,7 @@ struct npg_precond {
     // to the same `memory` basis / Z column pairs in every restart cycle, so a cycle's ~300 launches (most of them
     // latency-bound coarse-level kernels) are enqueued by one hipGraphLaunch
     std::map<std::pair<const double *, double *>, hipGraphExec_t> graphs;
+    uint64_t graphs_gen = 0;   // sum of the borrowed level matrices' generation counters when the graphs were captured
     bool use_graphs = true;
     // block diagonal
     std::vector<BlockPc> blocks;
@@ -293,9 +294,18 @@ static int dense_build(npg_precond *pc, const npg_csr *A, bool fp32) {
     hipLaunchKernelGGL(k_densify, dim3(grid_for(n)), dim3(kBlock), 0, st, A->rowptr, A->col, A->val, n, d.M);
     NPG_HIP(hipGetLastError());
     rocblas_handle h = nullptr;
+    rocblas_int *ipiv = nullptr, *info = nullptr;
+    struct Guard {                       // every early return below releases the handle and the temporaries
+        rocblas_handle &h;
+        rocblas_int *&ipiv, *&info;
+        ~Guard() {
+            if (ipiv) hipFree(ipiv);
+            if (info) hipFree(info);
+            if (h) rocblas_destroy_handle(h);
+        }
+    } guard{h, ipiv, info};
     NPG_REQUIRE(rocblas_create_handle(&h) == rocblas_status_success, "dense inverse: rocblas_create_handle failed");
     rocblas_set_stream(h, st);
-    rocblas_int *ipiv = nullptr, *info = nullptr;
     NPG_HIP(hipMalloc((void **)&ipiv, (size_t)n * sizeof(rocblas_int)));
     NPG_HIP(hipMalloc((void **)&info, sizeof(rocblas_int)));
     rocblas_status s1 = rocsolver_dgetrf(h, (rocblas_int)n, (rocblas_int)n, d.M, (rocblas_int)n, ipiv, info);
@@ -308,9 +318,6 @@ static int dense_build(npg_precond *pc, const npg_csr *A, bool fp32) {
         NPG_HIP(hipMemcpyAsync(&i2, info, sizeof i2, hipMemcpyDeviceToHost, st));
         NPG_HIP(hipStreamSynchronize(st));
     }
-    hipFree(ipiv);
-    hipFree(info);
-    rocblas_destroy_handle(h);
     NPG_REQUIRE(s1 == rocblas_status_success && i1 == 0 && s2 == rocblas_status_success && i2 == 0,
                 "dense inverse: rocSOLVER getrf/getri failed (status %d/%d, info %d/%d: the matrix is singular to working "
                 "precision, or out of memory)", (int)s1, (int)s2, (int)i1, (int)i2);
@@ -560,6 +567,17 @@ static int precond_apply_raw(npg_precond *pc, const double *r, double *z) {
         const int top = (int)pc->L.size() - 1;
         if (!pc->use_graphs) return mg_vcycle(pc, top, z, r);
         hipStream_t st = pc->ctx->stream;
+        // the captured cycles bake in the borrowed matrices' tile tables and value arrays: a matrix whose layout was
+        // rebuilt since (build_tiles, block_nodes, first fp32 copy) invalidates them.  (A borrowed matrix must outlive the
+        // preconditioner or be replaced through the setters, which drop the graphs.)
+        uint64_t gsum = 0;
+        for (const MgLevel &lv : pc->L)
+            for (const npg_csr *M : {lv.A, lv.G, lv.D, lv.Dinv, lv.S, lv.P, lv.R})
+                if (M) gsum += M->gen;
+        if (gsum != pc->graphs_gen) {
+            drop_graphs(pc);
+            pc->graphs_gen = gsum;
+        }
         auto key = std::make_pair(r, z);
         auto it = pc->graphs.find(key);
         if (it == pc->graphs.end()) {
@@ -568,11 +586,15 @@ static int precond_apply_raw(npg_precond *pc, const double *r, double *z) {
             NPG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             const int rcv = mg_vcycle(pc, top, z, r);
             const hipError_t ec = hipStreamEndCapture(st, &g);
-            if (rcv) return rcv;
+            if (rcv || ec != hipSuccess) {
+                if (g) hipGraphDestroy(g);
+                if (rcv) return rcv;
+            }
             NPG_HIP(ec);
             hipGraphExec_t ex = nullptr;
-            NPG_HIP(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+            const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
             hipGraphDestroy(g);
+            NPG_HIP(ei);
             it = pc->graphs.emplace(key, ex).first;
         }
         NPG_HIP(hipGraphLaunch(it->second, st));
@@ -669,7 +691,14 @@ NPG_API int npg_fgmres_solve(npg_fgmres *ws, const npg_csr *A, npg_precond *pc, 
     NPG_REQUIRE(scale > 0 && atol >= 0 && rtol >= 0, "npg_fgmres_solve: bad tolerance / scale");
     npg_ctx *c = ws->ctx;
     hipStream_t st = c->stream;
-    hipEvent_t e0, e1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct EvGuard {
+        hipEvent_t &a, &b;
+        ~EvGuard() {
+            if (a) hipEventDestroy(a);
+            if (b) hipEventDestroy(b);
+        }
+    } evguard{e0, e1};
     NPG_HIP(hipEventCreate(&e0));
     NPG_HIP(hipEventCreate(&e1));
     NPG_HIP(hipEventRecord(e0, st));
@@ -780,8 +809,6 @@ NPG_API int npg_fgmres_solve(npg_fgmres *ws, const npg_csr *A, npg_precond *pc, 
     NPG_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
     NPG_HIP(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
     stats->seconds = ms * 1e-3;
     stats->solved = solved ? 1 : 0;
     stats->niter = (int32_t)it;

@@ -6,8 +6,9 @@ reads it - so checkpoints can be exchanged with the reference in both directions
 directly).  A path ending in `.npz` selects a NumPy archive with the same four names instead (the committed fixtures under
 tests/golden/state_*.npz use it).  `save_vtk` writes an unstructured-grid `.vtu` (ASCII XML) with quadratic tetrahedra, as
 `writevtk(...; order=2)` does: u at the P2 nodes, p (P1, interpolated to the edge mid-points), the full buoyancy N2 z + b
-and the time as field data (the reference's extra diagnostic cell fields alpha b_z, nu, kappa_v - src/IO.jl:38-52 - are not
-written)."""
+and the time as field data, plus the reference's derived fields alpha b_z, nu, kappa_v (src/IO.jl:28-52; nodal recovery of
+b_z, closure formulas of src/inputs.jl).  `set_out_dir` mirrors set_out_dir! (src/nuPGCM.jl:26-54): run!'s n_save checkpoints
+go to <out_dir>/data/state_<i>.jld2 / .vtu (src/model.jl:194-197)."""
 from __future__ import annotations
 
 import numpy as np
@@ -15,6 +16,26 @@ import numpy as np
 # VTK_QUADRATIC_TETRA (type 24) lists the edge nodes as (0,1) (1,2) (0,2) (0,3) (1,3) (2,3); fe.Mesh numbers a cell's edges
 # (0,1) (0,2) (1,2) (0,3) (1,3) (2,3)
 _VTK_P2 = np.array([0, 1, 2, 3, 4, 6, 5, 7, 8, 9])
+
+out_dir = "."          # src/nuPGCM.jl:26
+
+
+def set_out_dir(d):
+    """set_out_dir!(dir) - src/nuPGCM.jl:36-54: creates dir, dir/images and dir/data"""
+    import os
+    global out_dir
+    out_dir = str(d)
+    for sub in ("", "images", "data"):
+        os.makedirs(os.path.join(out_dir, sub), exist_ok=True)
+    return out_dir
+
+
+def save_checkpoint(model, i):
+    """What run! does every n_save steps (src/model.jl:194-197): state_%016d.jld2 + state_%016d.vtu under out_dir/data."""
+    import os
+    os.makedirs(os.path.join(out_dir, "data"), exist_ok=True)
+    base = os.path.join(out_dir, "data", "state_%016d" % i)
+    return save_state(model, base + ".jld2"), save_vtk(model, base + ".vtu")
 
 
 def save_state(model, ofile):

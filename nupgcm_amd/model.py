@@ -125,7 +125,9 @@ def evolve(model: Model, x_inv_prev: DeviceVector, b_prev: DeviceVector):
 
 def run(model: Model, n_info=10, n_save=float("inf"), n_plot=float("inf"), advection=True, n_steps=None, log=None):
     """run!(model; n_info, n_save, n_plot, advection) - src/model.jl:90-211.  `n_steps` (extension) bounds the number of
-    steps taken by this call so that a caller can time a fixed number of steps; state carries over between calls."""
+    steps taken by this call so that a caller can time a fixed number of steps; state carries over between calls.
+    Every n_save steps the state goes to <out_dir>/data/state_<i>.jld2 and .vtu (src/model.jl:194-197, io.set_out_dir);
+    n_plot is accepted and ignored: sim_plots is plotting (out of scope)."""
     ts, prm, frc = model.timestepper, model.params, model.forcings
     inv_x, b = model.inversion.solver.x, model.b_vec
     fe = model.evolution.fe
@@ -177,6 +179,10 @@ def run(model: Model, n_info=10, n_save=float("inf"), n_plot=float("inf"), advec
             log(f"t = {ts.t:.3e}/{ts.t_stop:.3e} (i = {i}, Δt = {ts.dt:.3e}); step ~ {(t1 - t_last) / n_info:.3e} s; "
                 f"|u|max = {xm:.3e}; GMRES it = {model.stats[-1][1]['niter']}, CG it = {model.stats[-1][0]['niter']}")
             t_last = t1
+        if n_save != float("inf") and i % int(n_save) == 0:                                     # src/model.jl:194-197
+            from . import io as _io
+            if getattr(ctx, "rank", 0) == 0:
+                _io.save_checkpoint(model, i)
         model.step_index += 1
         taken += 1
     ctx.sync()

@@ -78,11 +78,14 @@ class BlockDiagonalPreconditioner(GeneralPreconditioner):
     def __init__(self, arch, params, fe_data, A_inversion=None, u_itmax=100, p_itmax=0, atol=1e-6, rtol=1e-6):
         super().__init__(arch.ctx, L.NPG_PC_BLOCKDIAG, 2)
         d, ctx = fe_data.dofs, arch.ctx
-        fe = device_fe(arch, fe_data)
+        # a PRIVATE assembly engine: the friction-only matrix needs nu = 1, f = 0, and the engine cached per FEData is
+        # shared with the solver (a later build_A_inversion(..., nu=None) keeps whatever table the device holds)
+        from .assembly import DeviceFE
+        fe = DeviceFE(ctx, fe_data)
         fe.set_coeff("nu", 1.0)
         fe.set_coeff("f", 0.0)                                       # friction_only = true
         Afr = fe.assemble(L.NPG_MAT_A, fe.new_matrix("A"), scale=params.alpha ** 2 * params.eps ** 2).to_scipy_csr()
-        fe.set_coeff("f", params.f)
+        del fe
         F = sp.csr_matrix(Afr[:d.nu, :d.nu])
         F.eliminate_zeros()                                          # dropzeros!(A)  (:80)
         T = pressure_mass_matrix(fe_data) / (params.alpha ** 2 * params.eps ** 2)

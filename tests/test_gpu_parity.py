@@ -854,6 +854,25 @@ def test_full_size_properties(arch):
     assert abs(np.linalg.norm(r) / h ** 3 - st["rnorm"]) <= 1e-6 * st["rnorm0"] + 1e-6 * st["rnorm"]
 
 
+def test_run_saves_checkpoints_every_n_save(arch, tmp_path):
+    """run!(model; n_save) - src/model.jl:194-197: state_%016d.jld2 and .vtu under <out_dir>/data every n_save steps
+    (set_out_dir!, src/nuPGCM.jl:36-54); the last checkpoint holds the state the run ended with."""
+    out = npg.set_out_dir(str(tmp_path / "sim"))
+    try:
+        assert os.path.isdir(os.path.join(out, "data")) and os.path.isdir(os.path.join(out, "images"))
+        m = build_model("bowl_surface_flux")
+        npg.run(m, n_steps=4, n_save=2)
+        names = sorted(os.listdir(os.path.join(out, "data")))
+        assert names == ["state_%016d.%s" % (i, e) for i in (2, 4) for e in ("jld2", "vtu")]
+        m2 = build_model("bowl_surface_flux")
+        npg.set_state_from_file(m2, os.path.join(out, "data", "state_%016d.jld2" % 4))
+        assert np.array_equal(m2.state.u, m.state.u) and np.array_equal(m2.state.b, m.state.b)
+        assert m2.timestepper.t == m.timestepper.t
+    finally:
+        from nupgcm_amd import io as npg_io
+        npg_io.out_dir = "."
+
+
 def test_checkpoint_and_vtk(arch, golden_dir, tmp_path):
     """save_state / set_state_from_file! / save_vtk (src/IO.jl:1-59): a checkpoint restores {u, p, b, t} exactly, a run
     resumed from it is bit-reproducible, the reference's own state files load, and the .vtu holds the quadratic mesh and fields."""
