@@ -354,6 +354,16 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a.workload, base_model, a.dt, gm_its, cg_its, a.cpu_seconds, A_host=A_host,
                                            h=model.fe_data.mesh.median_edge_length() if big else None,
                                            ncell=int(model.fe_data.mesh.ncell))
+    if dist is not None:
+        # evidence of the communicator the timed region used: ncclCommCount / rank / device as RCCL reports them, the
+        # transport of the in-cycle halo and all-reduce, and every rank's share of the system
+        mine = dict(ctx.comm_info(), **getattr(model, "comm_layout", {}))
+        infos = [None] * world
+        dist.all_gather_object(infos, mine)
+        out["comm"] = {"rccl_ranks": infos[0].get("rccl_ranks"), "in_cycle_transport": infos[0].get("in_cycle_transport"),
+                       "cycle_replayed_from_hipgraph": bool(infos[0].get("in_cycle_transport") == "peer"
+                                                           and os.environ.get("NPG_DIST_GRAPH", "1") != "0"),
+                       "ranks": infos}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -330,6 +330,8 @@ int npg_fe_cfl_ratio(npg_fe *fe, const double *h_cells_host, double u_min, const
 #define NPG_UNIQUE_ID_BYTES 128
 int npg_comm_unique_id(void *id128);                                  /* rank 0 makes it, the launcher broadcasts it */
 int npg_comm_init(npg_ctx *ctx, const void *id128, int rank, int nranks);
+/* one line of JSON about the communicator: rank, nranks, rccl_ranks (ncclCommCount), device, in_cycle_transport */
+int npg_comm_info(npg_ctx *ctx, char *buf, size_t cap);
 int npg_comm_allreduce_sum(npg_ctx *ctx, double *host_inout, int n);  /* tiny host-side helper for tests/bench */
 /* Replicate a row-block distributed vector on every rank: segment s of `full` ([global_off, global_off + len)) is owned
  * by rank seg_rank[s], who holds it at local[local_off ..].  One grouped ncclBroadcast per segment over xGMI. */

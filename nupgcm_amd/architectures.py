@@ -84,6 +84,13 @@ class Context:
         L.check(L.lib().npg_comm_init(self.h, buf, rank, nranks))
         self.rank, self.nranks = rank, nranks
 
+    def comm_info(self):
+        """dict describing the communicator: rank, nranks, rccl_ranks (ncclCommCount), device, in_cycle_transport"""
+        import json
+        buf = C.create_string_buffer(1024)
+        L.check(L.lib().npg_comm_info(self.h, buf, 1024))
+        return json.loads(buf.value.decode())
+
     def allreduce_sum(self, values):
         a = np.ascontiguousarray(values, dtype=np.float64).copy()
         L.check(L.lib().npg_comm_allreduce_sum(self.h, a.ctypes.data_as(C.POINTER(C.c_double)), a.size))

@@ -195,7 +195,7 @@ struct npg_cg {
     CParams *h_prm = nullptr;
     int64_t hist_len = 0;
     npg_halo *halo = nullptr;
-    double *Rg = nullptr;          // 2 doubles: all-reduced p'Ap and r'z (distributed mode)
+    double *Rg = nullptr;          // 2 rows of kPartStride doubles: all-reduced p'Ap and r'z in their first entries (distributed mode)
     int64_t n_ghost = 0;
     static constexpr int kMaxG = npg::kMaxG;
 };
@@ -250,15 +250,15 @@ NPG_API int npg_cg_set_halo(npg_cg *ws, npg_halo *h) {
     NPG_HIP(hipMalloc((void **)&ws->p, nb));
     NPG_HIP(hipMemset(ws->p, 0, nb));
     if (h && !ws->Rg) {
-        NPG_HIP(hipMalloc((void **)&ws->Rg, 2 * sizeof(double)));
-        NPG_HIP(hipMemset(ws->Rg, 0, 2 * sizeof(double)));
+        NPG_HIP(hipMalloc((void **)&ws->Rg, 2 * kPartStride * sizeof(double)));
+        NPG_HIP(hipMemset(ws->Rg, 0, 2 * kPartStride * sizeof(double)));
     }
     return NPG_OK;
 }
 
+// fold the partial rows and sum over the ranks: one kernel on the peer transport (comm.hip), fold + collective otherwise
 static int cg_dist_reduce(npg_cg *ws, const double *part, int nrows, int slot, hipStream_t st) {
-    hipLaunchKernelGGL(k_cg_reduce_rows, dim3(1), dim3(kKB), 0, st, part, nrows, ws->Rg + slot);
-    return allreduce_sum_device(ws->ctx, ws->Rg + slot, 1);
+    return fold_allreduce_rows(ws->ctx, part, nrows, ws->Rg + slot * kPartStride, st);
 }
 
 template <int L>
@@ -270,7 +270,7 @@ static int cg_run(npg_cg *ws, const CDev &d, int64_t itmax, CSnap *last) {
     hipLaunchKernelGGL(k_cg_init<L>, dim3(d.G1), dim3(kKB), 0, st, d);
     if (dist && (rc = cg_dist_reduce(ws, d.Pg, d.G1, 1, st))) return rc;
     // slot 0 = initial state; r'z comes from the init kernel's G1 partial rows (or from the all-reduced scalar)
-    hipLaunchKernelGGL(k_cg_direction, dim3(d.G2), dim3(kKB), 0, st, d, 0, 1, dist ? ws->Rg + 1 : d.Pg, dist ? 1 : d.G1);
+    hipLaunchKernelGGL(k_cg_direction, dim3(d.G2), dim3(kKB), 0, st, d, 0, 1, dist ? ws->Rg + kPartStride : d.Pg, dist ? 1 : d.G1);
     int cur = 1;
     const int chunk = 4;
     int64_t it = 0;
@@ -285,7 +285,7 @@ static int cg_run(npg_cg *ws, const CDev &d, int64_t itmax, CSnap *last) {
             if (dist && (rc = cg_dist_reduce(ws, d.Pp, d.G1, 0, st))) return rc;
             hipLaunchKernelGGL(k_cg_update, dim3(d.G2), dim3(kKB), 0, st, d, cur);
             if (dist && (rc = cg_dist_reduce(ws, d.Pg, d.G2, 1, st))) return rc;
-            hipLaunchKernelGGL(k_cg_direction, dim3(d.G2), dim3(kKB), 0, st, d, cur, cur ^ 1, dist ? ws->Rg + 1 : d.Pg,
+            hipLaunchKernelGGL(k_cg_direction, dim3(d.G2), dim3(kKB), 0, st, d, cur, cur ^ 1, dist ? ws->Rg + kPartStride : d.Pg,
                                dist ? 1 : d.G2);
             cur ^= 1;
         }
@@ -351,6 +351,7 @@ NPG_API int npg_cg_solve(npg_cg *ws, const npg_csr *A, int precond_kind, double 
         default: rc = cg_run<32>(ws, d, itmax, &last); break;
     }
     if (rc) return rc;
+    if (ws->halo && (rc = comm_check(ctx))) return rc;
     ws->hist_len = std::min<int64_t>((int64_t)last.iter + 1, ws->hist_cap);
     if (stats) {
         stats->solved = (last.done == 1 || last.done == 4) ? 1 : 0;

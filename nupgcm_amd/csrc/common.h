@@ -67,6 +67,7 @@ struct npg_ctx {
     // communicator (RCCL), opaque here
     void *comm = nullptr;
     void *shm = nullptr;    // loop-back rehearsal transport (NPG_COMM_TRANSPORT=shm, comm.hip)
+    void *peer = nullptr;   // peer-mapped windows (comm.hip, PeerComm): in-cycle halo / all-reduce by xGMI stores + flags
     int rank = 0, nranks = 1;
 };
 
@@ -123,6 +124,7 @@ struct npg_halo {
     hipStream_t cstream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
     double *pending_x = nullptr;   // vector of the exchange begun by halo_exchange_async()
+    void *pw = nullptr;            // peer-transport part of the plan (comm.hip, HaloPeer); null for RCCL / shm
 };
 
 namespace npg {
@@ -134,6 +136,14 @@ int halo_exchange_raw(npg_halo *h, double *x);
 int halo_exchange_async(npg_halo *h, double *x);
 int halo_exchange_wait(npg_halo *h);
 int allreduce_sum_device(npg_ctx *ctx, double *buf, int n);
+// fold `nrows` partial rows of kPartStride doubles into one row and sum it over the ranks into out[0 .. kPartStride):
+// one kernel on the peer transport (fold + push + poll), fold kernel + collective otherwise
+int fold_allreduce_rows(npg_ctx *ctx, const double *part, int nrows, double *out, hipStream_t st);
+// true when every in-cycle communication call only launches kernels on HIP streams (the peer transport): a solver may
+// then capture its distributed cycle into a hipGraph without any library's captured nodes
+bool comm_is_kernel_only(const npg_ctx *ctx);
+// NPG_OK, or NPG_ECOMM when a device-side wait of the peer transport has timed out since the communicator was created
+int comm_check(const npg_ctx *ctx);
 int ensure_stage(npg_ctx *ctx, size_t doubles);
 int build_tiles(npg_csr *A);
 // tile boundaries (consecutive whole rows, at most tile_slots LDS product slots) for any tile size: tuning harness

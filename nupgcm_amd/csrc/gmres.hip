@@ -660,7 +660,8 @@ struct npg_gmres {
     bool safe_mode = false;       // one GPU: a solve in fast mode met a column that was due a second Gram-Schmidt pass
     int split_mode = -1;
     int halo_overlap = 1;         // distributed split cycle: interior tiles beside the halo exchange (npg_gmres_set_dist_options)
-    int dist_graph = 0;           // distributed cycles replayed from a hipGraph that holds the RCCL calls (opt-in)
+    int dist_graph = -1;          // distributed cycles replayed from a hipGraph: -1 = default (on for the kernel-only peer
+                                  // transport, off with RCCL calls in the cycle), 0 = off, 1 = on
     std::vector<hipEvent_t> pev;
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
@@ -672,8 +673,9 @@ struct npg_gmres {
 // fold one set of partial rows into a single row (split and distributed modes) and sum it over the ranks (distributed)
 static int fold_rows(npg_gmres *ws, const double *part, int nrows, int slot, hipStream_t st, bool dist) {
     double *out = ws->Rg + slot * kKP;
+    if (dist) return fold_allreduce_rows(ws->ctx, part, nrows, out, st);     // peer transport: fold + exchange in ONE kernel
     hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(1024), 0, st, part, nrows, out);
-    return dist ? allreduce_sum_device(ws->ctx, out, kKP) : NPG_OK;
+    return NPG_OK;
 }
 
 template <int NG>
@@ -962,18 +964,24 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     static const int eager = getenv("NPG_GMRES_EAGER") ? atoi(getenv("NPG_GMRES_EAGER")) : traced;
     static const int trace = getenv("NPG_GMRES_TRACE") ? atoi(getenv("NPG_GMRES_TRACE")) : 0;
 
-    // Distributed cycles are launched eagerly unless asked otherwise: RCCL calls can be captured (the exchange stream
-    // forks from and joins the captured stream through the plan's events), but a captured collective has only been run on
-    // a one-rank communicator so far (tests/rccl_selftest_worker.py) - NPG_DIST_GRAPH=1 / npg_gmres_set_dist_options opt in.
-    static const int dist_graph_env = getenv("NPG_DIST_GRAPH") ? atoi(getenv("NPG_DIST_GRAPH")) : 0;
-    const bool graph_dist = dist && (ws->dist_graph || dist_graph_env) && ws->ctx->comm && !ws->ctx->shm;
+    // Distributed cycles.  On the peer transport (comm.hip) every communication step is a kernel on a HIP stream, so the
+    // cycle replays from one hipGraph exactly like the single-GPU cycle - the default there (NPG_DIST_GRAPH=0 turns it off).
+    // With RCCL in the cycle the calls can be captured too (the exchange stream forks from and joins the captured stream
+    // through the plan's events), but a captured collective costs more than an eager one and has only
+    // run on a one-rank communicator: opt-in (NPG_DIST_GRAPH=1 / npg_gmres_set_dist_options).  The host-driven shm
+    // rehearsal transport cannot be captured.
+    static const int dist_graph_env = getenv("NPG_DIST_GRAPH") ? atoi(getenv("NPG_DIST_GRAPH")) : -1;
+    const bool kernel_only = dist && comm_is_kernel_only(ws->ctx);
+    const bool graph_dist = dist && !ws->ctx->shm &&
+                            (kernel_only ? (dist_graph_env != 0 && ws->dist_graph != 0) : ((ws->dist_graph > 0 || dist_graph_env > 0) && ws->ctx->comm));
     // (re)capture the per-cycle graphs when any baked-in argument changed
-    if ((!dist || graph_dist) && !eager && !ws->profile && (!ws->have_graph || memcmp(&ws->key, &d, sizeof(GDev)) != 0)) {
+    auto capture_graphs = [&]() -> int {
         for (int k = 0; k < 2; ++k) {
             if (ws->exec[k]) hipGraphExecDestroy(ws->exec[k]);
             if (ws->graph[k]) hipGraphDestroy(ws->graph[k]);
             ws->exec[k] = nullptr;
             ws->graph[k] = nullptr;
+            ws->have_graph = false;
             NPG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             int rcg = launch_cycle(d, A->lanes, st, nullptr, ws, dist != nullptr);
             if (rcg) {
@@ -988,6 +996,12 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
         }
         memcpy(&ws->key, &d, sizeof d);
         ws->have_graph = true;
+        return NPG_OK;
+    };
+    const bool use_graph = (!dist || graph_dist) && !eager && !ws->profile;
+    if (use_graph && (!ws->have_graph || memcmp(&ws->key, &d, sizeof(GDev)) != 0)) {
+        int rcg = capture_graphs();
+        if (rcg) return rcg;
     }
 
     // first true residual, then cycles until the carried state says done
@@ -1040,6 +1054,12 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
                 NPG_HIP(hipStreamSynchronize(st));           // the cycle enqueued ahead has exited at once
                 d.pyth = 0;
                 ws->explicit_norm = true;
+                if (use_graph) {
+                    // the captured cycles have pyth = 1 baked into their kernel arguments: replaying them would flag the
+                    // same cancellation for ever - capture the explicit-norm cycle
+                    rc0 = capture_graphs();
+                    if (rc0) return rc0;
+                }
                 last.done = 0;
                 last.inner = 0;
                 ws->h_C[cur] = last;
@@ -1099,6 +1119,10 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
         }
     }
     ws->hist_len = std::min<int64_t>((int64_t)last.iter + 1, ws->hist_cap);
+    if (dist) {
+        int rcc = comm_check(ctx);      // a replayed cycle reports communication timeouts through the status word only
+        if (rcc) return rcc;
+    }
     if (stats) {
         stats->solved = (last.done == 1 || last.done == 4) ? 1 : 0;
         stats->niter = last.iter;
@@ -1119,7 +1143,7 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
 NPG_API int npg_gmres_set_dist_options(npg_gmres *ws, int overlap, int graph) {
     NPG_REQUIRE(ws, "npg_gmres_set_dist_options: NULL workspace");
     ws->halo_overlap = overlap ? 1 : 0;
-    ws->dist_graph = graph ? 1 : 0;
+    ws->dist_graph = graph < 0 ? -1 : (graph ? 1 : 0);
     ws->have_graph = false;
     return NPG_OK;
 }

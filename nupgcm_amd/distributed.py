@@ -280,6 +280,11 @@ def distribute_model(model, dist, block_nodes=None):
     ev.solver.load_owned_from_full()
     model._prev = None
     torch.cuda.synchronize()
+    # leave set-up together: device-side waits of the peer transport are bounded (NPG_PEER_TIMEOUT_S), and the first
+    # collective should not have to sit out another rank's host-side set-up
+    dist.barrier()
+    model.comm_layout = dict(n_owned_inv=int(len(owned)), n_ghost_inv=int(halo.n_ghost), n_owned_b=int(len(bo)),
+                             n_ghost_b=int(halo_b.n_ghost), peers_inv=[int(q) for q in halo._keep["peers"]])
     return model
 
 

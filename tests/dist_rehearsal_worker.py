@@ -1,8 +1,9 @@
 """One rank of the multi-rank rehearsal (launched by tests/test_gpu_distributed.py through torch.distributed.run).
 
-All ranks share GPU 0 (NPG_FORCE_DEVICE=0) and talk through the shared-memory loop-back transport of
-nupgcm_amd/csrc/comm.hip (NPG_COMM_TRANSPORT=shm): RCCL refuses two ranks on one device, everything else - partition,
-local blocks, halo plan, the distributed GMRES/CG kernels and their collective call sequence - is the production path."""
+All ranks share GPU 0 (NPG_FORCE_DEVICE=0) and talk through the transport NPG_COMM_TRANSPORT names (comm.hip): `peer` - the
+production peer-window kernels over hipIpc mappings of the same device - or `shm`, the host-driven loop-back.  RCCL refuses
+two ranks on one device; everything else - partition, local blocks, halo plan, the distributed GMRES/CG kernels and their
+collective call sequence - is the production path."""
 import os
 import sys
 
@@ -45,7 +46,7 @@ def main():
     npg.run(m, n_steps=nsteps)
     ctx.sync()
     peers = np.asarray(s.halo._keep["peers"])
-    np.savez(f"{out}.rank{rank}.npz", peers=peers, dt=m.timestepper.dt, storage=np.array(s.A.storage()), owned=owned, y_loc=y_loc, n_ghost=len(ghosts), u=m.state.u, p=m.state.p,
+    np.savez(f"{out}.rank{rank}.npz", transport=ctx.comm_info()["in_cycle_transport"], peers=peers, dt=m.timestepper.dt, storage=np.array(s.A.storage()), owned=owned, y_loc=y_loc, n_ghost=len(ghosts), u=m.state.u, p=m.state.p,
              b=m.state.b, gm=[st[1]["niter"] for st in m.stats], cg=[st[0]["niter"] for st in m.stats],
              solved=[bool(st[1]["solved"]) and bool(st[0]["solved"]) for st in m.stats])
     dist.barrier()

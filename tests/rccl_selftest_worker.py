@@ -1,10 +1,13 @@
-"""RCCL call sites on ONE GPU (launched by tests/test_gpu_rccl_selftest.py with NPG_COMM_SELFTEST=1).
+"""RCCL call sites - and, with NPG_COMM_TRANSPORT=peer, the peer-window kernels - on ONE GPU (launched by
+tests/test_gpu_rccl_selftest.py with NPG_COMM_SELFTEST=1).
 
 RCCL refuses two ranks on one device, so the multi-rank rehearsals use the shared-memory loop-back transport and the
 product transport's call sites never ran on a development box.  A ONE-rank RCCL communicator does run them: with
 NPG_COMM_SELFTEST=1 csrc/comm.hip skips its single-rank shortcuts and allows a halo plan whose peer is the rank itself,
 so ncclCommInitRank, ncclAllReduce, grouped ncclSend/ncclRecv, ncclBroadcast and the distributed GMRES / CG cycles built
-on them execute on hardware and are checked against the serial solvers."""
+on them execute on hardware and are checked against the serial solvers.  With NPG_COMM_TRANSPORT=peer the same sequence runs
+on the peer-window transport of comm.hip (the rank maps its own window as its neighbour's): push / flag / unpack /
+acknowledge kernels, the one-kernel fold + all-reduce, and the distributed cycle replayed from ONE hipGraph by default."""
 import ctypes as C
 import os
 import sys
@@ -21,9 +24,12 @@ from nupgcm_amd.architectures import comm_unique_id               # noqa: E402
 
 def main():
     assert os.environ.get("NPG_COMM_SELFTEST") == "1" and os.environ.get("NPG_COMM_TRANSPORT", "") != "shm"
+    transport = "peer" if os.environ.get("NPG_COMM_TRANSPORT", "") == "peer" else "rccl"
     arch = npg.GPU(0)
     ctx = arch.ctx
     ctx.comm_init(comm_unique_id(), 0, 1)                        # ncclGetUniqueId + ncclCommInitRank
+    info = ctx.comm_info()
+    assert info["in_cycle_transport"] == transport and info["rccl_ranks"] == (1 if transport == "rccl" else 0), info
     rng = np.random.default_rng(5)
 
     # ncclAllReduce (one rank: the sum is the input)
@@ -120,7 +126,24 @@ def main():
     xc = x2.to_host()[:n]
     assert st2["solved"], st2
     assert np.linalg.norm(Sy @ xc - rhs) <= 1e-8 * np.linalg.norm(rhs)
-    print(f"RCCL self-test OK: gmres {st0['niter']} / {st1['niter']} iterations (serial / through RCCL), cg {st2['niter']}")
+    # the cancellation fallback with the cycle replayed from a hipGraph (the captured cycle has the Pythagorean norm baked
+    # in: the solver must re-capture, not replay it for ever): A = I + small, as in test_gmres_fast_mode_falls_back...
+    nn = 600
+    Ai = sp.csr_matrix(sp.eye(nn) + 1e-3 * sp.random(nn, nn, density=0.05, random_state=np.random.default_rng(42), format="csr"))
+    bi = np.random.default_rng(43).standard_normal(nn)
+    halo0 = distributed.Halo(ctx, nn, 0, dict(peers=np.zeros(0, np.int32), send_ptr=np.zeros(1, np.int64),
+                                              send_idx=np.zeros(0, np.int32), recv_ptr=np.zeros(1, np.int64)))
+    ws5 = npg.GmresWorkspace(ctx, nn, memory=30)
+    L.check(L.lib().npg_gmres_set_halo(ws5.h, halo0.h))
+    L.check(L.lib().npg_gmres_set_dist_options(ws5.h, 1, 1))
+    st5 = ws5.solve(npg.DeviceCSR.from_scipy(ctx, Ai), npg.DeviceVector.from_host(ctx, bi), ws5.x, None, atol=0.0, rtol=1e-10,
+                    itmax=300)
+    import scipy.sparse.linalg as spla
+    xi = spla.spsolve(Ai.tocsc(), bi)
+    assert st5["solved"] == 1 and st5["nflagged"] > 0, st5
+    assert np.linalg.norm(ws5.x.to_host() - xi) <= 1e-8 * np.linalg.norm(xi)
+    print(f"{transport.upper()} self-test OK: gmres {st0['niter']} / {st1['niter']} iterations (serial / through {transport}), "
+          f"cg {st2['niter']}; cancellation fallback under graph replay {st5['niter']} iterations")
 
 
 if __name__ == "__main__":

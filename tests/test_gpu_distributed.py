@@ -1,6 +1,8 @@
-"""Multi-rank rehearsal of the distributed timestep on ONE GPU: 2 and 3 ranks share the device and exchange through the
-shared-memory loop-back transport (RCCL cannot place two ranks on one device; the driver's 8-GPU run uses RCCL).  Checks
-that the distributed SpMV (halo), the distributed GMRES/CG and the replicated state reproduce the single-GPU run."""
+"""Multi-rank rehearsal of the distributed timestep on ONE GPU: 2 to 4 ranks share the device (RCCL cannot place two ranks on
+one device) and exchange either through the PEER-WINDOW transport - the production kernels and protocol of comm.hip: hipIpc-
+mapped windows, push / flag / unpack kernels, one-kernel all-reduce, the cycle replayed from one hipGraph - or through the
+host-driven shared-memory loop-back transport.  Checks that the distributed SpMV (halo), the distributed GMRES/CG and the
+replicated state reproduce the single-GPU run, and that both transports produce the same bits."""
 import os
 import socket
 import subprocess
@@ -36,22 +38,45 @@ def serial():
     return m, y
 
 
-@pytest.mark.parametrize("world,blocks,split", [(2, False, False), (3, False, False), (3, True, False), (4, True, False),
-                                                (3, True, True)])
-def test_multi_rank_rehearsal(serial, world, blocks, split, tmp_path):
+def _launch(world, out, nsteps, mode, transport, split=False, timeout=600):
+    env = dict(os.environ, NPG_COMM_TRANSPORT=transport, NPG_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               OMP_NUM_THREADS="2", NPG_PEER_TIMEOUT_S="60")
+    if split:
+        env.update(NPG_GMRES_SPLIT="1", NPG_HALO_OVERLAP_VERBOSE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_rehearsal_worker.py"), out, str(nsteps),
+           mode]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r
+
+
+def test_peer_and_shm_transports_give_the_same_bits(tmp_path):
+    """3 ranks, node-record blocks, the split cycle with the interior tiles beside the exchange: the peer-window transport
+    (graph-replayed cycle, device-side all-reduce in rank order) and the host-driven rehearsal transport run the same kernels
+    and sum in the same order - identical iterates, iteration counts and state."""
+    outs = {}
+    for tr in ("peer", "shm"):
+        out = str(tmp_path / tr)
+        r = _launch(3, out, 3, "blocks", tr, split=True)
+        assert "halo overlap on" in r.stderr
+        outs[tr] = [np.load(f"{out}.rank{k}.npz") for k in range(3)]
+    for a, b in zip(outs["peer"], outs["shm"]):
+        assert np.array_equal(a["gm"], b["gm"]) and np.array_equal(a["cg"], b["cg"])
+        assert np.array_equal(a["u"], b["u"]) and np.array_equal(a["p"], b["p"]) and np.array_equal(a["b"], b["b"])
+        assert np.array_equal(a["y_loc"], b["y_loc"])
+    assert all(str(z["transport"]) == "peer" for z in outs["peer"]) and all(str(z["transport"]) == "shm" for z in outs["shm"])
+
+
+@pytest.mark.parametrize("world,blocks,split,transport", [(2, False, False, "peer"), (3, False, False, "shm"),
+                                                          (3, True, False, "peer"), (4, True, False, "peer"),
+                                                          (3, True, True, "peer")])
+def test_multi_rank_rehearsal(serial, world, blocks, split, transport, tmp_path):
     """split: force the split GMRES cycle that rank blocks of >= 8192 rows use - its Arnoldi step runs the tiles without
     ghost columns before the halo exchange has completed and the others behind it (gmres.hip, launch_cycle_L)."""
     ref, y = serial
     out = str(tmp_path / "dist")
-    env = dict(os.environ, NPG_COMM_TRANSPORT="shm", NPG_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               OMP_NUM_THREADS="2")
-    if split:
-        env.update(NPG_GMRES_SPLIT="1", NPG_HALO_OVERLAP_VERBOSE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_rehearsal_worker.py"), out, "3",
-           "blocks" if blocks else "csr"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    r = _launch(world, out, 3, "blocks" if blocks else "csr", transport, split=split)
     if split:
         assert "halo overlap on" in r.stderr, r.stderr[-2000:]
     ranks = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
@@ -87,13 +112,7 @@ def test_channel_basin_closures_and_periodic_seam_distributed(tmp_path):
     ref = workloads.channel_basin_model(arch, mesh_model=mm, element_precision="fp64")
     npg.run(ref, n_steps=nsteps)
     out = str(tmp_path / "cb")
-    env = dict(os.environ, NPG_COMM_TRANSPORT="shm", NPG_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_rehearsal_worker.py"), out, str(nsteps),
-           "channel"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    _launch(world, out, nsteps, "channel", "peer")
     ranks = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
     for z in ranks[1:]:
         assert np.array_equal(z["b"], ranks[0]["b"]) and np.array_equal(z["u"], ranks[0]["u"]) and z["dt"] == ranks[0]["dt"]
