@@ -161,9 +161,13 @@ def main():
         mesh_model = channel_basin.channel_basin_model(hh, workloads.CB_ALPHA)
     else:
         mesh_model = workloads.bowl_mesh_model(a.workload)
+    replicated = bool(os.environ.get("NPG_BENCH_REPLICATED"))      # round-2 multi-GPU layout: rows partitioned, mesh / state replicated
     if channel:
         surf = "dirichlet" if a.workload.endswith("dirichlet") else "flux"
-        if world > 1 or force_dist:
+        if (world > 1 or force_dist) and not replicated:
+            from nupgcm_amd import partition                        # mesh, matrices and state partitioned over the ranks
+            model = partition.channel_basin_model(arch, mesh_model, dist, surface=surf)
+        elif world > 1 or force_dist:
             from nupgcm_amd import distributed
             model = distributed.channel_basin_model(arch, mesh_model, dist, surface=surf)
         elif a.preconditioner == "multigrid":
@@ -172,6 +176,9 @@ def main():
             model = workloads.channel_basin_model(arch, h=hh, levels=2, surface=surf, itmax=0)
         else:
             model = workloads.channel_basin_model(arch, mesh_model=mesh_model, surface=surf)
+    elif (world > 1 or force_dist) and not replicated:
+        from nupgcm_amd import partition
+        model = partition.example_model(arch, mesh_model, dist, dt=a.dt)
     elif world > 1 or force_dist:
         from nupgcm_amd import distributed
         model = distributed.example_model(arch, mesh_model, dist, dt=a.dt)
@@ -181,6 +188,27 @@ def main():
             model = workloads.example_model(arch, a.workload, dt=a.dt, preconditioner=a.preconditioner, **kw)
         else:
             model = workloads.example_model(arch, mesh_model, dt=a.dt, **kw)
+    transport_check = None
+    if hasattr(model, "verify_transport"):
+        # end-to-end check of halo + all-reduce on this hardware before anything is timed; if the peer windows fail it, fall
+        # back on RCCL for the in-cycle traffic (auto transport) and build the model again
+        transport_check = "passed"
+        if not model.verify_transport():
+            was = ctx.comm_info()["in_cycle_transport"]
+            if was != "peer":
+                raise SystemExit(f"bench: the {was} transport failed the halo / all-reduce check")
+            if rank == 0:
+                print("[bench] peer-window transport failed its end-to-end check: falling back on RCCL", file=sys.stderr)
+            import gc
+            del model
+            gc.collect()
+            ctx.disable_peer()
+            from nupgcm_amd import partition
+            model = (partition.channel_basin_model(arch, mesh_model, dist, surface=surf) if channel else
+                     partition.example_model(arch, mesh_model, dist, dt=a.dt))
+            if not model.verify_transport():
+                raise SystemExit("bench: the RCCL transport failed the halo / all-reduce check too")
+            transport_check = "peer failed, rccl passed"
     d = model.fe_data.dofs
     if not channel:
         npg.invert(model)                                 # examples/bowl_mixing.jl:194 (the channel model is built inverted)
@@ -212,7 +240,10 @@ def main():
 
     # ---- profile pass: HIP events around every Arnoldi (SpMV) kernel of one more timestep -------------------------
     A = model.inversion.solver.A
-    N, nnz = A.shape[0], A.nnz
+    N, nnz = A.shape[0], A.nnz                            # this rank's row block when distributed
+    N_glob, nnz_glob = int(d.nu + d.np), int(nnz)
+    if dist is not None and world > 1:
+        nnz_glob = int(round(ctx.allreduce_sum([float(nnz)])[0]))
     ws = model.inversion.solver.workspace
     ms_total, launches = 0.0, 0
     if not a.no_profile_pass and hasattr(ws, "set_profile"):
@@ -226,6 +257,7 @@ def main():
         avg_ms = ms_total / launches
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
         roofline = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                        scope="one GPU" if world == 1 else f"rank 0's row block ({N} of {N_glob} rows), one of {world} GPUs",
                         traffic=pmc_traffic(a.workload),
                         traffic_source=(f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier builder "
                                         "run on this workload, not measured in this run)"
@@ -280,13 +312,15 @@ def main():
                                 f"{a.workload}: example parameters of examples/bowl_mixing.jl (eps=0.2, alpha=1/2, "
                                 f"mu_rho=1, N2=2, BDF2 dt={a.dt:g}), full evolve!+invert! timestep loop"),
                    "tets": int(model.fe_data.mesh.ncell), "nu": int(d.nu), "np": int(d.np), "nb": int(d.nb),
-                   "N_inversion": int(N), "nnz_A": int(nnz), "node_block_storage": bool(getattr(A, "paired", False)),
+                   "N_inversion": N_glob, "nnz_A": nnz_glob, "node_block_storage": bool(getattr(A, "paired", False)),
                    "full_nodes": int(d.n_full), "surface_nodes": int(d.n_surf), "gmres_iterations_per_step": gm_its,
                    "cg_iterations_per_step": cg_its, "gmres_second_gs_passes_per_step": [s[1]["nreorth"] for s in stats],
                    "inversion_seconds_per_step": [round(s[1]["seconds"], 4) for s in stats],
                    "gmres_memory": 20, "atol": 1e-6, "rtol": 1e-6, "gmres_itmax": model.inversion.solver.kwargs["itmax"],
                    "all_solved": all(s[1]["solved"] == 1 for s in stats), "preconditioner": repr(model.inversion.solver.P),
-                   "setup_seconds": round(t_setup, 1), "parallelism": f"row-partitioned x{world}" if world > 1 else "1 GPU"},
+                   "setup_seconds": round(t_setup, 1),
+                   "parallelism": ("1 GPU" if world == 1 else f"rows partitioned x{world}, mesh and state replicated" if replicated
+                                   else f"mesh, matrices and state partitioned x{world} (node-aligned, one ghost-cell layer)")},
         "roofline": roofline,
         "spmv_standalone": {"avg_launch_us": spmv_ms * 1e3, "GBps": alg_bytes / (spmv_ms * 1e-3) / 1e9},
         "spmv_plain_csr": spmv_plain,
@@ -361,6 +395,7 @@ def main():
         infos = [None] * world
         dist.all_gather_object(infos, mine)
         out["comm"] = {"rccl_ranks": infos[0].get("rccl_ranks"), "in_cycle_transport": infos[0].get("in_cycle_transport"),
+                       "transport_check": transport_check,
                        "cycle_replayed_from_hipgraph": bool(infos[0].get("in_cycle_transport") == "peer"
                                                            and os.environ.get("NPG_DIST_GRAPH", "1") != "0"),
                        "ranks": infos}

@@ -332,6 +332,8 @@ int npg_comm_unique_id(void *id128);                                  /* rank 0 
 int npg_comm_init(npg_ctx *ctx, const void *id128, int rank, int nranks);
 /* one line of JSON about the communicator: rank, nranks, rccl_ranks (ncclCommCount), device, in_cycle_transport */
 int npg_comm_info(npg_ctx *ctx, char *buf, size_t cap);
+/* auto transport only: drop the peer windows, RCCL carries the in-cycle traffic from here on (no live halo plans) */
+int npg_comm_disable_peer(npg_ctx *ctx);
 int npg_comm_allreduce_sum(npg_ctx *ctx, double *host_inout, int n);  /* tiny host-side helper for tests/bench */
 /* Replicate a row-block distributed vector on every rank: segment s of `full` ([global_off, global_off + len)) is owned
  * by rank seg_rank[s], who holds it at local[local_off ..].  One grouped ncclBroadcast per segment over xGMI. */

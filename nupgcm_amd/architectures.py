@@ -91,6 +91,10 @@ class Context:
         L.check(L.lib().npg_comm_info(self.h, buf, 1024))
         return json.loads(buf.value.decode())
 
+    def disable_peer(self):
+        """auto transport: drop the peer windows; RCCL carries the in-cycle traffic from here on (npg_comm_disable_peer)"""
+        L.check(L.lib().npg_comm_disable_peer(self.h))
+
     def allreduce_sum(self, values):
         a = np.ascontiguousarray(values, dtype=np.float64).copy()
         L.check(L.lib().npg_comm_allreduce_sum(self.h, a.ctypes.data_as(C.POINTER(C.c_double)), a.size))

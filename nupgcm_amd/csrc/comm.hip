@@ -611,6 +611,19 @@ NPG_API int npg_comm_init(npg_ctx *ctx, const void *id128, int rank, int nranks)
     return NPG_OK;
 }
 
+// Drop the peer windows and carry the in-cycle traffic through RCCL from here on (a caller whose end-to-end check of the
+// peer transport failed on its hardware).  Needs the RCCL communicator of the auto transport, and no live halo plan or
+// solver that was created while the windows existed.
+NPG_API int npg_comm_disable_peer(npg_ctx *ctx) {
+    NPG_REQUIRE(ctx, "npg_comm_disable_peer: NULL context");
+    if (!ctx->peer) return NPG_OK;
+    NPG_REQUIRE(ctx->comm, "npg_comm_disable_peer: no RCCL communicator to fall back on (NPG_COMM_TRANSPORT=peer)");
+    NPG_HIP(hipStreamSynchronize(ctx->stream));
+    peer_free((PeerComm *)ctx->peer);
+    ctx->peer = nullptr;
+    return NPG_OK;
+}
+
 // one line of JSON describing the communicator (bench.py puts it into its record)
 NPG_API int npg_comm_info(npg_ctx *ctx, char *buf, size_t cap) {
     NPG_REQUIRE(ctx && buf && cap > 0, "npg_comm_info: bad argument");

@@ -800,13 +800,16 @@ NPG_API int npg_fe_assemble_matrix(npg_fe *fe, int which, double scale, int full
         case NPG_MAT_M:
         case NPG_MAT_KH:
         case NPG_MAT_KV: {
-            NPG_REQUIRE(A->m == fe->n_b && A->n == fe->n_b, "npg_fe_assemble_matrix: matrix must be n_b x n_b");
-            NPG_REQUIRE(!lift || lift->n == fe->n_b, "npg_fe_assemble_matrix: lift must have n_b entries");
+            // (a mesh-partitioned rank assembles its OWNED rows only: they lead the local numbering, and their columns -
+            // owned + first ghost layer - lead the column numbering; the engine's vectors carry further ghosts behind them)
+            NPG_REQUIRE(A->m <= fe->n_b && A->n <= fe->n_b && A->m <= A->n,
+                        "npg_fe_assemble_matrix: matrix must be n_b x n_b (or the leading owned rows x leading columns of it)");
+            NPG_REQUIRE(!lift || (lift->n >= A->m && lift->n <= fe->n_b), "npg_fe_assemble_matrix: lift must have n_b entries");
             NPG_REQUIRE(which == NPG_MAT_M || (which == NPG_MAT_KH ? d.kh : d.kv),
                         "npg_fe_assemble_matrix: diffusivity coefficient has not been set");
-            const int grid = cell_grid(fe->n_b * kQL);
+            const int grid = cell_grid(A->m * kQL);
             auto go = [&](auto kern) {
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, st, d, which, fe->gptr, fe->gidx, fe->n_b, A->rowptr,
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, st, d, which, fe->gptr, fe->gidx, A->m, A->rowptr,
                                    A->col, A->val, lift ? lift->d : nullptr, fe->missing);
             };
             if (d.nb == 10) f32 ? go(k_assemble_b<float, 10>) : go(k_assemble_b<double, 10>);
@@ -814,21 +817,22 @@ NPG_API int npg_fe_assemble_matrix(npg_fe *fe, int which, double scale, int full
             break;
         }
         case NPG_MAT_A: {
-            NPG_REQUIRE(A->m == fe->n_inv && A->n == fe->n_inv, "npg_fe_assemble_matrix: A must be n_inv x n_inv");
+            NPG_REQUIRE(A->m <= fe->n_inv && A->n <= fe->n_inv && A->m <= A->n,
+                        "npg_fe_assemble_matrix: A must be n_inv x n_inv (or the leading owned rows x leading columns of it)");
             NPG_REQUIRE(d.nu && d.f, "npg_fe_assemble_matrix: coefficients nu and f must be set");
             auto go = [&](auto kern) {
-                hipLaunchKernelGGL(kern, dim3(cell_grid(fe->n_inv * kQL)), dim3(kBlock), 0, st, d, scale, full_stress,
-                                   fe->iptr, fe->iidx, fe->n_inv, A->rowptr, A->col, A->val, fe->missing);
+                hipLaunchKernelGGL(kern, dim3(cell_grid(A->m * kQL)), dim3(kBlock), 0, st, d, scale, full_stress,
+                                   fe->iptr, fe->iidx, A->m, A->rowptr, A->col, A->val, fe->missing);
             };
             f32 ? go(k_assemble_A<float>) : go(k_assemble_A<double>);
             break;
         }
         case NPG_MAT_B: {
-            NPG_REQUIRE(A->m == fe->n_inv && A->n == fe->n_b, "npg_fe_assemble_matrix: B must be n_inv x n_b");
-            NPG_REQUIRE(!lift || lift->n == fe->n_inv, "npg_fe_assemble_matrix: lift must have n_inv entries");
-            const int grid = cell_grid(fe->n_inv * kQL);
+            NPG_REQUIRE(A->m <= fe->n_inv && A->n == fe->n_b, "npg_fe_assemble_matrix: B must be n_inv (or its leading owned rows) x n_b");
+            NPG_REQUIRE(!lift || (lift->n >= A->m && lift->n <= fe->n_inv), "npg_fe_assemble_matrix: lift must have n_inv entries");
+            const int grid = cell_grid(A->m * kQL);
             auto go = [&](auto kern) {
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, st, d, scale, fe->iptr, fe->iidx, fe->n_inv, A->rowptr,
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, st, d, scale, fe->iptr, fe->iidx, A->m, A->rowptr,
                                    A->col, A->val, lift ? lift->d : nullptr, fe->missing);
             };
             if (d.nb == 10) f32 ? go(k_assemble_B<float, 10>) : go(k_assemble_B<double, 10>);

@@ -74,6 +74,8 @@ struct GDev {
     int64_t ldv;          // split mode stores the basis column-major, Vi[k * ldv + row] (0: group-interleaved layout)
     int pyth;             // distributed runs: ||w - V h||^2 = ||w||^2 - ||h||^2 instead of a second all-reduce
     int lazy2;            // one GPU: the same identity decides whether the second-pass sums need reducing at all
+    int rev;              // split mode: the orthogonalisation kernel walks the row blocks downwards, the dots kernel upwards -
+                          // what one sweep read last is what the next reads first (Infinity Cache reuse of the basis)
     int fast;             // one GPU, split mode: the orthogonalisation kernel does not form the second-pass sums at all; a
                           // column that would have needed them is counted (pad1) and later solves run the full kernels
     // what the CONSUMER prologues reduce: the producers' partial rows on one GPU, or the single all-reduced row when
@@ -480,7 +482,10 @@ __global__ void __launch_bounds__(kRB, (NG < 4 || FAST) ? 3 : 2) k_gmres_orth_ro
             d.hcol1[j * kKP + threadIdx.x] = ((int)threadIdx.x <= j) ? red[threadIdx.x] : 0.0;
             if (threadIdx.x == 0) d.wnorm2[j] = red[kNormSlot];
         }
-        for (int64_t row = blockIdx.x * (int64_t)kRB + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kRB) {
+        const int64_t nblk = ((int64_t)d.n + kRB - 1) / kRB;
+        for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+            const int64_t row = (d.rev ? nblk - 1 - blk : blk) * kRB + threadIdx.x;
+            if (row >= d.n) continue;
             double v[8 * NG];
             load_row_cols<NG>(d.Vi, row, d.ldv, j, v);          // split mode: the basis is column-major
             double wp = d.w[row];
@@ -916,6 +921,8 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     // summed norm is what the explicit-norm fallback reduces over the ranks
     d.fast = (d.split && fast_env && reorth_eta <= 0.1 + 1e-12 && (dist || (d.lazy2 && !ws->safe_mode))) ? 1 : 0;
     d.GR = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + kRB - 1) / kRB, std::min(kMaxG, 3 * ctx->num_cu)));
+    static const int rev_env = getenv("NPG_ORTH_REVERSE") ? atoi(getenv("NPG_ORTH_REVERSE")) : 0;
+    d.rev = rev_env;
     d.ldv = d.split ? (int64_t)((ws->n + 31) / 32) * 32 : 0;
     d.GP1 = d.split ? d.GR : d.G1;
     d.GP2 = d.split ? d.GR : d.G2;
@@ -957,11 +964,17 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     NPG_HIP(hipMemcpyAsync(ws->C, ws->h_C, sizeof(Snap), hipMemcpyHostToDevice, st));
     NPG_HIP(hipStreamSynchronize(st));      // h_C[0] is reused below as a result slot
 
-    // Under rocprofv3's kernel tracer (ROCm 7.2) relaunching the per-cycle hipGraphs segfaults inside hipGraphLaunch, in the
-    // tool library's packet interception (backtrace: profiles/r02_rocprofv3_graph_crash.txt; the same command with eager
-    // launches profiles cleanly) - so a traced process launches eagerly.  rocprofv3 marks its child with these variables.
+    // Under rocprofv3's kernel tracer (ROCm 7.2) a hipGraphLaunch whose batch of AQL packets straddles the end of the 1 MiB
+    // queue ring segfaults inside librocprofiler-sdk.so's queue interception (it reads the batch as one contiguous block and
+    // runs off the ring's mapping; symbolised backtrace and a library-free reproducer: profiles/r03_rocprofv3_graph_fault.txt,
+    // tools/graph_trace_probe.hip).  A traced process therefore launches eagerly unless told otherwise (NPG_GMRES_EAGER=0
+    // forces graph replay; short runs that never wrap the ring profile fine).  rocprofv3 marks its child with these variables.
     static const int traced = getenv("ROCPROFILER_LIBRARY_CTOR") || getenv("ROCPROF_OUTPUT_PATH") || getenv("ROCP_TOOL_LIBRARIES");
     static const int eager = getenv("NPG_GMRES_EAGER") ? atoi(getenv("NPG_GMRES_EAGER")) : traced;
+    static bool said = false;
+    if (eager && traced && !getenv("NPG_GMRES_EAGER") && !said && (said = true))
+        fprintf(stderr, "[npg] rocprofv3 detected: GMRES restart cycles are launched eagerly instead of replayed from hipGraphs "
+                        "(rocprofiler-sdk faults on graph launches that wrap the AQL ring; NPG_GMRES_EAGER=0 overrides)\n");
     static const int trace = getenv("NPG_GMRES_TRACE") ? atoi(getenv("NPG_GMRES_TRACE")) : 0;
 
     // Distributed cycles.  On the peer transport (comm.hip) every communication step is a kernel on a HIP stream, so the

@@ -238,9 +238,15 @@ NPG_API int npg_precond_create(npg_ctx *ctx, int kind, int nparts, npg_precond *
     npg_precond *pc = new npg_precond();
     pc->ctx = ctx;
     pc->kind = kind;
-    // relaunching hipGraphs under rocprofv3's kernel tracer crashes the tool (profiles/r02_rocprofv3_graph_crash.txt)
+    // relaunching hipGraphs under rocprofv3's kernel tracer can fault inside the tool (a batch of AQL packets that straddles
+    // the end of the queue ring: profiles/r03_rocprofv3_graph_fault.txt): a traced process launches the cycle eagerly unless
+    // NPG_MG_EAGER=0 says otherwise
     const bool traced = getenv("ROCPROFILER_LIBRARY_CTOR") || getenv("ROCPROF_OUTPUT_PATH") || getenv("ROCP_TOOL_LIBRARIES");
     pc->use_graphs = getenv("NPG_MG_EAGER") ? atoi(getenv("NPG_MG_EAGER")) == 0 : !traced;
+    static bool said = false;
+    if (traced && !getenv("NPG_MG_EAGER") && !said && (said = true))
+        fprintf(stderr, "[npg] rocprofv3 detected: multigrid cycles are launched eagerly instead of replayed from hipGraphs "
+                        "(NPG_MG_EAGER=0 overrides)\n");
     if (kind == NPG_PC_MG) pc->L.resize(nparts);
     if (kind == NPG_PC_BLOCKDIAG) pc->blocks.resize(nparts);
     *out = pc;

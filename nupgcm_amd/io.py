@@ -43,11 +43,14 @@ def save_state(model, ofile):
     s = model.state
     t = 0.0 if model.timestepper is None else float(model.timestepper.t)
     ofile = str(ofile)
+    u, p, b = s.u, s.p, s.b                     # (distributed models: each a collective gather of the owned slices)
+    if getattr(model.arch.ctx, "rank", 0) != 0:
+        return ofile                            # one writer
     if ofile.endswith(".npz"):
-        np.savez(ofile, u=s.u, p=s.p, b=s.b, t=t)
+        np.savez(ofile, u=u, p=p, b=b, t=t)
     else:
         from . import _hdf5
-        _hdf5.write_flat(ofile, dict(u=s.u, p=s.p, b=s.b, t=np.float64(t)))     # jldsave(ofile; u, p, b, t)
+        _hdf5.write_flat(ofile, dict(u=u, p=p, b=b, t=np.float64(t)))           # jldsave(ofile; u, p, b, t)
     return ofile                                                               # the path actually written
 
 
@@ -139,7 +142,9 @@ def save_vtk(model, ofile):
     """save_vtk(model; ofile) - src/IO.jl:25-59 with order = 2 (quadratic tetrahedra): fields u, p, b = N2 z + b',
     alpha*b_z, nu, kappa_v and t."""
     m = model.fe_data.mesh
-    u, p, b = _nodal_fields(model)
+    u, p, b = _nodal_fields(model)                 # (distributed models: collective gathers of the state)
+    if getattr(model.arch.ctx, "rank", 0) != 0:
+        return ofile                               # one writer
     abz, nu, kv = _nodal_closure_fields(model, b)
     t = 0.0 if model.timestepper is None else float(model.timestepper.t)
     conn = m.cell_nodes[:, _VTK_P2]

@@ -117,8 +117,9 @@ def evolve(model: Model, x_inv_prev: DeviceVector, b_prev: DeviceVector):
     if frc.conv_param.is_on or ts.adaptive:
         collect_evolution_LHS_into(solver.A, solver.P, prm, ts, ev.M, ev.Kh, ev.Kv)            # src/model.jl:251-261
     x_inv = model.inversion.solver.x
+    # (mesh-partitioned models: the element kernels write every local row, the solver reads the owned ones - a view)
     fe.evolution_rhs(_scheme(ts), ts.dt, prm.N2, theta, model.b_vec, b_prev, x_inv, x_inv_prev, ev.rhs_diff,
-                     ev.rhs_flux, ev.rhs_M, ev.rhs_h, ev.rhs_v, solver.y)                      # src/model.jl:269-278
+                     ev.rhs_flux, ev.rhs_M, ev.rhs_h, ev.rhs_v, getattr(solver, "y_full", solver.y))   # src/model.jl:269-278
     iterative_solve(solver)                                                                    # src/model.jl:279
     return model
 
@@ -132,11 +133,12 @@ def run(model: Model, n_info=10, n_save=float("inf"), n_plot=float("inf"), advec
     inv_x, b = model.inversion.solver.x, model.b_vec
     fe = model.evolution.fe
     ctx = model.arch.ctx
+    comm = getattr(model, "comm", None)          # partition.PartitionedModel: host-level reductions over the ranks
     if model._prev is None:
         # copies of previous and current u, b (src/model.jl:119-123)
         model._prev = dict(x_prev=inv_x.copy(), b_prev=b.copy(), x_curr=inv_x.copy(), b_curr=b.copy())
         if isinstance(ts, BDF1):
-            model._h_cells = model.fe_data.mesh.h_cells()                                       # src/model.jl:100
+            model._h_cells = model.h_cells() if hasattr(model, "h_cells") else model.fe_data.mesh.h_cells()   # src/model.jl:100
     pv = model._prev
     t0 = t_last = time.time()
     taken = 0
@@ -144,6 +146,8 @@ def run(model: Model, n_info=10, n_save=float("inf"), n_plot=float("inf"), advec
         i = model.step_index
         if isinstance(ts, BDF1):
             update_dt(ts, fe, inv_x, h_cells=model.__dict__.pop("_h_cells", None))              # src/model.jl:131
+            if comm is not None:
+                ts.dt = comm.min(ts.dt)                           # partitioned mesh: every rank saw its own cells only
         if i == 2 and isinstance(ts, BDF2):
             collect_evolution_LHS(model.evolution, prm, frc, ts)                                # src/model.jl:134-137
         pv["x_curr"].copy_from(inv_x)                                                           # src/model.jl:140-141
@@ -158,7 +162,10 @@ def run(model: Model, n_info=10, n_save=float("inf"), n_plot=float("inf"), advec
         # blow-up guard (src/model.jl:149-153): device reductions over [u; p] and b
         xm, xnan = model._u_view.maxabs()
         bm, bnan = b.maxabs()
-        if max(xm, bm) > 1e3 or xnan or bnan:
+        blow = max(xm, bm) > 1e3 or xnan or bnan
+        if comm is not None:
+            blow = comm.any(blow)                                 # every rank leaves the loop together
+        if blow:
             raise BlowUp("Blow-up detected, stopping simulation")
         pv["x_prev"], pv["x_curr"] = pv["x_curr"], pv["x_prev"]                                 # src/model.jl:156-157
         pv["b_prev"], pv["b_curr"] = pv["b_curr"], pv["b_prev"]
@@ -166,7 +173,9 @@ def run(model: Model, n_info=10, n_save=float("inf"), n_plot=float("inf"), advec
             ep = frc.eddy_param
             fe.update_nu_eddy(ep.N2min, prm.alpha, prm.N2, b)
             sol = model.inversion.solver
-            if hasattr(sol, "A_full"):    # distributed: re-assemble the replicated matrix, gather this rank's row block
+            if hasattr(model, "reassemble_A"):    # mesh-partitioned: the rank's cells into the rank's rows
+                model.reassemble_A()
+            elif hasattr(sol, "A_full"):    # distributed: re-assemble the replicated matrix, gather this rank's row block
                 build_A_inversion(model.arch, model.fe_data, prm, None, A=sol.A_full)
                 sol.A.gather_values(sol.A_full, sol.A_map)
             else:
@@ -181,8 +190,7 @@ def run(model: Model, n_info=10, n_save=float("inf"), n_plot=float("inf"), advec
             t_last = t1
         if n_save != float("inf") and i % int(n_save) == 0:                                     # src/model.jl:194-197
             from . import io as _io
-            if getattr(ctx, "rank", 0) == 0:
-                _io.save_checkpoint(model, i)
+            _io.save_checkpoint(model, i)                         # collective for distributed models; rank 0 writes
         model.step_index += 1
         taken += 1
     ctx.sync()

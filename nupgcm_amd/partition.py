@@ -1,0 +1,490 @@
+"""Mesh-partitioned execution of the hot path: every rank holds ITS cells, ITS rows and ITS slice of the state - nothing
+global lives on a device (new work; the reference is single-device).  north_star: "the unstructured mesh is partitioned
+across the 8 GPUs of one node with RCCL over xGMI carrying the Krylov global inner products and interface halo exchange".
+
+Decomposition (owner computes, one ghost-cell layer):
+
+  * rows     - `distributed.RowPartition`: contiguous blocks of the RCM-ordered inversion rows [u; p] and buoyancy rows;
+  * cells    - a rank keeps every cell that touches one of its rows (C = C_inv + C_b).  Row-owner assembly
+               (csrc/fe.hip: the lanes that own a CSR row walk the (cell, local DoF) pairs carrying it) then produces the
+               owned rows of every matrix and right-hand side completely and touches no other row: no atomics, no
+               reduction over ranks, the same bits as the one-GPU assembly for every owned entry;
+  * vectors  - a field lives as [ owned | solver ghosts | further ghosts ]: the solver ghosts are the off-rank columns of
+               the owned rows (what the Krylov SpMV needs: the solvers work on the leading [owned | solver ghosts] VIEW of
+               the state vector, no copy), the further ghosts are the remaining DoFs of the rank's cells (what the element
+               kernels read: advection velocity, buoyancy gradient for the closures).  Two halo plans per field fill them -
+               the solver's own (every Krylov iteration) and the extra one (once after a solve);
+  * state    - never replicated and never all-gathered: after a solve the ghosts are refreshed from their owners
+               (two ghost-sized messages) where the replicated design moved 8 N bytes per step;
+  * closures - kappa_v (every step) and nu (every 10th step) are re-evaluated and K_v / A re-assembled on the rank's cells
+               only, straight into the rank's row block (src/model.jl:160-170,229-261).
+
+Host side: every rank still builds the global FEData (mesh topology, RCM, DoF tables - integer index work at set-up) to
+derive its layout; everything that touches values is local and on the device."""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib as L
+from .architectures import DeviceCSR, DeviceVector
+from .assembly import DeviceFE
+from .distributed import Halo, RowPartition, halo_plan
+from .evolution import collect_evolution_LHS_into, evolution_parameter
+from .fe import DeviceTables
+from .inputs import SurfaceFluxBC
+from .iterative_solvers import CgWorkspace, Diagonal, GmresWorkspace, IterativeSolverToolkit
+from .model import Model
+from .timesteppers import BDF1
+
+
+class NodePartition:
+    """Ownership by mesh NODE: the P2 nodes are swept in reverse-Cuthill-McKee order of the node graph and cut into
+    `nranks` consecutive chunks of equal SpMV work (non-zeros of the inversion rows a node carries); every DoF - velocity
+    components, pressure, buoyancy - belongs to the rank of its node.  All fields are therefore cut along the SAME surfaces:
+    a rank's pressure rows sit where its velocity rows sit, its buoyancy rows too, and the ghost layer of every matrix is the
+    one layer of cells across those surfaces (`distributed.RowPartition` cuts each field's own RCM sequence separately,
+    which leaves e.g. all surface nodes with the last rank).  Same interface as RowPartition where partition.py uses it."""
+
+    def __init__(self, fe_data, nranks):
+        from scipy.sparse.csgraph import reverse_cuthill_mckee
+        m, t, d = fe_data.mesh, fe_data.tables, fe_data.dofs
+        self.nu, self.np, self.nb, self.nranks = d.nu, d.np, d.nb, int(nranks)
+        self.n_full, self.n_surf = d.n_full, d.n_surf
+        order = np.asarray(reverse_cuthill_mckee(sp.csr_matrix(d.adj2), symmetric_mode=True), dtype=np.int64)
+        rowlen = np.diff(fe_data.pattern_A()[0]).astype(np.float64)
+        w = np.zeros(m.nn)
+        for a in range(3):
+            on = t.u_pos[:, a] >= 0
+            w[on] += rowlen[t.u_pos[on, a]]
+        on = t.p_pos >= 0
+        w[:m.nv][on] += rowlen[t.p_pos[on]]
+        cum = np.cumsum(w[order])
+        cuts = np.searchsorted(cum, cum[-1] * np.arange(1, nranks) / nranks, side="left")
+        node_owner = np.empty(m.nn, dtype=np.int32)
+        node_owner[order] = np.searchsorted(cuts, np.arange(m.nn), side="right").astype(np.int32)
+        self.node_owner = node_owner
+        self._inv_owner = np.empty(d.nu + d.np, dtype=np.int32)
+        for a in range(3):
+            on = t.u_pos[:, a] >= 0
+            self._inv_owner[t.u_pos[on, a]] = node_owner[on]
+        on = t.p_pos >= 0
+        self._inv_owner[t.p_pos[on]] = node_owner[:m.nv][on]
+        nbn = len(t.b_pos)
+        on = t.b_pos >= 0
+        self._b_owner = np.empty(d.nb, dtype=np.int32)
+        self._b_owner[t.b_pos[on]] = node_owner[:nbn][on]
+
+    def inv_owner(self):
+        return self._inv_owner
+
+    def b_owner(self):
+        return self._b_owner
+
+    def inv_owned(self, r):
+        return np.nonzero(self._inv_owner == r)[0]
+
+    def b_owned(self, r):
+        return np.nonzero(self._b_owner == r)[0]
+
+    def n_own_u(self, r):
+        return int((self._inv_owner[:self.nu] == r).sum())
+
+    def local_nodes(self, r):
+        """(full nodes, surface nodes) whose rows rank r owns: they lead its local numbering in this order (ascending global
+        ids keep [x y z of full nodes | x y of surface nodes | other u | p])"""
+        own = self._inv_owner[:self.nu] == r
+        nf3, nbr = 3 * self.n_full, 3 * self.n_full + 2 * self.n_surf
+        a, b = int(own[:nf3].sum()), int(own[nf3:nbr].sum())
+        assert a % 3 == 0 and b % 2 == 0
+        return a // 3, b // 2
+
+
+class FieldLayout:
+    """Local numbering of one field on one rank: [owned | solver ghosts | further ghosts]."""
+
+    def __init__(self, n_global, owned, g_sol, g_ext):
+        self.owned, self.g_sol, self.g_ext = owned, g_sol, g_ext
+        self.n_own, self.n_sol, self.n_loc = len(owned), len(owned) + len(g_sol), len(owned) + len(g_sol) + len(g_ext)
+        self.lut = np.full(n_global, -1, dtype=np.int64)
+        self.lut[owned] = np.arange(self.n_own)
+        self.lut[g_sol] = self.n_own + np.arange(len(g_sol))
+        self.lut[g_ext] = self.n_sol + np.arange(len(g_ext))
+
+    def globals(self):
+        return np.concatenate([self.owned, self.g_sol, self.g_ext])
+
+
+def _by_owner(ids, owner):
+    ids = np.asarray(ids, dtype=np.int64)
+    return ids[np.lexsort((ids, owner[ids]))]
+
+
+class RankLayout:
+    """What rank `rank` keeps: its cells and the local numberings of both fields.  Pure host logic (numpy) - exercised on
+    CPU by tests/test_partition.py."""
+
+    def __init__(self, fe_data, part, rank):
+        t, d = fe_data.tables, fe_data.dofs
+        self.rank, self.part = rank, part
+        nc = len(t.cell_p)
+        inv_ids = np.concatenate([t.cell_u.reshape(nc, 30), t.cell_p], axis=1).astype(np.int64)     # (nc, 34), < 0: constrained
+        b_ids = t.cell_b.astype(np.int64)
+        own_inv, own_b = part.inv_owner(), part.b_owner()
+        self.owner_inv, self.owner_b = own_inv, own_b
+        mine_i = np.zeros(d.nu + d.np + 1, dtype=bool)            # (+1: slot for the negative codes)
+        mine_i[:-1] = own_inv == rank
+        mine_b = np.zeros(d.nb + 1, dtype=bool)
+        mine_b[:-1] = own_b == rank
+        c_inv = mine_i[np.where(inv_ids >= 0, inv_ids, -1)].any(axis=1)
+        c_b = mine_b[np.where(b_ids >= 0, b_ids, -1)].any(axis=1)
+        self.cells = np.nonzero(c_inv | c_b)[0]
+        self.n_cells_inv, self.n_cells_b = int(c_inv.sum()), int(c_b.sum())
+
+        def layout(ids, c_rows, owned, owner, n):
+            sol = np.unique(ids[c_rows][ids[c_rows] >= 0])
+            sol = sol[owner[sol] != rank]
+            allc = np.unique(ids[self.cells][ids[self.cells] >= 0])
+            ext = allc[owner[allc] != rank]
+            ext = np.setdiff1d(ext, sol, assume_unique=True)
+            return FieldLayout(n, owned, _by_owner(sol, owner), _by_owner(ext, owner))
+
+        self.inv = layout(inv_ids, c_inv, part.inv_owned(rank), own_inv, d.nu + d.np)
+        self.b = layout(b_ids, c_b, part.b_owned(rank), own_b, d.nb)
+        self.n_own_u = part.n_own_u(rank) if hasattr(part, "n_own_u") else int(part.u_bounds[rank + 1] - part.u_bounds[rank])
+
+    def local_tables(self, fe_data) -> DeviceTables:
+        t = fe_data.tables
+        cu, cp, cb = t.cell_u[self.cells], t.cell_p[self.cells], t.cell_b[self.cells]
+        lu = np.where(cu >= 0, self.inv.lut[np.maximum(cu, 0)], cu)
+        lp = np.where(cp >= 0, self.inv.lut[np.maximum(cp, 0)], cp)
+        lb = np.where(cb >= 0, self.b.lut[np.maximum(cb, 0)], cb)
+        assert (lu[cu >= 0] >= 0).all() and (lp[cp >= 0] >= 0).all() and (lb[cb >= 0] >= 0).all()
+        return DeviceTables(cell_u=np.ascontiguousarray(lu, dtype=np.int32), cell_p=np.ascontiguousarray(lp, dtype=np.int32),
+                            cell_b=np.ascontiguousarray(lb, dtype=np.int32), u_diri=t.u_diri, b_diri=t.b_diri,
+                            u_pos=None, p_pos=None, b_pos=None)
+
+    def local_pattern(self, pattern, rows: FieldLayout, cols: FieldLayout, solver_cols=True):
+        """rows `rows.owned` of a global CSR pattern in local numbering; solver_cols: the column space is the solver's
+        [owned | solver ghosts] (square systems), else the full local numbering (B: inversion rows x buoyancy columns)."""
+        rp, ci, shape = pattern
+        P = sp.csr_matrix((np.ones(len(ci), dtype=np.int8), ci, rp), shape=shape)[rows.owned]
+        lc = cols.lut[P.indices]
+        ncol = cols.n_sol if solver_cols else cols.n_loc
+        assert (lc >= 0).all() and (lc < ncol).all()
+        Q = sp.csr_matrix((P.data, lc, P.indptr), shape=(rows.n_own, ncol))
+        Q.sort_indices()
+        return Q.indptr.astype(np.int64), Q.indices.astype(np.int32), Q.shape
+
+
+class _LocalMesh:
+    """The slice of fe.Mesh that assembly.DeviceFE and the coefficient evaluation read, restricted to a rank's cells."""
+
+    def __init__(self, mesh, cells):
+        self.cells_global = cells
+        self.grad_lambda = np.ascontiguousarray(mesh.grad_lambda[cells])
+        self.detJ = np.ascontiguousarray(mesh.detJ[cells])
+        self.q_w, self.q_lam = mesh.q_w, mesh.q_lam
+        self.N2, self.dN2, self.N1, self.dN1 = mesh.N2, mesh.dN2, mesh.N1, mesh.dN1
+        self._X = mesh.geo_coords[mesh.cell_geo[cells]]            # (ncell, 4, 3) every cell's own vertex coordinates
+        self.ncell = len(cells)
+
+    def quad_points(self):
+        return np.einsum("qk,cki->cqi", self.q_lam, self._X)
+
+    def h_cells(self):
+        X = self._X
+        return np.linalg.norm(X[:, :, None, :] - X[:, None, :, :], axis=-1).max(axis=(1, 2))
+
+
+class LocalFEData:
+    """Quacks like fe.FEData for assembly.DeviceFE: a rank's cells with DoF tables in the rank's local numbering."""
+
+    def __init__(self, fe_data, lay: RankLayout):
+        self.mesh = _LocalMesh(fe_data.mesh, lay.cells)
+        self.spaces = SimpleNamespace(b_order=fe_data.spaces.b_order)
+        self.tables = lay.local_tables(fe_data)
+        self.dofs = SimpleNamespace(nu=lay.inv.n_loc, np=0, nb=lay.b.n_loc)
+
+
+class _Comm:
+    """The few host-level reductions a timestep needs beside the solvers' own (blow-up guard, CFL step)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def any(self, flag):
+        return self.ctx.allreduce_sum([1.0 if flag else 0.0])[0] > 0.0
+
+    def min(self, value):
+        v = np.zeros(self.ctx.nranks)
+        v[self.ctx.rank] = value
+        return float(self.ctx.allreduce_sum(v).min())
+
+    def max(self, value):
+        v = np.zeros(self.ctx.nranks)
+        v[self.ctx.rank] = value
+        return float(self.ctx.allreduce_sum(v).max())
+
+
+class PartitionedSolverToolkit:
+    """IterativeSolverToolkit of a rank's row block.  `x` is the rank's state vector [owned | solver ghosts | further
+    ghosts]; the Krylov solver works on its leading view `x_sol` (warm start included) and the ghosts are refreshed from
+    their owners when it returns."""
+
+    def __init__(self, A, P, y, workspace, kwargs, label, x, lay: FieldLayout, halo_sol, halo_ext):
+        self.A, self.P, self.y, self.workspace, self.kwargs, self.label = A, P, y, workspace, dict(kwargs), label
+        self.x, self.lay, self.halo, self.halo_ext = x, lay, halo_sol, halo_ext
+        self.x_sol = x.view(0, lay.n_sol)
+        self.x_own = x.view(0, lay.n_own)
+
+    def refresh_ghosts(self):
+        self.halo.exchange(self.x_sol)
+        if self.halo_ext is not None:
+            self.halo_ext.exchange(self.x)
+
+    def solve(self):
+        self.workspace.solve(self.A, self.y, self.x_sol, self.P, **self.kwargs)
+        self.refresh_ghosts()
+
+
+class PartitionedState:
+    """model.state of a partitioned model: u, p, b in the native (Gridap) DoF order, gathered from the ranks' owned
+    slices.  COLLECTIVE - every rank must read the same attribute (diagnostics, checkpoints, tests)."""
+
+    def __init__(self, model):
+        self._m = model
+
+    def _gather(self, x, lay, n):
+        m = self._m
+        parts = [None] * m.dist.get_world_size()
+        m.dist.all_gather_object(parts, (lay.owned, x.view(0, lay.n_own).to_host()))
+        full = np.empty(n)
+        for ids, vals in parts:
+            full[ids] = vals
+        return full
+
+    def _inv(self):
+        d = self._m.fe_data.dofs
+        full = self._gather(self._m.inversion.solver.x, self._m.layout.inv, d.nu + d.np)
+        return full[d.inv_p_inversion]
+
+    @property
+    def u(self):
+        return self._inv()[:self._m.fe_data.dofs.nu]
+
+    @property
+    def p(self):
+        return self._inv()[self._m.fe_data.dofs.nu:]
+
+    @property
+    def b(self):
+        d = self._m.fe_data.dofs
+        return self._gather(self._m.b_vec, self._m.layout.b, d.nb)[d.inv_p_b]
+
+
+def halo_plans(dist, rank, lay: FieldLayout, owner):
+    """(solver plan, extra plan) of one field - host logic, collective over `dist` (any backend; exercised with gloo on CPU).
+    The extra ghosts sit behind [owned | solver ghosts]: for their plan that whole leading part is the "owned" segment
+    (send indices only ever name truly owned entries)."""
+    allg = [None] * dist.get_world_size()
+    dist.all_gather_object(allg, (lay.g_sol, lay.g_ext))
+    return (halo_plan(rank, lay.owned, owner, [a[0] for a in allg]), halo_plan(rank, lay.owned, owner, [a[1] for a in allg]))
+
+
+def _make_halos(ctx, dist, rank, lay: FieldLayout, owner):
+    plan_s, plan_e = halo_plans(dist, rank, lay, owner)
+    return Halo(ctx, lay.n_own, len(lay.g_sol), plan_s), Halo(ctx, lay.n_sol, len(lay.g_ext), plan_e)
+
+
+def partitioned_model(arch, fe_data, params, forcings, ts, dist, atol=1e-6, rtol=1e-6, itmax=0, memory=20, reorth_eta=0.1,
+                      block_nodes=None, first_step_lhs="bdf1", element_precision=None, b0=None, partition="node"):
+    """Model(arch, params, forcings, fe_data, InversionToolkit(...), EvolutionToolkit(...), ts) with the mesh, the matrices
+    and the state partitioned over the ranks of `dist` (torch.distributed, initialised).  Call on every rank.  Mirrors
+    src/inversion.jl:20-94 and src/evolution.jl:62-126 on the rank's cells and rows; the reference's GPU preconditioner
+    Diagonal(1/h^dim) uses the GLOBAL median edge length (src/inversion.jl:42-54)."""
+    import torch
+    from .architectures import comm_unique_id
+    ctx = arch.ctx
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if ctx.nranks != world:
+        ids = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(ids[0], rank, world)
+    d = fe_data.dofs
+    part = (NodePartition(fe_data, world) if partition == "node" else
+            RowPartition(d.nu, d.np, d.nb, world, d.n_full, d.n_surf))
+    lay = RankLayout(fe_data, part, rank)
+    lfd = LocalFEData(fe_data, lay)
+    fe = DeviceFE(ctx, lfd)
+    if element_precision is not None:
+        fe.set_precision(element_precision)
+    full_stress = callable(forcings.nu) or forcings.eddy_param.is_on
+    # ---- inversion (src/inversion.jl:20-94) --------------------------------------------------------------------------
+    fe.set_coeff("nu", forcings.nu)
+    fe.set_coeff("f", params.f)
+    a2e2 = params.alpha ** 2 * params.eps ** 2
+    rp, ci, shp = lay.local_pattern(fe_data.pattern_A(structural=full_stress), lay.inv, lay.inv)
+    A = DeviceCSR.from_pattern(ctx, shp[0], shp[1], rp, ci)
+    fe.assemble(L.NPG_MAT_A, A, scale=a2e2, full_stress=full_stress)
+    if block_nodes is None:
+        block_nodes = d.nu + d.np >= 100000
+    if block_nodes and not full_stress:
+        A.block_nodes(*part.local_nodes(rank))             # owned nodes lead the local numbering; ghost couplings stay CSR
+    rp, ci, shp = lay.local_pattern(fe_data.pattern_B(), lay.inv, lay.b, solver_cols=False)
+    B = DeviceCSR.from_pattern(ctx, shp[0], shp[1], rp, ci)
+    b0v = DeviceVector(ctx, lay.inv.n_own)
+    fe.assemble(L.NPG_MAT_B, B, scale=1.0 / params.alpha, lift=b0v)
+    wind = np.zeros(d.nu + d.np)                           # build_b_inversion, src/inversion.jl:226-249 (host, surface only)
+    for comp, tau in ((0, forcings.tau_x), (1, forcings.tau_y)):
+        if callable(tau) or float(tau) != 0.0:
+            fn = tau if callable(tau) else (lambda x, c=float(tau): np.full(x.shape[:-1], c))
+            load = fe_data.mesh.surface_load(lambda x: params.alpha * fn(x))
+            pos = fe_data.tables.u_pos[:, comp]
+            wind[pos[pos >= 0]] += load[pos >= 0]
+    if np.any(wind != 0.0):
+        b0v.axpby(1.0, DeviceVector.from_host(ctx, wind[lay.inv.owned]), 1.0)
+    h_sol_i, h_ext_i = _make_halos(ctx, dist, rank, lay.inv, lay.owner_inv)
+    ws = GmresWorkspace(ctx, lay.inv.n_own, memory=memory)
+    L.check(L.lib().npg_gmres_set_halo(ws.h, h_sol_i.h))
+    x_inv = DeviceVector(ctx, lay.inv.n_loc)
+    x_inv.fill(0.0)
+    h = fe_data.mesh.median_edge_length()
+    kw = dict(atol=atol, rtol=rtol, itmax=itmax, history=True, verbose=0, restart=True, reorth_eta=reorth_eta)
+    inv = SimpleNamespace(arch=arch, B=B, b=b0v)
+    inv.solver = PartitionedSolverToolkit(A, Diagonal(scalar=1.0 / h ** 3, n=lay.inv.n_own), DeviceVector(ctx, lay.inv.n_own),
+                                          ws, kw, "Inversion", x_inv, lay.inv, h_sol_i, h_ext_i)
+    # ---- evolution (src/evolution.jl:62-126) -------------------------------------------------------------------------
+    fe.set_coeff("kappa_h", forcings.kappa_h)
+    fe.set_coeff("kappa_v", forcings.kappa_v)
+    nbl, nbo = lay.b.n_loc, lay.b.n_own
+    pat_b = lay.local_pattern(fe_data.pattern_b(), lay.b, lay.b)
+    proto = DeviceCSR.from_pattern(ctx, pat_b[2][0], pat_b[2][1], pat_b[0], pat_b[1])
+    ev = SimpleNamespace(arch=arch, fe=fe, fe_data=fe_data, params=params, forcings=forcings)
+    ev.rhs_M, ev.rhs_h, ev.rhs_v = (DeviceVector(ctx, nbl) for _ in range(3))       # owned entries meaningful
+    for v in (ev.rhs_M, ev.rhs_h, ev.rhs_v):
+        v.fill(0.0)
+    ev.M = fe.assemble(L.NPG_MAT_M, proto.clone(), lift=ev.rhs_M)
+    ev.Kh = fe.assemble(L.NPG_MAT_KH, proto.clone(), lift=ev.rhs_h)
+    ev.Kv = fe.assemble(L.NPG_MAT_KV, proto.clone(), lift=ev.rhs_v)
+    ev.rhs_diff = fe.rhs_diff(params.N2, DeviceVector(ctx, nbl))
+    flux = np.zeros(d.nb)                                   # build_rhs_flux, src/evolution.jl:280-296
+    bc = forcings.b_surface_bc
+    if isinstance(bc, SurfaceFluxBC):
+        fn = bc.flux if callable(bc.flux) else (lambda x, c=float(bc.flux): np.full(x.shape[:-1], c))
+        load = fe_data.mesh.surface_load(lambda x: params.alpha * fn(x))[:fe_data.spaces.nb_nodes]
+        pos = fe_data.tables.b_pos
+        flux[pos[pos >= 0]] = load[pos >= 0]
+    ev.rhs_flux = DeviceVector.from_host(ctx, flux[lay.b.globals()])
+    ts1 = BDF1(t_start=ts.t_start, t_stop=ts.t_stop, dt=ts.dt) if first_step_lhs == "bdf1" else ts
+    A_evo = proto.clone()
+    P_evo = Diagonal(DeviceVector(ctx, nbo))
+    collect_evolution_LHS_into(A_evo, P_evo, params, ts1, ev.M, ev.Kh, ev.Kv)
+    h_sol_b, h_ext_b = _make_halos(ctx, dist, rank, lay.b, lay.owner_b)
+    wsb = CgWorkspace(ctx, nbo)
+    L.check(L.lib().npg_cg_set_halo(wsb.h, h_sol_b.h))
+    b_vec = DeviceVector(ctx, nbl)
+    b_vec.fill(0.0)
+    y_full = DeviceVector(ctx, nbl)                         # the element kernels write all local rows; the solver reads the owned ones
+    kwb = dict(atol=atol, rtol=rtol, itmax=itmax, history=True, verbose=0)
+    ev.solver = PartitionedSolverToolkit(A_evo, P_evo, y_full.view(0, nbo), wsb, kwb, "Evolution", b_vec, lay.b, h_sol_b,
+                                         h_ext_b)
+    ev.solver.y_full = y_full
+    model = PartitionedModel(arch, params, forcings, fe_data, inv, ev, ts, lay, dist, fe)
+    if b0 is not None:
+        model.set_b(b0)
+    torch.cuda.synchronize()
+    dist.barrier()
+    model.comm_layout = dict(n_owned_inv=lay.inv.n_own, n_ghost_inv=len(lay.inv.g_sol), n_ghost_inv_extra=len(lay.inv.g_ext),
+                             n_owned_b=lay.b.n_own, n_ghost_b=len(lay.b.g_sol), n_ghost_b_extra=len(lay.b.g_ext),
+                             cells=int(len(lay.cells)), cells_global=int(fe_data.mesh.ncell),
+                             peers_inv=[int(q) for q in h_sol_i._keep["peers"]],
+                             matrix_bytes=int(sum(M.stored_spmv_bytes() for M in (A, B, ev.M, ev.Kh, ev.Kv, A_evo))))
+    return model
+
+
+class PartitionedModel(Model):
+    """Model whose mesh, matrices and state are partitioned (see the module docstring); run!, evolve!, invert! of model.py
+    drive it unchanged - the differences are the hooks below."""
+
+    def __init__(self, arch, params, forcings, fe_data, inversion, evolution, timestepper, layout, dist, fe):
+        self.arch, self.params, self.forcings, self.fe_data = arch, params, forcings, fe_data
+        self.inversion, self.evolution, self.timestepper = inversion, evolution, timestepper
+        self.layout, self.dist, self.fe = layout, dist, fe
+        self.partition = layout.part
+        self.b_vec = evolution.solver.x
+        self.state = PartitionedState(self)
+        self.step_index = 1
+        self.extrapolate_guess = False
+        self.stats = []
+        self._prev = None
+        self._u_view = inversion.solver.x.view(0, layout.n_own_u)
+        self.comm = _Comm(arch.ctx)
+
+    def set_b(self, b):
+        """set_b!(model, b) - src/model.jl:77-88 on the rank's slice (owned + both ghost layers at once)"""
+        s, d = self.fe_data.spaces, self.fe_data.dofs
+        vals = s.interpolate_b(b) if callable(b) else np.asarray(b, dtype=float)
+        dev = np.empty(d.nb)
+        dev[d.inv_p_b] = vals                                # native -> device (p_b) order
+        self.b_vec.upload(dev[self.layout.b.globals()])
+        return self
+
+    def h_cells(self):
+        return self.fe.fe_data.mesh.h_cells()
+
+    def verify_transport(self):
+        """End-to-end check of the communication layer on THIS hardware (collective; True on every rank or on none): a
+        known function of the global DoF id is placed in the owned entries of scratch vectors, both halo plans of both fields
+        run, and every ghost must hold its owner's value bit for bit; the small all-reduce must give the closed-form sum."""
+        ctx, lay = self.arch.ctx, self.layout
+        ok = True
+        for f, sol in ((lay.inv, self.inversion.solver), (lay.b, self.evolution.solver)):
+            g = f.globals()
+            want = np.sin(0.001 * g) + 1e-3 * g
+            x = DeviceVector(ctx, f.n_loc)
+            x.fill(0.0)
+            x.view(0, f.n_own).upload(want[:f.n_own])
+            for rep in range(3):                         # both window slots and the acknowledgement path
+                sol.halo.exchange(x.view(0, f.n_sol))
+                if sol.halo_ext is not None:
+                    sol.halo_ext.exchange(x)
+            ok = ok and np.array_equal(x.to_host(), want)
+        n = ctx.nranks
+        s = ctx.allreduce_sum(np.arange(1.0, 6.0) * (ctx.rank + 1))
+        ok = ok and np.array_equal(s, np.arange(1.0, 6.0) * n * (n + 1) / 2)
+        bad = ctx.allreduce_sum([0.0 if ok else 1.0])[0]
+        return bad == 0.0
+
+    def reassemble_A(self):
+        """the eddy closure's refresh (src/model.jl:160-170): full-stress A on the rank's cells into the rank's rows"""
+        prm = self.params
+        self.fe.assemble(L.NPG_MAT_A, self.inversion.solver.A, scale=prm.alpha ** 2 * prm.eps ** 2, full_stress=True)
+
+
+# ---- named workloads, partitioned ------------------------------------------------------------------------------------------
+def example_model(arch, mesh_model, dist, dt=1e-3, t_stop=1e9, **kw):
+    """workloads.example_model (examples/bowl_mixing.jl:171-190) with the mesh partitioned over the ranks of `dist`"""
+    from . import workloads
+    from .timesteppers import BDF2
+    prm, frc = workloads.example_parameters()
+    fed = workloads.example_fe_data(mesh_model)
+    return partitioned_model(arch, fed, prm, frc, BDF2(t_start=0.0, t_stop=t_stop, dt=dt), dist, **kw)
+
+
+def channel_basin_model(arch, mesh_model, dist, surface="flux", itmax=1000, CFL_factor=0.8, element_precision="fp32",
+                        atol=1e-6, rtol=1e-6, **kw):
+    """workloads.channel_basin_model (scratch/run.jl:146-172: BASELINE configs[4]) with the mesh partitioned over the ranks
+    of `dist`: x-periodic mesh, P1 buoyancy, full-stress A, BDF1 with the CFL step, both closures - each re-evaluated and
+    re-assembled on the rank's own cells."""
+    from . import workloads
+    from .model import invert
+    fed = workloads.channel_basin_fe_data(mesh_model, surface)
+    prm, frc, _, _, dt, b0 = workloads.channel_basin_parameters(surface)
+    ts = BDF1(t_start=0.0, t_stop=prm.mu_rho / prm.eps ** 2, dt=dt, adaptive=True, CFL_factor=CFL_factor)
+    model = partitioned_model(arch, fed, prm, frc, ts, dist, atol=atol, rtol=rtol, itmax=itmax,
+                              element_precision=element_precision, b0=b0, **kw)
+    invert(model)
+    return model

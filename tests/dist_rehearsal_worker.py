@@ -22,14 +22,20 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     arch = npg.GPU(int(os.environ.get("NPG_FORCE_DEVICE", 0)))
     ctx = arch.ctx
-    channel = len(sys.argv) > 3 and sys.argv[3] == "channel"
+    mode = sys.argv[3] if len(sys.argv) > 3 else "csr"
+    channel = mode in ("channel", "pchannel")
+    partitioned = mode in ("part", "partcsr", "pchannel")          # mesh-partitioned model (nupgcm_amd.partition)
+    if partitioned:
+        from nupgcm_amd import partition
     if channel:
         from nupgcm_amd import channel_basin
         mm = channel_basin.channel_basin_model(0.0625, workloads.CB_ALPHA)
-        m = distributed.channel_basin_model(arch, mm, dist, element_precision="fp64")
+        m = (partition.channel_basin_model(arch, mm, dist, element_precision="fp64") if partitioned else
+             distributed.channel_basin_model(arch, mm, dist, element_precision="fp64"))
     else:
         mm = workloads.bowl_mesh_model("bowl3D_h0.1")
-        m = distributed.example_model(arch, mm, dist, block_nodes=block_nodes)
+        m = (partition.example_model(arch, mm, dist, block_nodes=mode == "part") if partitioned else
+             distributed.example_model(arch, mm, dist, block_nodes=block_nodes))
     # distributed SpMV: owned rows of A x for a known global x
     s = m.inversion.solver
     part = m.partition
@@ -41,13 +47,21 @@ def main():
     s.halo.exchange(x_loc)
     y_loc = s.A.mul(x_loc).to_host()
     ghosts = x_loc.to_host()[len(owned):]
+    if partitioned:
+        assert np.array_equal(ghosts, xg[m.layout.inv.g_sol])          # the ghosts arrived, in layout order
     if not channel:
         npg.invert(m)
     npg.run(m, n_steps=nsteps)
     ctx.sync()
     peers = np.asarray(s.halo._keep["peers"])
-    np.savez(f"{out}.rank{rank}.npz", transport=ctx.comm_info()["in_cycle_transport"], peers=peers, dt=m.timestepper.dt, storage=np.array(s.A.storage()), owned=owned, y_loc=y_loc, n_ghost=len(ghosts), u=m.state.u, p=m.state.p,
-             b=m.state.b, gm=[st[1]["niter"] for st in m.stats], cg=[st[0]["niter"] for st in m.stats],
+    extra = {}
+    if partitioned:
+        extra = dict(layout=np.array([m.layout.inv.n_own, len(m.layout.inv.g_sol), len(m.layout.inv.g_ext), m.layout.b.n_own,
+                                      len(m.layout.b.g_sol), len(m.layout.b.g_ext), len(m.layout.cells),
+                                      m.fe_data.mesh.ncell, m.comm_layout["matrix_bytes"]]))
+    u_, p_, b_ = m.state.u, m.state.p, m.state.b          # (collective for the partitioned model)
+    np.savez(f"{out}.rank{rank}.npz", transport=ctx.comm_info()["in_cycle_transport"], peers=peers, **extra, dt=m.timestepper.dt, storage=np.array(s.A.storage()), owned=owned, y_loc=y_loc, n_ghost=len(ghosts), u=u_, p=p_,
+             b=b_, gm=[st[1]["niter"] for st in m.stats], cg=[st[0]["niter"] for st in m.stats],
              solved=[bool(st[1]["solved"]) and bool(st[0]["solved"]) for st in m.stats])
     dist.barrier()
     dist.destroy_process_group()

@@ -101,6 +101,61 @@ def test_multi_rank_rehearsal(serial, world, blocks, split, transport, tmp_path)
     assert rel(z["u"], ref.state.u) < 1e-3 and rel(z["p"], ref.state.p) < 1e-3
 
 
+@pytest.mark.parametrize("world,mode", [(2, "partcsr"), (3, "part"), (4, "part")])
+def test_mesh_partitioned_model_rehearsal(serial, world, mode, tmp_path):
+    """nupgcm_amd.partition: every rank keeps its cells (one ghost layer), assembles its own rows with the element kernels,
+    holds its slice of the state [owned | solver ghosts | further ghosts] and refreshes ghosts instead of all-gathering.
+    Against the single-GPU run: the distributed SpMV of the locally ASSEMBLED blocks, the 3-step trajectory, and the
+    footprint - a rank's matrices are ~1/N of the serial ones, its cells ~1/N + the ghost layer."""
+    ref, y = serial
+    out = str(tmp_path / "part")
+    _launch(world, out, 3, mode, "peer")
+    ranks = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
+    owned = np.concatenate([z["owned"] for z in ranks])
+    assert np.array_equal(np.sort(owned), np.arange(len(y)))
+    yd = np.empty_like(y)
+    for z in ranks:
+        yd[z["owned"]] = z["y_loc"]
+        assert (z["storage"][1] > 0) == (mode == "part")
+    assert rel(yd, y) < 1e-13                     # locally assembled row blocks + halo == the serial matrix
+    for z in ranks[1:]:                           # the gathered state is the same object on every rank
+        assert np.array_equal(z["b"], ranks[0]["b"]) and np.array_equal(z["u"], ranks[0]["u"])
+        assert np.array_equal(z["gm"], ranks[0]["gm"])
+    z = ranks[0]
+    assert z["solved"].all()
+    ref_gm = np.array([s[1]["niter"] for s in ref.stats])
+    assert np.all(np.abs(z["gm"] - ref_gm) <= 0.1 * ref_gm + 20), (z["gm"], ref_gm)
+    assert rel(z["b"], ref.state.b) < 1e-6
+    assert rel(z["u"], ref.state.u) < 1e-3 and rel(z["p"], ref.state.p) < 1e-3
+    # footprint: rows are partitioned (not replicated) and only one layer of cells is shared
+    lay = np.array([zz["layout"] for zz in ranks])            # n_own_inv, g_sol, g_ext, n_own_b, g_sol_b, g_ext_b, cells, ncell, bytes
+    assert lay[:, 0].sum() == len(y) and lay[:, 6].max() < lay[0, 7] * (1.0 / world + 0.3)
+    sol = ref.inversion.solver
+    serial_bytes = sum(M.stored_spmv_bytes() for M in (sol.A, ref.inversion.B, ref.evolution.M, ref.evolution.Kh,
+                                                       ref.evolution.Kv, ref.evolution.solver.A))
+    assert lay[:, 8].max() < 1.25 * serial_bytes / world, (lay[:, 8], serial_bytes)
+
+
+def test_channel_basin_mesh_partitioned(tmp_path):
+    """BASELINE configs[4] on 3 ranks with the mesh partitioned: closures re-evaluated and K_v / the full-stress A
+    re-assembled on each rank's own cells (src/model.jl:160-170,229-261), CFL step from the global minimum."""
+    from nupgcm_amd import channel_basin
+    world, nsteps = 3, 11
+    arch = npg.GPU()
+    mm = channel_basin.channel_basin_model(0.0625, workloads.CB_ALPHA)
+    ref = workloads.channel_basin_model(arch, mesh_model=mm, element_precision="fp64")
+    npg.run(ref, n_steps=nsteps)
+    out = str(tmp_path / "pcb")
+    _launch(world, out, nsteps, "pchannel", "peer")
+    ranks = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
+    for z in ranks[1:]:
+        assert np.array_equal(z["b"], ranks[0]["b"]) and np.array_equal(z["u"], ranks[0]["u"]) and z["dt"] == ranks[0]["dt"]
+    z = ranks[0]
+    assert list(z["gm"]) == [1000] * nsteps
+    assert abs(z["dt"] - ref.timestepper.dt) < 1e-3 * ref.timestepper.dt
+    assert rel(z["b"], ref.state.b) < 1e-3 and rel(z["u"], ref.state.u) < 1e-2, (rel(z["b"], ref.state.b), rel(z["u"], ref.state.u))
+
+
 def test_channel_basin_closures_and_periodic_seam_distributed(tmp_path):
     """BASELINE configs[4] on 3 ranks (rehearsal transport): the x-periodic mesh, P1 buoyancy, full-stress A, BDF1 with the CFL
     step, the convection closure every step and the eddy closure's re-assembly of A at step 10 - each re-assembled as the

@@ -1,0 +1,139 @@
+"""Mesh partition host logic on CPU (nupgcm_amd.partition): node-aligned ownership, the cells / local numberings / local
+patterns a rank keeps, and the two halo plans per field - checked on the reference's bowl3D h = 0.1 mesh against the global
+objects, with two gloo ranks moving the ghost values the way the device transports do."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nupgcm_amd import workloads
+from nupgcm_amd.distributed import RowPartition
+from nupgcm_amd.partition import NodePartition, RankLayout, halo_plans
+
+from .test_distributed_plan import _exchange, _free_port
+
+
+@pytest.fixture(scope="module")
+def fed():
+    return workloads.example_fe_data(workloads.bowl_mesh_model("bowl3D_h0.1"))
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_node_partition_owns_every_dof_once_and_aligns_the_fields(fed, world):
+    d, t = fed.dofs, fed.tables
+    part = NodePartition(fed, world)
+    io, bo = part.inv_owner(), part.b_owner()
+    assert io.shape == (d.nu + d.np,) and bo.shape == (d.nb,) and io.min() == 0 and io.max() == world - 1
+    own = [part.inv_owned(r) for r in range(world)]
+    assert np.array_equal(np.sort(np.concatenate(own)), np.arange(d.nu + d.np))
+    assert np.array_equal(np.sort(np.concatenate([part.b_owned(r) for r in range(world)])), np.arange(d.nb))
+    # one owner per NODE: velocity components, pressure and buoyancy of a node sit on the same rank
+    for a in range(3):
+        on = t.u_pos[:, a] >= 0
+        assert np.array_equal(io[t.u_pos[on, a]], part.node_owner[on])
+    on = t.b_pos >= 0
+    assert np.array_equal(bo[t.b_pos[on]], part.node_owner[:len(t.b_pos)][on])
+    # equal SpMV work, whole nodes per rank in the [full | surface] order npg_csr_block_nodes wants
+    rowlen = np.diff(fed.pattern_A()[0])
+    work = np.array([rowlen[o].sum() for o in own])
+    assert work.max() <= 1.02 * work.mean()
+    nf = sum(part.local_nodes(r)[0] for r in range(world))
+    ns = sum(part.local_nodes(r)[1] for r in range(world))
+    assert (nf, ns) == (d.n_full, d.n_surf)
+    # and the point of it: far fewer ghosts than cutting each field's own RCM sequence
+    rowpart = RowPartition(d.nu, d.np, d.nb, world, d.n_full, d.n_surf)
+    g_node = sum(len(RankLayout(fed, part, r).inv.g_sol) for r in range(world))
+    g_row = sum(len(RankLayout(fed, rowpart, r).inv.g_sol) for r in range(world))
+    assert g_node < 0.5 * g_row, (g_node, g_row)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rank_layout_cells_tables_and_patterns(fed, world):
+    d, t = fed.dofs, fed.tables
+    part = NodePartition(fed, world)
+    rpA, ciA, shA = fed.pattern_A()
+    PA = sp.csr_matrix((np.ones(len(ciA)), ciA, rpA), shape=shA)
+    rpB, ciB, shB = fed.pattern_B()
+    PB = sp.csr_matrix((np.ones(len(ciB)), ciB, rpB), shape=shB)
+    ncells = 0
+    for r in range(world):
+        lay = RankLayout(fed, part, r)
+        ncells += len(lay.cells)
+        # every cell that carries an owned DoF is kept, and the kept cells' DoFs all have a local number
+        lt = lay.local_tables(fed)
+        assert lt.cell_u.shape == (len(lay.cells), 10, 3) and lt.cell_u.max() < lay.inv.n_loc and lt.cell_b.max() < lay.b.n_loc
+        gi = lay.inv.globals()
+        assert np.array_equal(gi[lt.cell_u[lt.cell_u >= 0]], t.cell_u[lay.cells][lt.cell_u >= 0])
+        touched = np.zeros(d.nu + d.np, dtype=bool)
+        cu = t.cell_u[lay.cells]
+        touched[cu[cu >= 0]] = True
+        all_cu = t.cell_u.reshape(len(t.cell_u), -1)
+        mine = np.isin(np.where(all_cu >= 0, all_cu, -1), lay.inv.owned[lay.inv.owned < d.nu]).any(axis=1)
+        assert set(np.nonzero(mine)[0]) <= set(lay.cells)
+        # the local pattern of A: the owned rows of the global one, columns inside [owned | solver ghosts]
+        rp, ci, shape = lay.local_pattern(fed.pattern_A(), lay.inv, lay.inv)
+        assert shape == (lay.inv.n_own, lay.inv.n_sol)
+        Pl = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=shape)
+        G = PA[lay.inv.owned][:, gi[:lay.inv.n_sol]]
+        assert (abs(Pl - G)).nnz == 0 and Pl.nnz == PA[lay.inv.owned].nnz
+        # B: inversion rows x ALL local buoyancy columns
+        rp, ci, shape = lay.local_pattern(fed.pattern_B(), lay.inv, lay.b, solver_cols=False)
+        Bl = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=shape)
+        assert (abs(Bl - PB[lay.inv.owned][:, lay.b.globals()])).nnz == 0 and Bl.nnz == PB[lay.inv.owned].nnz
+    # one ghost layer: the ranks' cell sets overlap, but by far less than replication
+    assert fed.mesh.ncell < ncells < 1.8 * fed.mesh.ncell
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fed = workloads.example_fe_data(workloads.bowl_mesh_model("bowl3D_h0.1"))
+        d = fed.dofs
+        part = NodePartition(fed, world)
+        lay = RankLayout(fed, part, rank)
+        for f, owner, n in ((lay.inv, lay.owner_inv, d.nu + d.np), (lay.b, lay.owner_b, d.nb)):
+            plan_s, plan_e = halo_plans(dist, rank, f, owner)
+            xg = np.sin(0.1 * np.arange(n))                      # a global field; every rank starts with its owned slice
+            x = np.zeros(f.n_loc)
+            x[:f.n_own] = xg[f.owned]
+            _exchange(rank, x[:f.n_sol], f.n_own, plan_s)         # the solver's plan fills the solver ghosts of the VIEW
+            assert np.array_equal(x[f.n_own:f.n_sol], xg[f.g_sol])
+            _exchange(rank, x, f.n_sol, plan_e)                   # the extra plan fills what is behind them
+            assert np.array_equal(x, xg[f.globals()])
+            assert all(int(i) < f.n_own for i in plan_e["send_idx"])       # only truly owned entries are ever sent
+        # the distributed SpMV of the inversion pattern (values = 1): owned rows of the global product
+        rp, ci, shape = lay.local_pattern(fed.pattern_A(), lay.inv, lay.inv)
+        Al = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=shape)
+        rpA, ciA, shA = fed.pattern_A()
+        Ag = sp.csr_matrix((np.ones(len(ciA)), ciA, rpA), shape=shA)
+        xg = np.cos(0.01 * np.arange(shA[0]))
+        xl = np.zeros(lay.inv.n_sol)
+        xl[:lay.inv.n_own] = xg[lay.inv.owned]
+        _exchange(rank, xl, lay.inv.n_own, halo_plans(dist, rank, lay.inv, lay.owner_inv)[0])
+        assert np.allclose(Al @ xl, (Ag @ xg)[lay.inv.owned], rtol=1e-13, atol=1e-13)
+        q.put((rank, "ok"))
+    except Exception as e:                                        # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc() + repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_plans_of_the_partitioned_fields_with_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == "ok" for r in res), res

@@ -7,6 +7,8 @@
 //   hipcc --offload-arch=gfx950 -O2 tools/graph_trace_probe.hip -o gpurun_out/graph_probe -ldl
 //   rocprofv3 --kernel-trace -d gpurun_out/probe_X -- gpurun_out/graph_probe <variant> [relaunches]
 // variants: memcpy | kernel_small | kernel_big | both | cycle (62 kernels + the copy, two ping-pong execs as gmres.hip)
+//           [relaunches] [kernels per graph]: enough relaunches x packets to wrap the 1 MiB AQL ring (16384 packets) several times,
+//           with a packet count per launch that does not divide the ring, reproduces the fault without any library code
 #include <dlfcn.h>
 #include <execinfo.h>
 #include <hip/hip_runtime.h>
@@ -101,7 +103,7 @@ int main(int argc, char **argv) {
     const bool want_copy = !strcmp(variant, "memcpy") || !strcmp(variant, "both") || !strcmp(variant, "cycle");
     const bool want_big = !strcmp(variant, "kernel_big") || !strcmp(variant, "both") || !strcmp(variant, "cycle");
     const bool want_small = !strcmp(variant, "kernel_small");
-    const int nk = !strcmp(variant, "cycle") ? 62 : 1;
+    const int nk = argc > 3 ? atoi(argv[3]) : (!strcmp(variant, "cycle") ? 62 : 1);
 
     hipGraph_t g[2];
     hipGraphExec_t ex[2];

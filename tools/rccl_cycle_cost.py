@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Per-iteration cost of the distributed GMRES cycle's RCCL calls on ONE GPU: a one-rank communicator in self-test mode
+"""Per-iteration cost of the distributed GMRES cycle's communication steps on ONE GPU: a one-rank communicator in self-test mode
 (NPG_COMM_SELFTEST=1, see tests/rccl_selftest_worker.py) against the serial cycle on the same matrix.
-Usage: NPG_COMM_SELFTEST=1 python tools/rccl_cycle_cost.py [n]"""
+Usage: NPG_COMM_SELFTEST=1 [NPG_COMM_TRANSPORT=peer] python tools/rccl_cycle_cost.py [n]
+RCCL (default): ncclAllReduce + grouped ncclSend/ncclRecv to self.  peer: the peer-window kernels of comm.hip with the rank as
+its own neighbour (push / flag / unpack / acknowledge, one-kernel fold + all-reduce)."""
 import os
 import sys
 import time
@@ -36,9 +38,10 @@ A_loc.sort_indices()
 A_ser, A_dis = npg.DeviceCSR.from_scipy(ctx, M), npg.DeviceCSR.from_scipy(ctx, A_loc)
 y = npg.DeviceVector.from_host(ctx, rng.standard_normal(n))
 P = npg.Diagonal(diag=npg.DeviceVector.from_host(ctx, 1.0 / M.diagonal()))
+tr = "peer windows" if os.environ.get("NPG_COMM_TRANSPORT") == "peer" else "RCCL"
 for label, A, nx, dist_, graph in (("serial (hipGraph cycles)", A_ser, n, False, 0),
-                                   ("through RCCL, one-rank communicator, eager launches", A_dis, n + len(S), True, 0),
-                                   ("through RCCL, one-rank communicator, hipGraph replay", A_dis, n + len(S), True, 1)):
+                                   (f"through {tr}, one-rank communicator, eager launches", A_dis, n + len(S), True, 0),
+                                   (f"through {tr}, one-rank communicator, hipGraph replay", A_dis, n + len(S), True, 1)):
     ws = npg.GmresWorkspace(ctx, n, memory=20)
     if dist_:
         L.check(L.lib().npg_gmres_set_halo(ws.h, halo.h))
