@@ -335,6 +335,7 @@ int npg_comm_info(npg_ctx *ctx, char *buf, size_t cap);
 /* auto transport only: drop the peer windows, RCCL carries the in-cycle traffic from here on (no live halo plans) */
 int npg_comm_disable_peer(npg_ctx *ctx);
 int npg_comm_allreduce_sum(npg_ctx *ctx, double *host_inout, int n);  /* tiny host-side helper for tests/bench */
+int npg_comm_allreduce_vec(npg_ctx *ctx, npg_vec *v);                 /* <= 32 doubles, in place, on the context's stream */
 /* Replicate a row-block distributed vector on every rank: segment s of `full` ([global_off, global_off + len)) is owned
  * by rank seg_rank[s], who holds it at local[local_off ..].  One grouped ncclBroadcast per segment over xGMI. */
 int npg_comm_allgather_segments(npg_ctx *ctx, const npg_vec *local, int nseg, const int32_t *seg_rank,

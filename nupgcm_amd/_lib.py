@@ -107,7 +107,7 @@ def _declare(L):
         "npg_fe_update_kappa_convection": [P, VP, D, D, D, D, P],
         "npg_fe_update_nu_eddy": [P, D, D, D, D, D, P], "npg_fe_cfl_ratio": [P, VP, D, P, C.POINTER(D)],
         "npg_comm_unique_id": [VP], "npg_comm_init": [P, VP, C.c_int, C.c_int],
-        "npg_comm_allreduce_sum": [P, C.POINTER(D), C.c_int], "npg_comm_info": [P, C.c_char_p, C.c_size_t], "npg_comm_disable_peer": [P],
+        "npg_comm_allreduce_sum": [P, C.POINTER(D), C.c_int], "npg_comm_info": [P, C.c_char_p, C.c_size_t], "npg_comm_disable_peer": [P], "npg_comm_allreduce_vec": [P, P],
         "npg_comm_allgather_segments": [P, P, C.c_int, VP, VP, VP, VP, P],
         "npg_halo_create": [P, I64, I64, C.c_int, VP, VP, VP, VP, PP], "npg_halo_destroy": [P],
         "npg_halo_exchange": [P, P], "npg_gmres_set_halo": [P, P], "npg_gmres_set_dist_options": [P, C.c_int, C.c_int], "npg_cg_set_halo": [P, P],

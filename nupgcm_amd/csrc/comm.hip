@@ -273,37 +273,41 @@ struct HaloPeerDev {
     int npeers;
 };
 
-__global__ void __launch_bounds__(256) k_halo_push(const double *__restrict__ x, const int32_t *__restrict__ send_idx,
-                                                   HaloPeerDev H) {
-    const int4 t = H.tab[blockIdx.x];
+// ONE kernel per exchange.  Workgroup b < npush: gather x[send_idx[s]] for its chunk straight into the neighbour's window
+// (write-through stores), drain, raise its flag.  Then workgroup b < nwait: wait for every neighbour's flags of this epoch,
+// copy its share of the window behind the owned entries; the last one acknowledges and completes the epoch.  Every
+// workgroup pushes BEFORE it waits, and pushes depend only on acknowledgements of epoch e - 2: no cycle of waits between
+// ranks.  (grid = max(npush, nwait) <= 15 * 32 workgroups: all resident.)
+__global__ void __launch_bounds__(256) k_halo_exchange(double *__restrict__ x, const int32_t *__restrict__ send_idx, int64_t n_owned,
+                                                       int npush, int nwait, HaloPeerDev H) {
     const uint64_t e = *H.epoch + 1;
-    if (threadIdx.x == 0 && e > 2) {
-        // the slot was last used by exchange e - 2: the peer must have copied it out
-        SpinGuard guard(H.ticks, H.status, 2);
-        while (ld_sys(H.ack + t.z) + 2 < e)
-            if (guard.expired()) break;
+    if ((int)blockIdx.x < npush) {
+        const int4 t = H.tab[blockIdx.x];
+        if (threadIdx.x == 0 && e > 2) {
+            // the slot was last used by exchange e - 2: the peer must have copied it out
+            SpinGuard guard(H.ticks, H.status, 2);
+            while (ld_sys(H.ack + t.z) + 2 < e)
+                if (guard.expired()) break;
+        }
+        __syncthreads();
+        double *dst = H.dst[t.z] + (e & 1) * H.dst_stride[t.z] - H.seg0[t.z];
+        // four independent index -> value chains per lane and trip
+        for (int64_t s0 = t.x + (int)threadIdx.x; s0 < t.y; s0 += 4 * 256) {
+            int32_t idx[4];
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) idx[u] = s0 + u * 256 < t.y ? send_idx[s0 + u * 256] : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = x[idx[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (s0 + u * 256 < t.y) st_sys_f64(dst + s0 + u * 256, v[u]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
+        __syncthreads();                                       // ... before one lane raises the workgroup's flag
+        if (threadIdx.x == 0) st_sys(H.flag_dst[t.z] + t.w, e);
     }
-    __syncthreads();
-    double *dst = H.dst[t.z] + (e & 1) * H.dst_stride[t.z] - H.seg0[t.z];
-    // four independent index -> value chains per lane and trip
-    for (int64_t s0 = t.x + (int)threadIdx.x; s0 < t.y; s0 += 4 * 256) {
-        int32_t idx[4];
-        double v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) idx[u] = s0 + u * 256 < t.y ? send_idx[s0 + u * 256] : 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = x[idx[u]];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (s0 + u * 256 < t.y) st_sys_f64(dst + s0 + u * 256, v[u]);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
-    __syncthreads();                                       // ... before one lane raises the workgroup's flag
-    if (threadIdx.x == 0) st_sys(H.flag_dst[t.z] + t.w, e);
-}
-
-__global__ void __launch_bounds__(256) k_halo_wait_unpack(double *__restrict__ xg, HaloPeerDev H) {
-    const uint64_t e = *H.epoch + 1;
+    if ((int)blockIdx.x >= nwait) return;
     if (threadIdx.x < 64) {
         SpinGuard guard(H.ticks, H.status, 3);
         for (int p = 0; p < H.npeers; ++p) {
@@ -319,9 +323,10 @@ __global__ void __launch_bounds__(256) k_halo_wait_unpack(double *__restrict__ x
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the invalidate has completed before the barrier opens
     }
     __syncthreads();
+    double *xg = x + n_owned;
     const double *src = H.rwin + (e & 1) * H.n_ghost;
     // eight loads in flight per lane (the window is uncached memory: every load is a round trip to HBM)
-    const int64_t stride = gridDim.x * 256LL;
+    const int64_t stride = nwait * 256LL;
     for (int64_t i0 = blockIdx.x * 256LL + threadIdx.x; i0 < H.n_ghost; i0 += 8 * stride) {
         double v[8];
 #pragma unroll
@@ -334,7 +339,7 @@ __global__ void __launch_bounds__(256) k_halo_wait_unpack(double *__restrict__ x
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long done = atomicAdd(H.arrive, 1ULL) + 1ULL;
-        if (done == (unsigned long long)gridDim.x * e) {
+        if (done == (unsigned long long)nwait * e) {
             // last workgroup of this exchange: the window slot is free again, tell the senders; the exchange is complete
             for (int p = 0; p < H.npeers; ++p)
                 if (H.nflag[p] > 0) st_sys(H.ack_dst[p], e);
@@ -668,6 +673,22 @@ NPG_API int npg_comm_allreduce_sum(npg_ctx *ctx, double *host_inout, int n) {
     return NPG_OK;
 }
 
+// in-place sum over the ranks of a device vector of at most 32 doubles, enqueued on the context's stream (no host
+// synchronisation): the collective the solvers use per iteration, exposed for host-side drivers and stress tests
+NPG_API int npg_comm_allreduce_vec(npg_ctx *ctx, npg_vec *v) {
+    NPG_REQUIRE(ctx && v && v->n >= 1 && v->n <= kPartStride, "npg_comm_allreduce_vec: 1 to %d entries", kPartStride);
+    if (ctx->peer && !single_rank_shortcut(ctx)) {
+        // the peer kernel always moves a whole row of 32 doubles: go through the context's scratch row
+        NPG_HIP(hipMemsetAsync(ctx->d_scratch, 0, kPartStride * sizeof(double), ctx->stream));
+        NPG_HIP(hipMemcpyAsync(ctx->d_scratch, v->d, (size_t)v->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        int rc = allreduce_sum_device(ctx, ctx->d_scratch, kPartStride);
+        if (rc) return rc;
+        NPG_HIP(hipMemcpyAsync(v->d, ctx->d_scratch, (size_t)v->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        return NPG_OK;
+    }
+    return allreduce_sum_device(ctx, v->d, (int)v->n);
+}
+
 NPG_API int npg_comm_allgather_segments(npg_ctx *ctx, const npg_vec *local, int nseg, const int32_t *seg_rank,
                                         const int64_t *seg_local_off, const int64_t *seg_global_off,
                                         const int64_t *seg_len, npg_vec *full) {
@@ -988,15 +1009,13 @@ static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st) {
     npg_ctx *ctx = h->ctx;
     if (h->npeers == 0 && !ctx->shm) return NPG_OK;
     if (h->pw) {
-        // peer windows: gather straight into the neighbours' windows, then wait for theirs and copy it behind the owned
-        // entries.  Two kernel launches, no host involvement: capturable, replayable.
+        // peer windows: gather straight into the neighbours' windows, wait for theirs and copy it behind the owned entries.
+        // One kernel launch, no host involvement: capturable, replayable.
         HaloPeer *w = (HaloPeer *)h->pw;
         int rc = peer_status(ctx);
         if (rc) return rc;
-        if (w->nwg_push > 0)
-            hipLaunchKernelGGL(k_halo_push, dim3(w->nwg_push), dim3(256), 0, st, (const double *)x, (const int32_t *)h->send_idx,
-                               w->dev);
-        hipLaunchKernelGGL(k_halo_wait_unpack, dim3(w->nwg_wait), dim3(256), 0, st, x + h->n_owned, w->dev);
+        hipLaunchKernelGGL(k_halo_exchange, dim3(std::max(w->nwg_push, w->nwg_wait)), dim3(256), 0, st, x,
+                           (const int32_t *)h->send_idx, h->n_owned, w->nwg_push, w->nwg_wait, w->dev);
         NPG_HIP(hipGetLastError());
         return NPG_OK;
     }

@@ -23,6 +23,7 @@ Host side: every rank still builds the global FEData (mesh topology, RCM, DoF ta
 derive its layout; everything that touches values is local and on the device."""
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -329,6 +330,8 @@ def partitioned_model(arch, fe_data, params, forcings, ts, dist, atol=1e-6, rtol
     rp, ci, shp = lay.local_pattern(fe_data.pattern_A(structural=full_stress), lay.inv, lay.inv)
     A = DeviceCSR.from_pattern(ctx, shp[0], shp[1], rp, ci)
     fe.assemble(L.NPG_MAT_A, A, scale=a2e2, full_stress=full_stress)
+    if block_nodes is None and os.environ.get("NPG_BLOCK_NODES"):
+        block_nodes = os.environ["NPG_BLOCK_NODES"] != "0"          # tuning / debugging override
     if block_nodes is None:
         block_nodes = d.nu + d.np >= 100000
     if block_nodes and not full_stress:
