@@ -273,15 +273,18 @@ struct HaloPeerDev {
     int npeers;
 };
 
-// ONE kernel per exchange.  Workgroup b < npush: gather x[send_idx[s]] for its chunk straight into the neighbour's window
-// (write-through stores), drain, raise its flag.  Then workgroup b < nwait: wait for every neighbour's flags of this epoch,
-// copy its share of the window behind the owned entries; the last one acknowledges and completes the epoch.  Every
+// ONE kernel per exchange (phase 0).  Workgroup b < npush: gather x[send_idx[s]] for its chunk straight into the neighbour's
+// window (write-through stores), drain, raise its flag.  Then workgroup b < nwait: wait for every neighbour's flags of this
+// epoch, copy its share of the window behind the owned entries; the last one acknowledges and completes the epoch.  Every
 // workgroup pushes BEFORE it waits, and pushes depend only on acknowledgements of epoch e - 2: no cycle of waits between
 // ranks.  (grid = max(npush, nwait) <= 15 * 32 workgroups: all resident.)
+// A solver that has work which needs no ghost value launches the two halves separately around it (phase 1 = push, phase 2 =
+// wait + unpack), on ONE stream: the neighbours' stores land in this rank's window while that work runs - the overlap needs
+// neither a second stream nor events.
 __global__ void __launch_bounds__(256) k_halo_exchange(double *__restrict__ x, const int32_t *__restrict__ send_idx, int64_t n_owned,
-                                                       int npush, int nwait, HaloPeerDev H) {
+                                                       int npush, int nwait, int phase, HaloPeerDev H) {
     const uint64_t e = *H.epoch + 1;
-    if ((int)blockIdx.x < npush) {
+    if (phase != 2 && (int)blockIdx.x < npush) {
         const int4 t = H.tab[blockIdx.x];
         if (threadIdx.x == 0 && e > 2) {
             // the slot was last used by exchange e - 2: the peer must have copied it out
@@ -307,7 +310,7 @@ __global__ void __launch_bounds__(256) k_halo_exchange(double *__restrict__ x, c
         __syncthreads();                                       // ... before one lane raises the workgroup's flag
         if (threadIdx.x == 0) st_sys(H.flag_dst[t.z] + t.w, e);
     }
-    if ((int)blockIdx.x >= nwait) return;
+    if (phase == 1 || (int)blockIdx.x >= nwait) return;
     if (threadIdx.x < 64) {
         SpinGuard guard(H.ticks, H.status, 3);
         for (int p = 0; p < H.npeers; ++p) {
@@ -983,6 +986,18 @@ int npg::halo_exchange_async(npg_halo *h, double *x) {
     if (h->npeers == 0 && !ctx->shm) return NPG_OK;
     h->pending_x = x;
     if (ctx->shm) return NPG_OK;          // host-driven loop-back transport: the exchange happens in halo_exchange_wait()
+    if (h->pw) {
+        // peer windows: push now, on the context's own stream; whatever the caller enqueues next runs while the neighbours'
+        // stores arrive in this rank's window; halo_exchange_wait() enqueues the wait + unpack half behind it
+        HaloPeer *w = (HaloPeer *)h->pw;
+        int rc = peer_status(ctx);
+        if (rc) return rc;
+        if (w->nwg_push > 0)
+            hipLaunchKernelGGL(k_halo_exchange, dim3(w->nwg_push), dim3(256), 0, ctx->stream, x, (const int32_t *)h->send_idx,
+                               h->n_owned, w->nwg_push, w->nwg_wait, 1, w->dev);
+        NPG_HIP(hipGetLastError());
+        return NPG_OK;
+    }
     if (!h->cstream) {
         NPG_HIP(hipSetDevice(ctx->device));
         NPG_HIP(hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking));
@@ -1001,6 +1016,13 @@ int npg::halo_exchange_wait(npg_halo *h) {
     npg_ctx *ctx = h->ctx;
     if (h->npeers == 0 && !ctx->shm) return NPG_OK;
     if (ctx->shm) return halo_exchange_on(h, h->pending_x, ctx->stream);
+    if (h->pw) {
+        HaloPeer *w = (HaloPeer *)h->pw;
+        hipLaunchKernelGGL(k_halo_exchange, dim3(w->nwg_wait), dim3(256), 0, ctx->stream, h->pending_x, (const int32_t *)h->send_idx,
+                           h->n_owned, w->nwg_push, w->nwg_wait, 2, w->dev);
+        NPG_HIP(hipGetLastError());
+        return NPG_OK;
+    }
     NPG_HIP(hipStreamWaitEvent(ctx->stream, h->ev_done, 0));
     return NPG_OK;
 }
@@ -1015,7 +1037,7 @@ static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st) {
         int rc = peer_status(ctx);
         if (rc) return rc;
         hipLaunchKernelGGL(k_halo_exchange, dim3(std::max(w->nwg_push, w->nwg_wait)), dim3(256), 0, st, x,
-                           (const int32_t *)h->send_idx, h->n_owned, w->nwg_push, w->nwg_wait, w->dev);
+                           (const int32_t *)h->send_idx, h->n_owned, w->nwg_push, w->nwg_wait, 0, w->dev);
         NPG_HIP(hipGetLastError());
         return NPG_OK;
     }

@@ -130,9 +130,10 @@ struct npg_halo {
 namespace npg {
 // enqueue the exchange of x's ghost segment / an in-place sum over ranks of n doubles on the context's stream
 int halo_exchange_raw(npg_halo *h, double *x);
-// The same exchange beside the compute stream: it starts once everything enqueued on the context's stream so far has
-// finished (x's owned entries are final) and runs on the plan's own stream; halo_exchange_wait() makes the context's
-// stream wait for the ghost segment.  Kernels enqueued between the two calls must not touch x's ghost segment.
+// The same exchange in two halves, for a caller with work that needs no ghost value: kernels enqueued between the two calls
+// run while the exchange is in flight and must not touch x's ghost segment.  Peer transport: the push half and the wait +
+// unpack half are kernels on the context's own stream (the neighbours' stores arrive meanwhile).  RCCL: the exchange runs on
+// the plan's own stream, ordered against the context's stream by two events.
 int halo_exchange_async(npg_halo *h, double *x);
 int halo_exchange_wait(npg_halo *h);
 int allreduce_sum_device(npg_ctx *ctx, double *buf, int n);

@@ -664,7 +664,8 @@ struct npg_gmres {
     bool explicit_norm = false;   // distributed: a solve met cancellation in the Pythagorean norm
     bool safe_mode = false;       // one GPU: a solve in fast mode met a column that was due a second Gram-Schmidt pass
     int split_mode = -1;
-    int halo_overlap = 1;         // distributed split cycle: interior tiles beside the halo exchange (npg_gmres_set_dist_options)
+    int halo_overlap = -1;        // distributed split cycle: interior tiles beside the halo exchange: -1 = default (on with the
+                                  // peer windows, off with RCCL), 0 / 1 = npg_gmres_set_dist_options
     int dist_graph = -1;          // distributed cycles replayed from a hipGraph: -1 = default (on for the kernel-only peer
                                   // transport, off with RCCL calls in the cycle), 0 = off, 1 = on
     std::vector<hipEvent_t> pev;
@@ -709,8 +710,12 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
     const bool fold = dist;
     // distributed split cycle: the tiles that read no ghost column run while the exchange of wt's ghost segment is in
     // flight on the plan's own stream (NPG_HALO_OVERLAP=0: exchange first, one launch)
-    static const bool overlap_env = !getenv("NPG_HALO_OVERLAP") || atoi(getenv("NPG_HALO_OVERLAP")) != 0;
-    const bool overlap = dist && d.split && overlap_env && ws->halo_overlap && d.nt_int > 0 && d.nt_int < d.ntiles;
+    // default: on with the peer windows (two kernels on one stream around the interior tiles); with RCCL (a second stream and
+    // two events, never run between two physical GPUs) only when asked for - NPG_HALO_OVERLAP=1 / npg_gmres_set_dist_options
+    static const int overlap_env = getenv("NPG_HALO_OVERLAP") ? atoi(getenv("NPG_HALO_OVERLAP")) : -1;
+    const bool kernel_only = dist && comm_is_kernel_only(ws->ctx);
+    const int want = !dist ? 0 : ws->halo_overlap >= 0 ? ws->halo_overlap : (overlap_env >= 0 ? overlap_env : (kernel_only || ws->ctx->shm ? 1 : 0));
+    const bool overlap = dist && d.split && want && d.nt_int > 0 && d.nt_int < d.ntiles;
     const int maxg = ws ? std::min(kMaxG, 3 * ws->ctx->num_cu) : kMaxG;
     static const int reserve_env = getenv("NPG_HALO_RESERVE_CUS") ? atoi(getenv("NPG_HALO_RESERVE_CUS")) : 4;
     const int reserve = std::max(0, std::min(reserve_env, maxg / 6));
@@ -725,10 +730,12 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
         if (overlap) {
             if ((rc = halo_exchange_async(ws->halo, d.wt))) return rc;
             if (pev) hipEventRecord(pev[2 * j], st);
-            // the interior launch leaves a few CUs free: its workgroups are persistent (they hold their CU until the last tile),
-            // and RCCL's send/recv kernels could otherwise not start before they are all done
-            hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(std::max(1, std::min(d.nt_int, maxg - 3 * reserve))), dim3(kKB), 0,
-                               st, d, j, 0, d.nt_int);
+            // RCCL: the interior launch leaves a few CUs free - its workgroups are persistent (they hold their CU until the last
+            // tile) and RCCL's send/recv kernels on the other stream could otherwise not start before they are all done.  Peer
+            // windows: nothing of ours runs beside it (the neighbours' stores need no CU here): full grid.
+            const int gi = kernel_only ? maxg : maxg - 3 * reserve;
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(std::max(1, std::min(d.nt_int, gi))), dim3(kKB), 0, st, d, j, 0,
+                               d.nt_int);
             if ((rc = halo_exchange_wait(ws->halo))) return rc;
             hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(std::max(1, std::min(d.ntiles - d.nt_int, maxg))), dim3(kKB), 0,
                                st, d, j, d.nt_int, d.ntiles);
@@ -1155,7 +1162,7 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
 
 NPG_API int npg_gmres_set_dist_options(npg_gmres *ws, int overlap, int graph) {
     NPG_REQUIRE(ws, "npg_gmres_set_dist_options: NULL workspace");
-    ws->halo_overlap = overlap ? 1 : 0;
+    ws->halo_overlap = overlap < 0 ? -1 : (overlap ? 1 : 0);
     ws->dist_graph = graph < 0 ? -1 : (graph ? 1 : 0);
     ws->have_graph = false;
     return NPG_OK;
