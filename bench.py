@@ -218,9 +218,11 @@ def main():
     def barrier():
         ctx.sync()
         if dist is not None:
-            import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if dist.get_backend() == "nccl":
+                import torch
+                torch.cuda.synchronize()
+            ctx.sync()
 
     npg.run(model, n_steps=a.warmup)
     barrier()
@@ -315,6 +317,9 @@ def main():
                    "N_inversion": N_glob, "nnz_A": nnz_glob, "node_block_storage": bool(getattr(A, "paired", False)),
                    "full_nodes": int(d.n_full), "surface_nodes": int(d.n_surf), "gmres_iterations_per_step": gm_its,
                    "cg_iterations_per_step": cg_its, "gmres_second_gs_passes_per_step": [s[1]["nreorth"] for s in stats],
+                   # scaled residual each inversion STARTS from (warm start = previous solution): its growth over the first
+                   # steps is what drives the iteration count up as the flow spins up
+                   "gmres_initial_residual_per_step": [float(f"{s[1]['rnorm0']:.4g}") for s in stats],
                    "inversion_seconds_per_step": [round(s[1]["seconds"], 4) for s in stats],
                    "gmres_memory": 20, "atol": 1e-6, "rtol": 1e-6, "gmres_itmax": model.inversion.solver.kwargs["itmax"],
                    "all_solved": all(s[1]["solved"] == 1 for s in stats), "preconditioner": repr(model.inversion.solver.P),

@@ -171,6 +171,10 @@ int npg_gmres_set_profile(npg_gmres *ws, int on);
 /* kernel organisation of the Arnoldi step: 0 = fused (SpMV + Gram-Schmidt dots in one kernel, group-interleaved basis:
  * latency-bound sizes), 1 = split (SpMV kernel + row-streaming dots/orthogonalisation kernels, column-major basis:
  * bandwidth-bound sizes), -1 = by size (split from 8192 rows; default).  Same arithmetic either way. */
+/* Stored Krylov basis of the split kernel organisation (n >= 8192): 64 = fp64, 32 = fp32 ("compressed basis": only the
+ * stored copy used by the Gram-Schmidt sums and x += V y is rounded; SpMV inputs, sums, the restart residual stay fp64),
+ * 0 = by tolerance (fp32 when rtol >= 1e-7, the reference's 1e-6 included).  NPG_GMRES_BASIS=32|64 overrides the default. */
+int npg_gmres_set_basis(npg_gmres *ws, int bits);
 int npg_gmres_set_split(npg_gmres *ws, int mode);
 int npg_gmres_get_profile(npg_gmres *ws, double *ms_total, int64_t *launches);
 /* residual history of the last solve (workspace.stats.residuals with history=true): returns entries written */

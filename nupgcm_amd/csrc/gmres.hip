@@ -72,6 +72,9 @@ struct GDev {
     int GR;               // grid of the row-streaming kernels (split mode)
     int split;
     int64_t ldv;          // split mode stores the basis column-major, Vi[k * ldv + row] (0: group-interleaved layout)
+    float *Vf;            // split mode, compressed basis: the SAME columns stored in fp32 (null: fp64 in Vi).  Only the stored
+                          // copy is rounded - every Krylov vector enters the SpMV in fp64 (it is formed from wt on the fly) -
+                          // and every product and sum with it stays fp64; see npg_gmres_set_basis
     int pyth;             // distributed runs: ||w - V h||^2 = ||w||^2 - ||h||^2 instead of a second all-reduce
     int lazy2;            // one GPU: the same identity decides whether the second-pass sums need reducing at all
     int rev;              // split mode: the orthogonalisation kernel walks the row blocks downwards, the dots kernel upwards -
@@ -254,9 +257,10 @@ struct CorrectedX {
     const double *wt, *Vi, *h2;
     int nb;
     int64_t n, ldv;
+    const float *Vf;
     __device__ __forceinline__ double operator()(int c) const {
         double v = wt[c];
-        for (int k = 0; k < nb; ++k) v -= h2[k] * Vi[vidx(c, k, n, ldv)];
+        for (int k = 0; k < nb; ++k) v -= h2[k] * (Vf ? (double)Vf[vidx(c, k, n, ldv)] : Vi[vidx(c, k, n, ldv)]);
         return v;
     }
     __device__ __forceinline__ double2 two(int i) const { return make_double2((*this)(i), (*this)(i + 1)); }
@@ -350,7 +354,7 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
         double wt_row = 0.0;
         if (!FUSED && (int)threadIdx.x < td.nrows) wt_row = d.wt[td.r0 + threadIdx.x];
         // one instantiation for both cases: without a second pass the correction loop has no trips
-        spmv_tile<kKB, L>(d.A, CorrectedX{d.wt, d.Vi, sh.h2, ro ? j : 0, d.n, d.ldv}, td, tl, sw);
+        spmv_tile<kKB, L>(d.A, CorrectedX{d.wt, d.Vi, sh.h2, ro ? j : 0, d.n, d.ldv, d.Vf}, td, tl, sw);
         const int nr = r1 - r0;
         if (!FUSED) {
             // split mode (large systems): only what depends on the SpMV result; the dots stream in k_gmres_dots_rows
@@ -360,8 +364,12 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
                 d.w[row] = sw[r] * inv_beta * precond_row(d, row);
                 double tv = wt_row;
                 if (ro)
-                    for (int q = 0; q < j; ++q) tv -= sh.h2[q] * d.Vi[vidx(row, q, d.n, d.ldv)];
-                d.Vi[vidx(row, j, d.n, d.ldv)] = tv * inv_beta;
+                    for (int q = 0; q < j; ++q)
+                        tv -= sh.h2[q] * (d.Vf ? (double)d.Vf[vidx(row, q, d.n, d.ldv)] : d.Vi[vidx(row, q, d.n, d.ldv)]);
+                if (d.Vf)
+                    d.Vf[vidx(row, j, d.n, d.ldv)] = (float)(tv * inv_beta);
+                else
+                    d.Vi[vidx(row, j, d.n, d.ldv)] = tv * inv_beta;
             }
             continue;
         }
@@ -406,12 +414,18 @@ constexpr int kRB = 256;
 constexpr int kMaxRowsI = kMaxG / (kRB / 32);      // chunks of reduce_partials over at most kMaxG partial rows
 
 // column-major layout: the j+1 columns in use, one coalesced 8-byte stream each (k <= j is wave-uniform)
-template <int NG>
-__device__ __forceinline__ void load_row_cols(const double *__restrict__ Vi, int64_t row, int64_t ldv, int j,
+template <int NG, typename BT>
+__device__ __forceinline__ void load_row_cols(const BT *__restrict__ Vi, int64_t row, int64_t ldv, int j,
                                               double (&v)[8 * NG]) {
 #pragma unroll
-    for (int k = 0; k < 8 * NG; ++k) v[k] = (k <= j) ? Vi[(size_t)k * (size_t)ldv + (size_t)row] : 0.0;
+    for (int k = 0; k < 8 * NG; ++k) v[k] = (k <= j) ? (double)Vi[(size_t)k * (size_t)ldv + (size_t)row] : 0.0;
 }
+template <typename BT>
+__device__ __forceinline__ const BT *basis_ptr(const GDev &d);
+template <>
+__device__ __forceinline__ const double *basis_ptr<double>(const GDev &d) { return d.Vi; }
+template <>
+__device__ __forceinline__ const float *basis_ptr<float>(const GDev &d) { return d.Vf; }
 
 template <int NG>
 __device__ __forceinline__ void store_partial_row_rows(const double (&acc)[8 * NG], double nrm, double *tmp, double *part) {
@@ -435,7 +449,24 @@ __device__ __forceinline__ void store_partial_row_rows(const double (&acc)[8 * N
     }
 }
 
+// (fp32-stored basis: two adjacent rows per thread, so that a lane still moves 8 bytes per column - with one row the loads
+//  are 4-byte ones and the kernel is bound by their number, not by the bytes: measured slower than the fp64 basis)
 template <int NG>
+__device__ __forceinline__ void load_row_pair_cols(const float *__restrict__ Vf, int64_t r0, bool two, int64_t ldv, int j,
+                                                   float2 (&v)[8 * NG]) {
+    // straight-line 8-byte loads (k <= j is wave-uniform and the loop is unrolled; a lane-varying branch around the loads
+    // would make hipcc wait for every one of them in turn).  r0 + 1 <= ldv - 1 always: the second element of the last pair of
+    // an odd n lies in the column's padding and is zeroed after the load.
+#pragma unroll
+    for (int k = 0; k < 8 * NG; ++k) {
+        float2 f = make_float2(0.f, 0.f);
+        if (k <= j) f = *reinterpret_cast<const float2 *>(Vf + (size_t)k * (size_t)ldv + (size_t)r0);   // 8-byte aligned
+        if (!two) f.y = 0.f;
+        v[k] = f;                                                              // kept in fp32 registers, widened at use
+    }
+}
+
+template <int NG, typename BT>
 __global__ void __launch_bounds__(kRB) k_gmres_dots_rows(GDev d, int j) {
     __shared__ double tmp[(kRB / 64) * kKP];
     double acc[8 * NG];
@@ -443,13 +474,29 @@ __global__ void __launch_bounds__(kRB) k_gmres_dots_rows(GDev d, int j) {
     for (int k = 0; k < 8 * NG; ++k) acc[k] = 0.0;
     double nrm = 0.0;
     if (d.T[j].done == 0) {
-        for (int64_t row = blockIdx.x * (int64_t)kRB + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kRB) {
-            double v[8 * NG];
-            load_row_cols<NG>(d.Vi, row, d.ldv, j, v);          // split mode: the basis is column-major
-            const double wv = d.w[row];
+        if constexpr (sizeof(BT) == 4) {
+            const int64_t nblk = ((int64_t)d.n + 2 * kRB - 1) / (2 * kRB);
+            for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+                const int64_t r0 = 2 * (blk * kRB + threadIdx.x);
+                if (r0 >= d.n) continue;
+                const bool two = r0 + 1 < d.n;
+                float2 v[8 * NG];
+                load_row_pair_cols<NG>(d.Vf, r0, two, d.ldv, j, v);
+                const double2 ww = *reinterpret_cast<const double2 *>(d.w + r0);     // (w is padded: the pair of an odd n's last row)
+                const double w0 = ww.x, w1 = two ? ww.y : 0.0;
 #pragma unroll
-            for (int k = 0; k < 8 * NG; ++k) acc[k] += v[k] * wv;
-            nrm += wv * wv;
+                for (int k = 0; k < 8 * NG; ++k) acc[k] += (double)v[k].x * w0 + (double)v[k].y * w1;
+                nrm += w0 * w0 + w1 * w1;
+            }
+        } else {
+            for (int64_t row = blockIdx.x * (int64_t)kRB + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kRB) {
+                double v[8 * NG];
+                load_row_cols<NG, BT>(basis_ptr<BT>(d), row, d.ldv, j, v);          // split mode: the basis is column-major
+                const double wv = d.w[row];
+#pragma unroll
+                for (int k = 0; k < 8 * NG; ++k) acc[k] += v[k] * wv;
+                nrm += wv * wv;
+            }
         }
     }
     store_partial_row_rows<NG>(acc, nrm, tmp, d.P1);
@@ -458,7 +505,7 @@ __global__ void __launch_bounds__(kRB) k_gmres_dots_rows(GDev d, int j) {
 // FAST: wt = w - V h and ||wt||^2 (one pass over the columns, nothing kept).  Otherwise also h2 = V'wt for the selective
 // second Gram-Schmidt pass.  The next Arnoldi kernel takes ||wt||^2 from Pythagoras and falls back on the sum formed here
 // when that is close to cancellation.
-template <int NG, bool FAST>
+template <int NG, bool FAST, typename BT>
 __global__ void __launch_bounds__(kRB, (NG < 4 || FAST) ? 3 : 2) k_gmres_orth_rows(GDev d, int j) {
     __shared__ double tmp[(kRB / 32) * kKP];
     __shared__ double red[kKP];
@@ -482,12 +529,38 @@ __global__ void __launch_bounds__(kRB, (NG < 4 || FAST) ? 3 : 2) k_gmres_orth_ro
             d.hcol1[j * kKP + threadIdx.x] = ((int)threadIdx.x <= j) ? red[threadIdx.x] : 0.0;
             if (threadIdx.x == 0) d.wnorm2[j] = red[kNormSlot];
         }
+        if constexpr (sizeof(BT) == 4) {
+            const int64_t nblk = ((int64_t)d.n + 2 * kRB - 1) / (2 * kRB);
+            for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+                const int64_t r0 = 2 * ((d.rev ? nblk - 1 - blk : blk) * kRB + threadIdx.x);
+                if (r0 >= d.n) continue;
+                const bool two = r0 + 1 < d.n;
+                float2 v[8 * NG];
+                load_row_pair_cols<NG>(d.Vf, r0, two, d.ldv, j, v);
+                const double2 ww = *reinterpret_cast<const double2 *>(d.w + r0);
+                double p0 = ww.x, p1 = two ? ww.y : 0.0;
+#pragma unroll
+                for (int k = 0; k < 8 * NG; ++k) {
+                    p0 -= h[k] * (double)v[k].x;
+                    p1 -= h[k] * (double)v[k].y;
+                }
+                if (two)
+                    *reinterpret_cast<double2 *>(d.wt + r0) = make_double2(p0, p1);
+                else
+                    d.wt[r0] = p0;
+                if (!FAST) {
+#pragma unroll
+                    for (int k = 0; k < 8 * NG; ++k) acc[k] += (double)v[k].x * p0 + (double)v[k].y * p1;
+                }
+                nrm += p0 * p0 + p1 * p1;
+            }
+        } else {
         const int64_t nblk = ((int64_t)d.n + kRB - 1) / kRB;
         for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
             const int64_t row = (d.rev ? nblk - 1 - blk : blk) * kRB + threadIdx.x;
             if (row >= d.n) continue;
             double v[8 * NG];
-            load_row_cols<NG>(d.Vi, row, d.ldv, j, v);          // split mode: the basis is column-major
+            load_row_cols<NG, BT>(basis_ptr<BT>(d), row, d.ldv, j, v);          // split mode: the basis is column-major
             double wp = d.w[row];
 #pragma unroll
             for (int k = 0; k < 8 * NG; ++k) wp -= h[k] * v[k];
@@ -497,6 +570,7 @@ __global__ void __launch_bounds__(kRB, (NG < 4 || FAST) ? 3 : 2) k_gmres_orth_ro
                 for (int k = 0; k < 8 * NG; ++k) acc[k] += v[k] * wp;
             }
             nrm += wp * wp;
+        }
         }
     }
     if (!FAST) {
@@ -595,7 +669,8 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_update(GDev d) {
         for (int64_t row = (int64_t)blockIdx.x * kKB + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kKB) {
             double s = 0.0;
 #pragma unroll 4
-            for (int q = 0; q < kk; ++q) s += sh.y[q] * d.Vi[(size_t)q * (size_t)d.ldv + (size_t)row];
+            for (int q = 0; q < kk; ++q)
+                s += sh.y[q] * (d.Vf ? (double)d.Vf[(size_t)q * (size_t)d.ldv + (size_t)row] : d.Vi[(size_t)q * (size_t)d.ldv + (size_t)row]);
             d.x[row] += s;
         }
         return;
@@ -664,6 +739,7 @@ struct npg_gmres {
     bool explicit_norm = false;   // distributed: a solve met cancellation in the Pythagorean norm
     bool safe_mode = false;       // one GPU: a solve in fast mode met a column that was due a second Gram-Schmidt pass
     int split_mode = -1;
+    int basis_bits = 0;           // stored Krylov basis of the split organisation: 64, 32, or 0 = by tolerance (npg_gmres_set_basis)
     int halo_overlap = -1;        // distributed split cycle: interior tiles beside the halo exchange: -1 = default (on with the
                                   // peer windows, off with RCCL), 0 / 1 = npg_gmres_set_dist_options
     int dist_graph = -1;          // distributed cycles replayed from a hipGraph: -1 = default (on for the kernel-only peer
@@ -684,14 +760,21 @@ static int fold_rows(npg_gmres *ws, const double *part, int nrows, int slot, hip
     return NPG_OK;
 }
 
+template <int NG, typename BT>
+static void launch_rows_bt(const GDev &d, int j, hipStream_t st, bool orth) {
+    if (orth && d.fast)
+        hipLaunchKernelGGL((k_gmres_orth_rows<NG, true, BT>), dim3(d.GR), dim3(kRB), 0, st, d, j);
+    else if (orth)
+        hipLaunchKernelGGL((k_gmres_orth_rows<NG, false, BT>), dim3(d.GR), dim3(kRB), 0, st, d, j);
+    else
+        hipLaunchKernelGGL((k_gmres_dots_rows<NG, BT>), dim3(d.GR), dim3(kRB), 0, st, d, j);
+}
 template <int NG>
 static void launch_rows(const GDev &d, int j, hipStream_t st, bool orth) {
-    if (orth && d.fast)
-        hipLaunchKernelGGL((k_gmres_orth_rows<NG, true>), dim3(d.GR), dim3(kRB), 0, st, d, j);
-    else if (orth)
-        hipLaunchKernelGGL((k_gmres_orth_rows<NG, false>), dim3(d.GR), dim3(kRB), 0, st, d, j);
+    if (d.Vf)
+        launch_rows_bt<NG, float>(d, j, st, orth);
     else
-        hipLaunchKernelGGL(k_gmres_dots_rows<NG>, dim3(d.GR), dim3(kRB), 0, st, d, j);
+        launch_rows_bt<NG, double>(d, j, st, orth);
 }
 
 static void launch_rows_kernel(const GDev &d, int j, hipStream_t st, bool orth) {
@@ -794,7 +877,7 @@ NPG_API int npg_gmres_create(npg_ctx *ctx, int64_t n, int memory, npg_gmres **ou
     ws->n = n;
     ws->mem = memory;
     NPG_HIP(hipSetDevice(ctx->device));
-    const size_t vb = (size_t)n * sizeof(double);
+    const size_t vb = ((size_t)n + 2) * sizeof(double);          // (+2: the row kernels of the fp32-stored basis read rows in pairs)
     const size_t vbytes = ((size_t)n + 32) * sizeof(double) * kKP;     // either layout: 32 columns of n (+ padding) doubles
     NPG_HIP(hipMalloc((void **)&ws->Vi, vbytes));
     NPG_HIP(hipMalloc((void **)&ws->w, vb));
@@ -931,6 +1014,19 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     static const int rev_env = getenv("NPG_ORTH_REVERSE") ? atoi(getenv("NPG_ORTH_REVERSE")) : 0;
     d.rev = rev_env;
     d.ldv = d.split ? (int64_t)((ws->n + 31) / 32) * 32 : 0;
+    // Compressed basis (split organisation only): the stored columns in fp32.  They serve the Gram-Schmidt sums and the
+    // update x += V y; the vector that enters the next SpMV is formed from wt in fp64, the true residual is recomputed in
+    // fp64 at every restart, and all arithmetic is fp64 - what the stored copy limits is the accuracy a SINGLE cycle can
+    // add (~1e-7 of the residual it starts from), so it is the default only for tolerances a cycle never exceeds.
+    static const int basis_env = getenv("NPG_GMRES_BASIS") ? atoi(getenv("NPG_GMRES_BASIS")) : 0;
+    const int basis_req = ws->basis_bits ? ws->basis_bits : basis_env;
+    const bool basis32 = d.split && (basis_req == 32 || (basis_req == 0 && rtol >= 1e-7));
+    d.Vf = basis32 ? reinterpret_cast<float *>(ws->Vi) : nullptr;
+    if (basis32) {          // the row kernels take two rows per thread there
+        d.GR = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + 2 * kRB - 1) / (2 * kRB), std::min(kMaxG, 3 * ctx->num_cu)));
+        d.GP1 = d.GR;
+        d.GP2 = d.GR;
+    }
     d.GP1 = d.split ? d.GR : d.G1;
     d.GP2 = d.split ? d.GR : d.G2;
     if (dist) {
@@ -1164,6 +1260,13 @@ NPG_API int npg_gmres_set_dist_options(npg_gmres *ws, int overlap, int graph) {
     NPG_REQUIRE(ws, "npg_gmres_set_dist_options: NULL workspace");
     ws->halo_overlap = overlap < 0 ? -1 : (overlap ? 1 : 0);
     ws->dist_graph = graph < 0 ? -1 : (graph ? 1 : 0);
+    ws->have_graph = false;
+    return NPG_OK;
+}
+
+NPG_API int npg_gmres_set_basis(npg_gmres *ws, int bits) {
+    NPG_REQUIRE(ws && (bits == 0 || bits == 32 || bits == 64), "npg_gmres_set_basis: bits must be 0 (by tolerance), 32 or 64");
+    ws->basis_bits = bits;
     ws->have_graph = false;
     return NPG_OK;
 }

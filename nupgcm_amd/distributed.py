@@ -192,7 +192,6 @@ def distribute_model(model, dist, block_nodes=None):
     """Turn a freshly built single-GPU Model into its distributed form (call on every rank, before the first solve).
     `dist` is torch.distributed (initialised); RCCL is bootstrapped from it.  block_nodes: store each rank's
     owned-by-owned velocity block by node records (None: from 100 000 global rows, as InversionToolkit does)."""
-    import torch
     from .architectures import DeviceCSR, DeviceVector, comm_unique_id
     from .iterative_solvers import CgWorkspace, Diagonal, GmresWorkspace
     arch, ctx = model.arch, model.arch.ctx
@@ -279,7 +278,7 @@ def distribute_model(model, dist, block_nodes=None):
     inv.solver.load_owned_from_full()
     ev.solver.load_owned_from_full()
     model._prev = None
-    torch.cuda.synchronize()
+    ctx.sync()                     # (the library's own stream; torch is only the launcher / bootstrap)
     # leave set-up together: device-side waits of the peer transport are bounded (NPG_PEER_TIMEOUT_S), and the first
     # collective should not have to sit out another rank's host-side set-up
     dist.barrier()

@@ -77,6 +77,10 @@ class GmresWorkspace(_Workspace):
         """-1: by size (default), 0: fused Arnoldi kernel, 1: split kernels + column-major basis (npg_gmres_set_split)"""
         L.check(L.lib().npg_gmres_set_split(self.h, int(mode)))
 
+    def set_basis(self, bits):
+        """stored Krylov basis of the split organisation: 64, 32 (compressed basis), 0 = by tolerance (npg_gmres_set_basis)"""
+        L.check(L.lib().npg_gmres_set_basis(self.h, int(bits)))
+
     def set_profile(self, on=True):
         """eager launches with HIP events around every Arnoldi (SpMV) kernel; see npg_gmres_set_profile"""
         L.check(L.lib().npg_gmres_set_profile(self.h, int(bool(on))))

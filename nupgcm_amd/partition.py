@@ -306,7 +306,6 @@ def partitioned_model(arch, fe_data, params, forcings, ts, dist, atol=1e-6, rtol
     and the state partitioned over the ranks of `dist` (torch.distributed, initialised).  Call on every rank.  Mirrors
     src/inversion.jl:20-94 and src/evolution.jl:62-126 on the rank's cells and rows; the reference's GPU preconditioner
     Diagonal(1/h^dim) uses the GLOBAL median edge length (src/inversion.jl:42-54)."""
-    import torch
     from .architectures import comm_unique_id
     ctx = arch.ctx
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -398,7 +397,7 @@ def partitioned_model(arch, fe_data, params, forcings, ts, dist, atol=1e-6, rtol
     model = PartitionedModel(arch, params, forcings, fe_data, inv, ev, ts, lay, dist, fe)
     if b0 is not None:
         model.set_b(b0)
-    torch.cuda.synchronize()
+    ctx.sync()                     # (the library's own stream; torch is only the launcher / bootstrap)
     dist.barrier()
     model.comm_layout = dict(n_owned_inv=lay.inv.n_own, n_ghost_inv=len(lay.inv.g_sol), n_ghost_inv_extra=len(lay.inv.g_ext),
                              n_owned_b=lay.b.n_own, n_ghost_b=len(lay.b.g_sol), n_ghost_b_extra=len(lay.b.g_ext),
