@@ -589,7 +589,7 @@ def test_distributed_path_single_rank(arch):
         assert np.all(np.abs(gm - gr) <= 0.01 * gr + 1), (gm, gr)       # (other summation order of the partial sums)
         assert [s[0]["niter"] for s in m.stats] == [s[0]["niter"] for s in ref.stats]
         # same iteration counts; the partial sums are folded in a different order, which GMRES amplifies to ~1e-7
-        assert rel(m.state.b, ref.state.b) < 1e-10 and rel(m.state.u, ref.state.u) < 1e-5
+        assert rel(m.state.b, ref.state.b) < 1e-9 and rel(m.state.u, ref.state.u) < 1e-5
     finally:
         dist.destroy_process_group()
 
