@@ -47,12 +47,12 @@ def parse():
     return ap.parse_args()
 
 
-PMC_FILE = "profiles/r02_pmc.json"
+PMC_FILE = "profiles/r03_pmc.json"
 
 
 def pmc_traffic(workload, kernel="k_gmres_arnoldi"):
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (a builder run, not this run:
-    profiles/r02_pmc.json, made by tools/pmc_probe.py + tools/pmc_summary.py on this workload; FETCH_SIZE / WRITE_SIZE in
+    profiles/r03_pmc.json, made by tools/pmc_probe.py + tools/pmc_summary.py on this workload; FETCH_SIZE / WRITE_SIZE in
     separate passes, gfx950 correction applied as described in profiles/README.md) - the line says so in `traffic_source`.
     None when no counters were collected for the workload."""
     p = os.path.join(ROOT, PMC_FILE)

@@ -245,6 +245,13 @@ int npg_precond_counters(npg_precond *pc, int64_t *applications, int64_t *inner_
  * returned rnorm is the TRUE residual recomputed after the last pass.  itmax == 0 means 2 n. */
 int npg_fgmres_create(npg_ctx *ctx, int64_t n, int memory, npg_fgmres **out);
 int npg_fgmres_destroy(npg_fgmres *ws);
+/* Distributed flexible GMRES: A = this rank's rows (columns [owned | ghosts]), x = [owned | ghosts]; SpMV inputs get their
+ * ghosts through `h`, reductions are summed over the ranks.  With npg_precond_mg_set_level_dist: the multigrid whose finest
+ * level is row-partitioned like the system and whose coarser levels are replicated (one coarse-vector all-reduce per cycle). */
+int npg_fgmres_set_halo(npg_fgmres *ws, npg_halo *h);
+int npg_precond_mg_set_level_dist(npg_precond *pc, int level, const npg_csr *A, int64_t nu_owned, const npg_csr *G,
+                                  const npg_csr *D, const npg_csr *Dinv, const npg_csr *S, const npg_csr *P, const npg_csr *R,
+                                  npg_halo *hx, npg_halo *hu, npg_halo *hp);
 int npg_fgmres_solve(npg_fgmres *ws, const npg_csr *A, npg_precond *pc, const npg_vec *y, npg_vec *x, double scale,
                      double atol, double rtol, int64_t itmax, npg_solve_stats *stats);
 int64_t npg_fgmres_history(npg_fgmres *ws, double *buf, int64_t cap);

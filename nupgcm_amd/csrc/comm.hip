@@ -364,6 +364,7 @@ struct PeerComm {
     int *h_status = nullptr;              // pinned, device-visible
     unsigned long long ticks = 0;
     bool ok = false;
+    double **d_stage = nullptr;           // device array of the ranks' staging windows (allreduce_big_device)
     PeerArDev ar() const { return PeerArDev{d_win, d_epoch, h_status, ticks, rank, nranks}; }
     char *stage_of(int r) const { return peer_base[r] + ar_bytes; }
 };
@@ -458,6 +459,7 @@ static void peer_free(PeerComm *pc) {
         if (r != pc->rank && pc->peer_base[r]) hipIpcCloseMemHandle(pc->peer_base[r]);
     if (pc->base) hipFree(pc->base);
     if (pc->d_win) hipFree(pc->d_win);
+    if (pc->d_stage) hipFree(pc->d_stage);
     if (pc->d_epoch) hipFree(pc->d_epoch);
     if (pc->h_status) hipHostFree(pc->h_status);
     delete pc;
@@ -1152,6 +1154,45 @@ int npg::fold_allreduce_rows(npg_ctx *ctx, const double *part, int nrows, double
     }
     hipLaunchKernelGGL(k_fold_rows, dim3(1), dim3(1024), 0, st, part, nrows, out);
     return allreduce_sum_device(ctx, out, kPartStride);
+}
+
+// out[i] = sum over ranks r (in rank order) of stage_r[i]: the ranks' staging windows are peer-mapped
+__global__ void __launch_bounds__(256) k_sum_stages(double *out, const double *const *stage, int nranks, int64_t n) {
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) {
+        double s = 0.0;
+        for (int r = 0; r < nranks; ++r) s += __builtin_nontemporal_load(stage[r] + i);
+        out[i] = s;
+    }
+}
+
+// In-place sum over the ranks of a LONG device vector (the restricted residual of a multigrid cycle whose coarse levels are
+// replicated: one n_coarse-vector per cycle).  RCCL where there is a communicator; on the peer-only transport (the one-device
+// rehearsal) through the staging windows with two host barriers - correct, not fast; shm: through the host.
+int npg::allreduce_big_device(npg_ctx *ctx, double *buf, int64_t n) {
+    if (single_rank_shortcut(ctx) || n <= 0) return NPG_OK;
+    if (ctx->shm) return shm_allreduce(ctx, buf, (int)n);
+    if (ctx->comm) {
+        NPG_NCCL(ncclAllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+        return NPG_OK;
+    }
+    PeerComm *pc = (PeerComm *)ctx->peer;
+    NPG_REQUIRE(pc, "allreduce_big_device: no communicator");
+    NPG_REQUIRE((size_t)n * sizeof(double) <= pc->stage_bytes, "peer transport: %lld doubles exceed the staging window (NPG_PEER_STAGE_MB)",
+                (long long)n);
+    if (!pc->d_stage) {
+        std::vector<double *> h(pc->nranks);
+        for (int r = 0; r < pc->nranks; ++r) h[r] = (double *)pc->stage_of(r);
+        NPG_HIP(hipMalloc((void **)&pc->d_stage, pc->nranks * sizeof(double *)));
+        NPG_HIP(hipMemcpy(pc->d_stage, h.data(), pc->nranks * sizeof(double *), hipMemcpyHostToDevice));
+    }
+    NPG_HIP(hipMemcpyAsync(pc->stage_of(pc->rank), buf, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    NPG_HIP(hipStreamSynchronize(ctx->stream));
+    NPG_SHM_BARRIER(pc->boot);
+    hipLaunchKernelGGL(k_sum_stages, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0, ctx->stream, buf,
+                       (const double *const *)pc->d_stage, pc->nranks, n);
+    NPG_HIP(hipStreamSynchronize(ctx->stream));
+    NPG_SHM_BARRIER(pc->boot);
+    return peer_status(ctx);
 }
 
 bool npg::comm_is_kernel_only(const npg_ctx *ctx) { return ctx->peer != nullptr; }

@@ -137,6 +137,8 @@ int halo_exchange_raw(npg_halo *h, double *x);
 int halo_exchange_async(npg_halo *h, double *x);
 int halo_exchange_wait(npg_halo *h);
 int allreduce_sum_device(npg_ctx *ctx, double *buf, int n);
+// in-place sum over the ranks of a long device vector (not a per-iteration collective: comm.hip)
+int allreduce_big_device(npg_ctx *ctx, double *buf, int64_t n);
 // fold `nrows` partial rows of kPartStride doubles into one row and sum it over the ranks into out[0 .. kPartStride):
 // one kernel on the peer transport (fold + push + poll), fold kernel + collective otherwise
 int fold_allreduce_rows(npg_ctx *ctx, const double *part, int nrows, double *out, hipStream_t st);

@@ -169,6 +169,11 @@ struct MgLevel {
     double *sdinv = nullptr;                         // 1 / diag(S)
     double *r = nullptr, *t = nullptr, *rhs = nullptr, *dp = nullptr, *dp2 = nullptr, *res = nullptr, *x = nullptr,
            *b = nullptr;
+    // distributed level (npg_precond_mg_set_level_dist): this rank's rows of every operator; n, nu, np count OWNED rows, the
+    // operators' column spaces are [owned | ghosts] and the vectors that feed them carry the ghost entries behind the owned
+    // ones, filled by these plans before each product - hx: whole vectors (A), hu: velocity parts (D), hp: pressure parts (G, S)
+    npg_halo *hx = nullptr, *hu = nullptr, *hp = nullptr;
+    bool dist = false;
 };
 
 struct BlockPc {
@@ -412,6 +417,46 @@ NPG_API int npg_precond_mg_set_level(npg_precond *pc, int level, const npg_csr *
     return NPG_OK;
 }
 
+// The finest level of a hierarchy, distributed: this rank's rows of every operator (column spaces [owned | ghosts]) and the
+// three halo plans that fill the ghosts of the vectors feeding them; the levels below it are replicated (set with
+// npg_precond_mg_set_level on every rank).  P: owned rows x all coarse columns, R: all coarse rows x owned columns.
+NPG_API int npg_precond_mg_set_level_dist(npg_precond *pc, int level, const npg_csr *A, int64_t nu, const npg_csr *G,
+                                          const npg_csr *D, const npg_csr *Dinv, const npg_csr *S, const npg_csr *P,
+                                          const npg_csr *R, npg_halo *hx, npg_halo *hu, npg_halo *hp) {
+    NPG_REQUIRE(pc && pc->kind == NPG_PC_MG, "npg_precond_mg_set_level_dist: not a multigrid preconditioner");
+    NPG_REQUIRE(level >= 1 && level == (int)pc->L.size() - 1, "npg_precond_mg_set_level_dist: only the finest level can be distributed");
+    NPG_REQUIRE(A && G && D && Dinv && S && P && R && hx && hu && hp, "npg_precond_mg_set_level_dist: NULL argument");
+    const int64_t n = A->m, np = n - nu;
+    NPG_REQUIRE(nu > 0 && np > 0 && hx->n_owned == n && A->n == n + hx->n_ghost && hu->n_owned == nu && D->m == np &&
+                    D->n == nu + hu->n_ghost && hp->n_owned == np && G->m == nu && G->n == np + hp->n_ghost && S->m == np &&
+                    S->n == G->n && Dinv->m == nu && Dinv->n == nu,
+                "npg_precond_mg_set_level_dist: operator shapes do not match the halo plans (n = %lld, nu = %lld)", (long long)n,
+                (long long)nu);
+    MgLevel &l = pc->L[level];
+    NPG_REQUIRE(l.A == nullptr && pc->L[level - 1].A, "npg_precond_mg_set_level_dist: set the coarser levels first, this one once");
+    const int64_t nc = pc->L[level - 1].n;
+    NPG_REQUIRE(P->m == n && P->n == nc && R->m == nc && R->n == n, "npg_precond_mg_set_level_dist: P must be %lld x %lld and R its transpose",
+                (long long)n, (long long)nc);
+    l.A = A; l.G = G; l.D = D; l.Dinv = Dinv; l.S = S; l.P = P; l.R = R;
+    l.n = n; l.nu = nu; l.np = np;
+    l.hx = hx; l.hu = hu; l.hp = hp;
+    l.dist = true;
+    int rc;
+    if ((rc = mg_alloc(pc, &l.sdinv, np))) return rc;
+    npg_vec sv;
+    sv.ctx = pc->ctx; sv.n = np; sv.d = l.sdinv; sv.owns = false;
+    if ((rc = npg_csr_inv_diag(S, &sv))) return rc;
+    if ((rc = mg_alloc(pc, &l.r, n)) || (rc = mg_alloc(pc, &l.t, D->n)) || (rc = mg_alloc(pc, &l.rhs, np)) ||
+        (rc = mg_alloc(pc, &l.dp, G->n)) || (rc = mg_alloc(pc, &l.dp2, G->n)) || (rc = mg_alloc(pc, &l.res, np)) ||
+        (rc = mg_alloc(pc, &l.x, A->n)))
+        return rc;
+    // the coarse level below receives its right-hand side and iterate buffers from its own setter (it is not the top level)
+    pc->n = n;
+    pc->use_graphs = false;      // host barriers (rehearsal transports) and library collectives sit inside the cycle
+    if (pc->mixed && (rc = mg_refresh_fp32(l))) return rc;
+    return NPG_OK;
+}
+
 // Swap in re-assembled operators of one level (same shapes): what the eddy closure's A refresh needs (src/model.jl:160-170)
 NPG_API int npg_precond_mg_update_level(npg_precond *pc, int level, const npg_csr *A, const npg_csr *G, const npg_csr *D,
                                         const npg_csr *Dinv, const npg_csr *S) {
@@ -484,12 +529,14 @@ static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int n
         if (zero) {
             r = b;                                                                   // r = b - A 0
         } else {
+            if (l.hx && (rc = halo_exchange_raw(l.hx, x))) return rc;
             SpmvEpi e{};                                                             // r = b - A x
             e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l.r; e.f32 = pc->mixed;
             if ((rc = spmv_epi(l.A, x, e))) return rc;
         }
         if ((rc = spmv_raw(l.Dinv, r, l.t, 1.0, 0.0, pc->mixed))) return rc;         // t = Dh^-1 r_u
         double *dp = l.dp, *dq = l.dp2;
+        if (l.hu && (rc = halo_exchange_raw(l.hu, l.t))) return rc;
         {
             SpmvEpi e{};                                                             // rhs = D t - w r_p ; dp = jw rhs / diag S
             e.alpha = 1.0; e.beta = -pc->omega; e.c = r + nu; e.y = l.rhs;
@@ -497,12 +544,14 @@ static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int n
             if ((rc = spmv_epi(l.D, l.t, e))) return rc;
         }
         for (int k = 1; k < pc->sweeps; ++k) {                                       // damped Jacobi on S dp = rhs
+            if (l.hp && (rc = halo_exchange_raw(l.hp, dp))) return rc;
             SpmvEpi e{};                                                             // res = rhs - S dp ; dq = dp + jw res / diag S
             e.alpha = -1.0; e.beta = 1.0; e.c = l.rhs; e.y = l.res;
             e.w = pc->jw; e.dg = l.sdinv; e.zin = dp; e.zc = 1.0; e.z = dq; e.f32 = pc->mixed;
             if ((rc = spmv_epi(l.S, dp, e))) return rc;
             std::swap(dp, dq);
         }
+        if (l.hp && (rc = halo_exchange_raw(l.hp, dp))) return rc;
         {
             SpmvEpi e{};                                                             // t = r_u - G dp   (t is free again)
             e.alpha = -1.0; e.beta = 1.0; e.c = r; e.y = l.t; e.f32 = pc->mixed;
@@ -533,11 +582,16 @@ static int mg_cycle(npg_precond *pc, int lev, double *x, const double *b, bool x
     if (still_zero) {
         if ((rc = spmv_raw(l.R, b, lc.b, 1.0, 0.0, pc->mixed))) return rc;
     } else {
+        if (l.hx && (rc = halo_exchange_raw(l.hx, x))) return rc;
         SpmvEpi e{};
         e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l.r; e.f32 = pc->mixed;
         if ((rc = spmv_epi(l.A, x, e))) return rc;
         if ((rc = spmv_raw(l.R, l.r, lc.b, 1.0, 0.0, pc->mixed))) return rc;
     }
+    // a distributed level above replicated ones: R holds this rank's columns of the restriction, the coarse right-hand side is
+    // the sum of the ranks' parts - after it every rank runs the coarse levels redundantly on identical data - and the
+    // prolongation back needs no communication (P holds this rank's rows)
+    if (l.dist && !lc.dist && (rc = allreduce_big_device(pc->ctx, lc.b, lc.n))) return rc;
     for (int g = 0; g < pc->gamma; ++g)
         if ((rc = mg_cycle(pc, lev - 1, lc.x, lc.b, g == 0))) return rc;
     if ((rc = spmv_raw(l.P, lc.x, x, 1.0, still_zero ? 0.0 : 1.0, pc->mixed))) return rc;
@@ -571,6 +625,14 @@ static int precond_apply_raw(npg_precond *pc, const double *r, double *z) {
     if (pc->kind == NPG_PC_MG) {
         NPG_REQUIRE(pc->L.back().A, "npg_precond_apply: multigrid levels are not all set");
         const int top = (int)pc->L.size() - 1;
+        if (pc->L[top].dist) {
+            // the iterate is an SpMV input: it lives in the level's own buffer, which has room for the ghost entries
+            MgLevel &lt = pc->L[top];
+            const int rcv = mg_vcycle(pc, top, lt.x, r);
+            if (rcv) return rcv;
+            NPG_HIP(hipMemcpyAsync(z, lt.x, (size_t)lt.n * sizeof(double), hipMemcpyDeviceToDevice, pc->ctx->stream));
+            return NPG_OK;
+        }
         if (!pc->use_graphs) return mg_vcycle(pc, top, z, r);
         hipStream_t st = pc->ctx->stream;
         // the captured cycles bake in the borrowed matrices' tile tables and value arrays: a matrix whose layout was
@@ -645,6 +707,9 @@ struct npg_fgmres {
     double *dsc = nullptr;                   // device scalars: h1 [0,32), h2 [32,64), norm^2 [64]
     double *hsc = nullptr;                   // pinned host copy
     std::vector<double> hist;
+    // distributed (npg_fgmres_set_halo): n counts OWNED rows; the columns of Z (SpMV inputs) have room for the ghost entries
+    npg_halo *halo = nullptr;
+    int64_t n_ghost = 0;
 };
 
 constexpr int kFgBlocks = 1024;
@@ -659,9 +724,27 @@ NPG_API int npg_fgmres_create(npg_ctx *ctx, int64_t n, int memory, npg_fgmres **
     NPG_HIP(hipMalloc((void **)&ws->V, (size_t)(memory + 1) * ws->ld * sizeof(double)));
     NPG_HIP(hipMalloc((void **)&ws->Z, (size_t)memory * ws->ld * sizeof(double)));
     NPG_HIP(hipMalloc((void **)&ws->part, (size_t)kFgBlocks * kPartStride * sizeof(double)));
-    NPG_HIP(hipMalloc((void **)&ws->dsc, 96 * sizeof(double)));
-    NPG_HIP(hipHostMalloc((void **)&ws->hsc, 96 * sizeof(double), hipHostMallocDefault));
+    NPG_HIP(hipMalloc((void **)&ws->dsc, 128 * sizeof(double)));          // (whole 32-double rows: the all-reduce moves rows)
+    NPG_HIP(hipMemset(ws->dsc, 0, 128 * sizeof(double)));
+    NPG_HIP(hipHostMalloc((void **)&ws->hsc, 128 * sizeof(double), hipHostMallocDefault));
     *out = ws;
+    return NPG_OK;
+}
+
+// Row-block distributed solves: A is this rank's rows (columns [owned | ghosts]), x holds [owned | ghosts]; the ghosts of every
+// SpMV input are filled through `h`, the Gram-Schmidt sums and norms are summed over the ranks (three 32-double all-reduces per
+// iteration - an iteration is a whole V-cycle).  Collective: every rank sets its plan before the first solve.
+NPG_API int npg_fgmres_set_halo(npg_fgmres *ws, npg_halo *h) {
+    NPG_REQUIRE(ws && h && h->n_owned == ws->n, "npg_fgmres_set_halo: the plan must own the workspace's %lld rows", ws ? (long long)ws->n : 0LL);
+    NPG_HIP(hipStreamSynchronize(ws->ctx->stream));
+    ws->halo = h;
+    ws->n_ghost = h->n_ghost;
+    ws->ld = (ws->n + ws->n_ghost + 31) / 32 * 32;
+    NPG_HIP(hipFree(ws->V));
+    NPG_HIP(hipFree(ws->Z));
+    NPG_HIP(hipMalloc((void **)&ws->V, (size_t)(ws->mem + 1) * ws->ld * sizeof(double)));
+    NPG_HIP(hipMalloc((void **)&ws->Z, (size_t)ws->mem * ws->ld * sizeof(double)));
+    NPG_HIP(hipMemset(ws->Z, 0, (size_t)ws->mem * ws->ld * sizeof(double)));
     return NPG_OK;
 }
 
@@ -691,8 +774,12 @@ NPG_API int npg_fgmres_solve(npg_fgmres *ws, const npg_csr *A, npg_precond *pc, 
                              double scale, double atol, double rtol, int64_t itmax, npg_solve_stats *stats) {
     NPG_REQUIRE(ws && A && y && x && stats, "npg_fgmres_solve: NULL argument");
     const int64_t n = ws->n, ld = ws->ld;
-    NPG_REQUIRE(A->m == n && A->n == n && y->n == n && x->n == n, "npg_fgmres_solve: system must be %lld x %lld", (long long)n,
-                (long long)n);
+    const int64_t nloc = n + ws->n_ghost;
+    NPG_REQUIRE(A->m == n && A->n == nloc && y->n == n && x->n == nloc, "npg_fgmres_solve: system must be %lld x %lld (+%lld ghosts)",
+                (long long)n, (long long)n, (long long)ws->n_ghost);
+    npg_halo *dh = ws->halo;
+    // sum over the ranks of a host scalar (distributed) - the host is synchronised at these points anyway
+    auto all_sum = [&](double *v) -> int { return dh ? npg_comm_allreduce_sum(ws->ctx, v, 1) : NPG_OK; };
     NPG_REQUIRE(!pc || pc->n == n, "npg_fgmres_solve: the preconditioner is for %lld unknowns", (long long)(pc ? pc->n : 0));
     NPG_REQUIRE(scale > 0 && atol >= 0 && rtol >= 0, "npg_fgmres_solve: bad tolerance / scale");
     npg_ctx *c = ws->ctx;
@@ -717,12 +804,13 @@ NPG_API int npg_fgmres_solve(npg_fgmres *ws, const npg_csr *A, npg_precond *pc, 
     double *V = ws->V, *Z = ws->Z;
     // r0 = y - A x
     {
+        if (dh && (rc = halo_exchange_raw(dh, x->d))) return rc;
         SpmvEpi e{};
         e.alpha = -1.0; e.beta = 1.0; e.c = y->d; e.y = V;
         if ((rc = spmv_epi(A, x->d, e))) return rc;
     }
     double dd;
-    if ((rc = reduce_dot(c, V, V, n, &dd))) return rc;
+    if ((rc = reduce_dot(c, V, V, n, &dd)) || (rc = all_sum(&dd))) return rc;
     double beta = std::sqrt(dd);
     const double rnorm0 = scale * beta, eps = atol + rtol * rnorm0;
     stats->rnorm0 = rnorm0;
@@ -745,6 +833,7 @@ NPG_API int npg_fgmres_solve(npg_fgmres *ws, const npg_csr *A, npg_precond *pc, 
             } else {
                 axpby(c, zj, 1.0, vj, 0.0, n);
             }
+            if (dh && (rc = halo_exchange_raw(dh, zj))) return rc;
             if ((rc = spmv_raw(A, zj, w, 1.0, 0.0))) return rc;
             const int kk = j + 1;
             // classical Gram-Schmidt, two full passes; everything the host needs arrives in one copy
@@ -754,12 +843,14 @@ NPG_API int npg_fgmres_solve(npg_fgmres *ws, const npg_csr *A, npg_precond *pc, 
                     hipLaunchKernelGGL(k_mdot<decltype(ng)::value>, dim3(grid), dim3(kBlock), 0, st, V, ld, kk, w, n, ws->part);
                 });
                 hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, st, ws->part, grid, kk, hd);
+                if (dh && (rc = allreduce_sum_device(c, hd, kPartStride))) return rc;
                 by_groups(kk, [&](auto ng) {
                     hipLaunchKernelGGL(k_mupdate<decltype(ng)::value>, dim3(grid), dim3(kBlock), 0, st, V, ld, kk, hd, w, n,
                                        ws->part);
                 });
             }
             hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, st, ws->part, grid, 1, ws->dsc + 64);
+            if (dh && (rc = allreduce_sum_device(c, ws->dsc + 64, kPartStride))) return rc;
             NPG_HIP(hipMemcpyAsync(ws->hsc, ws->dsc, 65 * sizeof(double), hipMemcpyDeviceToHost, st));
             NPG_HIP(hipStreamSynchronize(st));
             double *Hj = &H[(size_t)j * (mem + 1)];          // column j
@@ -800,11 +891,12 @@ NPG_API int npg_fgmres_solve(npg_fgmres *ws, const npg_csr *A, npg_precond *pc, 
         if (k > 0) hipLaunchKernelGGL(k_combine_z, dim3(grid), dim3(kBlock), 0, st, x->d, Z, ld, k, cf, n);
         // true residual: the next pass starts from it, and a pass that met the estimate is confirmed by it
         {
+            if (dh && (rc = halo_exchange_raw(dh, x->d))) return rc;
             SpmvEpi e{};
             e.alpha = -1.0; e.beta = 1.0; e.c = y->d; e.y = V;
             if ((rc = spmv_epi(A, x->d, e))) return rc;
         }
-        if ((rc = reduce_dot(c, V, V, n, &dd))) return rc;
+        if ((rc = reduce_dot(c, V, V, n, &dd)) || (rc = all_sum(&dd))) return rc;
         beta = std::sqrt(dd);
         stats->rnorm = scale * beta;
         solved = stats->rnorm <= eps;

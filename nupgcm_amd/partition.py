@@ -490,3 +490,193 @@ def channel_basin_model(arch, mesh_model, dist, surface="flux", itmax=1000, CFL_
                               element_precision=element_precision, b0=b0, **kw)
     invert(model)
     return model
+
+
+# ---- multigrid-preconditioned inversion on the partitioned mesh -----------------------------------------------------------
+class DistributedMultigridPreconditioner:
+    """The geometric multigrid of multigrid.MultigridPreconditioner with its FINEST level distributed like the partitioned
+    system and the coarser levels replicated (every rank runs the coarse part of the cycle redundantly on the all-reduced
+    restricted residual; levels of <= a few 1e5 unknowns are latency-bound anyway).  Same algorithm, same parameters: the
+    Braess-Sarazin step needs the ghosts of three kinds of vectors (whole vectors for A, velocity parts for D, pressure parts
+    for G and S) - three halo plans - and ONE operator that is not a row block of something local: S = D Dinv G, whose rows
+    reach through ghost velocity nodes.  T = Dinv G is formed on the owned rows, the rows a neighbour needs travel once at
+    set-up, and S_own = D_own T follows (host-side scipy on the rank's block here: static viscosity only - the eddy closure's
+    refresh of a distributed level is not implemented)."""
+
+    def __init__(self, arch, params, forcings, hierarchy, model, omega=2.5, jacobi_weight=0.7, schur_sweeps=3, nu1=2, nu2=2,
+                 coarse_sweeps=20, cycle="V", coarse_dense=None):
+        import ctypes as C
+        from . import multigrid as mgm
+        from .inversion import build_A_inversion
+        if len(hierarchy) < 2:
+            raise ValueError("DistributedMultigridPreconditioner: needs a refinement hierarchy (>= 2 levels)")
+        if forcings.eddy_param.is_on:
+            raise NotImplementedError("distributed multigrid: the eddy closure's refresh of the distributed level is not implemented")
+        ctx = arch.ctx
+        self.ctx, self.arch = ctx, arch
+        h = C.c_void_p()
+        L.check(L.lib().npg_precond_create(ctx.h, L.NPG_PC_MG, len(hierarchy), C.byref(h)))
+        self.h, self._keep, self.levels = h, [], []
+        full = callable(forcings.nu)
+        # ---- replicated coarse levels: exactly MultigridPreconditioner's set-up --------------------------------------
+        prev = None
+        for lev, fed in enumerate(hierarchy[:-1]):
+            d = fed.dofs
+            A = build_A_inversion(arch, fed, params, forcings.nu, structural=full)
+            ops = mgm._LevelOperators(ctx, fed, fed.pattern_A(structural=full)).update(A)
+            if not full and A.shape[0] >= 100000:
+                A.block_nodes(d.n_full, d.n_surf)
+            Pd = Rd = None
+            if prev is not None:
+                P = mgm.prolongation(prev, fed)
+                Pd, Rd = DeviceCSR.from_scipy(ctx, P), DeviceCSR.from_scipy(ctx, sp.csr_matrix(P.T))
+            self._keep += [A, ops, Pd, Rd]
+            L.check(L.lib().npg_precond_mg_set_level(self.h, lev, A.h, int(d.nu), ops.G.h, ops.D.h, ops.Dinv.h, ops.S.h,
+                                                     None if Pd is None else Pd.h, None if Rd is None else Rd.h))
+            self.levels.append(d.nu + d.np)
+            prev = fed
+        # ---- the distributed finest level ------------------------------------------------------------------------------
+        fed, lay, part, dist = hierarchy[-1], model.layout, model.partition, model.dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        f = lay.inv
+        nu_g = fed.dofs.nu
+        nu_o, n_own, n_sol = lay.n_own_u, f.n_own, f.n_sol
+        a2e2 = params.alpha ** 2 * params.eps ** 2
+        rp, ci, shp = lay.local_pattern(fed.pattern_A(structural=full), f, f)
+        Ap = DeviceCSR.from_pattern(ctx, shp[0], shp[1], rp, ci)             # a plain-CSR copy of the rank's rows for the host
+        model.fe.assemble(L.NPG_MAT_A, Ap, scale=a2e2, full_stress=full)
+        Ah = Ap.to_scipy_csr()
+        del Ap
+        g = f.globals()[:n_sol]                                              # global id of every local column
+        ghost = np.arange(n_own, n_sol)
+        gu_idx, gp_idx = ghost[g[ghost] < nu_g], ghost[g[ghost] >= nu_g]      # (kept in ghost order: sorted by owner, id)
+        u_cols = np.concatenate([np.arange(nu_o), gu_idx])
+        p_cols_A = np.concatenate([np.arange(nu_o, n_own), gp_idx])
+        Ah = Ah.tocsc()
+        G0 = sp.csr_matrix(Ah[:nu_o][:, p_cols_A])                            # own_u x [own_p | ghost p of A]
+        Dh = sp.csr_matrix(Ah[nu_o:n_own][:, u_cols])                         # own_p x [own_u | ghost u]
+        nfl, nsl = part.local_nodes(rank)
+        Dinv = mgm.node_block_inverse(sp.csr_matrix(Ah[:nu_o][:, :nu_o]), nfl, nsl)
+        # T = Dinv G on the owned velocity rows, columns as GLOBAL pressure ids; its ghost rows come from their owners
+        T = sp.csr_matrix(Dinv @ G0)
+        T = sp.csr_matrix((T.data, g[p_cols_A][T.indices], T.indptr), shape=(nu_o, fed.dofs.nu + fed.dofs.np))
+        want = g[gu_idx]
+        wants = [None] * world
+        dist.all_gather_object(wants, want)
+        lut_u = np.full(nu_g, -1, dtype=np.int64)
+        lut_u[f.owned[:nu_o]] = np.arange(nu_o)
+        replies = {}
+        for q in range(world):
+            if q == rank:
+                continue
+            mine = wants[q][lay.owner_inv[wants[q]] == rank]
+            if len(mine):
+                rows = T[lut_u[mine]]
+                replies[q] = (mine, rows.indptr, rows.indices, rows.data)
+        allrep = [None] * world
+        dist.all_gather_object(allrep, replies)
+        ip, ix, dv = [np.zeros(1, dtype=np.int64)], [], []
+        pos = {}
+        for q in range(world):
+            rep = allrep[q].get(rank) if q != rank else None
+            if rep is not None:
+                ids, rptr, rind, rdat = rep
+                for k, gid in enumerate(ids):
+                    pos[int(gid)] = (q, k)
+        Text_rows = [T]
+        if len(want):
+            blocks = []
+            for gid in want:                                                  # ghost rows in D's column order
+                q, k = pos[int(gid)]
+                ids, rptr, rind, rdat = allrep[q][rank]
+                blocks.append((rind[rptr[k]:rptr[k + 1]], rdat[rptr[k]:rptr[k + 1]]))
+            indptr = np.concatenate([[0], np.cumsum([len(b[0]) for b in blocks])])
+            Tg = sp.csr_matrix((np.concatenate([b[1] for b in blocks]) if indptr[-1] else np.zeros(0),
+                                np.concatenate([b[0] for b in blocks]) if indptr[-1] else np.zeros(0, dtype=np.int64), indptr),
+                               shape=(len(want), T.shape[1]))
+            Text_rows.append(Tg)
+        Text = sp.vstack(Text_rows, format="csr")                             # rows [own_u | ghost u], global columns
+        Sg = sp.csr_matrix(Dh @ Text)                                         # own_p x global ids
+        # pressure layout [own_p | ghost p]: everything G and S touch
+        own_p = f.owned[nu_o:]
+        cols_used = np.union1d(np.unique(Sg.indices), g[p_cols_A])
+        gp = cols_used[lay.owner_inv[cols_used] != rank]
+        gp = gp[np.lexsort((gp, lay.owner_inv[gp]))]
+        lut_p = np.full(fed.dofs.nu + fed.dofs.np, -1, dtype=np.int64)
+        lut_p[own_p] = np.arange(len(own_p))
+        lut_p[gp] = len(own_p) + np.arange(len(gp))
+        npl = len(own_p) + len(gp)
+
+        def to_p_layout(M_global_cols):
+            M = sp.csr_matrix(M_global_cols)
+            lc = lut_p[M.indices]
+            assert (lc >= 0).all()
+            Q = sp.csr_matrix((M.data, lc, M.indptr), shape=(M.shape[0], npl))
+            Q.sort_indices()
+            return Q
+        Sl = to_p_layout(Sg)
+        Gl = to_p_layout(sp.csr_matrix((G0.data, g[p_cols_A][G0.indices], G0.indptr), shape=(nu_o, fed.dofs.nu + fed.dofs.np)))
+        # halo plans of the velocity-part and pressure-part vectors
+        allg = [None] * world
+        dist.all_gather_object(allg, (want, gp))
+        own_u = f.owned[:nu_o]
+        plan_u = halo_plan(rank, own_u, lay.owner_inv, [a[0] for a in allg])
+        plan_p = halo_plan(rank, own_p, lay.owner_inv, [a[1] for a in allg])
+        self.hu = Halo(ctx, nu_o, len(want), plan_u)
+        self.hp = Halo(ctx, len(own_p), len(gp), plan_p)
+        self.hx = model.inversion.solver.halo
+        Pg = mgm.prolongation(hierarchy[-2], fed)
+        Pl = sp.csr_matrix(Pg[f.owned])
+        ops = [DeviceCSR.from_scipy(ctx, M) for M in (Gl, Dh, sp.csr_matrix(Dinv), Sl, Pl, sp.csr_matrix(Pl.T))]
+        self._keep += ops
+        A_sol = model.inversion.solver.A
+        L.check(L.lib().npg_precond_mg_set_level_dist(self.h, len(hierarchy) - 1, A_sol.h, int(nu_o), ops[0].h, ops[1].h,
+                                                      ops[2].h, ops[3].h, ops[4].h, ops[5].h, self.hx.h, self.hu.h, self.hp.h))
+        self.levels.append(fed.dofs.nu + fed.dofs.np)
+        L.check(L.lib().npg_precond_mg_set_params(self.h, float(omega), float(jacobi_weight), int(schur_sweeps), int(nu1),
+                                                  int(nu2), int(coarse_sweeps)))
+        L.check(L.lib().npg_precond_mg_set_cycle(self.h, {"V": 1, "W": 2}[cycle]))
+        if coarse_dense is None:
+            coarse_dense = self.levels[0] <= 40000
+        if coarse_dense:
+            L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, 1 if coarse_dense == "fp64" else 2))
+        self.coarse_dense = bool(coarse_dense)
+        self.params = dict(omega=omega, jacobi_weight=jacobi_weight, schur_sweeps=schur_sweeps, nu1=nu1, nu2=nu2,
+                           coarse_sweeps=coarse_sweeps, cycle=cycle)
+        self.layout_mg = dict(ghost_u=int(len(want)), ghost_p=int(len(gp)), S_nnz=int(Sl.nnz))
+
+    def counters(self):
+        import ctypes as C
+        a, b = C.c_int64(), C.c_int64()
+        L.check(L.lib().npg_precond_counters(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.lib().npg_precond_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def __repr__(self):
+        return (f"DistributedMultigridPreconditioner({self.levels}: finest level row-partitioned, coarser ones replicated; "
+                f"{self.params}, coarsest level: {'dense inverse' if self.coarse_dense else 'smoothing steps'})")
+
+
+def use_multigrid(model, hierarchy, memory=20, **mg_kw):
+    """Replace the partitioned model's inversion solver (GMRES + Diagonal(1/h^3)) by flexible GMRES behind the distributed
+    multigrid; the stopping rule keeps the reference's 1/h^dim scaling.  Collective."""
+    from .multigrid import FgmresWorkspace
+    s = model.inversion.solver
+    if hierarchy[-1] is not model.fe_data:
+        raise ValueError("use_multigrid: hierarchy[-1] must be the model's own fe_data")
+    P = DistributedMultigridPreconditioner(model.arch, model.params, model.forcings, hierarchy, model, **mg_kw)
+    ws = FgmresWorkspace(model.arch.ctx, s.lay.n_own, memory=memory)
+    L.check(L.lib().npg_fgmres_set_halo(ws.h, s.halo.h))
+    kw = dict(s.kwargs, scale=float(s.P.scalar))
+    model.inversion.solver = PartitionedSolverToolkit(s.A, P, s.y, ws, kw, s.label, s.x, s.lay, s.halo, s.halo_ext)
+    model._u_view = model.inversion.solver.x.view(0, model.layout.n_own_u)
+    model.extrapolate_guess = True
+    model.dist.barrier()
+    return model

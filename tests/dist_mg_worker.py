@@ -1,0 +1,38 @@
+"""One rank of the distributed-multigrid rehearsal (launched by tests/test_gpu_distributed.py through torch.distributed.run; all
+ranks share GPU 0, NPG_COMM_TRANSPORT selects the transport).  bowl3D h = 0.05 (134 866 unknowns) with its two-level
+hierarchy: the finest level row-partitioned on the partitioned mesh, the coarse level (h = 0.1, dense inverse) replicated."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import nupgcm_amd as npg                                     # noqa: E402
+from nupgcm_amd import partition, workloads                  # noqa: E402
+
+
+def main():
+    out, nsteps, label = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    arch = npg.GPU(int(os.environ.get("NPG_FORCE_DEVICE", 0)))
+    hier = [workloads.example_fe_data(m) for m in workloads.bowl_hierarchy_models(label)]
+    prm, frc = workloads.example_parameters()
+    m = partition.partitioned_model(arch, hier[-1], prm, frc, npg.BDF2(t_start=0.0, t_stop=1e9, dt=1e-3), dist)
+    partition.use_multigrid(m, hier)
+    assert m.verify_transport()
+    npg.invert(m)
+    npg.run(m, n_steps=nsteps)
+    arch.ctx.sync()
+    u, p, b = m.state.u, m.state.p, m.state.b
+    np.savez(f"{out}.rank{rank}.npz", u=u, p=p, b=b, its=[s[1]["niter"] for s in m.stats],
+             solved=[bool(s[1]["solved"]) and bool(s[0]["solved"]) for s in m.stats], rn=[s[1]["rnorm"] for s in m.stats],
+             mg=np.array([m.inversion.solver.P.layout_mg[k] for k in ("ghost_u", "ghost_p", "S_nnz")]),
+             precond=repr(m.inversion.solver.P))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -136,6 +136,34 @@ def test_mesh_partitioned_model_rehearsal(serial, world, mode, tmp_path):
     assert lay[:, 8].max() < 1.25 * serial_bytes / world, (lay[:, 8], serial_bytes)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_multigrid_rehearsal(world, tmp_path):
+    """The multigrid-preconditioned inversion on the partitioned mesh (partition.DistributedMultigridPreconditioner: finest
+    level row-partitioned, coarse level replicated, flexible GMRES with all-reduced Gram-Schmidt sums) against the one-GPU
+    multigrid model of the same hierarchy: the same outer iteration counts step by step and the same trajectory to the solver
+    tolerance - it is the same algorithm, only the summation orders differ."""
+    arch = npg.GPU()
+    label, nsteps = "bowl3D_h0.05", 4
+    ref = workloads.example_model(arch, label, preconditioner="multigrid")
+    npg.invert(ref)
+    npg.run(ref, n_steps=nsteps)
+    ref_its = [s[1]["niter"] for s in ref.stats]
+    out = str(tmp_path / "dmg")
+    env = dict(os.environ, NPG_COMM_TRANSPORT="peer", NPG_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
+               NPG_PEER_TIMEOUT_S="90")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_mg_worker.py"), out, str(nsteps), label]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ranks = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
+    for z in ranks[1:]:
+        assert np.array_equal(z["u"], ranks[0]["u"]) and np.array_equal(z["its"], ranks[0]["its"])
+    z = ranks[0]
+    assert z["solved"].all() and "row-partitioned" in str(z["precond"])
+    assert list(z["its"]) == ref_its, (list(z["its"]), ref_its)
+    assert rel(z["b"], ref.state.b) < 1e-6 and rel(z["u"], ref.state.u) < 2e-3 and rel(z["p"], ref.state.p) < 2e-3
+
+
 def test_channel_basin_mesh_partitioned(tmp_path):
     """BASELINE configs[4] on 3 ranks with the mesh partitioned: closures re-evaluated and K_v / the full-stress A
     re-assembled on each rank's own cells (src/model.jl:160-170,229-261), CFL step from the global minimum."""
