@@ -178,7 +178,10 @@ def main():
             model = workloads.channel_basin_model(arch, mesh_model=mesh_model, surface=surf)
     elif (world > 1 or force_dist) and not replicated:
         from nupgcm_amd import partition
-        model = partition.example_model(arch, mesh_model, dist, dt=a.dt)
+        if a.preconditioner == "multigrid":     # finest level row-partitioned, coarser levels replicated
+            model = partition.example_model(arch, a.workload, dist, dt=a.dt, preconditioner="multigrid")
+        else:
+            model = partition.example_model(arch, mesh_model, dist, dt=a.dt)
     elif world > 1 or force_dist:
         from nupgcm_amd import distributed
         model = distributed.example_model(arch, mesh_model, dist, dt=a.dt)
@@ -205,7 +208,8 @@ def main():
             ctx.disable_peer()
             from nupgcm_amd import partition
             model = (partition.channel_basin_model(arch, mesh_model, dist, surface=surf) if channel else
-                     partition.example_model(arch, mesh_model, dist, dt=a.dt))
+                     partition.example_model(arch, a.workload if a.preconditioner == "multigrid" else mesh_model, dist, dt=a.dt,
+                                             preconditioner=a.preconditioner if a.preconditioner == "multigrid" else "diagonal"))
             if not model.verify_transport():
                 raise SystemExit("bench: the RCCL transport failed the halo / all-reduce check too")
             transport_check = "peer failed, rccl passed"

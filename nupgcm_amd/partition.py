@@ -467,13 +467,19 @@ class PartitionedModel(Model):
 
 
 # ---- named workloads, partitioned ------------------------------------------------------------------------------------------
-def example_model(arch, mesh_model, dist, dt=1e-3, t_stop=1e9, **kw):
-    """workloads.example_model (examples/bowl_mixing.jl:171-190) with the mesh partitioned over the ranks of `dist`"""
+def example_model(arch, mesh_model, dist, dt=1e-3, t_stop=1e9, preconditioner="diagonal", **kw):
+    """workloads.example_model (examples/bowl_mixing.jl:171-190) with the mesh partitioned over the ranks of `dist`.
+    preconditioner="multigrid": `mesh_model` is the LABEL of a refined bowl mesh; its refinement hierarchy preconditions the
+    inversion (finest level row-partitioned, coarser levels replicated)."""
     from . import workloads
     from .timesteppers import BDF2
     prm, frc = workloads.example_parameters()
-    fed = workloads.example_fe_data(mesh_model)
-    return partitioned_model(arch, fed, prm, frc, BDF2(t_start=0.0, t_stop=t_stop, dt=dt), dist, **kw)
+    ts = BDF2(t_start=0.0, t_stop=t_stop, dt=dt)
+    if preconditioner == "multigrid":
+        hier = [workloads.example_fe_data(m) for m in workloads.bowl_hierarchy_models(mesh_model)]
+        return use_multigrid(partitioned_model(arch, hier[-1], prm, frc, ts, dist, **kw), hier)
+    fed = workloads.example_fe_data(workloads.bowl_mesh_model(mesh_model) if isinstance(mesh_model, str) else mesh_model)
+    return partitioned_model(arch, fed, prm, frc, ts, dist, **kw)
 
 
 def channel_basin_model(arch, mesh_model, dist, surface="flux", itmax=1000, CFL_factor=0.8, element_precision="fp32",
