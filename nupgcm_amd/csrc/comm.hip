@@ -36,6 +36,7 @@
 #include <chrono>
 
 #include "common.h"
+#include "peer_device.h"
 
 namespace npg {
 
@@ -150,37 +151,7 @@ constexpr int kMaxRanks = 16;      // ranks of one node
 constexpr int kArSlots = 4;        // ring of all-reduce slots (2 would do: a rank cannot get two collectives ahead of a peer)
 constexpr int kArGran = 2 * kPartStride;   // 8-byte granules per all-reduced row: {epoch, low half}, {epoch, high half}
 constexpr int kMaxPeers = 15;      // neighbours of one halo plan
-constexpr int kHaloWG = 32;        // most sender workgroups (= flags) per (sender, receiver) pair
 constexpr int kHaloChunk = 1024;   // entries per sender workgroup before the cap above stretches the chunks
-
-// system-scope (cross-device) accesses: write-through stores / cache-bypassing loads (sc0 sc1 on gfx950)
-// (global address space spelled out: global_load / global_store, never flat_)
-typedef __attribute__((address_space(1))) uint64_t gu64;
-__device__ __forceinline__ void st_sys(uint64_t *p, uint64_t v) {
-    __hip_atomic_store((gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ uint64_t ld_sys(const uint64_t *p) {
-    return __hip_atomic_load((gu64 *)const_cast<uint64_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ void st_sys_f64(double *p, double v) {
-    __hip_atomic_store((gu64 *)reinterpret_cast<uint64_t *>(p), (uint64_t)__double_as_longlong(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// every wait is bounded: `ticks` of the 100 MHz constant clock, then the status word (pinned host memory) is set and the
-// kernel carries on with whatever it has - the host sees the status at its next look and fails the call
-struct SpinGuard {
-    unsigned long long t0, ticks;
-    int *status;
-    int code;
-    __device__ __forceinline__ SpinGuard(unsigned long long tk, int *st, int c) : t0(__builtin_amdgcn_s_memrealtime()), ticks(tk), status(st), code(c) {}
-    __device__ __forceinline__ bool expired() {
-        __builtin_amdgcn_s_sleep(2);
-        if (__builtin_amdgcn_s_memrealtime() - t0 < ticks) return false;
-        __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return true;
-    }
-};
 
 struct PeerArDev {
     uint64_t *const *win;      // device array [nranks]: every rank's all-reduce window (own included)
@@ -250,29 +221,6 @@ __global__ void __launch_bounds__(1024) k_peer_fold_allreduce(const double *part
     if (threadIdx.x == 0) *P.epoch = e;
 }
 
-// halo plan, device view (tables live in device memory; pointers into peers' windows are IPC mappings)
-struct HaloPeerDev {
-    // sender side: workgroup b gathers x[send_idx[s]] for s in [tab[b].x, tab[b].y) into peer tab[b].z's window and raises
-    // that peer's flag tab[b].w
-    const int4 *tab;
-    const int64_t *seg0;          // [npeers] first send offset of the peer's segment
-    double *const *dst;           // [npeers] peer's receive window at MY segment, slot 0
-    const int64_t *dst_stride;    // [npeers] slot stride there (= the peer's ghost count)
-    uint64_t *const *flag_dst;    // [npeers] my kHaloWG flags in the peer's window
-    const uint64_t *ack;          // [npeers] local: last epoch peer p has finished reading (stored by p)
-    // receiver side
-    const int *nflag;             // [npeers] sender workgroups of peer p (0: nothing comes from p)
-    const uint64_t *flags;        // local [npeers][kHaloWG]
-    const double *rwin;           // local [2][n_ghost]
-    uint64_t *const *ack_dst;     // [npeers] my word in peer p's ack array
-    unsigned long long *arrive;   // local device word: unpack workgroups done so far (monotonic)
-    uint64_t *epoch;              // local device word: exchanges completed
-    int *status;
-    unsigned long long ticks;
-    int64_t n_ghost;
-    int npeers;
-};
-
 // ONE kernel per exchange (phase 0).  Workgroup b < npush: gather x[send_idx[s]] for its chunk straight into the neighbour's
 // window (write-through stores), drain, raise its flag.  Then workgroup b < nwait: wait for every neighbour's flags of this
 // epoch, copy its share of the window behind the owned entries; the last one acknowledges and completes the epoch.  Every
@@ -311,20 +259,7 @@ __global__ void __launch_bounds__(256) k_halo_exchange(double *__restrict__ x, c
         if (threadIdx.x == 0) st_sys(H.flag_dst[t.z] + t.w, e);
     }
     if (phase == 1 || (int)blockIdx.x >= nwait) return;
-    if (threadIdx.x < 64) {
-        SpinGuard guard(H.ticks, H.status, 3);
-        for (int p = 0; p < H.npeers; ++p) {
-            const bool need = (int)threadIdx.x < H.nflag[p];
-            const uint64_t *f = H.flags + (size_t)p * kHaloWG + (threadIdx.x & (kHaloWG - 1));
-            for (;;) {
-                const bool ok = !need || ld_sys(f) >= e;
-                if (__all(ok)) break;
-                if (__any(guard.expired())) break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");       // system scope: nothing stale of the window in this CU
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the invalidate has completed before the barrier opens
-    }
+    halo_window_ready(H, e);
     __syncthreads();
     double *xg = x + n_owned;
     const double *src = H.rwin + (e & 1) * H.n_ghost;
@@ -338,17 +273,7 @@ __global__ void __launch_bounds__(256) k_halo_exchange(double *__restrict__ x, c
         for (int u = 0; u < 8; ++u)
             if (i0 + u * stride < H.n_ghost) xg[i0 + u * stride] = v[u];
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long done = atomicAdd(H.arrive, 1ULL) + 1ULL;
-        if (done == (unsigned long long)nwait * e) {
-            // last workgroup of this exchange: the window slot is free again, tell the senders; the exchange is complete
-            for (int p = 0; p < H.npeers; ++p)
-                if (H.nflag[p] > 0) st_sys(H.ack_dst[p], e);
-            *H.epoch = e;
-        }
-    }
+    halo_consumed(H, e, (unsigned)nwait);
 }
 
 static int halo_wg_count(int64_t cnt) { return (int)std::min<int64_t>(kHaloWG, (cnt + kHaloChunk - 1) / kHaloChunk); }

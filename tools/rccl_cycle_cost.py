@@ -16,17 +16,21 @@ import nupgcm_amd as npg                                          # noqa: E402
 from nupgcm_amd import _lib as L, distributed                     # noqa: E402
 from nupgcm_amd.architectures import comm_unique_id               # noqa: E402
 
-n = min(int(sys.argv[1]) if len(sys.argv) > 1 else 20000, 100000)      # a latency probe: small systems only
+n = min(int(sys.argv[1]) if len(sys.argv) > 1 else 20000, 400000)      # a latency probe: one rank's share of a large system at most
 arch = npg.GPU(0)
 ctx = arch.ctx
 ctx.comm_init(comm_unique_id(), 0, 1)
 rng = np.random.default_rng(5)
-S = np.arange(n - 256, n)[::-1].copy()
+S = np.arange(n - (256 if n <= 50000 else 30000), n)[::-1].copy()       # ghost columns: a slab interface at the larger sizes
 plan = dict(peers=np.array([0], np.int32), send_ptr=np.array([0, len(S)], np.int64), send_idx=S.astype(np.int32),
             recv_ptr=np.array([0, len(S)], np.int64))
 halo = distributed.Halo(ctx, n, len(S), plan)
 # slowly converging: a shifted 1-D Laplacian-like band + random couplings
-M = sp.diags([-1.0, 2.0005, -1.0], [-1, 0, 1], shape=(n, n), format="csr") + 1e-3 * sp.random(n, n, density=4.0 / n, random_state=1)
+# (banded like an RCM-ordered FE row block, ~40 entries per row at the larger sizes so that the SpMV has a rank's weight)
+offs = [-1, 0, 1] if n <= 50000 else list(range(-20, 21))
+M = sp.diags([(2.0005 if o == 0 else -1.0 / max(1, abs(o)) ** 2) * np.ones(n - abs(o)) for o in offs], offs, shape=(n, n), format="csr")
+if n <= 50000:
+    M = M + 1e-3 * sp.random(n, n, density=4.0 / n, random_state=1)
 M = sp.csr_matrix(M)
 Mc = M.tocsc()
 keep = np.ones(n)
