@@ -72,10 +72,14 @@ class Mesh:
         if degree != 4:
             raise NotImplementedError("only Measure(., 4) - the reference's default and only used degree - is tabulated")
         model = ifile if isinstance(ifile, gmsh_io.GmshModel) else gmsh_io.load_model(ifile)
-        if model.dim != 3:
-            raise NotImplementedError("nupgcm_amd covers the 3-D (tetrahedral) configurations of the hot path")
+        if model.dim not in (2, 3):
+            raise NotImplementedError("nupgcm_amd covers the 3-D (tetrahedral) and embedded 2-D (triangular) meshes of the hot path")
         self.model = model
+        self.dim = int(model.dim)
         self.surface_tags = tuple(surface_tags)
+        if self.dim == 2:
+            self._init_embedded_2d(model)
+            return
         # Periodic meshes (meshes/channel_basin.jl:103-108): GridapGmsh glues paired nodes into one topological vertex while
         # cells keep their own node coordinates.  `cells` / `coords` are the TOPOLOGY (vertex ids, one coordinate per vertex:
         # the master's); `cell_geo` / `geo_coords` are the GEOMETRY (the Gmsh nodes of each cell, in the order of its sorted
@@ -153,6 +157,65 @@ class Mesh:
         self.N1 = self.q_lam.copy()
         self.dN1 = np.broadcast_to(np.eye(4), (len(self.q_w), 4, 4)).copy()
 
+    def _init_embedded_2d(self, model):
+        """Triangles embedded in 3-D (the reference's bowl2D meshes, test/bowl_mixing_tests.jl:112-114), with GridapGmsh's
+        conventions for them: cells keep their RAW vertex order (only 3-D simplices in 3-D are re-oriented by sorting), edges
+        are numbered at first encounter in local order (0,1) (0,2) (1,2), an edge carries the tag of the matching 1-D boundary
+        element, gradients are tangential (pseudo-inverse of the 3 x 2 Jacobian), |J| = sqrt(det J'J), Measure(., 4) = the
+        3 x 3 collapsed rule.  The DEVICE sees every triangle as a tetrahedron whose fourth barycentric coordinate is
+        identically zero: the element kernels are table-driven (shape values, barycentric derivatives, barycentric gradients,
+        weights all come from the host), so with grad(lambda_4) = 0, lambda_4 = 0 at every quadrature point and the four
+        P2 / one P1 functions of the missing vertex constrained to zero (FEData pads the DoF tables) they integrate exactly
+        the triangle forms - no 2-D instances of the kernels are needed."""
+        if getattr(model, "periodic", None) is not None:
+            raise NotImplementedError("periodic embedded 2-D meshes")
+        self.geo_coords = np.ascontiguousarray(model.coords, dtype=np.float64)
+        self.vertex_of = np.arange(len(self.geo_coords), dtype=np.int64)
+        self.periodic = False
+        self.coords = self.geo_coords
+        self.nv = len(self.coords)
+        self.cells = np.asarray(model.cells, dtype=np.int64).copy()         # raw order
+        self.cell_geo = self.cells
+        nc = len(self.cells)
+        a, b = self.cells[:, _TRI_EDGE_A].ravel(), self.cells[:, _TRI_EDGE_B].ravel()
+        lo, hi = np.minimum(a, b), np.maximum(a, b)
+        key = lo * self.nv + hi
+        uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+        rank = np.empty(len(uniq), dtype=np.int64)
+        rank[np.argsort(first, kind="stable")] = np.arange(len(uniq))       # first-encounter numbering
+        self.cell_edges = rank[inv].reshape(nc, 3)
+        self.edges = np.empty((len(uniq), 2), dtype=np.int64)
+        self.edges[rank] = np.stack([uniq // self.nv, uniq % self.nv], axis=1)
+        self.ne = len(self.edges)
+        self.nn = self.nv + self.ne
+        self._edge_key_sorted, self._edge_rank = uniq, rank
+        self.cell_nodes = np.hstack([self.cells, self.nv + self.cell_edges])  # (nc, 6) P2 nodes
+        self.node_coords = np.vstack([self.coords, 0.5 * (self.coords[self.edges[:, 0]] + self.coords[self.edges[:, 1]])])
+        self.phys_names = list(model.phys_names)
+        emask = np.zeros(self.ne, dtype=np.uint32)
+        fg = np.asarray(model.facets, dtype=np.int64).reshape(-1, 2)          # boundary elements are 1-D here
+        fac = np.sort(fg, axis=1)
+        fph = np.asarray(model.facets_phys, dtype=np.uint32)
+        eid = self.edge_ids(fac[:, 0], fac[:, 1])
+        ok = eid >= 0
+        emask[eid[ok]] = fph[ok]
+        vmask = np.zeros(self.nv, dtype=np.uint32)
+        np.bitwise_or.at(vmask, self.vertex_of, np.asarray(model.node_phys, dtype=np.uint32))
+        self.node_mask = np.concatenate([vmask, emask])
+        self._facets, self._facets_phys, self._facets_geo = fac, fph, fac
+        X = self.geo_coords[self.cell_geo]                                    # (nc, 3, 3)
+        J = np.transpose(X[:, 1:, :] - X[:, :1, :], (0, 2, 1))                # (nc, 3, 2): columns = edge vectors
+        JtJ = np.einsum("cik,cil->ckl", J, J)
+        self.detJ = np.sqrt(np.linalg.det(JtJ))
+        gref = np.einsum("ckl,cil->cki", np.linalg.inv(JtJ), J)               # pseudo-inverse rows: tangential gradients
+        g3 = np.concatenate([-gref.sum(axis=1, keepdims=True), gref], axis=1) # (nc, 3, 3)
+        self.grad_lambda = np.ascontiguousarray(np.concatenate([g3, np.zeros((nc, 1, 3))], axis=1))   # lambda_4 = 0: no gradient
+        lam3, self.q_w = tri_quadrature_degree4()
+        self.q_lam = np.concatenate([lam3, np.zeros((len(lam3), 1))], axis=1)
+        self.N2, self.dN2 = p2_tables(self.q_lam, _TET_EDGE_A, _TET_EDGE_B)   # the tetrahedron's tables on its face lambda_4 = 0
+        self.N1 = self.q_lam.copy()
+        self.dN1 = np.broadcast_to(np.eye(4), (len(self.q_w), 4, 4)).copy()
+
     @property
     def ncell(self):
         return len(self.cells)
@@ -173,7 +236,8 @@ class Mesh:
 
     def quad_points(self):
         """physical quadrature points (ncell, nq, 3) - where the host evaluates the user's coefficient closures"""
-        return np.einsum("qk,cki->cqi", self.q_lam, self.geo_coords[self.cell_geo])
+        k = self.cell_geo.shape[1]
+        return np.einsum("qk,cki->cqi", self.q_lam[:, :k], self.geo_coords[self.cell_geo])
 
     def boundary_faces(self, names, with_geometry=False):
         """boundary triangles carrying any of `names` as sorted vertex ids (and, on request, their Gmsh nodes in that order)"""
@@ -188,6 +252,19 @@ class Mesh:
         faces, fgeo = self.boundary_faces(self.surface_tags if names is None else names, with_geometry=True)
         out = np.zeros(self.nn)
         if len(faces) == 0:
+            return out
+        if getattr(self, "dim", 3) == 2:
+            # boundary = segments: 3-point Gauss-Legendre (exact to degree 5), P2 on the segment = two ends + the edge node
+            t, w = roots_legendre(3)
+            t, w = (t + 1) / 2, w / 2
+            N = np.stack([(1 - t) * (1 - 2 * t), t * (2 * t - 1), 4 * t * (1 - t)], axis=1)        # (nq, 3)
+            X = self.geo_coords[fgeo]                                                              # (nf, 2, 3)
+            length = np.linalg.norm(X[:, 1] - X[:, 0], axis=1)
+            xq = X[:, None, 0, :] * (1 - t)[None, :, None] + X[:, None, 1, :] * t[None, :, None]
+            en = self.edge_ids(faces[:, 0], faces[:, 1])
+            nodes = np.stack([faces[:, 0], faces[:, 1], self.nv + en], axis=1)
+            vals = np.einsum("f,q,fq,qi->fi", length, w, np.asarray(g(xq), dtype=float) * np.ones(xq.shape[:2]), N)
+            np.add.at(out, nodes, vals)
             return out
         lam, w = tri_quadrature_degree4()
         N, _ = p2_tables(lam, _TRI_EDGE_A, _TRI_EDGE_B)
@@ -209,7 +286,7 @@ class Mesh:
         """The `h` of src/inversion.jl:44-49: median over the unique edges built from local pairs (1,2),(2,3),(3,1) only
         (all_edges, src/meshes.jl:94-108, written for triangles) - `hs[length(hs) // 2]` 1-based."""
         t, g = self.cells, self.cell_geo
-        e = np.sort(np.vstack([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]]), axis=1)
+        e = np.sort(np.vstack([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]]), axis=1)      # (a triangle's three edges, dim 2 or 3)
         eg = np.vstack([g[:, [0, 1]], g[:, [1, 2]], g[:, [2, 0]]])
         _, first = np.unique(e[:, 0] * self.nv + e[:, 1], return_index=True)
         eg = eg[first]                                          # lengths from the cell's own nodes (periodic seam)
@@ -400,9 +477,27 @@ class FEData:
         b_code = b_pos.copy()
         b_code[bdn] = -1 - np.arange(len(bdn))
         b_diri = s.b_diri_val[bdn]
-        return DeviceTables(cell_u=np.ascontiguousarray(u_code[m.cell_nodes], dtype=np.int32),
-                            cell_p=np.ascontiguousarray(p_pos[m.cells], dtype=np.int32),
-                            cell_b=np.ascontiguousarray(b_code[s.cell_b_nodes], dtype=np.int32),
+        cell_u, cell_p, cell_b = u_code[m.cell_nodes], p_pos[m.cells], b_code[s.cell_b_nodes]
+        if getattr(m, "dim", 3) == 2:
+            # the device's element is the tetrahedron: a triangle fills its face lambda_4 = 0 (Mesh._init_embedded_2d); the
+            # local functions of the missing vertex - P2 slots 3 (vertex) and 7, 8, 9 (its edges), P1 slot 3 - are
+            # homogeneous Dirichlet DoFs: one extra zero at the end of each value table, no row, no column
+            nc = len(cell_p)
+            zu, zb = -1 - len(u_diri), -1 - len(b_diri)
+            u_diri, b_diri = np.append(u_diri, 0.0), np.append(b_diri, 0.0)
+            cu = np.full((nc, 10, 3), zu, dtype=np.int64)
+            cu[:, [0, 1, 2, 4, 5, 6]] = cell_u                     # vertices 0..2, edges (0,1) (0,2) (1,2)
+            cell_u = cu
+            cell_p = np.concatenate([cell_p, np.full((nc, 1), -1, dtype=np.int64)], axis=1)
+            if cell_b.shape[1] == 6:
+                cb = np.full((nc, 10), zb, dtype=np.int64)
+                cb[:, [0, 1, 2, 4, 5, 6]] = cell_b
+            else:
+                cb = np.concatenate([cell_b, np.full((nc, 1), zb, dtype=np.int64)], axis=1)
+            cell_b = cb
+        return DeviceTables(cell_u=np.ascontiguousarray(cell_u, dtype=np.int32),
+                            cell_p=np.ascontiguousarray(cell_p, dtype=np.int32),
+                            cell_b=np.ascontiguousarray(cell_b, dtype=np.int32),
                             u_diri=np.ascontiguousarray(u_diri), b_diri=np.ascontiguousarray(b_diri),
                             u_pos=u_pos, p_pos=p_pos, b_pos=b_pos)
 

@@ -101,7 +101,7 @@ class InversionToolkit:
             b0 = build_b_inversion(arch, fe_data, params, forcings, b0)
             # GPU preconditioner: Diagonal(1/h^dim) with the median edge length (src/inversion.jl:42-54)
             h = fe_data.mesh.median_edge_length()
-            P = Diagonal(scalar=1.0 / h ** 3, n=A.shape[0])
+            P = Diagonal(scalar=1.0 / h ** getattr(fe_data.mesh, "dim", 3), n=A.shape[0])      # 1/h^dim: dim = 2 on the embedded 2-D meshes
             if preconditioner != "diagonal":
                 from . import multigrid as mgm
                 self.scale = P.scalar                   # the residual keeps the reference's 1/h^dim scaling

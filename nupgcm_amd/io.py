@@ -105,16 +105,16 @@ def _nodal_closure_fields(model, b_full):
     evaluates cell by cell; here the cell-wise values at a node (d/dz of the P2 interpolant of b_full through the cell's own
     geometry) are averaged over the cells sharing it, and the closures (src/inputs.jl:87-91, 130-137) or the forcing
     functions are evaluated on that."""
-    from .fe import _TET_EDGE_A, _TET_EDGE_B, p2_tables
+    from .fe import _TET_EDGE_A, _TET_EDGE_B, _TRI_EDGE_A, _TRI_EDGE_B, p2_tables
     m, prm, frc = model.fe_data.mesh, model.params, model.forcings
-    lam = np.vstack([np.eye(4), 0.5 * (np.eye(4)[_TET_EDGE_A] + np.eye(4)[_TET_EDGE_B])])     # the 10 nodes of a cell
-    _, dN = p2_tables(lam, _TET_EDGE_A, _TET_EDGE_B)                 # (10 points, 10 basis, 4 barycentric)
-    X = m.geo_coords[m.cell_geo]                                     # (nc, 4, 3)
-    J = np.concatenate([np.ones((len(X), 4, 1)), X], axis=2)         # lambda = J^-T [1; x]: rows of inv(J) give grad lambda
-    G = np.linalg.inv(J)[:, 1:, :]                                   # (nc, 3, 4): d lambda_k / d x_i
-    bc = b_full[m.cell_nodes]                                        # (nc, 10)
+    k = m.cells.shape[1]                                             # 4 (tetrahedra) or 3 (embedded triangles)
+    ea, eb = (_TET_EDGE_A, _TET_EDGE_B) if k == 4 else (_TRI_EDGE_A, _TRI_EDGE_B)
+    lam = np.vstack([np.eye(k), 0.5 * (np.eye(k)[ea] + np.eye(k)[eb])])   # the nodes of a cell
+    _, dN = p2_tables(lam, ea, eb)                                   # (nodes, basis, barycentric)
+    Gz = m.grad_lambda[:, :k, 2]                                     # (nc, k): d lambda_k / d z (tangential on embedded meshes)
+    bc = b_full[m.cell_nodes]                                        # (nc, 10 | 6)
     dlam = np.einsum("qak,ca->cqk", dN, bc)                          # d b / d lambda_k at the cell's nodes
-    bz = np.einsum("cqk,ck->cq", dlam, G[:, 2, :])                   # d b / d z
+    bz = np.einsum("cqk,ck->cq", dlam, Gz)                           # d b / d z
     acc = np.zeros(m.nn)
     cnt = np.zeros(m.nn)
     np.add.at(acc, m.cell_nodes.ravel(), bz.ravel())
@@ -147,8 +147,10 @@ def save_vtk(model, ofile):
         return ofile                               # one writer
     abz, nu, kv = _nodal_closure_fields(model, b)
     t = 0.0 if model.timestepper is None else float(model.timestepper.t)
-    conn = m.cell_nodes[:, _VTK_P2]
-    nc = len(conn)
+    tet = m.cell_nodes.shape[1] == 10
+    # VTK_QUADRATIC_TETRA (24) / VTK_QUADRATIC_TRIANGLE (22: edge nodes (0,1) (1,2) (2,0); ours (0,1) (0,2) (1,2))
+    conn = m.cell_nodes[:, _VTK_P2] if tet else m.cell_nodes[:, [0, 1, 2, 3, 5, 4]]
+    nc, npc, vtype = len(conn), conn.shape[1], (24 if tet else 22)
 
     def arr(a, fmt):
         return "\n".join(" ".join(fmt % v for v in row) for row in np.atleast_2d(a))
@@ -162,8 +164,8 @@ def save_vtk(model, ofile):
                 + "\n</DataArray>\n</Points>\n<Cells>\n")
         f.write('<DataArray type="Int64" Name="connectivity" format="ascii">\n' + arr(conn, "%d") + "\n</DataArray>\n")
         f.write('<DataArray type="Int64" Name="offsets" format="ascii">\n'
-                + arr((10 * np.arange(1, nc + 1)).reshape(-1, 1), "%d") + "\n</DataArray>\n")
-        f.write('<DataArray type="UInt8" Name="types" format="ascii">\n' + arr(np.full((nc, 1), 24), "%d")
+                + arr((npc * np.arange(1, nc + 1)).reshape(-1, 1), "%d") + "\n</DataArray>\n")
+        f.write('<DataArray type="UInt8" Name="types" format="ascii">\n' + arr(np.full((nc, 1), vtype), "%d")
                 + "\n</DataArray>\n</Cells>\n<PointData>\n")
         f.write('<DataArray type="Float64" Name="u" NumberOfComponents="3" format="ascii">\n' + arr(u, "%.17g")
                 + "\n</DataArray>\n")

@@ -356,7 +356,7 @@ def partitioned_model(arch, fe_data, params, forcings, ts, dist, atol=1e-6, rtol
     h = fe_data.mesh.median_edge_length()
     kw = dict(atol=atol, rtol=rtol, itmax=itmax, history=True, verbose=0, restart=True, reorth_eta=reorth_eta)
     inv = SimpleNamespace(arch=arch, B=B, b=b0v)
-    inv.solver = PartitionedSolverToolkit(A, Diagonal(scalar=1.0 / h ** 3, n=lay.inv.n_own), DeviceVector(ctx, lay.inv.n_own),
+    inv.solver = PartitionedSolverToolkit(A, Diagonal(scalar=1.0 / h ** getattr(fe_data.mesh, "dim", 3), n=lay.inv.n_own), DeviceVector(ctx, lay.inv.n_own),
                                           ws, kw, "Inversion", x_inv, lay.inv, h_sol_i, h_ext_i)
     # ---- evolution (src/evolution.jl:62-126) -------------------------------------------------------------------------
     fe.set_coeff("kappa_h", forcings.kappa_h)

@@ -536,6 +536,44 @@ def test_50_steps_reference_bar(arch, name, fixture, golden_dir):
     assert all(s[1]["solved"] == 1 and s[0]["solved"] == 1 for s in m.stats)
 
 
+def test_embedded_2d_mesh_A_inversion_is_the_reference_fixture(arch, golden_dir):
+    """test/bowl_mixing_tests.jl:50-64 on the DEVICE: the un-permuted A_inversion of the 2-D bowl (triangles embedded in 3-D:
+    raw cell order, tangential gradients from the pseudo-inverse Jacobian, 3 x 3 collapsed rule) assembled by k_assemble_A -
+    every triangle handed to the tetrahedral kernels as the face lambda_4 = 0 of a tetrahedron (fe.Mesh._init_embedded_2d) -
+    against the reference's own matrix test/data/A_bowl_mixing_2D.jld2: the strictest reference-held vector, directly."""
+    fed, prm, frc, dt, b0 = build_fe_data("bowl_mixing", mesh="mesh_bowl2D_h0.1")
+    d = fed.dofs
+    assert (d.nu, d.np, d.nb) == (990, 108, 349)
+    z = np.load(f"{golden_dir}/A_bowl_mixing_2D.npz")
+    Af = sp.csc_matrix((z["nzval"], z["rowval"] - 1, z["colptr"] - 1), shape=(int(z["m"]), int(z["n"]))).tocsr()
+    A = npg.build_A_inversion(arch, fed, prm, frc.nu, structural=True).to_scipy_csr()     # device (p_inversion) order
+    ip = d.inv_p_inversion
+    An = sp.csr_matrix(A[ip][:, ip])                                                     # native Gridap order
+    assert spla.norm(An - Af) / spla.norm(Af) < 1e-13
+    # the numeric pattern the solver uses gives the same operator
+    A2 = npg.build_A_inversion(arch, fed, prm, frc.nu).to_scipy_csr()
+    assert spla.norm(sp.csr_matrix(A2[ip][:, ip]) - Af) / spla.norm(Af) < 1e-13
+
+
+def test_embedded_2d_bowl_mixing_50_steps(arch, golden_dir):
+    """test/bowl_mixing_tests.jl:112-114 - `bowl_mixing(2, GPU())`: 50 BDF2 steps on the 2-D bowl through the device path
+    (element kernels, CG, GMRES) against the reference's state file, at the reference's own bar."""
+    z = np.load(f"{golden_dir}/state_bowl_mixing_2D.npz")
+    m = build_model("bowl_mixing", mesh="mesh_bowl2D_h0.1")
+    npg.run(m, n_steps=50)
+    assert m.step_index == 51 and abs(m.timestepper.t - z["t"][0]) < 1e-9
+    S = rc.setup("bowl_mixing", mesh="mesh_bowl2D_h0.1")
+    u, b = m.state.u, m.state.b
+    eu = S.orc.l2_sq_u(u, z["u"]) / S.orc.l2_sq_u(z["u"])
+    eb = S.orc.l2_sq_b(b, z["b"]) / S.orc.l2_sq_b(z["b"])
+    assert eu < 1e-3 and eb < 1e-3, (eu, eb)
+    assert all(s[1]["solved"] == 1 and s[0]["solved"] == 1 for s in m.stats)
+    # and against the oracle's direct-solve recipe on the same mesh: the same discretisation, Krylov tolerance apart
+    # (atol = rtol = 1e-6 on the 1/h^2-scaled residual of a 1098-unknown system: measured 8e-4 / 3e-3)
+    uo, po, bo = rc.run(S, 50)
+    assert rel(b, bo) < 3e-3 and rel(u, uo) < 1e-2, (rel(b, bo), rel(u, uo))
+
+
 def test_50_steps_reproduce_the_exact_fixture_at_tight_tolerance(arch, golden_dir):
     """test/data/bowl_surface_flux.jld2 is the one state fixture that is exact to rounding (the oracle reproduces it to 1e-14
     with the BDF2 left-hand side on step 1 that the older revision used, K3).  With that switch and both Krylov solvers

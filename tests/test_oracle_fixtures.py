@@ -74,11 +74,12 @@ def test_K3_surface_flux_50_steps(flux_system, golden_dir):
 
 @pytest.mark.slow
 @pytest.mark.parametrize("name,fixture,eu_max,eb_max", [("bowl_mixing", "bowl_mixing_3D", 1e-5, 1e-4),
+                                                        ("bowl_mixing", "bowl_mixing_2D", 1e-5, 1e-4),   # test/bowl_mixing_tests.jl:109
                                                         ("bowl_diri", "bowl_diri", 2e-4, 4e-4),
                                                         ("bowl_wind", "bowl_wind", 4e-4, 1e-3)])
 def test_K4_reference_bar(name, fixture, eu_max, eb_max, golden_dir):
     """The reference's own metric (squared relative L2, < 1e-3): test/bowl_mixing_tests.jl:101-103 and siblings."""
-    S = rc.setup(name)
+    S = rc.setup(name, mesh="mesh_bowl2D_h0.1") if fixture.endswith("2D") else rc.setup(name)
     z = np.load(f"{golden_dir}/state_{fixture}.npz")
     u, p, b = rc.run(S, 50)
     eu = S.orc.l2_sq_u(u, z["u"]) / S.orc.l2_sq_u(z["u"])
