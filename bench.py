@@ -264,10 +264,11 @@ def main():
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
         roofline = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                         scope="one GPU" if world == 1 else f"rank 0's row block ({N} of {N_glob} rows), one of {world} GPUs",
-                        traffic=pmc_traffic(a.workload),
+                        # (the committed counters are for the whole matrix on one GPU: no figure for a rank's row block)
+                        traffic=pmc_traffic(a.workload) if world == 1 else None,
                         traffic_source=(f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier builder "
                                         "run on this workload, not measured in this run)"
-                                        if pmc_traffic(a.workload) is not None else None), kernel="k_gmres_arnoldi (Givens prologue + CSR-stream SpMV"
+                                        if world == 1 and pmc_traffic(a.workload) is not None else None), kernel="k_gmres_arnoldi (Givens prologue + CSR-stream SpMV"
                         + (")" if N >= 8192 else " + fused Gram-Schmidt dots)"),
                         avg_launch_us=avg_ms * 1e3, launches=launches, algorithmic_bytes_per_launch=alg_bytes,
                         cache_resident=bool(alg_bytes < 256 * 2 ** 20))
