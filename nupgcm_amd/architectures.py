@@ -330,11 +330,19 @@ class DeviceCSR:
         L.check(L.lib().npg_csr_storage(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def coupling_records(self):
+        """28-byte {c, d_x, d_y, d_z} records of the rows behind the block rows (0: those rows are plain CSR)"""
+        a = C.c_int64()
+        L.check(L.lib().npg_csr_coupling_records(self.h, C.byref(a)))
+        return a.value
+
     def stored_spmv_bytes(self):
         """bytes one SpMV streams from HBM with this layout (matrix arrays + x once + y once)"""
         nodes, rec, ent = self.storage()
+        drec = self.coupling_records()
         m, n = self.shape
-        return 20 * rec + 12 * ent + 8 * (m + 1) + (8 * (nodes + 1) if nodes else 0) + 8 * n + 8 * m
+        blk = 8 * (nodes + 1) if nodes else 0
+        return 20 * rec + 28 * drec + 12 * ent + 8 * (m + 1) + blk + (8 * (m + 1) - blk if drec else 0) + 8 * n + 8 * m
 
     def mul(self, x: DeviceVector, y: DeviceVector = None, alpha=1.0, beta=0.0):
         """mul!(y, A, x) / A*x"""

@@ -258,7 +258,11 @@ __global__ void __launch_bounds__(256) k_halo_exchange(double *__restrict__ x, c
         __syncthreads();                                       // ... before one lane raises the workgroup's flag
         if (threadIdx.x == 0) st_sys(H.flag_dst[t.z] + t.w, e);
     }
-    if (phase == 1 || (int)blockIdx.x >= nwait) return;
+    if (phase == 1) return;
+    if ((int)blockIdx.x >= nwait) {          // push-only workgroup of a one-kernel exchange (phase 2 launches consumers only)
+        halo_launch_done(H, e, gridDim.x);
+        return;
+    }
     halo_window_ready(H, e);
     __syncthreads();
     double *xg = x + n_owned;
@@ -273,7 +277,8 @@ __global__ void __launch_bounds__(256) k_halo_exchange(double *__restrict__ x, c
         for (int u = 0; u < 8; ++u)
             if (i0 + u * stride < H.n_ghost) xg[i0 + u * stride] = v[u];
     }
-    halo_consumed(H, e, (unsigned)nwait);
+    halo_consumed(H, e, (unsigned)nwait, phase == 2);
+    if (phase == 0) halo_launch_done(H, e, gridDim.x);
 }
 
 static int halo_wg_count(int64_t cnt) { return (int)std::min<int64_t>(kHaloWG, (cnt + kHaloChunk - 1) / kHaloChunk); }
@@ -807,7 +812,7 @@ static int halo_peer_setup(npg_halo *h) {
         return o;
     };
     const size_t o_tab = carve(nt * sizeof(int4)), o_seg = carve(npp * 8), o_str = carve(npp * 8), o_dst = carve(npp * 8),
-                 o_fl = carve(npp * 8), o_ack = carve(npp * 8), o_nf = carve(npp * 4), o_arr = carve(8), o_ep = carve(8);
+                 o_fl = carve(npp * 8), o_ack = carve(npp * 8), o_nf = carve(npp * 4), o_arr = carve(16), o_ep = carve(8);
     std::vector<char> host(off, 0);
     if (!tab.empty()) memcpy(host.data() + o_tab, tab.data(), tab.size() * sizeof(int4));
     memcpy(host.data() + o_seg, seg0.data(), npp * 8);

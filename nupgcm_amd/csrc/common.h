@@ -101,6 +101,14 @@ struct npg_csr {
     int32_t *pcol = nullptr;     // device, column node of a record
     double *pkc = nullptr;       // device, {K, C} per record
     std::vector<int64_t> h_prow;
+    // coupling records of the rows behind the block rows (the pressure rows of A_inversion; spmv_device.h): what such a row
+    // holds in the block COLUMNS is stored as one record {c, d_x, d_y, d_z} per column node; rowptr/col/val keep the rest
+    int64_t *drow = nullptr;     // device, (m - block_rows) + 1 record offsets; null without coupling records
+    int32_t *dcol = nullptr;     // device, column node of a record
+    double *dval = nullptr;      // device, [2 ndrec] (d_x, d_y) pairs followed by [ndrec] d_z
+    float *dval32 = nullptr;     // optional fp32 copy, same layout
+    int64_t ndrec = 0;
+    std::vector<int64_t> h_drow;
     // optional fp32 copies of the values (csr_refresh_fp32): read instead of val / pkc by SpMVs that ask for them
     // (SpmvEpi::f32 - the multigrid preconditioner's; results are still accumulated and returned in fp64)
     float *val32 = nullptr, *pkc32 = nullptr;

@@ -14,7 +14,8 @@ int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp, 
     const int64_t *pp = A->nnode() ? A->h_prow.data() : nullptr;
     const int64_t nf3 = 3 * (int64_t)A->nfull, nbr = A->block_rows();
     auto node = [&](int64_t r) { return r < nf3 ? r / 3 : A->nfull + (r - nf3) / 2; };      // r starts a node
-    const int64_t slots_total = rp[m] + (pp ? 3 * pp[A->nfull] + 2 * (pp[A->nnode()] - pp[A->nfull]) : 0);
+    const int64_t *dp = A->drow ? A->h_drow.data() : nullptr;          // coupling records of the rows behind the block rows
+    const int64_t slots_total = rp[m] + (pp ? 3 * pp[A->nfull] + 2 * (pp[A->nnode()] - pp[A->nfull]) : 0) + (dp ? dp[m - nbr] : 0);
     int64_t target = slots_total / (int64_t)A->ctx->num_cu;
     target = std::min<int64_t>(tile_slots, std::max<int64_t>(1024, target)); // >= 1 tile per CU on small matrices
     // LDS product slots of rows [a, b): their CSR entries + one per component per record (a, b on node boundaries of
@@ -22,8 +23,10 @@ int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp, 
     auto slots = [&](int64_t a, int64_t b) {
         int64_t s = rp[b] - rp[a];
         if (pp && a < nbr) s += (a < nf3 ? 3 : 2) * (pp[node(b)] - pp[node(a)]);
+        if (dp && a >= nbr) s += dp[b - nbr] - dp[a - nbr];
         return s;
     };
+    const int64_t max_rows_rec = std::min<int64_t>(max_rows, kTileRows / 2);      // TileLds::prp
     tp.clear();
     tp.push_back(0);
     int64_t r = 0;
@@ -31,8 +34,10 @@ int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp, 
         const bool inblk = r < nbr;
         const int64_t step = !inblk ? 1 : (r < nf3 ? 3 : 2), lim = !inblk ? m : (r < nf3 ? nf3 : nbr);
         int64_t r1 = r + step;
-        while (r1 < lim && r1 + step - r <= max_rows && slots(r, r1 + step) <= target) r1 += step;
+        const int64_t mr = (!inblk && dp) ? max_rows_rec : max_rows;
+        while (r1 < lim && r1 + step - r <= mr && slots(r, r1 + step) <= target) r1 += step;
         NPG_REQUIRE(!inblk || slots(r, r1) <= tile_slots, "build_tiles: the rows of one node do not fit one tile");
+        NPG_REQUIRE(inblk || !dp || slots(r, r1) <= tile_slots, "build_tiles: a row with coupling records does not fit one tile");
         tp.push_back((int32_t)r1);
         r = r1;
     }
@@ -59,7 +64,7 @@ int build_tiles(npg_csr *A) {
     // lanes per row in the segmented sums, from the LDS product slots per row (a lane takes two products per trip):
     // measured on bowl3D h = 0.02 (42 slots per row with node blocks) 8 lanes beat 16 by 2-3 % and 4 by 1 %
     const int64_t nrec = A->nnode() ? A->h_prow[A->nnode()] : 0;
-    const double mean = m > 0 ? (double)(A->rnnz + 3 * nrec) / (double)m : 0.0;
+    const double mean = m > 0 ? (double)(A->rnnz + 3 * nrec + A->ndrec) / (double)m : 0.0;
     A->lanes = mean <= 12 ? 4 : mean <= 64 ? 8 : mean <= 256 ? 16 : 32;
     if (getenv("NPG_SPMV_LANES")) A->lanes = atoi(getenv("NPG_SPMV_LANES"));      // tuning override: 4, 8, 16 or 32
     const int64_t *rp = A->h_rowptr.data();
@@ -78,6 +83,9 @@ int build_tiles(npg_csr *A) {
         if (r0 < nbr) {
             q.pbase = A->h_prow[node(r0)];
             q.npe = (int32_t)(A->h_prow[node(r1)] - q.pbase);
+        } else if (A->drow) {
+            q.pbase = A->h_drow[r0 - nbr];
+            q.npe = (int32_t)(A->h_drow[r1 - nbr] - q.pbase);
         }
     }
     if (A->tile_ptr) NPG_HIP(hipFree(A->tile_ptr));
@@ -218,6 +226,11 @@ int csr_refresh_fp32(const npg_csr *Ac) {
         hipLaunchKernelGGL(k_to_float32, dim3((unsigned)std::min<int64_t>(4096, (2 * nrec + 255) / 256)), dim3(256), 0,
                            A->ctx->stream, A->pkc, A->pkc32, 2 * nrec);
     }
+    if (A->ndrec) {
+        if (!A->dval32) NPG_HIP(hipMalloc((void **)&A->dval32, (size_t)3 * A->ndrec * sizeof(float)));
+        hipLaunchKernelGGL(k_to_float32, dim3((unsigned)std::min<int64_t>(4096, (3 * A->ndrec + 255) / 256)), dim3(256), 0,
+                           A->ctx->stream, A->dval, A->dval32, 3 * A->ndrec);
+    }
     return NPG_OK;
 }
 
@@ -234,6 +247,12 @@ CsrDev csr_view(const npg_csr *A) {
     v.nsurf = A->nsurf;
     v.val32 = A->val32;
     v.pkc32 = reinterpret_cast<const float2 *>(A->pkc32);
+    v.drow = A->drow;
+    v.dcol = A->dcol;
+    v.dxy = reinterpret_cast<const double2 *>(A->dval);
+    v.dz = A->dval ? A->dval + 2 * A->ndrec : nullptr;
+    v.dxy32 = reinterpret_cast<const float2 *>(A->dval32);
+    v.dz32 = A->dval32 ? A->dval32 + 2 * A->ndrec : nullptr;
     return v;
 }
 
@@ -305,8 +324,35 @@ NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double
             nrp[rx + a + 1] = (int64_t)ncol.size();
         }
     }
+    // rows behind the block rows: their entries in the block columns become coupling records {c, d_x, d_y, d_z} (spmv_device.h)
+    // unless NPG_SPMV_COUPLING=0 or a row would not fit a tile that way
+    const char *ce = getenv("NPG_SPMV_COUPLING");
+    bool coupling = !(ce && atoi(ce) == 0) && A->m > nbr;
+    std::vector<int64_t> drow;
+    std::vector<int32_t> dcol;
+    std::vector<double> dxy, dz;
+    if (coupling) {
+        drow.assign((size_t)(A->m - nbr) + 1, 0);
+        for (int64_t r = nbr; r < A->m && coupling; ++r) {
+            int64_t k = rp[r], nrec = 0;
+            while (k < rp[r + 1] && col[k] < nbr) {
+                const int64_t c0 = col[k];
+                const int64_t c = c0 < nf3 ? c0 / 3 : nfull + (c0 - nf3) / 2, f = first(c);
+                double d[3] = {0.0, 0.0, 0.0};
+                for (; k < rp[r + 1] && col[k] < nbr && col[k] - f < (c < nfull ? 3 : 2) && col[k] >= f; ++k) d[col[k] - f] = val[k];
+                dcol.push_back((int32_t)c);
+                dxy.push_back(d[0]);
+                dxy.push_back(d[1]);
+                dz.push_back(d[2]);
+                ++nrec;
+            }
+            drow[r - nbr + 1] = (int64_t)dcol.size();
+            if (nrec + (rp[r + 1] - k) > kTileNnz) coupling = false;
+        }
+    }
     for (int64_t r = nbr; r < A->m; ++r) {
         for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
+            if (coupling && col[k] < nbr) continue;
             ncol.push_back(col[k]);
             nval.push_back(val[k]);
         }
@@ -339,6 +385,18 @@ NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double
     if (!pcol.empty()) {
         NPG_HIP(hipMemcpy(A->pcol, pcol.data(), pcol.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         NPG_HIP(hipMemcpy(A->pkc, pkc.data(), pkc.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (coupling && !dcol.empty()) {
+        const size_t nd = dcol.size();
+        NPG_HIP(hipMalloc((void **)&A->drow, drow.size() * sizeof(int64_t)));
+        NPG_HIP(hipMalloc((void **)&A->dcol, nd * sizeof(int32_t)));
+        NPG_HIP(hipMalloc((void **)&A->dval, 3 * nd * sizeof(double)));
+        NPG_HIP(hipMemcpy(A->drow, drow.data(), drow.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        NPG_HIP(hipMemcpy(A->dcol, dcol.data(), nd * sizeof(int32_t), hipMemcpyHostToDevice));
+        NPG_HIP(hipMemcpy(A->dval, dxy.data(), 2 * nd * sizeof(double), hipMemcpyHostToDevice));
+        NPG_HIP(hipMemcpy(A->dval + 2 * nd, dz.data(), nd * sizeof(double), hipMemcpyHostToDevice));
+        A->ndrec = (int64_t)nd;
+        A->h_drow = std::move(drow);
     }
     A->h_rowptr = std::move(nrp);
     A->h_prow = std::move(prow);
@@ -417,6 +475,10 @@ NPG_API int npg_csr_destroy(npg_csr *A) {
     if (A->pkc) hipFree(A->pkc);
     if (A->val32) hipFree(A->val32);
     if (A->pkc32) hipFree(A->pkc32);
+    if (A->drow) hipFree(A->drow);
+    if (A->dcol) hipFree(A->dcol);
+    if (A->dval) hipFree(A->dval);
+    if (A->dval32) hipFree(A->dval32);
     delete A;
     return NPG_OK;
 }
@@ -434,6 +496,12 @@ NPG_API int npg_csr_storage(const npg_csr *A, int64_t *npairs, int64_t *paired_r
     if (npairs) *npairs = A->nnode();
     if (paired_records) *paired_records = A->nnode() ? A->h_prow[A->nnode()] : 0;
     if (csr_entries) *csr_entries = A->rnnz;
+    return NPG_OK;
+}
+
+NPG_API int npg_csr_coupling_records(const npg_csr *A, int64_t *records) {
+    NPG_REQUIRE(A && records, "npg_csr_coupling_records: NULL argument");
+    *records = A->ndrec;
     return NPG_OK;
 }
 

@@ -54,8 +54,13 @@ struct HaloPeerDev {
     const uint64_t *flags;        // local [npeers][kHaloWG]
     const double *rwin;           // local [2][n_ghost]
     uint64_t *const *ack_dst;     // [npeers] my word in peer p's ack array
-    unsigned long long *arrive;   // local device word: unpack workgroups done so far (monotonic)
-    uint64_t *epoch;              // local device word: exchanges completed
+    unsigned long long *arrive;   // local device words: [0] consumer workgroups done with the window, [1] workgroups of a
+                                  // one-kernel exchange that have finished (both reset by the last arrival)
+    uint64_t *epoch;              // local device word: exchanges completed.  Every workgroup of an exchange reads it when it
+                                  // starts, so it may only move once ALL workgroups of the launch have started: a push
+                                  // workgroup dispatched late - after this rank's consumers are done, which needs the
+                                  // NEIGHBOURS' pushes only - would otherwise take the next epoch for its own and write
+                                  // the other window slot (seen as stale ghosts when another process held the CUs)
     int *status;
     unsigned long long ticks;
     int64_t n_ghost;
@@ -67,7 +72,8 @@ struct HaloPeerDev {
 //   halo_window_ready : ONE wave of the workgroup polls every neighbour's flags of epoch e (bounded), takes the system-scope
 //                       acquire; the caller's barrier then releases the other waves;
 //   halo_consumed     : every workgroup of the consuming launch calls it exactly once when it will read the window no more;
-//                       the last one acknowledges to the senders and completes the epoch.
+//                       the last one acknowledges to the senders and - when the launch holds consumers only - completes the
+//                       epoch (a one-kernel exchange completes it through halo_launch_done instead).
 __device__ __forceinline__ void halo_window_ready(const HaloPeerDev &H, uint64_t e) {
     if (threadIdx.x < 64) {
         SpinGuard guard(H.ticks, H.status, 3);
@@ -84,7 +90,7 @@ __device__ __forceinline__ void halo_window_ready(const HaloPeerDev &H, uint64_t
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the invalidate has completed before the barrier opens
     }
 }
-__device__ __forceinline__ void halo_consumed(const HaloPeerDev &H, uint64_t e, unsigned nworkgroups) {
+__device__ __forceinline__ void halo_consumed(const HaloPeerDev &H, uint64_t e, unsigned nworkgroups, bool completes_epoch = true) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -95,6 +101,17 @@ __device__ __forceinline__ void halo_consumed(const HaloPeerDev &H, uint64_t e, 
             *H.arrive = 0ULL;
             for (int p = 0; p < H.npeers; ++p)
                 if (H.nflag[p] > 0) st_sys(H.ack_dst[p], e);
+            if (completes_epoch) *H.epoch = e;
+        }
+    }
+}
+// one-kernel exchange: every workgroup of the launch calls it as its last action; the last one completes the epoch
+__device__ __forceinline__ void halo_launch_done(const HaloPeerDev &H, uint64_t e, unsigned nworkgroups) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long done = atomicAdd(H.arrive + 1, 1ULL) + 1ULL;
+        if (done == nworkgroups) {
+            H.arrive[1] = 0ULL;
             *H.epoch = e;
         }
     }

@@ -21,8 +21,14 @@
 // puts the components of a node next to each other: first the nodes with all three components free ("full", rows
 // 3q .. 3q+2), then the nodes with free x and y only ("surface": w = 0 at z = 0, rows 3 nfull + 2 (q - nfull) + {0, 1}).
 // Those five (four) CSR entries - 60 (48) bytes and five (four) 8-byte gathers - are stored ONCE as a record {c, K, C} of
-// 20 bytes and cost one 16-byte gather of (x, y)_c plus one 8-byte gather of z_c from the same cache line.  Everything else
-// (the velocity-pressure couplings, the pressure rows) stays plain CSR.
+// 20 bytes and cost one 16-byte gather of (x, y)_c plus one 8-byte gather of z_c from the same cache line.
+//
+// Coupling records (the rows BEHIND the block rows: the divergence rows of A_inversion).  Such a row p holds, for every node c
+// near it, the three numbers (d_x, d_y, d_z) that multiply (x, y, z)_c.  Those three (two) CSR entries - 36 (24) bytes and
+// three (two) gathers - are stored as one 28-byte record {c, d_x, d_y, d_z}: the same two gathers as a node record, the three
+// products summed in registers into ONE LDS slot.  These tiles are a tile class of their own (no node records in them), so
+// the record loop below is the only stream beside the CSR remainder.  The gradient entries of the velocity rows and whatever
+// a row holds outside the block columns (pressure columns, a rank's ghost columns) stay plain CSR.
 //
 // Configuration (512 threads, 5824 product slots and at most 256 rows per tile, 4 pairs per lane, 3 workgroups per CU: fp64
 // + 64-bit addressing needs ~80 VGPRs, which rules out two 1024-thread workgroups per CU) chosen from the sweep in
@@ -50,6 +56,12 @@ struct CsrDev {
     int nfull, nsurf;         // nodes with (x, y, z) rows / with (x, y) rows; block rows = 3 nfull + 2 nsurf
     const float *val32;       // fp32 copies of val / pkc (tile functions instantiated with F32 read these; null otherwise)
     const float2 *pkc32;
+    const int64_t *drow;      // [m - block rows + 1] offsets of a non-block row's coupling records; null without them
+    const int32_t *dcol;      // column node c
+    const double2 *dxy;       // (d_x, d_y): A[p, x_c], A[p, y_c]
+    const double *dz;         // d_z: A[p, z_c] (0 for a surface node)
+    const float2 *dxy32;      // fp32 copies
+    const float *dz32;
 };
 
 __device__ __forceinline__ int block_rows(const CsrDev &A) { return 3 * A.nfull + 2 * A.nsurf; }
@@ -81,8 +93,8 @@ template <int TNNZ>
 struct TileLdsT {
     double prod[TNNZ + 2];           // +2: the CSR part of a tile may start on an odd entry
     int32_t rp[kTileRows + 1];       // CSR row offsets into prod
-    int32_t prp[kTileRows / 2 + 1];  // node offsets into the block products
-};
+    int32_t prp[kTileRows / 2 + 1];  // node offsets into the block products / row offsets into the coupling-record sums
+};                                   // (a tile of rows with coupling records holds at most kTileRows / 2 rows)
 using TileLds = TileLdsT<kTileNnz>;
 
 // Phase 1 + 2 for one tile of rows [r0, r1).  On return (after the trailing barrier) out[r - r0] holds (A x)[r].
@@ -99,6 +111,7 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
     const bool blk = r0 < block_rows(A);
     const bool full = r0 < 3 * A.nfull;
     const int ncomp = full ? 3 : 2;
+    const bool drec = !blk && A.drow != nullptr;
     const int npe = td.npe;           // records of this tile
     const int64_t pbase = td.pbase;
     int nnode = 0, q0 = 0;
@@ -109,15 +122,60 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
     const int64_t abase = base & ~1LL;
     const int off = (int)(base - abase);
     const int total = n + off;
-    const int slot0 = blk ? ncomp * npe : 0;   // CSR products live behind the block product arrays
+    const int slot0 = blk ? ncomp * npe : (drec ? npe : 0);   // CSR products live behind the record products
     for (int r = threadIdx.x; r <= nrows; r += NT) t.rp[r] = (int32_t)(A.rowptr[r0 + r] - base) + off + slot0;
     if (blk)
         for (int q = threadIdx.x; q <= nnode; q += NT) t.prp[q] = (int32_t)(A.prow[q0 + q] - pbase);
+    else if (drec)
+        for (int q = threadIdx.x; q <= nrows; q += NT) t.prp[q] = (int32_t)(A.drow[r0 - block_rows(A) + q] - pbase);
     if (slot0 + total <= TNNZ + 2) {
         // ---- record stream: {c, K, C} -> products for the x row (first npe slots), the y row (next npe) and the z row.
         // A full tile holds at most TNNZ / 3 records: three per lane cover it in one trip.
         constexpr int UP = U2 > 3 ? 3 : U2;
-        for (int e0 = threadIdx.x; e0 < npe; e0 += UP * NT) {
+        if (drec) {
+            constexpr int UD = 2;        // records in flight per lane: a third one spills at the kernel's 80-VGPR cap
+            // ---- coupling records {c, d_x, d_y, d_z}: one product slot per record
+            for (int e0 = threadIdx.x; e0 < npe; e0 += UD * NT) {
+                int32_t c[UD];
+                double2 dd[UD], xx[UD];
+                double dz[UD], zz[UD];
+#pragma unroll
+                for (int u = 0; u < UD; ++u) {
+                    const int e = e0 + u * NT;
+                    if (e < npe) {
+                        c[u] = __builtin_nontemporal_load(A.dcol + pbase + e);
+                        if (F32) {
+                            const float *p = reinterpret_cast<const float *>(A.dxy32 + pbase + e);
+                            dd[u].x = (double)__builtin_nontemporal_load(p);
+                            dd[u].y = (double)__builtin_nontemporal_load(p + 1);
+                            dz[u] = (double)__builtin_nontemporal_load(A.dz32 + pbase + e);
+                        } else {
+                            const double *p = reinterpret_cast<const double *>(A.dxy + pbase + e);
+                            dd[u].x = __builtin_nontemporal_load(p);
+                            dd[u].y = __builtin_nontemporal_load(p + 1);
+                            dz[u] = __builtin_nontemporal_load(A.dz + pbase + e);
+                        }
+                    } else {
+                        c[u] = 0;
+                        dd[u] = make_double2(0.0, 0.0);
+                        dz[u] = 0.0;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UD; ++u) {
+                    const int cf = c[u] < A.nfull ? c[u] : A.nfull;
+                    const int xo = 2 * c[u] + cf;
+                    xx[u] = x.two(xo);
+                    zz[u] = c[u] < A.nfull ? x.third(xo + 2) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UD; ++u) {
+                    const int e = e0 + u * NT;
+                    if (e < npe) t.prod[e] = dd[u].x * xx[u].x + dd[u].y * xx[u].y + dz[u] * zz[u];
+                }
+            }
+        }
+        for (int e0 = threadIdx.x; e0 < (blk ? npe : 0); e0 += UP * NT) {
             int32_t c[UP];
             double2 kc[UP], xx[UP];
             double zz[UP];
@@ -209,9 +267,9 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
                 const double a = t.prod[k], b = t.prod[k + 1];       // k + 1 <= TNNZ + 2 stays inside the tile struct
                 s += a + (k + 1 < e ? b : 0.0);
             }
-            if (blk) {
-                const int q = full ? (r * 21846) >> 16 : r >> 1;     // r / 3 for r < 2^15
-                const int pb = (r - q * ncomp) * npe, pe = pb + t.prp[q + 1];
+            if (blk || drec) {
+                const int q = !blk ? r : full ? (r * 21846) >> 16 : r >> 1;     // r / 3 for r < 2^15
+                const int pb = blk ? (r - q * ncomp) * npe : 0, pe = pb + t.prp[q + 1];
                 for (int k = pb + t.prp[q] + 2 * l; k < pe; k += 2 * L) {
                     const double a = t.prod[k], b = t.prod[k + 1];
                     s += a + (k + 1 < pe ? b : 0.0);
@@ -252,6 +310,9 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, int r0, i
     if (r0 < block_rows(A)) {
         td.pbase = A.prow[node_of_row(A, r0)];
         td.npe = (int)(A.prow[node_of_row(A, r1)] - td.pbase);
+    } else if (A.drow) {
+        td.pbase = A.drow[r0 - block_rows(A)];
+        td.npe = (int)(A.drow[r1 - block_rows(A)] - td.pbase);
     }
     spmv_tile<NT, L, XF, TNNZ, U2>(A, x, td, t, out);
 }

@@ -60,6 +60,13 @@ def main():
                                       len(m.layout.b.g_sol), len(m.layout.b.g_ext), len(m.layout.cells),
                                       m.fe_data.mesh.ncell, m.comm_layout["matrix_bytes"]]))
     u_, p_, b_ = m.state.u, m.state.p, m.state.b          # (collective for the partitioned model)
+    ws = getattr(s, "workspace", None)
+    if ws is not None and getattr(ws, "stats", None):           # residual history and outcome of the last inversion (probes)
+        extra.update(hist_gm=ws.history(), stat_gm=np.array([ws.stats[k] for k in ("status", "npass", "nreorth", "nflagged")]))
+    if os.environ.get("NPG_WORKER_DUMP") == "1":                # pieces of the LAST step, for the repeatability probes
+        se = m.evolution.solver
+        extra.update(hist_cg=se.workspace.history(), rhs_b=se.y.to_host(), rhs_inv=s.y.to_host(),
+                     A_evol=se.A.to_scipy_csr().data, x_evol=(se.x_loc if hasattr(se, "x_loc") else se.x).to_host())
     np.savez(f"{out}.rank{rank}.npz", transport=ctx.comm_info()["in_cycle_transport"], peers=peers, **extra, dt=m.timestepper.dt, storage=np.array(s.A.storage()), owned=owned, y_loc=y_loc, n_ghost=len(ghosts), u=u_, p=p_,
              b=b_, gm=[st[1]["niter"] for st in m.stats], cg=[st[0]["niter"] for st in m.stats],
              solved=[bool(st[1]["solved"]) and bool(st[0]["solved"]) for st in m.stats])

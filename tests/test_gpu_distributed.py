@@ -184,6 +184,40 @@ def test_channel_basin_mesh_partitioned(tmp_path):
     assert rel(z["b"], ref.state.b) < 1e-3 and rel(z["u"], ref.state.u) < 1e-2, (rel(z["b"], ref.state.b), rel(z["u"], ref.state.u))
 
 
+def test_peer_transport_repeats_under_gpu_contention(tmp_path):
+    """The peer-window transport must not depend on WHEN its workgroups get to run.  Round 3 found (tools/dist_repeat_probe.py,
+    profiles/r03_halo_epoch_race.txt) that a push workgroup of the one-kernel halo exchange dispatched late - after the
+    rank's own consumers had completed the epoch, which needs only the NEIGHBOURS' pushes - read the advanced epoch and wrote
+    the other window slot: stale ghosts in one SpMV, visible as run-to-run differences of the unconverged channel-basin
+    inversions (itmax = 1000) whenever another process held the CUs.  Here this process keeps the card busy while the 3-rank
+    channel run goes through the peer windows twice and through the host-driven rehearsal transport once: identical bits."""
+    import threading
+    from nupgcm_amd import workloads as wl
+    arch = npg.GPU()
+    busy = wl.example_model(arch, "bowl3D_h0.05")
+    stop = []
+
+    def spin():
+        while not stop:
+            npg.run(busy, n_steps=1)
+
+    th = threading.Thread(target=spin)
+    th.start()
+    try:
+        res = {}
+        for tag, tr in (("peer1", "peer"), ("peer2", "peer"), ("shm", "shm")):
+            out = str(tmp_path / tag)
+            _launch(3, out, 3, "channel", tr)
+            res[tag] = np.load(f"{out}.rank0.npz")
+    finally:
+        stop.append(1)
+        th.join()
+    for tag in ("peer2", "shm"):
+        for key in ("u", "p", "b", "gm", "cg", "hist_gm"):
+            assert np.array_equal(res[tag][key], res["peer1"][key]), (tag, key)
+    assert str(res["peer1"]["transport"]) == "peer" and str(res["shm"]["transport"]) == "shm"
+
+
 def test_channel_basin_closures_and_periodic_seam_distributed(tmp_path):
     """BASELINE configs[4] on 3 ranks (rehearsal transport): the x-periodic mesh, P1 buoyancy, full-stress A, BDF1 with the CFL
     step, the convection closure every step and the eddy closure's re-assembly of A at step 10 - each re-assembled as the
@@ -204,6 +238,7 @@ def test_channel_basin_closures_and_periodic_seam_distributed(tmp_path):
     # (every inversion stops UNCONVERGED at the cap: the iterates, and with them the CFL step, depend on the summation order
     #  of the reductions at the 1e-3 level)
     assert abs(z["dt"] - ref.timestepper.dt) < 3e-3 * ref.timestepper.dt
+    print("channel, 3 ranks vs one GPU: rel(b) =", rel(z["b"], ref.state.b), "rel(u) =", rel(z["u"], ref.state.u))
     assert rel(z["b"], ref.state.b) < 1e-3 and rel(z["u"], ref.state.u) < 1e-2, (rel(z["b"], ref.state.b), rel(z["u"], ref.state.u))
     # the periodic seam: with contiguous RCM row blocks on a non-periodic mesh the middle rank of three talks to its two
     # neighbours; here some rank also holds columns across the seam

@@ -648,9 +648,20 @@ def test_node_block_storage(arch):
     assert A.block_nodes(d.n_full, d.n_surf)
     assert A.nnz == nnz0                                       # logical size unchanged
     nodes, rec, ent = A.storage()
-    assert nodes == d.n_full + d.n_surf and ent < 0.5 * nnz0 and 4 * rec <= nnz0 - ent <= 5 * rec
+    drec = A.coupling_records()                                # {c, d_x, d_y, d_z} records of the divergence rows
+    assert drec > 0 and nodes == d.n_full + d.n_surf and ent < 0.3 * nnz0
+    assert 4 * rec + drec <= nnz0 - ent <= 5 * rec + 3 * drec
     y1 = A.mul(npg.on_architecture(arch, x)).to_host()
     assert rel(y1, ref @ x) < 1e-13 and rel(y1, y0) < 1e-13
+    # the same matrix with the divergence rows left as CSR entries (NPG_SPMV_COUPLING=0): same product
+    os.environ["NPG_SPMV_COUPLING"] = "0"
+    try:
+        A0 = npg.build_A_inversion(arch, fed, prm, 1.0)
+        assert A0.block_nodes(d.n_full, d.n_surf) and A0.coupling_records() == 0
+        assert A0.storage()[1] == rec and A0.storage()[2] > ent
+    finally:
+        del os.environ["NPG_SPMV_COUPLING"]
+    assert rel(A0.mul(npg.on_architecture(arch, x)).to_host(), y1) < 1e-13
     with pytest.raises(L.DeviceError):
         A.to_scipy_csr()
     # the two-component special case on a synthetic [K -C; C K] matrix with interleaved components
@@ -879,7 +890,8 @@ def test_full_size_properties(arch):
     A_blk = npg.build_A_inversion(arch, fed, prm, frc.nu)
     assert A_blk.block_nodes(d.n_full, d.n_surf) and A_csr.nnz == A_blk.nnz == 126821881
     nodes, rec, ent = A_blk.storage()
-    assert nodes == d.n_full + d.n_surf and ent + 4 * rec <= A_csr.nnz <= ent + 5 * rec
+    drec = A_blk.coupling_records()
+    assert nodes == d.n_full + d.n_surf and drec > 0 and ent + 4 * rec + drec <= A_csr.nnz <= ent + 5 * rec + 3 * drec
     rng = np.random.default_rng(0)
     x, y = (npg.DeviceVector.from_host(ctx, rng.standard_normal(N)) for _ in range(2))
     ax, ay = A_csr.mul(x).to_host(), A_csr.mul(y).to_host()
