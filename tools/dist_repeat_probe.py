@@ -62,6 +62,31 @@ def main():
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
             print("stress: rc", r.returncode, [ln for ln in r.stdout.splitlines() if "rank" in ln or "STRESS" in ln], flush=True)
             continue
+        if name in ("mg", "bench"):
+            env = dict(os.environ, NPG_COMM_TRANSPORT="peer", NPG_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                       NPG_PEER_TIMEOUT_S="60", OMP_NUM_THREADS="2", NPG_TORCH_BACKEND="gloo")
+            got = []
+            for k in range(reps):
+                head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr",
+                        "127.0.0.1", "--master-port", str(T._free_port())]
+                if name == "mg":
+                    out = f"/tmp/rep_mg_{k}"
+                    r = subprocess.run(head + [os.path.join(ROOT, "tests", "dist_mg_worker.py"), out, "3", "bowl3D_h0.05"], env=env,
+                                       capture_output=True, text=True, timeout=900)
+                    assert r.returncode == 0, r.stderr[-2000:]
+                    z = np.load(out + ".rank0.npz")
+                    got.append((hashlib.sha1(z["u"].tobytes() + z["b"].tobytes()).hexdigest()[:12], list(map(int, z["its"]))))
+                else:
+                    r = subprocess.run(head + [os.path.join(ROOT, "bench.py"), "--gpus", "3", "--workload", "bowl3D_h0.04", "--steps",
+                                               "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900)
+                    assert r.returncode == 0, r.stderr[-2000:]
+                    import json
+                    d = json.loads(r.stdout.strip().splitlines()[-1])
+                    got.append((d["config"]["gmres_iterations_per_step"], d["config"]["gmres_initial_residual_per_step"],
+                                d["comm"]["transport_check"], round(d["ms_per_step"], 1)))
+                print("   ", name, k, got[-1], flush=True)
+            print(f"{name}: {len(set(map(str, [g[:2] for g in got])))} distinct result(s) in {reps} runs", flush=True)
+            continue
         mode, transport, extra = CONFIGS[name]
         os.environ.update(extra)
         seen, hists, pieces = {}, {}, {}

@@ -32,5 +32,5 @@ for _ in range(5):
     A.mul(x, out)
 arch.ctx.sync()
 print(f"{wl}: N={N} nnz={nnz_csr} algorithmic SpMV bytes={12 * nnz_csr + 4 * (N + 1) + 16 * N} iterations={st['niter']} "
-      f"node_blocks={bool(paired)} records={npe} csr_entries={nnz_rem} "
+      f"node_blocks={bool(paired)} records={npe} coupling_records={A.coupling_records()} csr_entries={nnz_rem} "
       f"stored SpMV bytes={A.stored_spmv_bytes()}")

@@ -4,5 +4,6 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/r03y
 mkdir -p $O
-timeout -k 10 1000 python3 tools/dist_repeat_probe.py 4 stress shm peer_eager_nooverlap peer ppeer pshm > $O/matrix5.txt 2> $O/matrix5.err
-cat $O/matrix5.txt | tee -a $O/summary.txt
+timeout -k 10 1000 python3 tools/dist_repeat_probe.py 3 mg bench > $O/matrix6.txt 2> $O/matrix6.err
+echo "rc=$?" >> $O/matrix6.txt
+cat $O/matrix6.txt | tee -a $O/summary.txt
