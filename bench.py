@@ -340,7 +340,7 @@ def main():
     if (rank == 0 and world == 1 and not channel and a.preconditioner == "diagonal" and not a.no_multigrid
             and workloads.BOWL_MESHES[a.workload][1] >= 1):
         t_mg = time.time()
-        mg = workloads.example_model(arch, a.workload, dt=a.dt, preconditioner="multigrid")
+        mg = workloads.example_model(arch, a.workload, dt=a.dt, preconditioner="multigrid", fine_fe_data=model.fe_data)
         npg.invert(mg)
         ctx.sync()
         t_mg = time.time() - t_mg

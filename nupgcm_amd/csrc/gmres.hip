@@ -465,6 +465,27 @@ __device__ __forceinline__ void load_row_pair_cols(const float *__restrict__ Vf,
         v[k] = f;                                                              // kept in fp32 registers, widened at use
     }
 }
+// One trip of the row-pair kernels: rows (r0, r0 + 1) of block `blk`, their basis entries and w.  A lane past the last row
+// loads row 0 instead (no lane-varying branch around the loads) and gets zero weights.  The kernels issue trip t + 1's loads
+// BEFORE trip t's arithmetic: with three waves per SIMD and one dependent round trip per loop trip the plain loop streamed at
+// 3.9 TB/s, the software-pipelined one at 5.5-6.9 TB/s (tools/rows_bench.hip, profiles/r03_rows_bench.txt).
+template <int NG>
+struct RowPair {
+    float2 v[8 * NG];
+    double w0, w1;
+    int64_t r0;
+    bool valid, two;
+    __device__ __forceinline__ void load(const GDev &d, int64_t blk, int j) {
+        r0 = 2 * (blk * kRB + threadIdx.x);
+        valid = r0 < d.n;
+        two = r0 + 1 < d.n;
+        const int64_t rc = valid ? r0 : 0;
+        load_row_pair_cols<NG>(d.Vf, rc, two, d.ldv, j, v);
+        const double2 ww = *reinterpret_cast<const double2 *>(d.w + rc);    // (w is padded: the pair of an odd n's last row)
+        w0 = valid ? ww.x : 0.0;
+        w1 = (valid && two) ? ww.y : 0.0;
+    }
+};
 
 template <int NG, typename BT>
 __global__ void __launch_bounds__(kRB) k_gmres_dots_rows(GDev d, int j) {
@@ -476,17 +497,16 @@ __global__ void __launch_bounds__(kRB) k_gmres_dots_rows(GDev d, int j) {
     if (d.T[j].done == 0) {
         if constexpr (sizeof(BT) == 4) {
             const int64_t nblk = ((int64_t)d.n + 2 * kRB - 1) / (2 * kRB);
-            for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-                const int64_t r0 = 2 * (blk * kRB + threadIdx.x);
-                if (r0 >= d.n) continue;
-                const bool two = r0 + 1 < d.n;
-                float2 v[8 * NG];
-                load_row_pair_cols<NG>(d.Vf, r0, two, d.ldv, j, v);
-                const double2 ww = *reinterpret_cast<const double2 *>(d.w + r0);     // (w is padded: the pair of an odd n's last row)
-                const double w0 = ww.x, w1 = two ? ww.y : 0.0;
+            RowPair<NG> cur, nxt;
+            int64_t blk = blockIdx.x;
+            if (blk < nblk) cur.load(d, blk, j);
+            for (; blk < nblk; blk += gridDim.x) {
+                const bool more = blk + gridDim.x < nblk;
+                if (more) nxt.load(d, blk + gridDim.x, j);                   // in flight during this trip's arithmetic
 #pragma unroll
-                for (int k = 0; k < 8 * NG; ++k) acc[k] += (double)v[k].x * w0 + (double)v[k].y * w1;
-                nrm += w0 * w0 + w1 * w1;
+                for (int k = 0; k < 8 * NG; ++k) acc[k] += (double)cur.v[k].x * cur.w0 + (double)cur.v[k].y * cur.w1;
+                nrm += cur.w0 * cur.w0 + cur.w1 * cur.w1;
+                if (more) cur = nxt;
             }
         } else {
             for (int64_t row = blockIdx.x * (int64_t)kRB + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kRB) {
@@ -510,6 +530,13 @@ __global__ void __launch_bounds__(kRB, (NG < 4 || FAST) ? 3 : 2) k_gmres_orth_ro
     __shared__ double tmp[(kRB / 32) * kKP];
     __shared__ double red[kKP];
     const Snap T = d.T[j];
+    // (fp32 basis, fast instance) the first trip's rows do not depend on h: their loads go out before the reduction below
+    constexpr bool kPipe = sizeof(BT) == 4 && FAST;
+    const int64_t nblk2 = ((int64_t)d.n + 2 * kRB - 1) / (2 * kRB);
+    RowPair<kPipe ? NG : 1> cur;
+    if constexpr (kPipe) {
+        if (T.done == 0 && (int64_t)blockIdx.x < nblk2) cur.load(d, d.rev ? nblk2 - 1 - blockIdx.x : blockIdx.x, j);
+    }
     // h1 = the dots kernel's partial rows summed in a fixed order by every workgroup (one GPU), or the single all-reduced
     // row (several GPUs)
     reduce_partials<kRB / 32, kMaxRowsI>(d.Q1, d.nQ1, kKP, tmp, red);
@@ -529,7 +556,33 @@ __global__ void __launch_bounds__(kRB, (NG < 4 || FAST) ? 3 : 2) k_gmres_orth_ro
             d.hcol1[j * kKP + threadIdx.x] = ((int)threadIdx.x <= j) ? red[threadIdx.x] : 0.0;
             if (threadIdx.x == 0) d.wnorm2[j] = red[kNormSlot];
         }
-        if constexpr (sizeof(BT) == 4) {
+        if constexpr (kPipe) {
+            const int64_t nblk = nblk2;
+            RowPair<NG> nxt;
+            for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+                const int64_t nb = blk + gridDim.x;
+                const bool more = nb < nblk;
+                if (more) nxt.load(d, d.rev ? nblk - 1 - nb : nb, j);        // in flight during this trip's arithmetic
+                double p0 = cur.w0, p1 = cur.w1;
+#pragma unroll
+                for (int k = 0; k < 8 * NG; ++k) {
+                    p0 -= h[k] * (double)cur.v[k].x;
+                    p1 -= h[k] * (double)cur.v[k].y;
+                }
+                if (cur.valid) {
+                    if (cur.two)
+                        *reinterpret_cast<double2 *>(d.wt + cur.r0) = make_double2(p0, p1);
+                    else
+                        d.wt[cur.r0] = p0;
+                } else {
+                    p0 = 0.0;                                               // (a clamped lane read row 0's basis entries)
+                    p1 = 0.0;
+                }
+                if (!cur.two) p1 = 0.0;
+                nrm += p0 * p0 + p1 * p1;
+                if (more) cur = nxt;
+            }
+        } else if constexpr (sizeof(BT) == 4) {       // full kernels: the second-pass sums leave no registers for a second trip
             const int64_t nblk = ((int64_t)d.n + 2 * kRB - 1) / (2 * kRB);
             for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
                 const int64_t r0 = 2 * ((d.rev ? nblk - 1 - blk : blk) * kRB + threadIdx.x);
@@ -664,6 +717,34 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_update(GDev d) {
     }
     __syncthreads();
     if (kk == 0) return;
+    if (d.ldv && d.Vf) {
+        // column-major fp32 basis: two adjacent rows per thread (8-byte loads, as the other row kernels), every column in use
+        // requested before the first is needed; kk <= kKP - 1 is wave-uniform
+        const int64_t nblk = ((int64_t)d.n + 2 * kKB - 1) / (2 * kKB);
+        for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+            const int64_t r0 = 2 * (blk * kKB + threadIdx.x);
+            if (r0 >= d.n) continue;
+            const bool two = r0 + 1 < d.n;
+            double2 xx = make_double2(d.x[r0], two ? d.x[r0 + 1] : 0.0);
+            for (int q0 = 0; q0 < kk; q0 += 16) {          // sixteen columns requested at a time (register budget: 80)
+                float2 f[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    f[q] = make_float2(0.f, 0.f);
+                    if (q0 + q < kk) f[q] = *reinterpret_cast<const float2 *>(d.Vf + (size_t)(q0 + q) * (size_t)d.ldv + (size_t)r0);
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (q0 + q < kk) {
+                        xx.x += sh.y[q0 + q] * (double)f[q].x;
+                        xx.y += sh.y[q0 + q] * (double)f[q].y;
+                    }
+            }
+            d.x[r0] = xx.x;
+            if (two) d.x[r0 + 1] = xx.y;
+        }
+        return;
+    }
     if (d.ldv) {
         // column-major basis: one thread per row, kk coalesced column streams
         for (int64_t row = (int64_t)blockIdx.x * kKB + threadIdx.x; row < d.n; row += (int64_t)gridDim.x * kKB) {

@@ -63,12 +63,18 @@ def example_fe_data(mesh_model):
     return FEData(mesh, spaces)
 
 
-def example_model(arch, label_or_model, dt=1e-3, t_stop=1e9, preconditioner="diagonal", **inv_kw):
+def example_model(arch, label_or_model, dt=1e-3, t_stop=1e9, preconditioner="diagonal", fine_fe_data=None, **inv_kw):
     """The full model of examples/bowl_mixing.jl:171-190 on the named mesh (BDF2, dt = 1e-3).  preconditioner="multigrid"
-    (named meshes with at least one refinement level) builds the refinement hierarchy of the mesh for the inversion."""
+    (named meshes with at least one refinement level) builds the refinement hierarchy of the mesh for the inversion;
+    fine_fe_data: the FEData of the named mesh if the caller has it already (its host set-up is the longest of the levels)."""
     prm, frc = example_parameters()
     if preconditioner == "multigrid":
-        hier = [example_fe_data(m) for m in bowl_hierarchy_models(label_or_model)]
+        models = bowl_hierarchy_models(label_or_model)
+        if fine_fe_data is not None:
+            mf = fine_fe_data.mesh.model
+            if not (np.array_equal(mf.coords, models[-1].coords) and np.array_equal(mf.cells, models[-1].cells)):
+                raise ValueError("fine_fe_data is not the FEData of the finest mesh of this hierarchy")
+        hier = [example_fe_data(m) for m in models[:-1]] + [fine_fe_data if fine_fe_data is not None else example_fe_data(models[-1])]
         if len(hier) < 2:
             raise ValueError(f"{label_or_model}: a multigrid hierarchy needs a refined mesh")
         fed = hier[-1]
