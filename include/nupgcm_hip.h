@@ -179,6 +179,12 @@ int npg_gmres_set_profile(npg_gmres *ws, int on);
  * stored copy used by the Gram-Schmidt sums and x += V y is rounded; SpMV inputs, sums, the restart residual stay fp64),
  * 0 = by tolerance (fp32 when rtol >= 1e-7, the reference's 1e-6 included).  NPG_GMRES_BASIS=32|64 overrides the default. */
 int npg_gmres_set_basis(npg_gmres *ws, int bits);
+/* Where the basis is stored in fp32 (above), with a node-blocked matrix, the Arnoldi kernel gathers its SpMV input
+ * from an fp32 copy of the Krylov vector laid out for gathering - a node's components padded to 16 bytes: one gather per node
+ * record instead of two (the kernel is bound by its gather instructions).  The copy carries the rounding the
+ * stored basis column has anyway; products and sums stay fp64.  mode: -1 = default (on where it applies; NPG_GMRES_XG=0 turns
+ * the default off), 0 = off, 1 = on where it applies. */
+int npg_gmres_set_gather(npg_gmres *ws, int mode);
 int npg_gmres_set_split(npg_gmres *ws, int mode);
 int npg_gmres_get_profile(npg_gmres *ws, double *ms_total, int64_t *launches);
 /* residual history of the last solve (workspace.stats.residuals with history=true): returns entries written */

@@ -87,7 +87,7 @@ def _declare(L):
         "npg_spmv": [P, P, P, D, D],
         "npg_gmres_create": [P, I64, C.c_int, PP], "npg_gmres_destroy": [P],
         "npg_gmres_solve": [P, P, C.c_int, D, P, P, P, D, D, I64, D, C.POINTER(SolveStats)],
-        "npg_gmres_set_profile": [P, C.c_int], "npg_gmres_set_split": [P, C.c_int], "npg_gmres_set_basis": [P, C.c_int], "npg_gmres_get_profile": [P, C.POINTER(D), C.POINTER(I64)],
+        "npg_gmres_set_profile": [P, C.c_int], "npg_gmres_set_split": [P, C.c_int], "npg_gmres_set_basis": [P, C.c_int], "npg_gmres_set_gather": [P, C.c_int], "npg_gmres_get_profile": [P, C.POINTER(D), C.POINTER(I64)],
         "npg_cg_create": [P, I64, PP], "npg_cg_destroy": [P],
         "npg_cg_solve": [P, P, C.c_int, D, P, P, P, D, D, I64, C.POINTER(SolveStats)],
         "npg_precond_create": [P, C.c_int, C.c_int, PP], "npg_precond_destroy": [P],

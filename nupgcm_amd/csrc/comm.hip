@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(1024) k_peer_fold_allreduce(const double *part
 // wait + unpack), on ONE stream: the neighbours' stores land in this rank's window while that work runs - the overlap needs
 // neither a second stream nor events.
 __global__ void __launch_bounds__(256) k_halo_exchange(double *__restrict__ x, const int32_t *__restrict__ send_idx, int64_t n_owned,
-                                                       int npush, int nwait, int phase, HaloPeerDev H) {
+                                                       int npush, int nwait, int phase, HaloPeerDev H, float *__restrict__ g32) {
     const uint64_t e = *H.epoch + 1;
     if (phase != 2 && (int)blockIdx.x < npush) {
         const int4 t = H.tab[blockIdx.x];
@@ -275,7 +275,10 @@ __global__ void __launch_bounds__(256) k_halo_exchange(double *__restrict__ x, c
         for (int u = 0; u < 8; ++u) v[u] = i0 + u * stride < H.n_ghost ? __builtin_nontemporal_load(src + i0 + u * stride) : 0.0;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (i0 + u * stride < H.n_ghost) xg[i0 + u * stride] = v[u];
+            if (i0 + u * stride < H.n_ghost) {
+                xg[i0 + u * stride] = v[u];
+                if (g32) g32[i0 + u * stride] = (float)v[u];
+            }
     }
     halo_consumed(H, e, (unsigned)nwait, phase == 2);
     if (phase == 0) halo_launch_done(H, e, gridDim.x);
@@ -909,14 +912,19 @@ NPG_API int npg_halo_destroy(npg_halo *h) {
     return NPG_OK;
 }
 
-static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st);
+static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st, float *g32);
 
-int npg::halo_exchange_raw(npg_halo *h, double *x) { return halo_exchange_on(h, x, h->ctx->stream); }
+__global__ void k_ghosts_to_f32(const double *__restrict__ src, float *__restrict__ dst, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
+}
 
-int npg::halo_exchange_async(npg_halo *h, double *x) {
+int npg::halo_exchange_raw(npg_halo *h, double *x, float *g32) { return halo_exchange_on(h, x, h->ctx->stream, g32); }
+
+int npg::halo_exchange_async(npg_halo *h, double *x, float *g32) {
     npg_ctx *ctx = h->ctx;
     if (h->npeers == 0 && !ctx->shm) return NPG_OK;
     h->pending_x = x;
+    h->pending_g32 = g32;
     if (ctx->shm) return NPG_OK;          // host-driven loop-back transport: the exchange happens in halo_exchange_wait()
     if (h->pw) {
         // peer windows: push now, on the context's own stream; whatever the caller enqueues next runs while the neighbours'
@@ -926,7 +934,7 @@ int npg::halo_exchange_async(npg_halo *h, double *x) {
         if (rc) return rc;
         if (w->nwg_push > 0)
             hipLaunchKernelGGL(k_halo_exchange, dim3(w->nwg_push), dim3(256), 0, ctx->stream, x, (const int32_t *)h->send_idx,
-                               h->n_owned, w->nwg_push, w->nwg_wait, 1, w->dev);
+                               h->n_owned, w->nwg_push, w->nwg_wait, 1, w->dev, (float *)nullptr);
         NPG_HIP(hipGetLastError());
         return NPG_OK;
     }
@@ -938,7 +946,7 @@ int npg::halo_exchange_async(npg_halo *h, double *x) {
     }
     NPG_HIP(hipEventRecord(h->ev_ready, ctx->stream));
     NPG_HIP(hipStreamWaitEvent(h->cstream, h->ev_ready, 0));
-    int rc = halo_exchange_on(h, x, h->cstream);
+    int rc = halo_exchange_on(h, x, h->cstream, g32);
     if (rc != NPG_OK) return rc;
     NPG_HIP(hipEventRecord(h->ev_done, h->cstream));
     return NPG_OK;
@@ -947,11 +955,11 @@ int npg::halo_exchange_async(npg_halo *h, double *x) {
 int npg::halo_exchange_wait(npg_halo *h) {
     npg_ctx *ctx = h->ctx;
     if (h->npeers == 0 && !ctx->shm) return NPG_OK;
-    if (ctx->shm) return halo_exchange_on(h, h->pending_x, ctx->stream);
+    if (ctx->shm) return halo_exchange_on(h, h->pending_x, ctx->stream, h->pending_g32);
     if (h->pw) {
         HaloPeer *w = (HaloPeer *)h->pw;
         hipLaunchKernelGGL(k_halo_exchange, dim3(w->nwg_wait), dim3(256), 0, ctx->stream, h->pending_x, (const int32_t *)h->send_idx,
-                           h->n_owned, w->nwg_push, w->nwg_wait, 2, w->dev);
+                           h->n_owned, w->nwg_push, w->nwg_wait, 2, w->dev, h->pending_g32);
         NPG_HIP(hipGetLastError());
         return NPG_OK;
     }
@@ -959,7 +967,7 @@ int npg::halo_exchange_wait(npg_halo *h) {
     return NPG_OK;
 }
 
-static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st) {
+static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st, float *g32) {
     npg_ctx *ctx = h->ctx;
     if (h->npeers == 0 && !ctx->shm) return NPG_OK;
     if (h->pw) {
@@ -969,7 +977,7 @@ static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st) {
         int rc = peer_status(ctx);
         if (rc) return rc;
         hipLaunchKernelGGL(k_halo_exchange, dim3(std::max(w->nwg_push, w->nwg_wait)), dim3(256), 0, st, x,
-                           (const int32_t *)h->send_idx, h->n_owned, w->nwg_push, w->nwg_wait, 0, w->dev);
+                           (const int32_t *)h->send_idx, h->n_owned, w->nwg_push, w->nwg_wait, 0, w->dev, g32);
         NPG_HIP(hipGetLastError());
         return NPG_OK;
     }
@@ -1019,6 +1027,9 @@ static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st) {
                               hipMemcpyHostToDevice));
         }
         NPG_SHM_BARRIER(c);
+        if (g32 && h->n_ghost > 0 && !bad)
+            hipLaunchKernelGGL(k_ghosts_to_f32, dim3((unsigned)std::min<int64_t>(256, (h->n_ghost + 255) / 256)), dim3(256), 0, st,
+                               (const double *)(x + h->n_owned), g32, h->n_ghost);
         return bad ? NPG_ECOMM : NPG_OK;
     }
     ncclComm_t comm = (ncclComm_t)ctx->comm;
@@ -1031,6 +1042,9 @@ static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st) {
             NPG_NCCL_IN_GROUP(ncclRecv(x + h->n_owned + r0, (size_t)(r1 - r0), ncclDouble, h->peer[p], comm, st));
     }
     NPG_NCCL(ncclGroupEnd());
+    if (g32 && h->n_ghost > 0)
+        hipLaunchKernelGGL(k_ghosts_to_f32, dim3((unsigned)std::min<int64_t>(256, (h->n_ghost + 255) / 256)), dim3(256), 0, st,
+                           (const double *)(x + h->n_owned), g32, h->n_ghost);
     return NPG_OK;
 }
 

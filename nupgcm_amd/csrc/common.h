@@ -132,17 +132,20 @@ struct npg_halo {
     hipStream_t cstream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
     double *pending_x = nullptr;   // vector of the exchange begun by halo_exchange_async()
+    float *pending_g32 = nullptr;  // ... and where its ghosts are ALSO stored as floats (null: nowhere)
     void *pw = nullptr;            // peer-transport part of the plan (comm.hip, HaloPeer); null for RCCL / shm
 };
 
 namespace npg {
 // enqueue the exchange of x's ghost segment / an in-place sum over ranks of n doubles on the context's stream
-int halo_exchange_raw(npg_halo *h, double *x);
+// g32 (optional): the received ghost values are also stored, rounded to fp32, in g32[0 .. n_ghost) - the Krylov kernels'
+// gather-layout copy of their SpMV input (gmres.hip)
+int halo_exchange_raw(npg_halo *h, double *x, float *g32 = nullptr);
 // The same exchange in two halves, for a caller with work that needs no ghost value: kernels enqueued between the two calls
 // run while the exchange is in flight and must not touch x's ghost segment.  Peer transport: the push half and the wait +
 // unpack half are kernels on the context's own stream (the neighbours' stores arrive meanwhile).  RCCL: the exchange runs on
 // the plan's own stream, ordered against the context's stream by two events.
-int halo_exchange_async(npg_halo *h, double *x);
+int halo_exchange_async(npg_halo *h, double *x, float *g32 = nullptr);
 int halo_exchange_wait(npg_halo *h);
 int allreduce_sum_device(npg_ctx *ctx, double *buf, int n);
 // in-place sum over the ranks of a long device vector (not a per-iteration collective: comm.hip)

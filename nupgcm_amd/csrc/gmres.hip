@@ -72,13 +72,15 @@ struct GDev {
     int GR;               // grid of the row-streaming kernels (split mode)
     int split;
     int64_t ldv;          // split mode stores the basis column-major, Vi[k * ldv + row] (0: group-interleaved layout)
-    float *Vf;            // split mode, compressed basis: the SAME columns stored in fp32 (null: fp64 in Vi).  Only the stored
-                          // copy is rounded - every Krylov vector enters the SpMV in fp64 (it is formed from wt on the fly) -
-                          // and every product and sum with it stays fp64; see npg_gmres_set_basis
+    float *Vf;            // split mode, compressed basis: the SAME columns stored in fp32 (null: fp64 in Vi).  Only stored
+                          // copies are rounded (the basis columns; with `xg` below also the SpMV's gather copy of the
+                          // Krylov vector) - every product and sum stays fp64; see npg_gmres_set_basis
     int pyth;             // distributed runs: ||w - V h||^2 = ||w||^2 - ||h||^2 instead of a second all-reduce
     int lazy2;            // one GPU: the same identity decides whether the second-pass sums need reducing at all
     int rev;              // split mode: the orthogonalisation kernel walks the row blocks downwards, the dots kernel upwards -
                           // what one sweep read last is what the next reads first (Infinity Cache reuse of the basis)
+    GatherMap xg;         // fp32-stored basis, fast mode, node-blocked A: wt ALSO in fp32 gather layout (spmv_device.h),
+                          // written by the kernels that write wt, gathered by the Arnoldi kernel (p = null: off)
     int fast;             // one GPU, split mode: the orthogonalisation kernel does not form the second-pass sums at all; a
                           // column that would have needed them is counted (pad1) and later solves run the full kernels
     // what the CONSUMER prologues reduce: the producers' partial rows on one GPU, or the single all-reduced row when
@@ -287,6 +289,7 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_residual(GDev d) {
                 const int row = r0 + r;
                 const double res = precond_row(d, row) * (d.b[row] - sw[r]);
                 d.wt[row] = res;
+                if (d.xg.p) d.xg.p[d.xg.pos(row)] = (float)res;
                 acc += res * res;
             }
         }
@@ -301,7 +304,8 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_residual(GDev d) {
 // Tiles [t0, t1).  The distributed split cycle launches it twice per step - the tiles without ghost columns while the halo
 // exchange is in flight, the others behind it; the prologue is a pure function of state neither launch changes, so
 // running it twice writes the same values twice.
-template <int L, bool FUSED>
+// XG: the SpMV input is gathered from the fp32 gather-layout copy of wt (GDev::xg; no second Gram-Schmidt pass in that mode).
+template <int L, bool FUSED, bool XG = false>
 __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, int j, int t0, int t1) {
     __shared__ KShared sh;
     __shared__ TileLds tl;
@@ -354,7 +358,10 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
         double wt_row = 0.0;
         if (!FUSED && (int)threadIdx.x < td.nrows) wt_row = d.wt[td.r0 + threadIdx.x];
         // one instantiation for both cases: without a second pass the correction loop has no trips
-        spmv_tile<kKB, L>(d.A, CorrectedX{d.wt, d.Vi, sh.h2, ro ? j : 0, d.n, d.ldv, d.Vf}, td, tl, sw);
+        if constexpr (XG)
+            spmv_tile<kKB, L>(d.A, PaddedX{d.xg}, td, tl, sw);
+        else
+            spmv_tile<kKB, L>(d.A, CorrectedX{d.wt, d.Vi, sh.h2, ro ? j : 0, d.n, d.ldv, d.Vf}, td, tl, sw);
         const int nr = r1 - r0;
         if (!FUSED) {
             // split mode (large systems): only what depends on the SpMV result; the dots stream in k_gmres_dots_rows
@@ -574,6 +581,10 @@ __global__ void __launch_bounds__(kRB, (NG < 4 || FAST) ? 3 : 2) k_gmres_orth_ro
                         *reinterpret_cast<double2 *>(d.wt + cur.r0) = make_double2(p0, p1);
                     else
                         d.wt[cur.r0] = p0;
+                    if (d.xg.p) {
+                        d.xg.p[d.xg.pos((int)cur.r0)] = (float)p0;
+                        if (cur.two) d.xg.p[d.xg.pos((int)cur.r0 + 1)] = (float)p1;
+                    }
                 } else {
                     p0 = 0.0;                                               // (a clamped lane read row 0's basis entries)
                     p1 = 0.0;
@@ -828,6 +839,11 @@ struct npg_gmres {
     std::vector<hipEvent_t> pev;
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
+    int gather32 = -1;            // SpMV input of the Arnoldi kernel from the fp32 gather-layout copy: -1 = default (on where it
+                                  // applies), 0 = off, 1 = on where it applies (npg_gmres_set_gather)
+    float *xg = nullptr;          // wt in fp32 gather layout (GDev::xg), allocated on first use
+    int64_t xg_len = 0;
+    int xg_key[3] = {-1, -1, -1}; // (nfull, nsurf, columns) the pads of xg were zeroed for
     npg_halo *halo = nullptr;
     double *Rg = nullptr;         // 3 x 32 doubles: all-reduced rows (distributed mode)
     int64_t n_ghost = 0;
@@ -890,25 +906,39 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
             fprintf(stderr, "halo overlap %s: %d interior / %d boundary tiles per Arnoldi step (split %d)\n", overlap ? "on" : "off",
                     d.nt_int, d.ntiles - d.nt_int, d.split);
     }
+    // distributed + gather-layout input: the ghosts of wt are also stored as floats behind the owned part of the copy
+    float *g32 = (dist && d.xg.p) ? d.xg.p + d.xg.pos(d.n) : nullptr;
     for (int j = 0; j < d.mem; ++j) {
         if (overlap) {
-            if ((rc = halo_exchange_async(ws->halo, d.wt))) return rc;
+            if ((rc = halo_exchange_async(ws->halo, d.wt, g32))) return rc;
             if (pev) hipEventRecord(pev[2 * j], st);
             // RCCL: the interior launch leaves a few CUs free - its workgroups are persistent (they hold their CU until the last
             // tile) and RCCL's send/recv kernels on the other stream could otherwise not start before they are all done.  Peer
             // windows: nothing of ours runs beside it (the neighbours' stores need no CU here): full grid.
             const int gi = kernel_only ? maxg : maxg - 3 * reserve;
-            hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(std::max(1, std::min(d.nt_int, gi))), dim3(kKB), 0, st, d, j, 0,
-                               d.nt_int);
+            if (d.xg.p)
+                hipLaunchKernelGGL((k_gmres_arnoldi<L, false, true>), dim3(std::max(1, std::min(d.nt_int, gi))), dim3(kKB), 0, st, d, j,
+                                   0, d.nt_int);
+            else
+                hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(std::max(1, std::min(d.nt_int, gi))), dim3(kKB), 0, st, d, j, 0,
+                                   d.nt_int);
             if ((rc = halo_exchange_wait(ws->halo))) return rc;
-            hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(std::max(1, std::min(d.ntiles - d.nt_int, maxg))), dim3(kKB), 0,
-                               st, d, j, d.nt_int, d.ntiles);
+            if (d.xg.p)
+                hipLaunchKernelGGL((k_gmres_arnoldi<L, false, true>), dim3(std::max(1, std::min(d.ntiles - d.nt_int, maxg))), dim3(kKB),
+                                   0, st, d, j, d.nt_int, d.ntiles);
+            else
+                hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(std::max(1, std::min(d.ntiles - d.nt_int, maxg))), dim3(kKB), 0,
+                                   st, d, j, d.nt_int, d.ntiles);
             if (pev) hipEventRecord(pev[2 * j + 1], st);
             launch_rows_kernel(d, j, st, false);
         } else {
-        if (dist && (rc = halo_exchange_raw(ws->halo, d.wt))) return rc;
+        if (dist && (rc = halo_exchange_raw(ws->halo, d.wt, g32))) return rc;
         if (pev) hipEventRecord(pev[2 * j], st);
-        if (d.split) {
+        if (d.split && d.xg.p) {
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, true>), dim3(d.G1), dim3(kKB), 0, st, d, j, 0, d.ntiles);
+            if (pev) hipEventRecord(pev[2 * j + 1], st);
+            launch_rows_kernel(d, j, st, false);
+        } else if (d.split) {
             hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(d.G1), dim3(kKB), 0, st, d, j, 0, d.ntiles);
             if (pev) hipEventRecord(pev[2 * j + 1], st);
             launch_rows_kernel(d, j, st, false);
@@ -1010,7 +1040,7 @@ NPG_API int npg_gmres_destroy(npg_gmres *ws) {
     }
     for (hipEvent_t e : ws->pev) hipEventDestroy(e);
     void *ptrs[] = {ws->Vi, ws->w, ws->wt, ws->P1, ws->P2, ws->PR, ws->C, ws->T, ws->c, ws->s,
-                    ws->z, ws->R, ws->hcol1, ws->wnorm2, ws->hist, ws->prm, ws->Rg};
+                    ws->z, ws->R, ws->hcol1, ws->wnorm2, ws->hist, ws->prm, ws->Rg, ws->xg};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (ws->h_C) hipHostFree(ws->h_C);
@@ -1114,6 +1144,28 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     }
     d.GP1 = d.split ? d.GR : d.G1;
     d.GP2 = d.split ? d.GR : d.G2;
+    // Gather-layout fp32 copy of the SpMV input (one GPU, fp32-stored basis, fast mode, node-blocked matrix): the Arnoldi kernel
+    // is bound by its gather instructions and a node's three components then come with ONE 16-byte gather.
+    // The rounding is the one the stored basis column has anyway.  NPG_GMRES_XG=0 turns it off.
+    static const int xg_env = getenv("NPG_GMRES_XG") ? atoi(getenv("NPG_GMRES_XG")) : 1;
+    d.xg = GatherMap{nullptr, 0, 0, 0, 0};
+    if ((ws->gather32 >= 0 ? ws->gather32 : xg_env) && basis32 && d.fast && A->nnode() > 0 && (dist ? A->n == A->m + ws->n_ghost : A->n == A->m)) {
+        const int64_t nbr = A->block_rows(), need = 4 * A->nnode() + (A->n - nbr) + 8;
+        if (ws->xg_len < need) {
+            if (ws->xg) NPG_HIP(hipFree(ws->xg));
+            ws->xg = nullptr;
+            NPG_HIP(hipMalloc((void **)&ws->xg, (size_t)need * sizeof(float)));
+            ws->xg_len = need;
+            ws->xg_key[0] = -1;
+        }
+        if (ws->xg_key[0] != A->nfull || ws->xg_key[1] != A->nsurf || ws->xg_key[2] != (int)A->n) {
+            NPG_HIP(hipMemsetAsync(ws->xg, 0, (size_t)ws->xg_len * sizeof(float), st));      // the pads must read as zero
+            ws->xg_key[0] = A->nfull;
+            ws->xg_key[1] = A->nsurf;
+            ws->xg_key[2] = (int)A->n;
+        }
+        d.xg = GatherMap{ws->xg, 3 * A->nfull, A->nfull, (int)nbr, (int)(4 * A->nnode() - nbr)};
+    }
     if (dist) {
         d.Q1 = ws->Rg;
         d.Q2 = ws->Rg + kKP;
@@ -1353,6 +1405,12 @@ NPG_API int npg_gmres_set_basis(npg_gmres *ws, int bits) {
     NPG_REQUIRE(ws && (bits == 0 || bits == 32 || bits == 64), "npg_gmres_set_basis: bits must be 0 (by tolerance), 32 or 64");
     ws->basis_bits = bits;
     ws->have_graph = false;
+    return NPG_OK;
+}
+
+NPG_API int npg_gmres_set_gather(npg_gmres *ws, int mode) {
+    NPG_REQUIRE(ws && mode >= -1 && mode <= 1, "npg_gmres_set_gather: mode must be -1 (default), 0 or 1");
+    ws->gather32 = mode;
     return NPG_OK;
 }
 

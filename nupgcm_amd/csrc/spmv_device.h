@@ -84,6 +84,40 @@ struct PlainX {
     __device__ __forceinline__ double third(int i) const { return x[i]; }
 };
 
+// An accessor may serve a node's components with ONE 16-byte gather (kNode4 = true, node4(c) -> (x, y, z, pad)); the tile
+// function then skips the (x, y) + z pair of gathers.  Detected by name so that plain accessors need not mention it.
+template <class XF, class = void>
+struct node4_of {
+    static constexpr bool value = false;
+};
+template <class XF>
+struct node4_of<XF, decltype((void)XF::kNode4)> {
+    static constexpr bool value = XF::kNode4;
+};
+
+// fp32 copy of a vector in GATHER layout: the components of block node c in floats [4c, 4c + 3) (the fourth, and the third of
+// an (x, y)-only node, stay zero), every other entry i (pressure rows, a rank's ghosts) at 4 nnode + (i - block rows).
+// The Krylov kernels keep their SpMV input in this form beside the fp64 vector (gmres.hip): a node record then costs one
+// 16-byte gather instead of a 16-byte and an 8-byte one, a coupling record likewise, a CSR entry a 4-byte gather.
+struct GatherMap {
+    float *p;
+    int nf3, nf, nbr, off;        // 3 nfull, nfull, block rows, 4 nnode - block rows
+    __host__ __device__ __forceinline__ int pos(int i) const {
+        if (i >= nbr) return i + off;
+        if (i < nf3) return i + (int)(((unsigned long long)(unsigned)i * 0xAAAAAAABull) >> 33);      // i + i / 3
+        const int r = i - nf3;
+        return 4 * nf + 2 * r - (r & 1);
+    }
+};
+struct PaddedX {
+    static constexpr bool kNode4 = true;
+    GatherMap g;
+    __device__ __forceinline__ double operator()(int c) const { return (double)g.p[g.pos(c)]; }
+    __device__ __forceinline__ float4 node4(int c) const { return *reinterpret_cast<const float4 *>(g.p + 4 * (size_t)c); }
+    __device__ __forceinline__ double2 two(int i) const { return make_double2((*this)(i), (*this)(i + 1)); }
+    __device__ __forceinline__ double third(int i) const { return (*this)(i); }
+};
+
 // optional phase profiling of spmv_tile (tuning harness): the default does nothing
 struct NoProf {
     __device__ __forceinline__ void stamp(int) const {}
@@ -163,10 +197,16 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
                 }
 #pragma unroll
                 for (int u = 0; u < UD; ++u) {
-                    const int cf = c[u] < A.nfull ? c[u] : A.nfull;
-                    const int xo = 2 * c[u] + cf;
-                    xx[u] = x.two(xo);
-                    zz[u] = c[u] < A.nfull ? x.third(xo + 2) : 0.0;
+                    if constexpr (node4_of<XF>::value) {
+                        const float4 f = x.node4(c[u]);               // (an (x, y)-only node's third float is its zero pad)
+                        xx[u] = make_double2((double)f.x, (double)f.y);
+                        zz[u] = (double)f.z;
+                    } else {
+                        const int cf = c[u] < A.nfull ? c[u] : A.nfull;
+                        const int xo = 2 * c[u] + cf;
+                        xx[u] = x.two(xo);
+                        zz[u] = c[u] < A.nfull ? x.third(xo + 2) : 0.0;
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < UD; ++u) {
@@ -200,10 +240,16 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
             }
 #pragma unroll
             for (int u = 0; u < UP; ++u) {
-                const int cf = c[u] < A.nfull ? c[u] : A.nfull;
-                const int xo = 2 * c[u] + cf;                       // first DoF of node c
-                xx[u] = x.two(xo);
-                zz[u] = (full && c[u] < A.nfull) ? x.third(xo + 2) : 0.0;
+                if constexpr (node4_of<XF>::value) {
+                    const float4 f = x.node4(c[u]);
+                    xx[u] = make_double2((double)f.x, (double)f.y);
+                    zz[u] = full ? (double)f.z : 0.0;
+                } else {
+                    const int cf = c[u] < A.nfull ? c[u] : A.nfull;
+                    const int xo = 2 * c[u] + cf;                       // first DoF of node c
+                    xx[u] = x.two(xo);
+                    zz[u] = (full && c[u] < A.nfull) ? x.third(xo + 2) : 0.0;
+                }
             }
 #pragma unroll
             for (int u = 0; u < UP; ++u) {

@@ -81,6 +81,11 @@ class GmresWorkspace(_Workspace):
         """stored Krylov basis of the split organisation: 64, 32 (compressed basis), 0 = by tolerance (npg_gmres_set_basis)"""
         L.check(L.lib().npg_gmres_set_basis(self.h, int(bits)))
 
+    def set_gather(self, mode):
+        """Arnoldi kernel's SpMV input from the fp32 gather-layout copy of the Krylov vector (npg_gmres_set_gather):
+        -1 = default (on where it applies: one GPU, fp32-stored basis, node-blocked matrix), 0 = off, 1 = on where it applies"""
+        L.check(L.lib().npg_gmres_set_gather(self.h, int(mode)))
+
     def set_profile(self, on=True):
         """eager launches with HIP events around every Arnoldi (SpMV) kernel; see npg_gmres_set_profile"""
         L.check(L.lib().npg_gmres_set_profile(self.h, int(bool(on))))
