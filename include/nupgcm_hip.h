@@ -117,9 +117,12 @@ int npg_csr_pair_xy(npg_csr *A, int64_t npairs, double rtol, int *paired);
 /* how the matrix is laid out in HBM: number of block nodes, {c, K, C} records (20 bytes each, standing for 4 or 5 CSR
  * entries) and plain CSR entries (12 bytes each).  Plain matrix: 0, 0, nnz. */
 int npg_csr_storage(const npg_csr *A, int64_t *nodes, int64_t *records, int64_t *csr_entries);
-/* npg_csr_block_nodes also packs what the rows BEHIND the block rows (the divergence rows of A_inversion, the last block row
+/* npg_csr_block_nodes also packs (a) what the rows BEHIND the block rows (the divergence rows of A_inversion, the last block row
  * of src/inversion.jl:183-192) hold in the block columns: one 28-byte record {c, d_x, d_y, d_z} per (row, column node) in
- * place of three (two) CSR entries; NPG_SPMV_COUPLING=0 keeps them as CSR entries.  *records = how many (0: none). */
+ * place of three (two) CSR entries (NPG_SPMV_COUPLING=0 keeps them as CSR entries); (b) what the block rows hold OUTSIDE the
+ * block columns (the gradient entries, a rank's ghost columns): one 28-byte record {m, a_x, a_y, a_z} per (node, column) - the
+ * coefficients of column m in the node's x, y, z rows - whenever that is fewer bytes than the entries (NPG_SPMV_COLUMN_RECORDS=0:
+ * never).  *records = how many 28-byte records of both kinds (0: none). */
 int npg_csr_coupling_records(const npg_csr *A, int64_t *records);
 /* dst.val[k] = src.val[map[k]]: a matrix whose entries are a fixed subset / rearrangement of another's - a rank's row block
  * of a replicated, re-assembled matrix (closure refreshes of K_v and A, src/model.jl:160-170,229-261, when the solve is

@@ -331,7 +331,8 @@ class DeviceCSR:
         return a.value, b.value, c.value
 
     def coupling_records(self):
-        """28-byte {c, d_x, d_y, d_z} records of the rows behind the block rows (0: those rows are plain CSR)"""
+        """28-byte records: {c, d_x, d_y, d_z} of the rows behind the block rows + {m, a_x, a_y, a_z} column records of the
+        block rows (0: all of that is plain CSR)"""
         a = C.c_int64()
         L.check(L.lib().npg_csr_coupling_records(self.h, C.byref(a)))
         return a.value
@@ -342,7 +343,7 @@ class DeviceCSR:
         drec = self.coupling_records()
         m, n = self.shape
         blk = 8 * (nodes + 1) if nodes else 0
-        return 20 * rec + 28 * drec + 12 * ent + 8 * (m + 1) + blk + (8 * (m + 1) - blk if drec else 0) + 8 * n + 8 * m
+        return 20 * rec + 28 * drec + 12 * ent + 8 * (m + 1) + 2 * blk + 8 * n + 8 * m          # (+ the records' offset arrays)
 
     def mul(self, x: DeviceVector, y: DeviceVector = None, alpha=1.0, beta=0.0):
         """mul!(y, A, x) / A*x"""

@@ -109,6 +109,14 @@ struct npg_csr {
     float *dval32 = nullptr;     // optional fp32 copy, same layout
     int64_t ndrec = 0;
     std::vector<int64_t> h_drow;
+    // column records of the block rows (spmv_device.h): what node q's rows hold OUTSIDE the block columns, one record
+    // {m, a_x, a_y, a_z} per distinct column; the block rows then have no entries left in rowptr/col/val
+    int64_t *grow = nullptr;     // device, nfull + nsurf + 1 record offsets; null without column records
+    int32_t *gcol = nullptr;     // device, column of a record
+    double *gval = nullptr;      // device, [2 ngrec] (a_x, a_y) pairs followed by [ngrec] a_z
+    float *gval32 = nullptr;     // optional fp32 copy, same layout
+    int64_t ngrec = 0;
+    std::vector<int64_t> h_grow;
     // optional fp32 copies of the values (csr_refresh_fp32): read instead of val / pkc by SpMVs that ask for them
     // (SpmvEpi::f32 - the multigrid preconditioner's; results are still accumulated and returned in fp64)
     float *val32 = nullptr, *pkc32 = nullptr;

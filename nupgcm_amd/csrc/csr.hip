@@ -15,7 +15,9 @@ int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp, 
     const int64_t nf3 = 3 * (int64_t)A->nfull, nbr = A->block_rows();
     auto node = [&](int64_t r) { return r < nf3 ? r / 3 : A->nfull + (r - nf3) / 2; };      // r starts a node
     const int64_t *dp = A->drow ? A->h_drow.data() : nullptr;          // coupling records of the rows behind the block rows
-    const int64_t slots_total = rp[m] + (pp ? 3 * pp[A->nfull] + 2 * (pp[A->nnode()] - pp[A->nfull]) : 0) + (dp ? dp[m - nbr] : 0);
+    const int64_t *gp = A->grow ? A->h_grow.data() : nullptr;          // column records of the block rows
+    const int64_t slots_total = rp[m] + (pp ? 3 * pp[A->nfull] + 2 * (pp[A->nnode()] - pp[A->nfull]) : 0) + (dp ? dp[m - nbr] : 0) +
+                                (gp ? 3 * gp[A->nfull] + 2 * (gp[A->nnode()] - gp[A->nfull]) : 0);
     int64_t target = slots_total / (int64_t)A->ctx->num_cu;
     target = std::min<int64_t>(tile_slots, std::max<int64_t>(1024, target)); // >= 1 tile per CU on small matrices
     // LDS product slots of rows [a, b): their CSR entries + one per component per record (a, b on node boundaries of
@@ -23,6 +25,7 @@ int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp, 
     auto slots = [&](int64_t a, int64_t b) {
         int64_t s = rp[b] - rp[a];
         if (pp && a < nbr) s += (a < nf3 ? 3 : 2) * (pp[node(b)] - pp[node(a)]);
+        if (gp && a < nbr) s += (a < nf3 ? 3 : 2) * (gp[node(b)] - gp[node(a)]);
         if (dp && a >= nbr) s += dp[b - nbr] - dp[a - nbr];
         return s;
     };
@@ -46,11 +49,13 @@ int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp, 
 
 // flag[t] != 0: tile t reads a column >= first_ghost (one 64-thread workgroup per tile)
 __global__ void k_tile_ghost_flags(const TileDesc *__restrict__ td, int ntiles, const int32_t *__restrict__ col,
-                                   int32_t first_ghost, int32_t *__restrict__ flag) {
+                                   const int32_t *__restrict__ gcol, int32_t block_rows, int32_t first_ghost,
+                                   int32_t *__restrict__ flag) {
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const TileDesc q = td[t];
+        const int32_t *__restrict__ cc = (gcol && q.r0 < block_rows) ? gcol : col;     // column records or CSR entries
         int f = 0;
-        for (int k = threadIdx.x; k < q.n; k += blockDim.x) f |= col[q.base + k] >= first_ghost;
+        for (int k = threadIdx.x; k < q.n; k += blockDim.x) f |= cc[q.base + k] >= first_ghost;
         if (f) flag[t] = 1;
     }
 }
@@ -64,7 +69,7 @@ int build_tiles(npg_csr *A) {
     // lanes per row in the segmented sums, from the LDS product slots per row (a lane takes two products per trip):
     // measured on bowl3D h = 0.02 (42 slots per row with node blocks) 8 lanes beat 16 by 2-3 % and 4 by 1 %
     const int64_t nrec = A->nnode() ? A->h_prow[A->nnode()] : 0;
-    const double mean = m > 0 ? (double)(A->rnnz + 3 * nrec + A->ndrec) / (double)m : 0.0;
+    const double mean = m > 0 ? (double)(A->rnnz + 3 * nrec + A->ndrec + 3 * A->ngrec) / (double)m : 0.0;
     A->lanes = mean <= 12 ? 4 : mean <= 64 ? 8 : mean <= 256 ? 16 : 32;
     if (getenv("NPG_SPMV_LANES")) A->lanes = atoi(getenv("NPG_SPMV_LANES"));      // tuning override: 4, 8, 16 or 32
     const int64_t *rp = A->h_rowptr.data();
@@ -83,6 +88,10 @@ int build_tiles(npg_csr *A) {
         if (r0 < nbr) {
             q.pbase = A->h_prow[node(r0)];
             q.npe = (int32_t)(A->h_prow[node(r1)] - q.pbase);
+            if (A->grow) {          // (base, n) of a block tile describe its column records
+                q.base = A->h_grow[node(r0)];
+                q.n = (int32_t)(A->h_grow[node(r1)] - q.base);
+            }
         } else if (A->drow) {
             q.pbase = A->h_drow[r0 - nbr];
             q.npe = (int32_t)(A->h_drow[r1 - nbr] - q.pbase);
@@ -93,7 +102,7 @@ int build_tiles(npg_csr *A) {
     NPG_HIP(hipMalloc((void **)&A->tile_ptr, std::max<size_t>(1, td.size()) * sizeof(TileDesc)));
     NPG_HIP(hipMemcpy(A->tile_ptr, td.data(), td.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
     A->ntiles_interior = A->ntiles;
-    if (A->n > A->m && A->ntiles > 0 && A->rnnz > 0) {
+    if (A->n > A->m && A->ntiles > 0 && (A->rnnz > 0 || A->ngrec > 0)) {
         // row block of a distributed matrix: tiles that read no ghost column come first, so that a solver can run them
         // while the halo exchange is in flight (record columns are owned nodes by construction: only the CSR part counts)
         int32_t *dflag;
@@ -101,7 +110,7 @@ int build_tiles(npg_csr *A) {
         NPG_HIP(hipMalloc((void **)&dflag, flag.size() * sizeof(int32_t)));
         NPG_HIP(hipMemsetAsync(dflag, 0, flag.size() * sizeof(int32_t), A->ctx->stream));
         hipLaunchKernelGGL(k_tile_ghost_flags, dim3(std::min<int>(A->ntiles, 4096)), dim3(64), 0, A->ctx->stream, A->tile_ptr,
-                           A->ntiles, A->col, (int32_t)A->m, dflag);
+                           A->ntiles, A->col, (const int32_t *)A->gcol, (int32_t)A->block_rows(), (int32_t)A->m, dflag);
         NPG_HIP(hipMemcpyAsync(flag.data(), dflag, flag.size() * sizeof(int32_t), hipMemcpyDeviceToHost, A->ctx->stream));
         NPG_HIP(hipStreamSynchronize(A->ctx->stream));
         NPG_HIP(hipFree(dflag));
@@ -226,6 +235,11 @@ int csr_refresh_fp32(const npg_csr *Ac) {
         hipLaunchKernelGGL(k_to_float32, dim3((unsigned)std::min<int64_t>(4096, (2 * nrec + 255) / 256)), dim3(256), 0,
                            A->ctx->stream, A->pkc, A->pkc32, 2 * nrec);
     }
+    if (A->ngrec) {
+        if (!A->gval32) NPG_HIP(hipMalloc((void **)&A->gval32, (size_t)3 * A->ngrec * sizeof(float)));
+        hipLaunchKernelGGL(k_to_float32, dim3((unsigned)std::min<int64_t>(4096, (3 * A->ngrec + 255) / 256)), dim3(256), 0,
+                           A->ctx->stream, A->gval, A->gval32, 3 * A->ngrec);
+    }
     if (A->ndrec) {
         if (!A->dval32) NPG_HIP(hipMalloc((void **)&A->dval32, (size_t)3 * A->ndrec * sizeof(float)));
         hipLaunchKernelGGL(k_to_float32, dim3((unsigned)std::min<int64_t>(4096, (3 * A->ndrec + 255) / 256)), dim3(256), 0,
@@ -253,6 +267,12 @@ CsrDev csr_view(const npg_csr *A) {
     v.dz = A->dval ? A->dval + 2 * A->ndrec : nullptr;
     v.dxy32 = reinterpret_cast<const float2 *>(A->dval32);
     v.dz32 = A->dval32 ? A->dval32 + 2 * A->ndrec : nullptr;
+    v.grow = A->grow;
+    v.gcol = A->gcol;
+    v.gxy = reinterpret_cast<const double2 *>(A->gval);
+    v.gz = A->gval ? A->gval + 2 * A->ngrec : nullptr;
+    v.gxy32 = reinterpret_cast<const float2 *>(A->gval32);
+    v.gz32 = A->gval32 ? A->gval32 + 2 * A->ngrec : nullptr;
     return v;
 }
 
@@ -277,8 +297,9 @@ NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double
     NPG_HIP(hipMemcpy(val.data(), A->val, val.size() * sizeof(double), hipMemcpyDeviceToHost));
     const std::vector<int64_t> &rp = A->h_rowptr;
     std::vector<int64_t> prow((size_t)nnode + 1, 0), nrp((size_t)A->m + 1, 0);
-    std::vector<int32_t> pcol, ncol;
-    std::vector<double> pkc, nval;
+    std::vector<int32_t> pcol, ncol, gcolv;
+    std::vector<double> pkc, nval, gxy, gzv;
+    std::vector<int64_t> growv((size_t)nnode + 1, 0);
     pcol.reserve((size_t)A->nnz / 5);
     pkc.reserve((size_t)A->nnz / 5 * 2);
     ncol.reserve((size_t)A->nnz / 2);
@@ -316,6 +337,26 @@ NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double
         if (qfull && iz < z1 && col[iz] < nbr) return NPG_OK;
         prow[q + 1] = (int64_t)pcol.size();
         const int64_t lo[3] = {ia, ib, iz}, hi[3] = {a1, b1, z1};
+        // what is left of the node's rows (columns outside the block): as column records {m, a_x, a_y, a_z} - a three-way
+        // merge of the sorted rows - and, in case they are not used, as plain CSR entries
+        {
+            int64_t it[3] = {lo[0], lo[1], qfull ? lo[2] : 0};
+            const int nc = qfull ? 3 : 2;
+            for (;;) {
+                int64_t mcol = INT64_MAX;
+                for (int a = 0; a < nc; ++a)
+                    if (it[a] < hi[a]) mcol = std::min<int64_t>(mcol, col[it[a]]);
+                if (mcol == INT64_MAX) break;
+                double a3[3] = {0.0, 0.0, 0.0};
+                for (int a = 0; a < nc; ++a)
+                    if (it[a] < hi[a] && col[it[a]] == mcol) a3[a] = val[it[a]++];
+                gcolv.push_back((int32_t)mcol);
+                gxy.push_back(a3[0]);
+                gxy.push_back(a3[1]);
+                gzv.push_back(a3[2]);
+            }
+            growv[q + 1] = (int64_t)gcolv.size();
+        }
         for (int a = 0; a < (qfull ? 3 : 2); ++a) {
             for (int64_t k = lo[a]; k < hi[a]; ++k) {
                 ncol.push_back(col[k]);
@@ -323,6 +364,14 @@ NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double
             }
             nrp[rx + a + 1] = (int64_t)ncol.size();
         }
+    }
+    // column records pay when they replace more than 28 / 12 entries each (NPG_SPMV_COLUMN_RECORDS=0: never)
+    const char *ge = getenv("NPG_SPMV_COLUMN_RECORDS");
+    const bool colrec = !(ge && atoi(ge) == 0) && !gcolv.empty() && 28 * gcolv.size() <= 12 * ncol.size();
+    if (colrec) {           // the block rows keep no CSR entries
+        ncol.clear();
+        nval.clear();
+        for (int64_t r = 0; r < nbr; ++r) nrp[r + 1] = 0;
     }
     // rows behind the block rows: their entries in the block columns become coupling records {c, d_x, d_y, d_z} (spmv_device.h)
     // unless NPG_SPMV_COUPLING=0 or a row would not fit a tile that way
@@ -385,6 +434,18 @@ NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double
     if (!pcol.empty()) {
         NPG_HIP(hipMemcpy(A->pcol, pcol.data(), pcol.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         NPG_HIP(hipMemcpy(A->pkc, pkc.data(), pkc.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (colrec) {
+        const size_t ng = gcolv.size();
+        NPG_HIP(hipMalloc((void **)&A->grow, growv.size() * sizeof(int64_t)));
+        NPG_HIP(hipMalloc((void **)&A->gcol, ng * sizeof(int32_t)));
+        NPG_HIP(hipMalloc((void **)&A->gval, 3 * ng * sizeof(double)));
+        NPG_HIP(hipMemcpy(A->grow, growv.data(), growv.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        NPG_HIP(hipMemcpy(A->gcol, gcolv.data(), ng * sizeof(int32_t), hipMemcpyHostToDevice));
+        NPG_HIP(hipMemcpy(A->gval, gxy.data(), 2 * ng * sizeof(double), hipMemcpyHostToDevice));
+        NPG_HIP(hipMemcpy(A->gval + 2 * ng, gzv.data(), ng * sizeof(double), hipMemcpyHostToDevice));
+        A->ngrec = (int64_t)ng;
+        A->h_grow = std::move(growv);
     }
     if (coupling && !dcol.empty()) {
         const size_t nd = dcol.size();
@@ -475,6 +536,10 @@ NPG_API int npg_csr_destroy(npg_csr *A) {
     if (A->pkc) hipFree(A->pkc);
     if (A->val32) hipFree(A->val32);
     if (A->pkc32) hipFree(A->pkc32);
+    if (A->grow) hipFree(A->grow);
+    if (A->gcol) hipFree(A->gcol);
+    if (A->gval) hipFree(A->gval);
+    if (A->gval32) hipFree(A->gval32);
     if (A->drow) hipFree(A->drow);
     if (A->dcol) hipFree(A->dcol);
     if (A->dval) hipFree(A->dval);
@@ -501,7 +566,7 @@ NPG_API int npg_csr_storage(const npg_csr *A, int64_t *npairs, int64_t *paired_r
 
 NPG_API int npg_csr_coupling_records(const npg_csr *A, int64_t *records) {
     NPG_REQUIRE(A && records, "npg_csr_coupling_records: NULL argument");
-    *records = A->ndrec;
+    *records = A->ndrec + A->ngrec;
     return NPG_OK;
 }
 

@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
 
     const int k = threadIdx.x & (kKP - 1), slot = threadIdx.x >> 5;
     const double inv_beta = 1.0 / T.beta;
-    const bool ro = sh.reorth != 0;
+    const bool ro = !XG && sh.reorth != 0;        // (the gather-layout instance runs in fast mode: never a second pass)
     const double h2k = (ro && k < j) ? sh.h2[k] : 0.0;
     double acc = 0.0;
     TileDesc nd = d.tile_ptr[t0 + (int)blockIdx.x < t1 ? t0 + (int)blockIdx.x : 0];
@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
         if (!FUSED && (int)threadIdx.x < td.nrows) wt_row = d.wt[td.r0 + threadIdx.x];
         // one instantiation for both cases: without a second pass the correction loop has no trips
         if constexpr (XG)
-            spmv_tile<kKB, L>(d.A, PaddedX{d.xg}, td, tl, sw);
+            spmv_tile<kKB, L, PaddedX, kTileNnz, 2, NoProf, false, true>(d.A, PaddedX{d.xg}, td, tl, sw);     // (node-blocked by definition: hardly any CSR entries - two pairs per lane there keep the records' loops inside the register budget)
         else
             spmv_tile<kKB, L>(d.A, CorrectedX{d.wt, d.Vi, sh.h2, ro ? j : 0, d.n, d.ldv, d.Vf}, td, tl, sw);
         const int nr = r1 - r0;

@@ -27,8 +27,13 @@
 // near it, the three numbers (d_x, d_y, d_z) that multiply (x, y, z)_c.  Those three (two) CSR entries - 36 (24) bytes and
 // three (two) gathers - are stored as one 28-byte record {c, d_x, d_y, d_z}: the same two gathers as a node record, the three
 // products summed in registers into ONE LDS slot.  These tiles are a tile class of their own (no node records in them), so
-// the record loop below is the only stream beside the CSR remainder.  The gradient entries of the velocity rows and whatever
-// a row holds outside the block columns (pressure columns, a rank's ghost columns) stay plain CSR.
+// the record loop below is the only stream beside the CSR remainder.
+//
+// Column records (the block rows' entries OUTSIDE the block columns: the gradient entries of the velocity rows, a rank's ghost
+// columns).  For node q every distinct column m its rows touch there is stored as one 28-byte record {m, a_x, a_y, a_z} - the
+// coefficients of x_m in the rows x_q, y_q, z_q: one gather of x_m and three products instead of up to three CSR entries with a
+// gather each.  With them the block rows hold no CSR entries at all, so a block tile runs the node-record loop and this loop,
+// a pressure-row tile the coupling-record loop and the CSR loop: never more than two streams per tile.
 //
 // Configuration (512 threads, 5824 product slots and at most 256 rows per tile, 4 pairs per lane, 3 workgroups per CU: fp64
 // + 64-bit addressing needs ~80 VGPRs, which rules out two 1024-thread workgroups per CU) chosen from the sweep in
@@ -62,6 +67,13 @@ struct CsrDev {
     const double *dz;         // d_z: A[p, z_c] (0 for a surface node)
     const float2 *dxy32;      // fp32 copies
     const float *dz32;
+    const int64_t *grow;      // [nfull + nsurf + 1] offsets of node q's column records; null without them (block rows then
+                              // keep their remaining entries in rowptr / col / val)
+    const int32_t *gcol;      // column m (any column outside the block columns)
+    const double2 *gxy;       // (a_x, a_y): A[x_q, m], A[y_q, m]
+    const double *gz;         // a_z: A[z_q, m] (0 for an (x, y)-only node)
+    const float2 *gxy32;      // fp32 copies
+    const float *gz32;
 };
 
 __device__ __forceinline__ int block_rows(const CsrDev &A) { return 3 * A.nfull + 2 * A.nsurf; }
@@ -136,16 +148,24 @@ using TileLds = TileLdsT<kTileNnz>;
 // Inside the block rows a tile holds whole nodes of one kind (full or surface).
 // F32: the matrix values come from the fp32 copies (8 instead of 12 bytes per CSR entry, 12 instead of 20 per record);
 // products and sums stay fp64.
-template <int NT, int L, class XF, int TNNZ = kTileNnz, int U2 = 4, class PROF = NoProf, bool F32 = false>
+// REMAT: see the comment at `tid` below.
+template <int NT, int L, class XF, int TNNZ = kTileNnz, int U2 = 4, class PROF = NoProf, bool F32 = false, bool REMAT = false>
 __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const TileDesc &td, TileLdsT<TNNZ> &t,
                                           double *__restrict__ out, PROF prof = PROF()) {
     const int r0 = td.r0, nrows = td.nrows, r1 = r0 + nrows;
     const int64_t base = td.base;
     const int n = td.n;
+    // REMAT: the lane's stream offsets are re-made per tile.  Left to itself hipcc hoists the per-lane base addresses of every
+    // stream out of the caller's tile loop; in the Arnoldi kernel, at its 80-register cap, they were then spilled and reloaded
+    // tile by tile (three dependent scratch round trips at the head of a record loop).  The stand-alone SpMV has the
+    // registers and is 2 % faster with the hoisted addresses.
+    int tid = threadIdx.x;
+    if constexpr (REMAT) asm volatile("" : "+v"(tid));
     const bool blk = r0 < block_rows(A);
     const bool full = r0 < 3 * A.nfull;
     const int ncomp = full ? 3 : 2;
     const bool drec = !blk && A.drow != nullptr;
+    const bool grec = blk && A.grow != nullptr;      // the tile's (base, n) then describe column records, not CSR entries
     const int npe = td.npe;           // records of this tile
     const int64_t pbase = td.pbase;
     int nnode = 0, q0 = 0;
@@ -154,10 +174,13 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
         nnode = node_of_row(A, r1) - q0;
     }
     const int64_t abase = base & ~1LL;
-    const int off = (int)(base - abase);
-    const int total = n + off;
-    const int slot0 = blk ? ncomp * npe : (drec ? npe : 0);   // CSR products live behind the record products
-    for (int r = threadIdx.x; r <= nrows; r += NT) t.rp[r] = (int32_t)(A.rowptr[r0 + r] - base) + off + slot0;
+    const int off = grec ? 0 : (int)(base - abase);
+    const int total = grec ? ncomp * n : n + off;             // product slots behind the record products
+    const int slot0 = blk ? ncomp * npe : (drec ? npe : 0);   // CSR / column-record products live behind the record products
+    if (grec)       // (rp is free in these tiles: it holds the nodes' column-record offsets)
+        for (int q = threadIdx.x; q <= nnode; q += NT) t.rp[q] = (int32_t)(A.grow[q0 + q] - base);
+    else
+        for (int r = threadIdx.x; r <= nrows; r += NT) t.rp[r] = (int32_t)(A.rowptr[r0 + r] - base) + off + slot0;
     if (blk)
         for (int q = threadIdx.x; q <= nnode; q += NT) t.prp[q] = (int32_t)(A.prow[q0 + q] - pbase);
     else if (drec)
@@ -167,9 +190,11 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
         // A full tile holds at most TNNZ / 3 records: three per lane cover it in one trip.
         constexpr int UP = U2 > 3 ? 3 : U2;
         if (drec) {
-            constexpr int UD = 2;        // records in flight per lane: a third one spills at the kernel's 80-VGPR cap
+            // records in flight per lane: with the (x, y) + z pair of fp64 gathers a third one spills at the Arnoldi kernel's
+            // 80-VGPR cap; the single 16-byte gather of the padded accessor leaves room for it
+            constexpr int UD = node4_of<XF>::value ? 3 : 2;
             // ---- coupling records {c, d_x, d_y, d_z}: one product slot per record
-            for (int e0 = threadIdx.x; e0 < npe; e0 += UD * NT) {
+            for (int e0 = tid; e0 < npe; e0 += UD * NT) {
                 int32_t c[UD];
                 double2 dd[UD], xx[UD];
                 double dz[UD], zz[UD];
@@ -215,7 +240,7 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
                 }
             }
         }
-        for (int e0 = threadIdx.x; e0 < (blk ? npe : 0); e0 += UP * NT) {
+        for (int e0 = tid; e0 < (blk ? npe : 0); e0 += UP * NT) {
             int32_t c[UP];
             double2 kc[UP], xx[UP];
             double zz[UP];
@@ -261,8 +286,50 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
                 }
             }
         }
+        // ---- column records {m, a_x, a_y, a_z}: products for the x row (n slots behind the node-record products), y, z
+        if (grec) {
+            constexpr int UG = UP;
+            for (int e0 = tid; e0 < n; e0 += UG * NT) {
+                int32_t c[UG];
+                double2 aa[UG];
+                double az[UG], xv[UG];
+#pragma unroll
+                for (int u = 0; u < UG; ++u) {
+                    const int e = e0 + u * NT;
+                    if (e < n) {
+                        c[u] = __builtin_nontemporal_load(A.gcol + base + e);
+                        if (F32) {
+                            const float *p = reinterpret_cast<const float *>(A.gxy32 + base + e);
+                            aa[u].x = (double)__builtin_nontemporal_load(p);
+                            aa[u].y = (double)__builtin_nontemporal_load(p + 1);
+                            az[u] = full ? (double)__builtin_nontemporal_load(A.gz32 + base + e) : 0.0;
+                        } else {
+                            const double *p = reinterpret_cast<const double *>(A.gxy + base + e);
+                            aa[u].x = __builtin_nontemporal_load(p);
+                            aa[u].y = __builtin_nontemporal_load(p + 1);
+                            az[u] = full ? __builtin_nontemporal_load(A.gz + base + e) : 0.0;
+                        }
+                    } else {
+                        c[u] = 0;
+                        aa[u] = make_double2(0.0, 0.0);
+                        az[u] = 0.0;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UG; ++u) xv[u] = x(c[u]);
+#pragma unroll
+                for (int u = 0; u < UG; ++u) {
+                    const int e = e0 + u * NT;
+                    if (e < n) {
+                        t.prod[slot0 + e] = aa[u].x * xv[u];
+                        t.prod[slot0 + n + e] = aa[u].y * xv[u];
+                        if (full) t.prod[slot0 + 2 * n + e] = az[u] * xv[u];
+                    }
+                }
+            }
+        }
         // ---- CSR stream
-        for (int k0 = 2 * threadIdx.x; k0 < total; k0 += 2 * NT * U2) {
+        for (int k0 = 2 * tid; k0 < (grec ? 0 : total); k0 += 2 * NT * U2) {
             int2 c[U2];
             double2 v[U2];
             double xa[U2], xb[U2];
@@ -308,13 +375,15 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
         const int g = threadIdx.x / L, l = threadIdx.x % L;
         for (int r = g; r < nrows; r += NT / L) {
             double s = 0.0;
-            const int e = t.rp[r + 1];
-            for (int k = t.rp[r] + 2 * l; k < e; k += 2 * L) {
+            const int q = !blk ? r : full ? (r * 21846) >> 16 : r >> 1;     // node of a block row: r / 3 for r < 2^15
+            // second segment: the row's CSR products, or (column records) its component's share of the node's records
+            const int sb = grec ? slot0 + (r - q * ncomp) * n : 0;
+            const int e = grec ? sb + t.rp[q + 1] : t.rp[r + 1];
+            for (int k = (grec ? sb + t.rp[q] : t.rp[r]) + 2 * l; k < e; k += 2 * L) {
                 const double a = t.prod[k], b = t.prod[k + 1];       // k + 1 <= TNNZ + 2 stays inside the tile struct
                 s += a + (k + 1 < e ? b : 0.0);
             }
             if (blk || drec) {
-                const int q = !blk ? r : full ? (r * 21846) >> 16 : r >> 1;     // r / 3 for r < 2^15
                 const int pb = blk ? (r - q * ncomp) * npe : 0, pe = pb + t.prp[q + 1];
                 for (int k = pb + t.prp[q] + 2 * l; k < pe; k += 2 * L) {
                     const double a = t.prod[k], b = t.prod[k + 1];
@@ -356,6 +425,10 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, int r0, i
     if (r0 < block_rows(A)) {
         td.pbase = A.prow[node_of_row(A, r0)];
         td.npe = (int)(A.prow[node_of_row(A, r1)] - td.pbase);
+        if (A.grow) {
+            td.base = A.grow[node_of_row(A, r0)];
+            td.n = (int)(A.grow[node_of_row(A, r1)] - td.base);
+        }
     } else if (A.drow) {
         td.pbase = A.drow[r0 - block_rows(A)];
         td.npe = (int)(A.drow[r1 - block_rows(A)] - td.pbase);

@@ -659,8 +659,9 @@ def test_distributed_path_single_rank(arch):
         gm, gr = np.array([s[1]["niter"] for s in m.stats]), np.array([s[1]["niter"] for s in ref.stats])
         assert np.all(np.abs(gm - gr) <= 0.01 * gr + 1), (gm, gr)       # (other summation order of the partial sums)
         assert [s[0]["niter"] for s in m.stats] == [s[0]["niter"] for s in ref.stats]
-        # same iteration counts; the partial sums are folded in a different order, which GMRES amplifies to ~1e-7
-        assert rel(m.state.b, ref.state.b) < 1e-9 and rel(m.state.u, ref.state.u) < 1e-5
+        # same iteration counts; the partial sums are folded in a different order (256 rows instead of 768), which the
+        # 600-iteration solves amplify to the level their stopping rule (rtol = 1e-6 on the scaled residual) allows
+        assert rel(m.state.b, ref.state.b) < 1e-9 and rel(m.state.u, ref.state.u) < 1e-4
     finally:
         dist.destroy_process_group()
 
@@ -682,7 +683,7 @@ def test_node_block_storage(arch):
     assert A.nnz == nnz0                                       # logical size unchanged
     nodes, rec, ent = A.storage()
     drec = A.coupling_records()                                # {c, d_x, d_y, d_z} records of the divergence rows
-    assert drec > 0 and nodes == d.n_full + d.n_surf and ent < 0.3 * nnz0
+    assert drec > 0 and nodes == d.n_full + d.n_surf and ent < 0.01 * nnz0     # (what is left as CSR: pressure-pressure entries)
     assert 4 * rec + drec <= nnz0 - ent <= 5 * rec + 3 * drec
     y1 = A.mul(npg.on_architecture(arch, x)).to_host()
     assert rel(y1, ref @ x) < 1e-13 and rel(y1, y0) < 1e-13
@@ -690,10 +691,12 @@ def test_node_block_storage(arch):
     os.environ["NPG_SPMV_COUPLING"] = "0"
     try:
         A0 = npg.build_A_inversion(arch, fed, prm, 1.0)
+        os.environ["NPG_SPMV_COLUMN_RECORDS"] = "0"
         assert A0.block_nodes(d.n_full, d.n_surf) and A0.coupling_records() == 0
-        assert A0.storage()[1] == rec and A0.storage()[2] > ent
+        assert A0.storage()[1] == rec and A0.storage()[2] > 0.25 * nnz0 > ent
     finally:
         del os.environ["NPG_SPMV_COUPLING"]
+        os.environ.pop("NPG_SPMV_COLUMN_RECORDS", None)
     assert rel(A0.mul(npg.on_architecture(arch, x)).to_host(), y1) < 1e-13
     with pytest.raises(L.DeviceError):
         A.to_scipy_csr()
