@@ -76,9 +76,10 @@ def cpu_baseline(workload, mesh_model, dt, gm_its, cg_its, budget, A_host=None, 
 
     from oracle import krylov_c as kc
     from oracle import recipe as rc
-    cores = kc.usable_cores()
+    visible = cores = kc.usable_cores()             # affinity mask and cgroup quota
     if cores > 32 and not os.environ.get("NPG_CPU_CORES"):
-        cores = 16          # no cgroup quota visible but the box's share for a one-GPU job is 16 cores: do not oversubscribe
+        cores = 16          # no quota visible, but a one-GPU job's share of the box is 16 cores: do not oversubscribe it
+                            # (`cores` in the JSON is the thread count actually used, `cores_visible` what the OS showed)
     cores = int(os.environ.get("NPG_CPU_CORES", cores))
     kc.set_threads(cores)
     if A_host is None:
@@ -88,7 +89,7 @@ def cpu_baseline(workload, mesh_model, dt, gm_its, cg_its, budget, A_host=None, 
         per = max(timer["loop_seconds"], 1e-3)
         n = int(max(2, min(50, budget / per)))
         rc.run(S, n, timer=timer)
-        return dict(value=n / timer["loop_seconds"], unit="timesteps/s", cores=1, host_cores=cores, kind="port",
+        return dict(value=n / timer["loop_seconds"], unit="timesteps/s", cores=1, host_cores=cores, cores_visible=visible, kind="port",
                     sample=f"{n} timesteps of the oracle's direct-solve path (reference CPU() recipe: advection "
                            f"assembly + 2 sparse-LU solves per step, factorisation excluded; numpy + SuperLU, one core) "
                            f"on {workload}")
@@ -117,7 +118,7 @@ def cpu_baseline(workload, mesh_model, dt, gm_its, cg_its, budget, A_host=None, 
     per_cell = (time.perf_counter() - t2) / len(S.orc.topo.cells)
     nb_big = int(round(Ab.shape[0] * ncell / len(S.orc.topo.cells)))
     step = per_gm * np.mean(gm_its) + per_cg_row * nb_big * np.mean(cg_its) + per_cell * ncell
-    return dict(value=1.0 / step, unit="timesteps/s", cores=cores, kind="port",
+    return dict(value=1.0 / step, unit="timesteps/s", cores=cores, cores_visible=visible, kind="port",
                 sample=f"host Krylov branch of the reference (src/iterative_solvers.jl:58) restated in C + OpenMP on {cores} "
                        f"cores: {its} GMRES(20) iterations on the {workload} inversion matrix = {per_gm * 1e3:.1f} ms/iteration "
                        f"x {np.mean(gm_its):.0f} iterations per timestep (the GPU run's count: same algorithm and stopping "
