@@ -373,7 +373,47 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
         // by instruction issue (every wave of the CU is in it at once), not by LDS latency - an unrolled
         // several-rows-in-flight version measured 1.5x slower
         const int g = threadIdx.x / L, l = threadIdx.x % L;
-        for (int r = g; r < nrows; r += NT / L) {
+        if (grec) {
+            // block tile in all-record form: a lane group sums the two or three rows of a NODE together - their segments have
+            // the same shape, so the offsets, the loop control and the latency of the LDS reads are paid once for three
+            // independent accumulations (per row the same terms in the same order as the row-wise loop below)
+            for (int q = g; q < nnode; q += NT / L) {
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                const int cb = t.rp[q], ce = t.rp[q + 1];
+                for (int k = cb + 2 * l; k < ce; k += 2 * L) {
+                    const bool two = k + 1 < ce;
+                    const double a0 = t.prod[slot0 + k], b0 = t.prod[slot0 + k + 1];
+                    const double a1 = t.prod[slot0 + n + k], b1 = t.prod[slot0 + n + k + 1];
+                    s0 += a0 + (two ? b0 : 0.0);
+                    s1 += a1 + (two ? b1 : 0.0);
+                    if (full) {
+                        const double a2 = t.prod[slot0 + 2 * n + k], b2 = t.prod[slot0 + 2 * n + k + 1];
+                        s2 += a2 + (two ? b2 : 0.0);
+                    }
+                }
+                const int pb = t.prp[q], pe = t.prp[q + 1];
+                for (int k = pb + 2 * l; k < pe; k += 2 * L) {
+                    const bool two = k + 1 < pe;
+                    const double a0 = t.prod[k], b0 = t.prod[k + 1];
+                    const double a1 = t.prod[npe + k], b1 = t.prod[npe + k + 1];
+                    s0 += a0 + (two ? b0 : 0.0);
+                    s1 += a1 + (two ? b1 : 0.0);
+                    if (full) {
+                        const double a2 = t.prod[2 * npe + k], b2 = t.prod[2 * npe + k + 1];
+                        s2 += a2 + (two ? b2 : 0.0);
+                    }
+                }
+                s0 = group_sum_dpp<L>(s0);
+                s1 = group_sum_dpp<L>(s1);
+                if (full) s2 = group_sum_dpp<L>(s2);
+                if (l == 0) {
+                    out[q * ncomp] = s0;
+                    out[q * ncomp + 1] = s1;
+                    if (full) out[q * ncomp + 2] = s2;
+                }
+            }
+        }
+        for (int r = g; r < (grec ? 0 : nrows); r += NT / L) {
             double s = 0.0;
             const int q = !blk ? r : full ? (r * 21846) >> 16 : r >> 1;     // node of a block row: r / 3 for r < 2^15
             // second segment: the row's CSR products, or (column records) its component's share of the node's records

@@ -47,6 +47,8 @@ for label, A, nx, dist_, graph in (("serial (hipGraph cycles)", A_ser, n, False,
                                    (f"through {tr}, one-rank communicator, eager launches", A_dis, n + len(S), True, 0),
                                    (f"through {tr}, one-rank communicator, hipGraph replay", A_dis, n + len(S), True, 1)):
     ws = npg.GmresWorkspace(ctx, n, memory=20)
+    if os.environ.get("CYCLE_BASIS"):                     # 32: the fp32-stored basis the reference's tolerance selects (the probe's
+        ws.set_basis(int(os.environ["CYCLE_BASIS"]))      # rtol = 1e-14 would pick fp64)
     if dist_:
         L.check(L.lib().npg_gmres_set_halo(ws.h, halo.h))
         L.check(L.lib().npg_gmres_set_dist_options(ws.h, 1, graph))
