@@ -131,6 +131,74 @@ __global__ void __launch_bounds__(kBlock) k_dense_gemv_part(const T *__restrict_
     part[(int64_t)blockIdx.y * n + i] = acc;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float *p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// fp32 inverse with a padded leading dimension (ld = n rounded up to 4 floats: every column starts 16-byte aligned): thread =
+// FOUR adjacent rows (one 16-byte load per column), four columns per trip and the next trip's loads issued before this trip's
+// arithmetic (the pattern that took the Krylov row kernels from 3.9 to 5.5 TB/s: profiles/r03_rows_bench.txt)
+__global__ void __launch_bounds__(kBlock) k_dense_gemv_part4(const float *__restrict__ M, int64_t n, int64_t ld,
+                                                             const double *__restrict__ x, double *__restrict__ part) {
+    __shared__ double xs[kGemvChunkCols];
+    const int64_t j0 = (int64_t)blockIdx.y * kGemvChunkCols;
+    const int nj = (int)min((int64_t)kGemvChunkCols, n - j0);
+    for (int j = threadIdx.x; j < nj; j += kBlock) xs[j] = x[j0 + j];
+    __syncthreads();
+    const int64_t i = 4 * (blockIdx.x * (int64_t)kBlock + threadIdx.x);
+    if (i >= n) return;
+    const float *__restrict__ Mi = M + i + j0 * ld;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    constexpr int U = 4;
+    float4 v[U], vn[U];
+    const int ntrip = nj / U;                        // whole trips; the tail columns one by one below
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (ntrip > 0) v[u] = nt_load4(Mi + (int64_t)u * ld);
+    for (int tr = 0; tr < ntrip; ++tr) {
+        const int j = tr * U;
+        if (tr + 1 < ntrip) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) vn[u] = nt_load4(Mi + (int64_t)(j + U + u) * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double xv = xs[j + u];
+            a0 += (double)v[u].x * xv;
+            a1 += (double)v[u].y * xv;
+            a2 += (double)v[u].z * xv;
+            a3 += (double)v[u].w * xv;
+        }
+        if (tr + 1 < ntrip) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = vn[u];
+        }
+    }
+    for (int j = ntrip * U; j < nj; ++j) {
+        const float4 f = *reinterpret_cast<const float4 *>(Mi + (int64_t)j * ld);
+        const double xv = xs[j];
+        a0 += (double)f.x * xv;
+        a1 += (double)f.y * xv;
+        a2 += (double)f.z * xv;
+        a3 += (double)f.w * xv;
+    }
+    double *out = part + (int64_t)blockIdx.y * n + i;          // (rows past n are padding of M: computed, not stored)
+    out[0] = a0;
+    if (i + 1 < n) out[1] = a1;
+    if (i + 2 < n) out[2] = a2;
+    if (i + 3 < n) out[3] = a3;
+}
+
+// fp64 column-major n x n -> fp32 with leading dimension ld >= n (pad rows zeroed)
+__global__ void k_to_float_ld(const double *__restrict__ src, float *__restrict__ dst, int64_t n, int64_t ld) {
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < ld * n; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = k / ld, i = k - j * ld;
+        dst[k] = i < n ? (float)src[j * n + i] : 0.f;
+    }
+}
+
 // z = a (sum_s part[s]) + b z   (fixed order)
 __global__ void __launch_bounds__(kBlock) k_dense_gemv_sum(const double *__restrict__ part, int nsplit, int64_t n, double a,
                                                            double b, double *__restrict__ z) {
@@ -189,7 +257,8 @@ struct BlockPc {
 struct DenseInv {
     int64_t n = 0;
     double *M = nullptr;       // A^-1, column-major (fp64 storage) ...
-    float *Mf = nullptr;       // ... or rounded to fp32 (half the bytes per application; a preconditioner may be inexact)
+    float *Mf = nullptr;       // ... or rounded to fp32 (half the bytes per application; a preconditioner may be inexact),
+    int64_t ldf = 0;           //     leading dimension ldf = n rounded up to 4 (16-byte aligned columns)
     double *part = nullptr;    // [nsplit][n] partial products
     int nsplit = 0;
 };
@@ -279,7 +348,8 @@ static int dense_apply(npg_precond *pc, const double *r, double *z, double a, do
     hipStream_t st = pc->ctx->stream;
     const int gx = (int)((d.n + kBlock - 1) / kBlock);
     if (d.Mf)
-        hipLaunchKernelGGL(k_dense_gemv_part<float>, dim3(gx, d.nsplit), dim3(kBlock), 0, st, d.Mf, d.n, r, d.part);
+        hipLaunchKernelGGL(k_dense_gemv_part4, dim3((unsigned)((d.n + 4 * kBlock - 1) / (4 * kBlock)), d.nsplit), dim3(kBlock), 0, st,
+                           (const float *)d.Mf, d.n, d.ldf, r, d.part);
     else
         hipLaunchKernelGGL(k_dense_gemv_part<double>, dim3(gx, d.nsplit), dim3(kBlock), 0, st, d.M, d.n, r, d.part);
     hipLaunchKernelGGL(k_dense_gemv_sum, dim3(gx), dim3(kBlock), 0, st, d.part, d.nsplit, d.n, a, b, z);
@@ -333,8 +403,9 @@ static int dense_build(npg_precond *pc, const npg_csr *A, bool fp32) {
                 "dense inverse: rocSOLVER getrf/getri failed (status %d/%d, info %d/%d: the matrix is singular to working "
                 "precision, or out of memory)", (int)s1, (int)s2, (int)i1, (int)i2);
     if (fp32) {
-        NPG_HIP(hipMalloc((void **)&d.Mf, (size_t)n * n * sizeof(float)));
-        hipLaunchKernelGGL(k_to_float, dim3(4096), dim3(kBlock), 0, st, d.M, d.Mf, n * n);
+        d.ldf = (n + 3) / 4 * 4;
+        NPG_HIP(hipMalloc((void **)&d.Mf, (size_t)d.ldf * n * sizeof(float)));
+        hipLaunchKernelGGL(k_to_float_ld, dim3(4096), dim3(kBlock), 0, st, d.M, d.Mf, n, d.ldf);
         NPG_HIP(hipGetLastError());
         NPG_HIP(hipStreamSynchronize(st));
         NPG_HIP(hipFree(d.M));
