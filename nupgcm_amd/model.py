@@ -62,8 +62,9 @@ class Model:
         self.b_vec = evolution.solver.x if evolution is not None else DeviceVector(ctx, fe_data.dofs.nb)
         self.state = State(self)
         self.step_index = 1
-        # True: run! starts each inversion from the extrapolation 2 x_{n-1} - x_{n-2} of the last two solutions instead of
-        # x_{n-1} alone (the reference's warm start); off by default = the reference's recipe
+        # True / 1: run! starts each inversion from the extrapolation 2 x_{n-1} - x_{n-2} of the last two solutions instead of
+        # x_{n-1} alone (the reference's warm start); 2: from the quadratic one through the last three; off by default = the
+        # reference's recipe
         self.extrapolate_guess = False
         self.stats = []
         self._prev = None
@@ -153,7 +154,12 @@ def run(model: Model, n_info=10, n_save=float("inf"), n_plot=float("inf"), advec
         pv["x_curr"].copy_from(inv_x)                                                           # src/model.jl:140-141
         pv["b_curr"].copy_from(b)
         evolve(model, pv["x_prev"], pv["b_prev"])                                               # src/model.jl:144
-        if getattr(model, "extrapolate_guess", False) and i > 1:
+        order = int(getattr(model, "extrapolate_guess", 0) or 0)
+        if order >= 2 and i > 2 and "x_prev2" in pv:
+            # ... or the quadratic one, 3 x_{n-1} - 3 x_{n-2} + x_{n-3}
+            inv_x.axpby(-3.0, pv["x_prev"], 3.0)
+            inv_x.axpby(1.0, pv["x_prev2"], 1.0)
+        elif order >= 1 and i > 1:
             # initial guess 2 x_{n-1} - x_{n-2} instead of the reference's x_{n-1} (x aliases workspace.x,
             # src/iterative_solvers.jl:26-29): changes the result only within the solver tolerance
             inv_x.axpby(-1.0, pv["x_prev"], 2.0)
@@ -167,6 +173,11 @@ def run(model: Model, n_info=10, n_save=float("inf"), n_plot=float("inf"), advec
             blow = comm.any(blow)                                 # every rank leaves the loop together
         if blow:
             raise BlowUp("Blow-up detected, stopping simulation")
+        if int(getattr(model, "extrapolate_guess", 0) or 0) >= 2:         # x_{n-2} of this step is x_{n-3} of the next
+            if "x_prev2" not in pv:
+                pv["x_prev2"] = pv["x_prev"].copy()
+            else:
+                pv["x_prev2"].copy_from(pv["x_prev"])
         pv["x_prev"], pv["x_curr"] = pv["x_curr"], pv["x_prev"]                                 # src/model.jl:156-157
         pv["b_prev"], pv["b_curr"] = pv["b_curr"], pv["b_prev"]
         if frc.eddy_param.is_on and advection and i % 10 == 0:                                  # src/model.jl:160-170

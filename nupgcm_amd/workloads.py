@@ -80,8 +80,11 @@ def example_model(arch, label_or_model, dt=1e-3, t_stop=1e9, preconditioner="dia
         fed = hier[-1]
         inv_kw = dict(inv_kw, hierarchy=hier)
     else:
-        mm = bowl_mesh_model(label_or_model) if isinstance(label_or_model, str) else label_or_model
-        fed = example_fe_data(mm)
+        if fine_fe_data is not None:
+            fed = fine_fe_data                  # (the caller's FEData of this very mesh: skips the host set-up)
+        else:
+            mm = bowl_mesh_model(label_or_model) if isinstance(label_or_model, str) else label_or_model
+            fed = example_fe_data(mm)
         if preconditioner == "dense_inverse":
             inv_kw = dict(inv_kw, block_nodes=False)                 # the dense inverse is built from the plain CSR matrix
     ts = BDF2(t_start=0.0, t_stop=t_stop, dt=dt)
