@@ -666,6 +666,27 @@ def test_distributed_path_single_rank(arch):
         dist.destroy_process_group()
 
 
+def test_extrapolated_initial_guess(arch):
+    """model.extrapolate_guess: every inversion of run! starts from 2 x_{n-1} - x_{n-2} (1) or from the quadratic extrapolation
+    through three solutions (2) instead of the reference's warm start x_{n-1} (src/iterative_solvers.jl:26-29).  Same solver and
+    stopping rule: every solve converges, the trajectory agrees with the warm-started one to the solver tolerance, and the
+    linear form needs clearly fewer GMRES iterations (it starts an order of magnitude closer)."""
+    from nupgcm_amd import workloads
+    runs = {}
+    for order in (0, 1, 2):
+        m = workloads.example_model(arch, "bowl3D_h0.1")
+        m.extrapolate_guess = order
+        npg.invert(m)
+        npg.run(m, n_steps=8)
+        assert all(st[1]["solved"] == 1 for st in m.stats)
+        runs[order] = (sum(st[1]["niter"] for st in m.stats[2:]), m.state.u, m.state.b, [st[1]["rnorm0"] for st in m.stats])
+    assert runs[1][0] < 0.8 * runs[0][0], (runs[1][0], runs[0][0])
+    assert runs[1][3][-1] < 0.3 * runs[0][3][-1] and runs[2][3][-1] < runs[1][3][-1]      # where the last inversion starts
+    for order in (1, 2):
+        # (two answers inside the same stopping rule: atol = 1e-6 on the scaled residual while the flow is still ~1e-5 in size)
+        assert rel(runs[order][2], runs[0][2]) < 1e-6 and rel(runs[order][1], runs[0][1]) < 2e-2
+
+
 def test_node_block_storage(arch):
     """npg_csr_block_nodes: the velocity block stored as one {c, K, C} record per coupled node pair gives the same SpMV and
     the same GMRES solve; matrices without the structure are left alone."""
