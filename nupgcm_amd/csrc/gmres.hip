@@ -304,8 +304,9 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_residual(GDev d) {
 // Tiles [t0, t1).  The distributed split cycle launches it twice per step - the tiles without ghost columns while the halo
 // exchange is in flight, the others behind it; the prologue is a pure function of state neither launch changes, so
 // running it twice writes the same values twice.
-// XG: the SpMV input is gathered from the fp32 gather-layout copy of wt (GDev::xg; no second Gram-Schmidt pass in that mode).
-template <int L, bool FUSED, bool XG = false>
+// XG: the SpMV input is gathered from the fp32 gather-layout copy of wt (GDev::xg; no second Gram-Schmidt pass in that mode):
+// 1 = node-blocked matrix (records), 2 = plain CSR matrix (the copy is then simply the vector in fp32: 4-byte gathers).
+template <int L, bool FUSED, int XG = 0>
 __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, int j, int t0, int t1) {
     __shared__ KShared sh;
     __shared__ TileLds tl;
@@ -344,7 +345,7 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
 
     const int k = threadIdx.x & (kKP - 1), slot = threadIdx.x >> 5;
     const double inv_beta = 1.0 / T.beta;
-    const bool ro = !XG && sh.reorth != 0;        // (the gather-layout instance runs in fast mode: never a second pass)
+    const bool ro = XG == 0 && sh.reorth != 0;        // (the gather-layout instance runs in fast mode: never a second pass)
     const double h2k = (ro && k < j) ? sh.h2[k] : 0.0;
     double acc = 0.0;
     TileDesc nd = d.tile_ptr[t0 + (int)blockIdx.x < t1 ? t0 + (int)blockIdx.x : 0];
@@ -358,7 +359,9 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
         double wt_row = 0.0;
         if (!FUSED && (int)threadIdx.x < td.nrows) wt_row = d.wt[td.r0 + threadIdx.x];
         // one instantiation for both cases: without a second pass the correction loop has no trips
-        if constexpr (XG)
+        if constexpr (XG == 2)
+            spmv_tile<kKB, L>(d.A, PaddedX{d.xg}, td, tl, sw);
+        else if constexpr (XG == 1)
             spmv_tile<kKB, L, PaddedX, kTileNnz, 2, NoProf, false, true>(d.A, PaddedX{d.xg}, td, tl, sw);     // (node-blocked by definition: hardly any CSR entries - two pairs per lane there keep the records' loops inside the register budget)
         else
             spmv_tile<kKB, L>(d.A, CorrectedX{d.wt, d.Vi, sh.h2, ro ? j : 0, d.n, d.ldv, d.Vf}, td, tl, sw);
@@ -916,15 +919,21 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
             // tile) and RCCL's send/recv kernels on the other stream could otherwise not start before they are all done.  Peer
             // windows: nothing of ours runs beside it (the neighbours' stores need no CU here): full grid.
             const int gi = kernel_only ? maxg : maxg - 3 * reserve;
-            if (d.xg.p)
-                hipLaunchKernelGGL((k_gmres_arnoldi<L, false, true>), dim3(std::max(1, std::min(d.nt_int, gi))), dim3(kKB), 0, st, d, j,
+            if (d.xg.p && d.xg.nbr == 0)
+                hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 2>), dim3(std::max(1, std::min(d.nt_int, gi))), dim3(kKB), 0, st, d, j,
+                                   0, d.nt_int);
+            else if (d.xg.p)
+                hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1>), dim3(std::max(1, std::min(d.nt_int, gi))), dim3(kKB), 0, st, d, j,
                                    0, d.nt_int);
             else
                 hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(std::max(1, std::min(d.nt_int, gi))), dim3(kKB), 0, st, d, j, 0,
                                    d.nt_int);
             if ((rc = halo_exchange_wait(ws->halo))) return rc;
-            if (d.xg.p)
-                hipLaunchKernelGGL((k_gmres_arnoldi<L, false, true>), dim3(std::max(1, std::min(d.ntiles - d.nt_int, maxg))), dim3(kKB),
+            if (d.xg.p && d.xg.nbr == 0)
+                hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 2>), dim3(std::max(1, std::min(d.ntiles - d.nt_int, maxg))), dim3(kKB),
+                                   0, st, d, j, d.nt_int, d.ntiles);
+            else if (d.xg.p)
+                hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1>), dim3(std::max(1, std::min(d.ntiles - d.nt_int, maxg))), dim3(kKB),
                                    0, st, d, j, d.nt_int, d.ntiles);
             else
                 hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(std::max(1, std::min(d.ntiles - d.nt_int, maxg))), dim3(kKB), 0,
@@ -935,7 +944,10 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
         if (dist && (rc = halo_exchange_raw(ws->halo, d.wt, g32))) return rc;
         if (pev) hipEventRecord(pev[2 * j], st);
         if (d.split && d.xg.p) {
-            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, true>), dim3(d.G1), dim3(kKB), 0, st, d, j, 0, d.ntiles);
+            if (d.xg.nbr == 0)
+                hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 2>), dim3(d.G1), dim3(kKB), 0, st, d, j, 0, d.ntiles);
+            else
+                hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1>), dim3(d.G1), dim3(kKB), 0, st, d, j, 0, d.ntiles);
             if (pev) hipEventRecord(pev[2 * j + 1], st);
             launch_rows_kernel(d, j, st, false);
         } else if (d.split) {
@@ -1149,7 +1161,13 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     // The rounding is the one the stored basis column has anyway.  NPG_GMRES_XG=0 turns it off.
     static const int xg_env = getenv("NPG_GMRES_XG") ? atoi(getenv("NPG_GMRES_XG")) : 1;
     d.xg = GatherMap{nullptr, 0, 0, 0, 0};
-    if ((ws->gather32 >= 0 ? ws->gather32 : xg_env) && basis32 && d.fast && A->nnode() > 0 && (dist ? A->n == A->m + ws->n_ghost : A->n == A->m)) {
+    // plain-CSR matrices (function-valued viscosity: the full-stress form has no node records): the copy is then the vector in
+    // fp32, every gather 4 bytes instead of 8 - measured on the channel basin at 4.1 M unknowns: Arnoldi kernel 1 019 against
+    // 1 075 us; from 100 000 rows on (below that the solve is latency-bound and the extra stores buy nothing);
+    // NPG_GMRES_XG_CSR=0 / 1 forces it off / on at any size
+    static const int xg_csr_env = getenv("NPG_GMRES_XG_CSR") ? atoi(getenv("NPG_GMRES_XG_CSR")) : -1;
+    const bool xg_csr = xg_csr_env >= 0 ? xg_csr_env != 0 : ws->n >= 100000;
+    if ((ws->gather32 >= 0 ? ws->gather32 : xg_env) && basis32 && d.fast && (A->nnode() > 0 || xg_csr) && (dist ? A->n == A->m + ws->n_ghost : A->n == A->m)) {
         const int64_t nbr = A->block_rows(), need = 4 * A->nnode() + (A->n - nbr) + 8;
         if (ws->xg_len < need) {
             if (ws->xg) NPG_HIP(hipFree(ws->xg));
