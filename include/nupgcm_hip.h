@@ -124,6 +124,18 @@ int npg_csr_storage(const npg_csr *A, int64_t *nodes, int64_t *records, int64_t 
  * coefficients of column m in the node's x, y, z rows - whenever that is fewer bytes than the entries (NPG_SPMV_COLUMN_RECORDS=0:
  * never).  *records = how many 28-byte records of both kinds (0: none). */
 int npg_csr_coupling_records(const npg_csr *A, int64_t *records);
+/* Record form for a matrix whose velocity block has NO {K, C} structure - function-valued viscosity, where the full-stress form
+ * (src/inversion.jl:172-181) couples all nine component pairs of a node pair, and the eddy closure re-assembles the values
+ * (src/model.jl:160-170).  The plain matrix A stays what it is (assembly target, download, clone ...); a companion in record form
+ * is attached to it: FULL node records {c, a_00 .. a_22} (76 bytes and one gather of node c's components for nine entries of
+ * 12 bytes and nine gathers), coupling records and column records as npg_csr_block_nodes builds them.  The companion knows where
+ * in A's value array each of its values comes from and follows every change of A on the device (npg_fe_assemble_matrix,
+ * npg_csr_combine, npg_csr_gather_values, npg_csr_zero_values); npg_spmv, npg_gmres_solve and the preconditioners read it.
+ * *packed = 0 and nothing attached if the rows of some node would not fit an SpMV tile. */
+int npg_csr_pack_nodes(npg_csr *A, int64_t n_full, int64_t n_surf, int *packed);
+/* bytes of the matrix arrays one SpMV streams from HBM in the form the kernels read (records and their offset arrays, remaining
+ * CSR entries, row offsets): plain CSR 12 nnz + 8 (m + 1); record forms as laid out by npg_csr_block_nodes / npg_csr_pack_nodes */
+int npg_csr_spmv_bytes(const npg_csr *A, int64_t *matrix_bytes);
 /* dst.val[k] = src.val[map[k]]: a matrix whose entries are a fixed subset / rearrangement of another's - a rank's row block
  * of a replicated, re-assembled matrix (closure refreshes of K_v and A, src/model.jl:160-170,229-261, when the solve is
  * distributed).  npg_index = a device-resident int64 index array, every entry checked against `bound` at creation. */

@@ -320,6 +320,14 @@ class DeviceCSR:
         self.paired = bool(flag.value)
         return self.paired
 
+    def pack_nodes(self, n_full, n_surf):
+        """attach a record-form companion with FULL node records (function-valued viscosity; npg_csr_pack_nodes): the matrix
+        stays plain for assembly / download, products and solves read the companion, which follows every re-assembly"""
+        flag = C.c_int()
+        L.check(L.lib().npg_csr_pack_nodes(self.h, int(n_full), int(n_surf), C.byref(flag)))
+        self.packed = bool(flag.value)
+        return self.packed
+
     def pair_xy(self, npairs, rtol=1e-12):
         """two-component special case of block_nodes: rows 2q, 2q+1 for q < npairs"""
         return self.block_nodes(0, npairs, rtol)
@@ -338,12 +346,11 @@ class DeviceCSR:
         return a.value
 
     def stored_spmv_bytes(self):
-        """bytes one SpMV streams from HBM with this layout (matrix arrays + x once + y once)"""
-        nodes, rec, ent = self.storage()
-        drec = self.coupling_records()
+        """bytes one SpMV streams from HBM with this layout (matrix arrays in the form the kernels read + x once + y once)"""
+        mb = C.c_int64()
+        L.check(L.lib().npg_csr_spmv_bytes(self.h, C.byref(mb)))
         m, n = self.shape
-        blk = 8 * (nodes + 1) if nodes else 0
-        return 20 * rec + 28 * drec + 12 * ent + 8 * (m + 1) + 2 * blk + 8 * n + 8 * m          # (+ the records' offset arrays)
+        return mb.value + 8 * n + 8 * m
 
     def mul(self, x: DeviceVector, y: DeviceVector = None, alpha=1.0, beta=0.0):
         """mul!(y, A, x) / A*x"""

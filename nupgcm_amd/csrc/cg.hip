@@ -294,10 +294,12 @@ static int cg_run(npg_cg *ws, const CDev &d, int64_t itmax, CSnap *last) {
     return NPG_OK;
 }
 
-NPG_API int npg_cg_solve(npg_cg *ws, const npg_csr *A, int precond_kind, double precond_scalar,
+NPG_API int npg_cg_solve(npg_cg *ws, const npg_csr *A_in, int precond_kind, double precond_scalar,
                          const npg_vec *precond_diag, const npg_vec *y, npg_vec *x, double atol, double rtol,
                          int64_t itmax, npg_solve_stats *stats) {
-    NPG_REQUIRE(ws && A && y && x, "npg_cg_solve: NULL argument");
+    NPG_REQUIRE(ws && A_in && y && x, "npg_cg_solve: NULL argument");
+    NPG_REQUIRE(!A_in->packed && !A_in->pk9, "npg_cg_solve: matrices with full node records are not served by the CG kernels");
+    const npg_csr *A = A_in;
     const int64_t nloc = ws->n + ws->n_ghost;     // distributed: vectors the SpMV reads hold [owned | ghosts]
     NPG_REQUIRE(A->m == ws->n && A->n == nloc && y->n == ws->n && x->n == nloc,
                 "npg_cg_solve: workspace is for n=%lld (+%lld ghosts) but A is %lldx%lld, y has %lld, x has %lld",

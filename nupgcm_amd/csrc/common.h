@@ -117,6 +117,15 @@ struct npg_csr {
     float *gval32 = nullptr;     // optional fp32 copy, same layout
     int64_t ngrec = 0;
     std::vector<int64_t> h_grow;
+    // FULL node records (npg_csr_pack_nodes: function-valued viscosity, all nine component pairs per node pair): a SEPARATE
+    // matrix object in record form hangs off the plain one (`packed`), which stays the assembly target; the packed object
+    // holds, beside the record arrays, for every stored value the position in the plain matrix's `val` it is refreshed from
+    // (-1: structural zero) - csr_repack() after every change of the plain values.  SpMV-side code goes through spmv_form().
+    npg_csr *packed = nullptr;
+    double *pk9 = nullptr;       // device, [9][npk9]: a_rs of record e at (3 r + s) npk9 + e (prow / pcol index the records)
+    float *pk9_32 = nullptr;
+    int64_t npk9 = 0;
+    int64_t *map9 = nullptr, *mapd = nullptr, *mapg = nullptr, *maprem = nullptr;   // device, same layouts as pk9 / dval / gval / val
     // optional fp32 copies of the values (csr_refresh_fp32): read instead of val / pkc by SpMVs that ask for them
     // (SpmvEpi::f32 - the multigrid preconditioner's; results are still accumulated and returned in fp64)
     float *val32 = nullptr, *pkc32 = nullptr;
@@ -169,6 +178,10 @@ int comm_check(const npg_ctx *ctx);
 int ensure_stage(npg_ctx *ctx, size_t doubles);
 int build_tiles(npg_csr *A);
 // tile boundaries (consecutive whole rows, at most tile_slots LDS product slots) for any tile size: tuning harness
+// the form the SpMV kernels read: the record-form companion of a plain matrix if it has one (npg_csr_pack_nodes)
+inline const npg_csr *spmv_form(const npg_csr *A) { return (A && A->packed) ? A->packed : A; }
+// refresh the companion's values from the plain matrix (no-op without one); enqueued on the context's stream
+NPG_SHARED int csr_repack(const npg_csr *A);
 NPG_SHARED int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp, int max_rows = kTileRows);
 struct CsrDev;
 NPG_SHARED CsrDev csr_view(const npg_csr *A);

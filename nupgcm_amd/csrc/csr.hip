@@ -128,7 +128,7 @@ int build_tiles(npg_csr *A) {
 
 constexpr int kSpmvThreads = 512;
 
-template <int L, bool F32>
+template <int L, bool F32, bool N9 = false>
 __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv(CsrDev A, const TileDesc *__restrict__ tile_ptr, int ntiles,
                                                         const double *__restrict__ x, SpmvEpi e) {
     __shared__ TileLds tl;
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv(CsrDev A, const TileDe
         const int tn = t + gridDim.x;
         TileDesc nd = td;
         if (tn < ntiles) nd = tile_ptr[tn];              // in flight during this tile
-        spmv_tile<kSpmvThreads, L, PlainX, kTileNnz, 4, NoProf, F32>(A, PlainX{x}, td, tl, sw);
+        spmv_tile<kSpmvThreads, L, PlainX, kTileNnz, 4, NoProf, F32, false, N9>(A, PlainX{x}, td, tl, sw);
         for (int r = threadIdx.x; r < td.nrows; r += kSpmvThreads) {
             const int row = td.r0 + r;
             double v = e.alpha * sw[r];
@@ -206,6 +206,11 @@ static int upload_csr(npg_ctx *ctx, int64_t m, int64_t n, std::vector<int64_t> &
 template <int L>
 static void launch_spmv(const npg_csr *A, const double *x, const SpmvEpi &e) {
     const int grid = std::min<int>(A->ntiles, 3 * A->ctx->num_cu);      // 3 x 38 KiB of LDS per CU
+    if (A->pk9) {               // full node records (their fp32 copies are not kept: the values change with the closures)
+        hipLaunchKernelGGL((k_spmv<L, false, true>), dim3(std::max(grid, 1)), dim3(kSpmvThreads), 0, A->ctx->stream, csr_view(A),
+                           A->tile_ptr, A->ntiles, x, e);
+        return;
+    }
     if (e.f32 && A->val32 && (A->nnode() == 0 || A->pkc32))
         hipLaunchKernelGGL((k_spmv<L, true>), dim3(std::max(grid, 1)), dim3(kSpmvThreads), 0, A->ctx->stream, csr_view(A),
                            A->tile_ptr, A->ntiles, x, e);
@@ -220,7 +225,8 @@ __global__ void k_to_float32(const double *__restrict__ src, float *__restrict__
 }
 
 int csr_refresh_fp32(const npg_csr *Ac) {
-    npg_csr *A = const_cast<npg_csr *>(Ac);       // the copies are a cache of val / pkc, not part of the matrix's value
+    npg_csr *A = const_cast<npg_csr *>(spmv_form(Ac));       // the copies are a cache of val / pkc, not part of the matrix's value
+    if (A->pk9) return NPG_OK;           // full node records: no fp32 copies (launch_spmv reads the fp64 values)
     NPG_HIP(hipSetDevice(A->ctx->device));
     const int64_t nz = A->rnnz, nrec = A->nnode() ? A->h_prow[A->nnode()] : 0;
     if (!A->val32) {
@@ -273,6 +279,9 @@ CsrDev csr_view(const npg_csr *A) {
     v.gz = A->gval ? A->gval + 2 * A->ngrec : nullptr;
     v.gxy32 = reinterpret_cast<const float2 *>(A->gval32);
     v.gz32 = A->gval32 ? A->gval32 + 2 * A->ngrec : nullptr;
+    v.pk9 = A->pk9;
+    v.pk9_32 = A->pk9_32;
+    v.npk9 = A->npk9;
     return v;
 }
 
@@ -470,6 +479,194 @@ NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double
     return NPG_OK;
 }
 
+namespace npg {
+__global__ void k_gather_map(double *__restrict__ dst, const double *__restrict__ src, const int64_t *__restrict__ map, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = map[i];
+        dst[i] = k >= 0 ? src[k] : 0.0;
+    }
+}
+
+int csr_repack(const npg_csr *A) {
+    if (!A || !A->packed) return NPG_OK;
+    npg_csr *P = A->packed;
+    auto go = [&](double *dst, const int64_t *map, int64_t n) {
+        if (n > 0)
+            hipLaunchKernelGGL(k_gather_map, dim3((unsigned)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, A->ctx->stream, dst,
+                               (const double *)A->val, map, n);
+    };
+    go(P->pk9, P->map9, 9 * P->npk9);
+    go(P->dval, P->mapd, 3 * P->ndrec);
+    go(P->gval, P->mapg, 3 * P->ngrec);
+    go(P->val, P->maprem, P->rnnz);
+    NPG_HIP(hipGetLastError());
+    return NPG_OK;
+}
+}  // namespace npg
+
+// Record-form companion of a PLAIN matrix whose velocity block has no {K, C} structure (function-valued viscosity: the
+// full-stress form couples all nine component pairs of a node pair, src/inversion.jl:172-181): FULL node records {c, a_00 .. a_22}
+// (one gather of node c's components for nine entries), coupling records for the rows behind the block rows and column records
+// for what the block rows hold outside the block columns - nothing is left as CSR entries but what the rows behind the block
+// hold outside it.  The plain matrix stays what the element kernels assemble into; the companion remembers for every value it
+// stores where in the plain `val` it comes from and is refreshed on the device after every change (csr_repack: assembly,
+// combine, gather_values, zero_values).  Products, solves and preconditioner applications read the companion (spmv_form).
+// *packed = 0 and nothing changed if the rows of some node would not fit a tile.
+NPG_API int npg_csr_pack_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, int *packed) {
+    NPG_REQUIRE(A && packed && nfull >= 0 && nsurf >= 0, "npg_csr_pack_nodes: bad argument");
+    const int64_t nf3 = 3 * nfull, nbr = nf3 + 2 * nsurf, nnode = nfull + nsurf;
+    NPG_REQUIRE(nbr <= A->m && nbr <= A->n, "npg_csr_pack_nodes: more block rows than the matrix has");
+    NPG_REQUIRE(A->nnode() == 0 && !A->packed, "npg_csr_pack_nodes: the matrix is in record form already");
+    *packed = 0;
+    if (nnode == 0) return NPG_OK;
+    NPG_HIP(hipSetDevice(A->ctx->device));
+    NPG_HIP(hipStreamSynchronize(A->ctx->stream));
+    std::vector<int32_t> col((size_t)A->nnz);
+    NPG_HIP(hipMemcpy(col.data(), A->col, col.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    const std::vector<int64_t> &rp = A->h_rowptr;
+    auto first = [&](int64_t c) { return c < nfull ? 3 * c : nf3 + 2 * (c - nfull); };
+    auto node_of = [&](int64_t c0) { return c0 < nf3 ? c0 / 3 : nfull + (c0 - nf3) / 2; };
+    std::vector<int64_t> prow((size_t)nnode + 1, 0), grow((size_t)nnode + 1, 0), nrp((size_t)A->m + 1, 0);
+    std::vector<int32_t> pcol, gcol, dcol, ncol;
+    std::vector<int64_t> m9, mg3, md3, mrem;          // source positions, record-major (re-laid below)
+    for (int64_t q = 0; q < nnode; ++q) {
+        const int nc = q < nfull ? 3 : 2;
+        const int64_t rx = first(q);
+        int64_t it[3] = {0, 0, 0}, en[3] = {0, 0, 0};
+        for (int a = 0; a < nc; ++a) {
+            it[a] = rp[rx + a];
+            en[a] = rp[rx + a + 1];
+        }
+        for (;;) {                                    // block columns, node by node (rows are sorted: block columns come first)
+            int64_t cn = INT64_MAX;
+            for (int a = 0; a < nc; ++a)
+                if (it[a] < en[a] && col[it[a]] < nbr) cn = std::min(cn, node_of(col[it[a]]));
+            if (cn == INT64_MAX) break;
+            int64_t src[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+            const int64_t f = first(cn);
+            for (int a = 0; a < nc; ++a)
+                while (it[a] < en[a] && col[it[a]] < nbr && node_of(col[it[a]]) == cn) {
+                    src[3 * a + (int)(col[it[a]] - f)] = it[a];
+                    ++it[a];
+                }
+            pcol.push_back((int32_t)cn);
+            m9.insert(m9.end(), src, src + 9);
+        }
+        prow[q + 1] = (int64_t)pcol.size();
+        for (;;) {                                    // what is left: columns outside the block, one record per column
+            int64_t mc = INT64_MAX;
+            for (int a = 0; a < nc; ++a)
+                if (it[a] < en[a]) mc = std::min<int64_t>(mc, col[it[a]]);
+            if (mc == INT64_MAX) break;
+            int64_t src[3] = {-1, -1, -1};
+            for (int a = 0; a < nc; ++a)
+                if (it[a] < en[a] && col[it[a]] == mc) src[a] = it[a]++;
+            gcol.push_back((int32_t)mc);
+            mg3.insert(mg3.end(), src, src + 3);
+        }
+        grow[q + 1] = (int64_t)gcol.size();
+    }
+    std::vector<int64_t> drow((size_t)(A->m - nbr) + 1, 0);
+    for (int64_t r = nbr; r < A->m; ++r) {
+        int64_t k = rp[r], nrec = 0;
+        while (k < rp[r + 1] && col[k] < nbr) {
+            const int64_t cn = node_of(col[k]), f = first(cn);
+            int64_t src[3] = {-1, -1, -1};
+            for (; k < rp[r + 1] && col[k] < nbr && node_of(col[k]) == cn; ++k) src[col[k] - f] = k;
+            dcol.push_back((int32_t)cn);
+            md3.insert(md3.end(), src, src + 3);
+            ++nrec;
+        }
+        drow[r - nbr + 1] = (int64_t)dcol.size();
+        for (; k < rp[r + 1]; ++k) {
+            ncol.push_back(col[k]);
+            mrem.push_back(k);
+        }
+        nrp[r + 1] = (int64_t)ncol.size();
+        if (nrec + (nrp[r + 1] - nrp[r]) > kTileNnz) return NPG_OK;          // (a row that would not fit a tile: stay plain)
+    }
+    for (int64_t q = 0; q < nnode; ++q)
+        if ((q < nfull ? 3 : 2) * ((prow[q + 1] - prow[q]) + (grow[q + 1] - grow[q])) > kTileNnz) return NPG_OK;
+    // the companion object
+    npg_csr *P = new npg_csr();
+    P->ctx = A->ctx;
+    P->m = A->m;
+    P->n = A->n;
+    P->nnz = A->nnz;
+    P->rnnz = (int64_t)ncol.size();
+    P->nfull = (int32_t)nfull;
+    P->nsurf = (int32_t)nsurf;
+    const int64_t n9 = (int64_t)pcol.size(), ng = (int64_t)gcol.size(), nd = (int64_t)dcol.size();
+    P->npk9 = n9;
+    P->ngrec = ng;
+    P->ndrec = nd;
+    std::vector<int64_t> map9((size_t)9 * n9), mapg((size_t)3 * ng), mapd((size_t)3 * nd);
+    for (int64_t e = 0; e < n9; ++e)
+        for (int s9 = 0; s9 < 9; ++s9) map9[(size_t)s9 * n9 + e] = m9[(size_t)9 * e + s9];
+    for (int64_t e = 0; e < ng; ++e) {               // [2 ng] (a_x, a_y) pairs, then [ng] a_z
+        mapg[2 * e] = mg3[3 * e];
+        mapg[2 * e + 1] = mg3[3 * e + 1];
+        mapg[2 * ng + e] = mg3[3 * e + 2];
+    }
+    for (int64_t e = 0; e < nd; ++e) {
+        mapd[2 * e] = md3[3 * e];
+        mapd[2 * e + 1] = md3[3 * e + 1];
+        mapd[2 * nd + e] = md3[3 * e + 2];
+    }
+    auto up = [&](void **dst, const void *src, size_t bytes) -> int {
+        NPG_HIP(hipMalloc(dst, std::max<size_t>(bytes, 16)));
+        if (bytes) NPG_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return NPG_OK;
+    };
+    int rc = NPG_OK;
+    auto chk = [&](int r) { if (rc == NPG_OK) rc = r; };
+    chk(up((void **)&P->rowptr, nrp.data(), nrp.size() * 8));
+    chk(up((void **)&P->col, ncol.data(), ncol.size() * 4));
+    chk(up((void **)&P->prow, prow.data(), prow.size() * 8));
+    chk(up((void **)&P->pcol, pcol.data(), pcol.size() * 4));
+    chk(up((void **)&P->grow, grow.data(), grow.size() * 8));
+    chk(up((void **)&P->gcol, gcol.data(), gcol.size() * 4));
+    chk(up((void **)&P->drow, drow.data(), drow.size() * 8));
+    chk(up((void **)&P->dcol, dcol.data(), dcol.size() * 4));
+    chk(up((void **)&P->map9, map9.data(), map9.size() * 8));
+    chk(up((void **)&P->mapg, mapg.data(), mapg.size() * 8));
+    chk(up((void **)&P->mapd, mapd.data(), mapd.size() * 8));
+    chk(up((void **)&P->maprem, mrem.data(), mrem.size() * 8));
+    if (rc == NPG_OK) {
+        hipError_t e1 = hipMalloc((void **)&P->val, std::max<size_t>(16, ncol.size() * 8));
+        hipError_t e2 = hipMalloc((void **)&P->pk9, std::max<size_t>(16, (size_t)9 * n9 * 8));
+        hipError_t e3 = hipMalloc((void **)&P->gval, std::max<size_t>(16, (size_t)3 * ng * 8));
+        hipError_t e4 = hipMalloc((void **)&P->dval, std::max<size_t>(16, (size_t)3 * nd * 8));
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+            set_error("npg_csr_pack_nodes: out of device memory");
+            rc = NPG_ENOMEM;
+        }
+    }
+    if (rc != NPG_OK) {
+        npg_csr_destroy(P);
+        return rc;
+    }
+    if (nd == 0) {                 // (no coupling records: the tile code keys on drow)
+        hipFree(P->drow);
+        P->drow = nullptr;
+    }
+    P->h_rowptr = std::move(nrp);
+    P->h_prow = std::move(prow);
+    P->h_grow = std::move(grow);
+    P->h_drow = std::move(drow);
+    P->owns_pattern = true;
+    A->packed = P;
+    rc = csr_repack(A);
+    if (rc == NPG_OK) rc = build_tiles(P);
+    if (rc != NPG_OK) {
+        A->packed = nullptr;
+        npg_csr_destroy(P);
+        return rc;
+    }
+    *packed = 1;
+    return NPG_OK;
+}
+
 // the (x, y)-only special case kept for callers that interleave two components: rows 2q, 2q+1 for q < npairs
 NPG_API int npg_csr_pair_xy(npg_csr *A, int64_t npairs, double rtol, int *paired) {
     return npg_csr_block_nodes(A, 0, npairs, rtol, paired);
@@ -536,6 +733,11 @@ NPG_API int npg_csr_destroy(npg_csr *A) {
     if (A->pkc) hipFree(A->pkc);
     if (A->val32) hipFree(A->val32);
     if (A->pkc32) hipFree(A->pkc32);
+    if (A->packed) npg_csr_destroy(A->packed);
+    if (A->pk9) hipFree(A->pk9);
+    if (A->pk9_32) hipFree(A->pk9_32);
+    for (int64_t *mp : {A->map9, A->mapd, A->mapg, A->maprem})
+        if (mp) hipFree(mp);
     if (A->grow) hipFree(A->grow);
     if (A->gcol) hipFree(A->gcol);
     if (A->gval) hipFree(A->gval);
@@ -561,6 +763,18 @@ NPG_API int npg_csr_storage(const npg_csr *A, int64_t *npairs, int64_t *paired_r
     if (npairs) *npairs = A->nnode();
     if (paired_records) *paired_records = A->nnode() ? A->h_prow[A->nnode()] : 0;
     if (csr_entries) *csr_entries = A->rnnz;
+    return NPG_OK;
+}
+
+NPG_API int npg_csr_spmv_bytes(const npg_csr *Ap, int64_t *matrix_bytes) {
+    NPG_REQUIRE(Ap && matrix_bytes, "npg_csr_spmv_bytes: NULL argument");
+    const npg_csr *A = spmv_form(Ap);
+    const int64_t nnode = A->nnode(), nrec = nnode ? A->h_prow[nnode] : 0;
+    int64_t b = 8 * (A->m + 1) + 12 * A->rnnz;
+    if (nnode) b += 8 * (nnode + 1) + 4 * nrec + (A->pk9 ? 72 : 16) * nrec;
+    if (A->grow) b += 8 * (nnode + 1) + 28 * A->ngrec;
+    if (A->drow) b += 8 * (A->m - A->block_rows() + 1) + 28 * A->ndrec;
+    *matrix_bytes = b;
     return NPG_OK;
 }
 
@@ -625,7 +839,7 @@ NPG_API int npg_csr_clone(const npg_csr *A, npg_csr **out) {
 NPG_API int npg_csr_zero_values(npg_csr *A) {
     NPG_REQUIRE(A, "npg_csr_zero_values: NULL matrix");
     NPG_HIP(hipMemsetAsync(A->val, 0, (size_t)A->nnz * sizeof(double), A->ctx->stream));
-    return NPG_OK;
+    return csr_repack(A);
 }
 
 NPG_API int npg_csr_combine(npg_csr *out, double a, const npg_csr *X, double b, const npg_csr *Y, const npg_csr *Z) {
@@ -637,7 +851,7 @@ NPG_API int npg_csr_combine(npg_csr *out, double a, const npg_csr *X, double b, 
     hipLaunchKernelGGL(k_combine, dim3(std::max(grid, 1)), dim3(kBlock), 0, out->ctx->stream, out->val, a, X->val, b,
                        Y->val, Z->val, out->nnz);
     NPG_HIP(hipGetLastError());
-    return NPG_OK;
+    return csr_repack(out);
 }
 
 // ---- device-side pieces of the multigrid set-up (mg.hip): node-block inverse and S = D Dinv G on fixed patterns --------------
@@ -765,7 +979,7 @@ NPG_API int npg_csr_gather_values(npg_csr *dst, const npg_csr *src, const npg_in
     hipLaunchKernelGGL(k_gather_values, dim3(std::max(grid, 1)), dim3(kBlock), 0, dst->ctx->stream, dst->val, src->val,
                        map->d, dst->nnz);
     NPG_HIP(hipGetLastError());
-    return NPG_OK;
+    return csr_repack(dst);
 }
 
 NPG_API int npg_csr_node_block_inverse(npg_csr *Dinv, const npg_csr *A, int64_t n_full, int64_t n_surf) {
@@ -815,7 +1029,8 @@ NPG_API int npg_csr_inv_diag(const npg_csr *A, npg_vec *d) {
 
 namespace npg {
 // y[0, m) = alpha A x[0, n) + beta y on raw device pointers (x and y may be windows into larger vectors; they must not overlap)
-int spmv_epi(const npg_csr *A, const double *x, const SpmvEpi &e) {
+int spmv_epi(const npg_csr *Ap, const double *x, const SpmvEpi &e) {
+    const npg_csr *A = spmv_form(Ap);
     switch (A->lanes) {
         case 4: launch_spmv<4>(A, x, e); break;
         case 8: launch_spmv<8>(A, x, e); break;

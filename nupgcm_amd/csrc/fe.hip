@@ -847,7 +847,7 @@ NPG_API int npg_fe_assemble_matrix(npg_fe *fe, int which, double scale, int full
     NPG_HIP(hipMemcpyAsync(&miss, fe->missing, sizeof(int), hipMemcpyDeviceToHost, st));
     NPG_HIP(hipStreamSynchronize(st));
     NPG_REQUIRE(miss == 0, "npg_fe_assemble_matrix: %d non-zero local entries fall outside the CSR pattern", miss);
-    return NPG_OK;
+    return csr_repack(A);           // (a record-form companion follows the assembled values: npg_csr_pack_nodes)
 }
 
 static int coeff_update(npg_fe *fe, int mode, const npg_vec *b, double p0, double p1, double alpha, double N2,

@@ -270,7 +270,7 @@ struct CorrectedX {
 };
 
 // ---- R1: wt = P (b - A x), partial ||wt||^2 ---------------------------------------------------------------------------
-template <int L>
+template <int L, bool N9 = false>
 __global__ void __launch_bounds__(kKB, 6) k_gmres_residual(GDev d) {
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_residual(GDev d) {
             const TileDesc td = nd;
             if (t + (int)gridDim.x < d.ntiles) nd = d.tile_ptr[t + gridDim.x];      // in flight during this tile
             const int r0 = td.r0, r1 = td.r0 + td.nrows;
-            spmv_tile<kKB, L>(d.A, PlainX{d.x}, td, tl, sw);
+            spmv_tile<kKB, L, PlainX, kTileNnz, 4, NoProf, false, false, N9>(d.A, PlainX{d.x}, td, tl, sw);
             const int r = threadIdx.x;
             if (r < r1 - r0) {
                 const int row = r0 + r;
@@ -306,7 +306,8 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_residual(GDev d) {
 // running it twice writes the same values twice.
 // XG: the SpMV input is gathered from the fp32 gather-layout copy of wt (GDev::xg; no second Gram-Schmidt pass in that mode):
 // 1 = node-blocked matrix (records), 2 = plain CSR matrix (the copy is then simply the vector in fp32: 4-byte gathers).
-template <int L, bool FUSED, int XG = 0>
+// N9: the matrix may hold FULL node records (spmv_device.h).
+template <int L, bool FUSED, int XG = 0, bool N9 = false>
 __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, int j, int t0, int t1) {
     __shared__ KShared sh;
     __shared__ TileLds tl;
@@ -362,9 +363,12 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
         if constexpr (XG == 2)
             spmv_tile<kKB, L>(d.A, PaddedX{d.xg}, td, tl, sw);
         else if constexpr (XG == 1)
-            spmv_tile<kKB, L, PaddedX, kTileNnz, 2, NoProf, false, true>(d.A, PaddedX{d.xg}, td, tl, sw);     // (node-blocked by definition: hardly any CSR entries - two pairs per lane there keep the records' loops inside the register budget)
+            // (node-blocked by definition: hardly any CSR entries - two pairs per lane there keep the records' loops inside the
+            //  register budget)
+            spmv_tile<kKB, L, PaddedX, kTileNnz, 2, NoProf, false, true, N9>(d.A, PaddedX{d.xg}, td, tl, sw);
         else
-            spmv_tile<kKB, L>(d.A, CorrectedX{d.wt, d.Vi, sh.h2, ro ? j : 0, d.n, d.ldv, d.Vf}, td, tl, sw);
+            spmv_tile<kKB, L, CorrectedX, kTileNnz, 4, NoProf, false, false, N9>(
+                d.A, CorrectedX{d.wt, d.Vi, sh.h2, ro ? j : 0, d.n, d.ldv, d.Vf}, td, tl, sw);
         const int nr = r1 - r0;
         if (!FUSED) {
             // split mode (large systems): only what depends on the SpMV result; the dots stream in k_gmres_dots_rows
@@ -886,6 +890,31 @@ static void launch_rows_kernel(const GDev &d, int j, hipStream_t st, bool orth) 
     }
 }
 
+// the Arnoldi kernel instance for this matrix / input form: tiles [t0, t1) on `grid` workgroups
+template <int L>
+static void launch_arnoldi_split(const GDev &d, int grid, int j, int t0, int t1, hipStream_t st) {
+    const dim3 g(std::max(1, grid)), b(kKB);
+    if (d.A.pk9) {
+        if (d.xg.p)
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1, true>), g, b, 0, st, d, j, t0, t1);
+        else
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 0, true>), g, b, 0, st, d, j, t0, t1);
+    } else if (d.xg.p && d.xg.nbr == 0) {
+        hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 2>), g, b, 0, st, d, j, t0, t1);
+    } else if (d.xg.p) {
+        hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1>), g, b, 0, st, d, j, t0, t1);
+    } else {
+        hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), g, b, 0, st, d, j, t0, t1);
+    }
+}
+template <int L>
+static void launch_residual_L(const GDev &d, hipStream_t st) {
+    if (d.A.pk9)
+        hipLaunchKernelGGL((k_gmres_residual<L, true>), dim3(d.G1), dim3(kKB), 0, st, d);
+    else
+        hipLaunchKernelGGL((k_gmres_residual<L>), dim3(d.G1), dim3(kKB), 0, st, d);
+}
+
 // One restart cycle.  `ws` is needed whenever partial rows are folded (split and/or distributed mode).
 template <int L>
 static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gmres *ws, bool dist) {
@@ -919,39 +948,16 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
             // tile) and RCCL's send/recv kernels on the other stream could otherwise not start before they are all done.  Peer
             // windows: nothing of ours runs beside it (the neighbours' stores need no CU here): full grid.
             const int gi = kernel_only ? maxg : maxg - 3 * reserve;
-            if (d.xg.p && d.xg.nbr == 0)
-                hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 2>), dim3(std::max(1, std::min(d.nt_int, gi))), dim3(kKB), 0, st, d, j,
-                                   0, d.nt_int);
-            else if (d.xg.p)
-                hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1>), dim3(std::max(1, std::min(d.nt_int, gi))), dim3(kKB), 0, st, d, j,
-                                   0, d.nt_int);
-            else
-                hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(std::max(1, std::min(d.nt_int, gi))), dim3(kKB), 0, st, d, j, 0,
-                                   d.nt_int);
+            launch_arnoldi_split<L>(d, std::min(d.nt_int, gi), j, 0, d.nt_int, st);
             if ((rc = halo_exchange_wait(ws->halo))) return rc;
-            if (d.xg.p && d.xg.nbr == 0)
-                hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 2>), dim3(std::max(1, std::min(d.ntiles - d.nt_int, maxg))), dim3(kKB),
-                                   0, st, d, j, d.nt_int, d.ntiles);
-            else if (d.xg.p)
-                hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1>), dim3(std::max(1, std::min(d.ntiles - d.nt_int, maxg))), dim3(kKB),
-                                   0, st, d, j, d.nt_int, d.ntiles);
-            else
-                hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(std::max(1, std::min(d.ntiles - d.nt_int, maxg))), dim3(kKB), 0,
-                                   st, d, j, d.nt_int, d.ntiles);
+            launch_arnoldi_split<L>(d, std::min(d.ntiles - d.nt_int, maxg), j, d.nt_int, d.ntiles, st);
             if (pev) hipEventRecord(pev[2 * j + 1], st);
             launch_rows_kernel(d, j, st, false);
         } else {
         if (dist && (rc = halo_exchange_raw(ws->halo, d.wt, g32))) return rc;
         if (pev) hipEventRecord(pev[2 * j], st);
-        if (d.split && d.xg.p) {
-            if (d.xg.nbr == 0)
-                hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 2>), dim3(d.G1), dim3(kKB), 0, st, d, j, 0, d.ntiles);
-            else
-                hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1>), dim3(d.G1), dim3(kKB), 0, st, d, j, 0, d.ntiles);
-            if (pev) hipEventRecord(pev[2 * j + 1], st);
-            launch_rows_kernel(d, j, st, false);
-        } else if (d.split) {
-            hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), dim3(d.G1), dim3(kKB), 0, st, d, j, 0, d.ntiles);
+        if (d.split) {
+            launch_arnoldi_split<L>(d, d.G1, j, 0, d.ntiles, st);
             if (pev) hipEventRecord(pev[2 * j + 1], st);
             launch_rows_kernel(d, j, st, false);
         } else {
@@ -968,17 +974,17 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
     }
     hipLaunchKernelGGL(k_gmres_update, dim3(d.G2), dim3(kKB), 0, st, d);
     if (dist && (rc = halo_exchange_raw(ws->halo, d.x))) return rc;
-    hipLaunchKernelGGL(k_gmres_residual<L>, dim3(d.G1), dim3(kKB), 0, st, d);
+    launch_residual_L<L>(d, st);
     if (fold && (rc = fold_rows(ws, d.PR, d.G1, 2, st, dist))) return rc;
     return rc;
 }
 
 static void launch_residual(const GDev &d, int lanes, hipStream_t st) {
     switch (lanes) {
-        case 4: hipLaunchKernelGGL(k_gmres_residual<4>, dim3(d.G1), dim3(kKB), 0, st, d); break;
-        case 8: hipLaunchKernelGGL(k_gmres_residual<8>, dim3(d.G1), dim3(kKB), 0, st, d); break;
-        case 16: hipLaunchKernelGGL(k_gmres_residual<16>, dim3(d.G1), dim3(kKB), 0, st, d); break;
-        default: hipLaunchKernelGGL(k_gmres_residual<32>, dim3(d.G1), dim3(kKB), 0, st, d); break;
+        case 4: launch_residual_L<4>(d, st); break;
+        case 8: launch_residual_L<8>(d, st); break;
+        case 16: launch_residual_L<16>(d, st); break;
+        default: launch_residual_L<32>(d, st); break;
     }
 }
 
@@ -1077,10 +1083,11 @@ NPG_API int npg_gmres_set_halo(npg_gmres *ws, npg_halo *h) {
     return NPG_OK;
 }
 
-NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, double precond_scalar,
+NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A_in, int precond_kind, double precond_scalar,
                             const npg_vec *precond_diag, const npg_vec *y, npg_vec *x, double atol, double rtol,
                             int64_t itmax, double reorth_eta, npg_solve_stats *stats) {
-    NPG_REQUIRE(ws && A && y && x, "npg_gmres_solve: NULL argument");
+    NPG_REQUIRE(ws && A_in && y && x, "npg_gmres_solve: NULL argument");
+    const npg_csr *A = spmv_form(A_in);           // (the record-form companion of a plain matrix, if it has one)
     const int64_t nloc = ws->n + ws->n_ghost;     // distributed: vectors the SpMV reads hold [owned | ghosts]
     NPG_REQUIRE(A->m == ws->n && A->n == nloc && y->n == ws->n && x->n == nloc,
                 "npg_gmres_solve: workspace is for n=%lld (+%lld ghosts) but A is %lldx%lld, y has %lld, x has %lld",
@@ -1121,6 +1128,7 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A, int precond_kind, d
     // measured on MI355X (bowl3D h = 0.1 / 0.08 / 0.05: 23.7 vs 26.0, 27.0 vs 32.0, 50.5 vs 72.6 us per iteration): the
     // split organisation wins from the smallest mesh of interest on; the fused kernels remain for tiny systems
     d.split = split_req >= 0 ? (split_req != 0) : (ws->n >= 8192 ? 1 : 0);
+    if (A->pk9) d.split = 1;        // (full node records are served by the split kernels only)
     // distributed: one all-reduce per Arnoldi step (norm of the orthogonalised vector by Pythagoras); NPG_GMRES_PYTH=0
     // or a cancellation flagged by an earlier cycle selects the explicitly reduced norm (a second all-reduce)
     static const int pyth_env = getenv("NPG_GMRES_PYTH") ? atoi(getenv("NPG_GMRES_PYTH")) : 1;

@@ -712,7 +712,7 @@ static int precond_apply_raw(npg_precond *pc, const double *r, double *z) {
         uint64_t gsum = 0;
         for (const MgLevel &lv : pc->L)
             for (const npg_csr *M : {lv.A, lv.G, lv.D, lv.Dinv, lv.S, lv.P, lv.R})
-                if (M) gsum += M->gen;
+                if (M) gsum += spmv_form(M)->gen;
         if (gsum != pc->graphs_gen) {
             drop_graphs(pc);
             pc->graphs_gen = gsum;

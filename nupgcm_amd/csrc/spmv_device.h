@@ -74,6 +74,11 @@ struct CsrDev {
     const double *gz;         // a_z: A[z_q, m] (0 for an (x, y)-only node)
     const float2 *gxy32;      // fp32 copies
     const float *gz32;
+    // full node records (function-valued viscosity: all nine component pairs of a node pair; npg_csr_pack_nodes): record e of
+    // the prow / pcol index holds a_rs = A[row component r of q, column component s of c] at pk9[(3 r + s) npk9 + e]
+    const double *pk9;
+    const float *pk9_32;
+    int64_t npk9;
 };
 
 __device__ __forceinline__ int block_rows(const CsrDev &A) { return 3 * A.nfull + 2 * A.nsurf; }
@@ -149,7 +154,10 @@ using TileLds = TileLdsT<kTileNnz>;
 // F32: the matrix values come from the fp32 copies (8 instead of 12 bytes per CSR entry, 12 instead of 20 per record);
 // products and sums stay fp64.
 // REMAT: see the comment at `tid` below.
-template <int NT, int L, class XF, int TNNZ = kTileNnz, int U2 = 4, class PROF = NoProf, bool F32 = false, bool REMAT = false>
+// N9: the instance knows the FULL node records (nine values per node pair) - compiled only into the kernels that serve such
+// matrices, so that the loop does not weigh on the register budget of the others.
+template <int NT, int L, class XF, int TNNZ = kTileNnz, int U2 = 4, class PROF = NoProf, bool F32 = false, bool REMAT = false,
+          bool N9 = false>
 __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const TileDesc &td, TileLdsT<TNNZ> &t,
                                           double *__restrict__ out, PROF prof = PROF()) {
     const int r0 = td.r0, nrows = td.nrows, r1 = r0 + nrows;
@@ -240,7 +248,58 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
                 }
             }
         }
-        for (int e0 = tid; e0 < (blk ? npe : 0); e0 += UP * NT) {
+        if constexpr (N9) {
+            // ---- full node records {c, a_00 .. a_22}: the same three product slots per record as the {c, K, C} form
+            if (blk && A.pk9) {
+                constexpr int U9 = 2;
+                for (int e0 = tid; e0 < npe; e0 += U9 * NT) {
+                    int32_t c[U9];
+                    double a[U9][9];
+                    double2 xx[U9];
+                    double zz[U9];
+#pragma unroll
+                    for (int u = 0; u < U9; ++u) {
+                        const int e = e0 + u * NT;
+                        const bool in = e < npe;
+                        c[u] = in ? __builtin_nontemporal_load(A.pcol + pbase + e) : 0;
+#pragma unroll
+                        for (int s9 = 0; s9 < 9; ++s9) {
+                            if (!full && s9 >= 6) {       // (x, y)-only row nodes have no z row (but their rows do reach z_c)
+                                a[u][s9] = 0.0;
+                            } else if (in) {
+                                a[u][s9] = F32 ? (double)__builtin_nontemporal_load(A.pk9_32 + (int64_t)s9 * A.npk9 + pbase + e)
+                                               : __builtin_nontemporal_load(A.pk9 + (int64_t)s9 * A.npk9 + pbase + e);
+                            } else {
+                                a[u][s9] = 0.0;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U9; ++u) {
+                        if constexpr (node4_of<XF>::value) {
+                            const float4 f = x.node4(c[u]);
+                            xx[u] = make_double2((double)f.x, (double)f.y);
+                            zz[u] = (double)f.z;                          // (zero pad for an (x, y)-only column node)
+                        } else {
+                            const int cf = c[u] < A.nfull ? c[u] : A.nfull;
+                            const int xo = 2 * c[u] + cf;
+                            xx[u] = x.two(xo);
+                            zz[u] = c[u] < A.nfull ? x.third(xo + 2) : 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U9; ++u) {
+                        const int e = e0 + u * NT;
+                        if (e < npe) {
+                            t.prod[e] = a[u][0] * xx[u].x + a[u][1] * xx[u].y + a[u][2] * zz[u];
+                            t.prod[npe + e] = a[u][3] * xx[u].x + a[u][4] * xx[u].y + a[u][5] * zz[u];
+                            if (full) t.prod[2 * npe + e] = a[u][6] * xx[u].x + a[u][7] * xx[u].y + a[u][8] * zz[u];
+                        }
+                    }
+                }
+            }
+        }
+        for (int e0 = tid; e0 < ((blk && !(N9 && A.pk9)) ? npe : 0); e0 += UP * NT) {
             int32_t c[UP];
             double2 kc[UP], xx[UP];
             double zz[UP];

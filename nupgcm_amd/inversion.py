@@ -97,6 +97,10 @@ class InversionToolkit:
                 # constant nu: K_xx = K_yy = K_zz and C_xy = -C_yx per node pair, stored once (no-op if the structure
                 # does not hold)
                 A.block_nodes(fe_data.dofs.n_full, fe_data.dofs.n_surf)
+            elif block_nodes and fe_data.dofs.n_full + fe_data.dofs.n_surf > 0 and os.environ.get("NPG_PACK_NODES", "1") != "0":
+                # function-valued nu / eddy closure (full-stress form): a record-form companion with FULL node records that
+                # follows every re-assembly; A itself stays plain (assembly target)
+                A.pack_nodes(fe_data.dofs.n_full, fe_data.dofs.n_surf)
             B = build_B_inversion(arch, fe_data, params, lift=b0)
             b0 = build_b_inversion(arch, fe_data, params, forcings, b0)
             # GPU preconditioner: Diagonal(1/h^dim) with the median edge length (src/inversion.jl:42-54)

@@ -335,6 +335,8 @@ def partitioned_model(arch, fe_data, params, forcings, ts, dist, atol=1e-6, rtol
         block_nodes = d.nu + d.np >= 100000
     if block_nodes and not full_stress:
         A.block_nodes(*part.local_nodes(rank))             # owned nodes lead the local numbering; ghost couplings stay CSR
+    elif block_nodes and sum(part.local_nodes(rank)) > 0 and os.environ.get("NPG_PACK_NODES", "1") != "0":
+        A.pack_nodes(*part.local_nodes(rank))              # full-stress form: record-form companion (follows re-assembly)
     rp, ci, shp = lay.local_pattern(fe_data.pattern_B(), lay.inv, lay.b, solver_cols=False)
     B = DeviceCSR.from_pattern(ctx, shp[0], shp[1], rp, ci)
     b0v = DeviceVector(ctx, lay.inv.n_own)

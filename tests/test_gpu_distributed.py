@@ -164,15 +164,22 @@ def test_distributed_multigrid_rehearsal(world, tmp_path):
     assert rel(z["b"], ref.state.b) < 1e-6 and rel(z["u"], ref.state.u) < 2e-3 and rel(z["p"], ref.state.p) < 2e-3
 
 
-def test_channel_basin_mesh_partitioned(tmp_path):
+@pytest.mark.parametrize("records", [False, True])
+def test_channel_basin_mesh_partitioned(tmp_path, records, monkeypatch):
     """BASELINE configs[4] on 3 ranks with the mesh partitioned: closures re-evaluated and K_v / the full-stress A
-    re-assembled on each rank's own cells (src/model.jl:160-170,229-261), CFL step from the global minimum."""
+    re-assembled on each rank's own cells (src/model.jl:160-170,229-261), CFL step from the global minimum.
+    records: every rank's row block with its record-form companion (full node records, npg_csr_pack_nodes - what production
+    sizes get), which follows the re-assembly of step 10."""
     from nupgcm_amd import channel_basin
+    if records:
+        monkeypatch.setenv("NPG_BLOCK_NODES", "1")          # (the workers inherit it; the serial reference below stays plain)
     world, nsteps = 3, 11
     arch = npg.GPU()
     mm = channel_basin.channel_basin_model(0.0625, workloads.CB_ALPHA)
+    monkeypatch.setenv("NPG_PACK_NODES", "0")
     ref = workloads.channel_basin_model(arch, mesh_model=mm, element_precision="fp64")
     npg.run(ref, n_steps=nsteps)
+    monkeypatch.delenv("NPG_PACK_NODES")
     out = str(tmp_path / "pcb")
     _launch(world, out, nsteps, "pchannel", "peer")
     ranks = [np.load(f"{out}.rank{k}.npz") for k in range(world)]

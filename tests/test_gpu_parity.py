@@ -666,6 +666,51 @@ def test_distributed_path_single_rank(arch):
         dist.destroy_process_group()
 
 
+def test_full_node_records(arch):
+    """npg_csr_pack_nodes: the full-stress matrix of a function-valued viscosity (all nine component pairs per node pair: no
+    {K, C} structure) gets a record-form companion - FULL node records, coupling records, column records - that SpMV and GMRES
+    read while the matrix itself stays plain (download, re-assembly); the companion follows a re-assembly with another
+    viscosity on the device.  Products equal the plain-CSR ones to rounding, solves agree to the solver tolerance."""
+    fed, prm, frc, dt, b0 = build_fe_data("bowl_mixing")
+    d = fed.dofs
+    nu1 = lambda x: 1.0 + 0.5 * np.sin(3.0 * x[..., 0]) * np.cos(2.0 * x[..., 2])
+    nu2 = lambda x: 0.7 + 0.2 * x[..., 1] ** 2 - 0.3 * x[..., 2]
+    A = npg.build_A_inversion(arch, fed, prm, nu1, structural=True)
+    ref1 = A.to_scipy_csr()
+    x = np.sin(np.arange(ref1.shape[1], dtype=float))
+    dx = npg.on_architecture(arch, x)
+    assert not A.block_nodes(d.n_full, d.n_surf)                 # nine pairs per node pair: the {K, C} form is refused
+    y_plain = A.mul(dx).to_host()
+    assert A.pack_nodes(d.n_full, d.n_surf)
+    assert A.coupling_records() == 0 and A.stored_spmv_bytes() < 0.9 * (12 * A.nnz + 8 * (A.shape[0] + 1) + 16 * A.shape[0])
+    assert np.array_equal(A.to_scipy_csr().data, ref1.data)      # the matrix itself is untouched ...
+    y1 = A.mul(dx).to_host()                                     # ... and products go through the records
+    assert rel(y1, ref1 @ x) < 1e-13 and rel(y1, y_plain) < 1e-13 and not np.array_equal(y1, y_plain)
+    # re-assembly in place with another viscosity: the companion follows
+    npg.build_A_inversion(arch, fed, prm, nu2, A=A)
+    ref2 = A.to_scipy_csr()
+    assert rel(ref2.data, ref1.data) > 1e-2
+    assert rel(A.mul(dx).to_host(), ref2 @ x) < 1e-13
+    # solves: packed against a plain matrix of the same values, fp32 gather copy on and off
+    h = fed.mesh.median_edge_length()
+    y = ref2 @ np.cos(np.arange(ref2.shape[1], dtype=float)) * 1e-3
+    dy = npg.on_architecture(arch, y)
+    P = npg.Diagonal(scalar=1 / h ** 3)
+    B = npg.build_A_inversion(arch, fed, prm, nu2, structural=True)
+    out = {}
+    for tag, M, gather in (("plain", B, 0), ("packed", A, 0), ("packed+gather", A, 1)):
+        ws = npg.GmresWorkspace(arch.ctx, ref2.shape[0], memory=20)
+        ws.set_basis(32)
+        ws.set_gather(gather)
+        st = ws.solve(M, dy, ws.x, P)
+        xs = ws.x.to_host()
+        assert st["solved"] == 1 and np.linalg.norm((y - ref2 @ xs) / h ** 3) <= 1.5 * (1e-6 + 1e-6 * st["rnorm0"])
+        out[tag] = (st["niter"], xs)
+    for tag in ("packed", "packed+gather"):
+        assert abs(out[tag][0] - out["plain"][0]) <= 0.06 * out["plain"][0], (tag, out[tag][0], out["plain"][0])
+        assert rel(out[tag][1], out["plain"][1]) < 2e-4
+
+
 def test_extrapolated_initial_guess(arch):
     """model.extrapolate_guess: every inversion of run! starts from 2 x_{n-1} - x_{n-2} (1) or from the quadratic extrapolation
     through three solutions (2) instead of the reference's warm start x_{n-1} (src/iterative_solvers.jl:26-29).  Same solver and
@@ -769,10 +814,15 @@ def test_bdf1_cfl_steps_against_oracle(arch, adaptive):
     assert rel(m.state.u, u) < 5e-3
 
 
-def test_closures_in_the_timestep_loop(arch):
+@pytest.mark.parametrize("records", [False, True])
+def test_closures_in_the_timestep_loop(arch, records, monkeypatch):
     """The channel-basin style path (scratch/run.jl): BDF1 with the adaptive CFL step, the convection closure
     refreshing kappa_v / K_v / rhs_diff / the LHS every step (src/model.jl:229-261) and the eddy closure re-assembling A
-    in the full-stress form every 10th step (src/model.jl:160-170) - 12 steps against the oracle's direct-solve recipe."""
+    in the full-stress form every 10th step (src/model.jl:160-170) - 12 steps against the oracle's direct-solve recipe.
+    records: the inversion matrix with its record-form companion (full node records, npg_csr_pack_nodes - what large systems
+    get), which has to follow the re-assembly of step 10."""
+    if records:
+        monkeypatch.setenv("NPG_BLOCK_NODES", "1")
     prm, frc, btags, bvals, dt, b0 = product_config("bowl_surface_flux")
     frc.conv_param = npg.ConvectionParameterization(kappa_c=0.5, N2min=0.5, is_on=True)
     frc.eddy_param = npg.EddyParameterization(f=prm.f, N2min=0.5, is_on=True)
@@ -784,9 +834,14 @@ def test_closures_in_the_timestep_loop(arch):
     inv = npg.InversionToolkit(arch, fed, prm, frc)
     evo = npg.EvolutionToolkit(arch, fed, prm, frc, ts)
     m = npg.Model(arch, prm, frc, fed, inv, evo, ts)
+    assert bool(getattr(inv.solver.A, "packed", False)) == records
     npg.set_b(m, lambda x: x[..., 2] / prm.alpha * (1 + 0.3 * np.sin(3 * x[..., 0])))     # unstable columns somewhere
     npg.invert(m)
     npg.run(m, n_steps=12)
+    if records:         # after the re-assembly of step 10 the companion still multiplies like the matrix it belongs to
+        A = inv.solver.A
+        xs = np.sin(np.arange(A.shape[1], dtype=float))
+        assert rel(A.mul(npg.on_architecture(arch, xs)).to_host(), A.to_scipy_csr() @ xs) < 1e-13
 
     S = rc.setup("bowl_surface_flux", b0=lambda x: x[..., 2] / 0.5 * (1 + 0.3 * np.sin(3 * x[..., 0])))
     u, p, b = rc.run(S, 12, solver="direct", scheme="BDF1", cfl_factor=0.3, adaptive=True, invert_first=True,
