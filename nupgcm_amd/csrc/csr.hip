@@ -296,7 +296,7 @@ NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double
     NPG_REQUIRE(A && blocked && nfull >= 0 && nsurf >= 0, "npg_csr_block_nodes: bad argument");
     const int64_t nf3 = 3 * nfull, nbr = nf3 + 2 * nsurf, nnode = nfull + nsurf;
     NPG_REQUIRE(nbr <= A->m && nbr <= A->n, "npg_csr_block_nodes: more block rows than the matrix has");
-    NPG_REQUIRE(A->nnode() == 0, "npg_csr_block_nodes: matrix is already stored by node blocks");
+    NPG_REQUIRE(A->nnode() == 0 && !A->packed, "npg_csr_block_nodes: matrix is already stored by node blocks (or has a record-form companion)");
     *blocked = 0;
     if (nnode == 0) return NPG_OK;
     NPG_HIP(hipStreamSynchronize(A->ctx->stream));
