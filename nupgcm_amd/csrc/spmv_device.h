@@ -251,7 +251,7 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
         if constexpr (N9) {
             // ---- full node records {c, a_00 .. a_22}: the same three product slots per record as the {c, K, C} form
             if (blk && A.pk9) {
-                constexpr int U9 = 2;
+                constexpr int U9 = 1;
                 for (int e0 = tid; e0 < npe; e0 += U9 * NT) {
                     int32_t c[U9];
                     double a[U9][9];
