@@ -63,8 +63,16 @@ class DeviceFE:
         return "fp32" if L.lib().npg_fe_get_precision(self.h) == L.NPG_FE_FP32 else "fp64"
 
     def set_coeff(self, name, v):
+        # the Coriolis table only ever changes through this call: setting the SAME function object again (every re-assembly of
+        # the eddy closure does, src/inversion.jl:149-170) would re-evaluate it at every quadrature point on the host for
+        # nothing - 0.4 s of the 0.6 s a re-assembly took at 3.9 M unknowns.  (nu / kappa tables are also rewritten on the
+        # device by the closures, so they are always re-set.)
+        if name == "f" and callable(v) and getattr(self, "_f_src", None) is v:
+            return
         tab = L.as_f64(eval_at_quad_points(self.fe_data.mesh, v))
         L.check(L.lib().npg_fe_set_coeff(self.h, name.encode(), L.ptr(tab)))
+        if name == "f":
+            self._f_src = v if callable(v) else None
 
     def new_matrix(self, kind, structural=False):
         """zero-valued DeviceCSR with the pattern of 'A', 'B' or 'b' (buoyancy-buoyancy)"""
