@@ -136,6 +136,20 @@ int npg_csr_pack_nodes(npg_csr *A, int64_t n_full, int64_t n_surf, int *packed);
 /* bytes of the matrix arrays one SpMV streams from HBM in the form the kernels read (records and their offset arrays, remaining
  * CSR entries, row offsets): plain CSR 12 nnz + 8 (m + 1); record forms as laid out by npg_csr_block_nodes / npg_csr_pack_nodes */
 int npg_csr_spmv_bytes(const npg_csr *A, int64_t *matrix_bytes);
+/* npg_csr_block_nodes also builds (NPG_SPMV_WINDOW=0: not) a WINDOWED tile set of the block rows for the Krylov kernels that
+ * gather their SpMV input from its fp32 gather-layout copy (npg_gmres_set_gather): every tile lists its distinct column nodes
+ * and distinct other columns, gathers each of them ONCE into an LDS window, and the node / column records address the window by
+ * 16-bit indices; a node's record list is padded to an even count with a zero record so that two adjacent records of one row
+ * node are summed before they reach LDS (csrc/spmv_window.h).  *tiles = tiles in that set (0: none), *block_tiles = how many of
+ * them are windowed block tiles, *distinct = entries of both window lists (= gathers of the input one product issues in the
+ * block rows), *matrix_bytes = what one product streams from HBM in that form (records with 2-byte indices, window lists,
+ * offsets, descriptors, and the coupling records / CSR entries of the rows behind the block rows). */
+int npg_csr_window_info(const npg_csr *A, int64_t *tiles, int64_t *block_tiles, int64_t *distinct, int64_t *matrix_bytes);
+/* y = A fl32(x): the product of the Krylov kernels' gather-layout instance as a call of its own - x is copied, rounded to fp32,
+ * into the gather layout (a node's components padded to 16 bytes) and multiplied in fp64 (synchronous).  windowed != 0: on the
+ * windowed tile set (an error without one), 0: on the ordinary tiles.  reps > 1 repeats the product (timing).  Only for matrices
+ * stored by {c, K, C} node blocks (npg_csr_block_nodes). */
+int npg_spmv_gather32(const npg_csr *A, const npg_vec *x, npg_vec *y, int windowed, int reps);
 /* dst.val[k] = src.val[map[k]]: a matrix whose entries are a fixed subset / rearrangement of another's - a rank's row block
  * of a replicated, re-assembled matrix (closure refreshes of K_v and A, src/model.jl:160-170,229-261, when the solve is
  * distributed).  npg_index = a device-resident int64 index array, every entry checked against `bound` at creation. */
@@ -198,7 +212,8 @@ int npg_gmres_set_basis(npg_gmres *ws, int bits);
  * from an fp32 copy of the Krylov vector laid out for gathering - a node's components padded to 16 bytes: one gather per node
  * record instead of two (the kernel is bound by its gather instructions).  The copy carries the rounding the
  * stored basis column has anyway; products and sums stay fp64.  mode: -1 = default (on where it applies; NPG_GMRES_XG=0 turns
- * the default off), 0 = off, 1 = on where it applies. */
+ * the default off), 0 = off, 1 = on where it applies, 2 = on, but on the matrix's ordinary tiles even when it has a windowed
+ * tile set (npg_csr_window_info; NPG_GMRES_WINDOW=0 makes that the default). */
 int npg_gmres_set_gather(npg_gmres *ws, int mode);
 int npg_gmres_set_split(npg_gmres *ws, int mode);
 int npg_gmres_get_profile(npg_gmres *ws, double *ms_total, int64_t *launches);

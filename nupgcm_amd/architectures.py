@@ -352,6 +352,23 @@ class DeviceCSR:
         m, n = self.shape
         return mb.value + 8 * n + 8 * m
 
+    def window_info(self):
+        """the windowed tile set of a node-blocked matrix (csrc/spmv_window.h): dict(tiles, block_tiles, distinct, bytes) -
+        bytes = what one product of the Krylov kernels' gather-layout instance streams from HBM (matrix + x + y); tiles = 0
+        without such a set"""
+        a, b, c, d = (C.c_int64() for _ in range(4))
+        L.check(L.lib().npg_csr_window_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        m, n = self.shape
+        return dict(tiles=a.value, block_tiles=b.value, distinct=c.value, bytes=d.value + (4 * c.value + 8 * m if a.value else 0))
+
+    def mul_gather32(self, x: DeviceVector, y: DeviceVector = None, windowed=True, reps=1):
+        """A * float32(x) in fp64 arithmetic: the product of the Krylov kernels' gather-layout instance (npg_spmv_gather32),
+        on the windowed tile set or on the ordinary tiles"""
+        if y is None:
+            y = DeviceVector(self.ctx, self.shape[0])
+        L.check(L.lib().npg_spmv_gather32(self.h, x.h, y.h, int(bool(windowed)), int(reps)))
+        return y
+
     def mul(self, x: DeviceVector, y: DeviceVector = None, alpha=1.0, beta=0.0):
         """mul!(y, A, x) / A*x"""
         if y is None:

@@ -44,10 +44,13 @@ constexpr int kTileRows = 256;     // most rows in one SpMV tile
 constexpr int kMaxMem = 30;        // largest GMRES memory supported (partial rows hold mem + 2 values)
 
 // one SpMV tile: rows [r0, r0 + nrows), its n CSR entries from `base` and (node-block rows) npe records from `pbase`.
-// 32 bytes = one scalar load; kernels fetch the next tile's descriptor while they work on the current one.
+// Kernels fetch the next tile's descriptor while they work on the current one.
+// Windowed block tiles (spmv_window.h; nw > 0): the tile's distinct column nodes wlist[woff .. woff + nw) and distinct other
+// columns vlist[voff .. voff + nv) are gathered ONCE into LDS; the records address them by 16-bit window indices.
 struct TileDesc {
     int64_t base, pbase;
     int32_t r0, nrows, n, npe;
+    int32_t woff, voff, nw, nv;      // zero in ordinary tiles
 };
 
 }  // namespace npg
@@ -126,6 +129,19 @@ struct npg_csr {
     float *pk9_32 = nullptr;
     int64_t npk9 = 0;
     int64_t *map9 = nullptr, *mapd = nullptr, *mapg = nullptr, *maprem = nullptr;   // device, same layouts as pk9 / dval / gval / val
+    // windowed tile set of the block rows (spmv_window.h, build_window_tiles): a SECOND tiling of the same matrix for the
+    // kernels that gather from the fp32 gather-layout copy of their input - every node's record list padded to an even
+    // count (zero records), 16-bit window indices beside pcol / gcol, per-tile lists of distinct columns
+    npg::TileDesc *wtile_ptr = nullptr; // device, nwtiles descriptors: windowed block tiles, then the ordinary tiles of the other rows
+    int32_t nwtiles = 0, nwtiles_interior = 0;
+    int32_t wlanes = 8;
+    uint16_t *widx = nullptr;    // device, window index of every node record (same indexing as pcol)
+    uint16_t *gidx = nullptr;    // device, window index of every column record (same indexing as gcol)
+    int32_t *wlist = nullptr;    // device, concatenated per-tile lists of distinct column nodes (ascending per tile)
+    int32_t *vlist = nullptr;    // device, concatenated per-tile lists of distinct columns of the column records
+    int64_t nwlist = 0, nvlist = 0;
+    int64_t nrec_real = 0;       // node records without the zero records that pad a node's list to an even count
+    std::vector<npg::TileDesc> h_tiles;   // host copy of tile_ptr (final order)
     // optional fp32 copies of the values (csr_refresh_fp32): read instead of val / pkc by SpMVs that ask for them
     // (SpmvEpi::f32 - the multigrid preconditioner's; results are still accumulated and returned in fp64)
     float *val32 = nullptr, *pkc32 = nullptr;

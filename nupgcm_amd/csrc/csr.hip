@@ -3,6 +3,7 @@
 
 #include "common.h"
 #include "spmv_device.h"
+#include "spmv_window.h"
 
 namespace npg {
 
@@ -85,6 +86,7 @@ int build_tiles(npg_csr *A) {
         q.n = (int32_t)(rp[r1] - rp[r0]);
         q.pbase = 0;
         q.npe = 0;
+        q.woff = q.voff = q.nw = q.nv = 0;
         if (r0 < nbr) {
             q.pbase = A->h_prow[node(r0)];
             q.npe = (int32_t)(A->h_prow[node(r1)] - q.pbase);
@@ -102,6 +104,7 @@ int build_tiles(npg_csr *A) {
     NPG_HIP(hipMalloc((void **)&A->tile_ptr, std::max<size_t>(1, td.size()) * sizeof(TileDesc)));
     NPG_HIP(hipMemcpy(A->tile_ptr, td.data(), td.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
     A->ntiles_interior = A->ntiles;
+    A->h_tiles = td;
     if (A->n > A->m && A->ntiles > 0 && (A->rnnz > 0 || A->ngrec > 0)) {
         // row block of a distributed matrix: tiles that read no ghost column come first, so that a solver can run them
         // while the halo exchange is in flight (record columns are owned nodes by construction: only the CSR part counts)
@@ -122,7 +125,146 @@ int build_tiles(npg_csr *A) {
             if (pass == 0) A->ntiles_interior = (int32_t)ord.size();
         }
         NPG_HIP(hipMemcpy(A->tile_ptr, ord.data(), ord.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+        A->h_tiles = ord;
     }
+    return NPG_OK;
+}
+
+static void free_window_tiles(npg_csr *A) {
+    for (void *p : {(void *)A->wtile_ptr, (void *)A->widx, (void *)A->gidx, (void *)A->wlist, (void *)A->vlist})
+        if (p) hipFree(p);
+    A->wtile_ptr = nullptr;
+    A->widx = A->gidx = nullptr;
+    A->wlist = A->vlist = nullptr;
+    A->nwtiles = A->nwtiles_interior = 0;
+    A->nwlist = A->nvlist = 0;
+}
+
+// The windowed tile set of a node-blocked matrix in all-record form (spmv_window.h): a second tiling of the block rows whose
+// tiles are sized by what they need in LDS - pair-summed products, column-record products, the window of distinct column
+// nodes (16 B each) and of distinct other columns (4 B each) - followed by the ordinary tiles of the rows behind the block
+// rows.  pcol / gcol: host copies of the record columns (every node's list already padded to an even count).
+// Leaves the matrix without a windowed set (no error) when some node's rows would not fit a tile.
+static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, const std::vector<int32_t> &gcol) {
+    free_window_tiles(A);
+    const int64_t nnode = A->nnode(), nfull = A->nfull, nbr = A->block_rows();
+    if (nnode == 0 || !A->grow || A->pk9) return NPG_OK;
+    const std::vector<int64_t> &prow = A->h_prow, &grow = A->h_grow;
+    constexpr int NT = 512;
+    const int64_t hard = 8 * (int64_t)kTileNnz;
+    // small matrices: about one tile per CU (as tile_boundaries does)
+    const int64_t total = 8 * (3 * (prow[nfull] / 2 + grow[nfull]) + 2 * ((prow[nnode] - prow[nfull]) / 2 + grow[nnode] - grow[nfull]));
+    const int64_t soft = std::min<int64_t>(hard, std::max<int64_t>(8 * 1024, total / std::max(1, A->ctx->num_cu)));
+    std::vector<int32_t> stampW((size_t)nnode, -1), stampV((size_t)A->n, -1), posW((size_t)nnode, 0), posV((size_t)A->n, 0);
+    std::vector<uint16_t> widx(pcol.size()), gidx(gcol.size());
+    std::vector<int32_t> wlist, vlist, tw, tv, nwl, nvl;
+    std::vector<TileDesc> blk;
+    std::vector<char> ghost;
+    auto bytes_of = [](int ncomp, int64_t np, int64_t ng, int64_t nw, int64_t nv) {
+        const int64_t slots = ncomp * (np + ng);
+        return 8 * ((slots + 1) & ~(int64_t)1) + 16 * nw + 4 * nv;
+    };
+    for (int kind = 0; kind < 2; ++kind) {
+        const int64_t lo = kind ? nfull : 0, hi = kind ? nnode : nfull;
+        const int ncomp = kind ? 2 : 3;
+        int64_t q = lo;
+        while (q < hi) {
+            const int32_t T = (int32_t)blk.size();
+            tw.clear();
+            tv.clear();
+            int64_t np = 0, ng = 0, qe = q;
+            while (qe < hi) {
+                nwl.clear();
+                nvl.clear();
+                for (int64_t e = prow[qe]; e < prow[qe + 1]; ++e)
+                    if (stampW[pcol[e]] != T) {
+                        stampW[pcol[e]] = T;
+                        nwl.push_back(pcol[e]);
+                    }
+                for (int64_t e = grow[qe]; e < grow[qe + 1]; ++e)
+                    if (stampV[gcol[e]] != T) {
+                        stampV[gcol[e]] = T;
+                        nvl.push_back(gcol[e]);
+                    }
+                const int64_t np2 = np + (prow[qe + 1] - prow[qe]) / 2, ng2 = ng + (grow[qe + 1] - grow[qe]);
+                const int64_t nw2 = (int64_t)(tw.size() + nwl.size()), nv2 = (int64_t)(tv.size() + nvl.size());
+                const int64_t by = bytes_of(ncomp, np2, ng2, nw2, nv2);
+                const bool shape = (qe + 1 - q) * ncomp <= kTileRows && np2 <= kWinPairs * NT && ng2 <= kWinCols * NT &&
+                                   nw2 <= kWinNodes * NT && nv2 <= NT;
+                if (qe == q && !(shape && by <= hard)) return NPG_OK;       // one node's rows do not fit: no windowed set
+                if (qe > q && !(shape && by <= soft)) {
+                    for (int32_t c : nwl) stampW[c] = -1;
+                    for (int32_t c : nvl) stampV[c] = -1;
+                    break;
+                }
+                tw.insert(tw.end(), nwl.begin(), nwl.end());
+                tv.insert(tv.end(), nvl.begin(), nvl.end());
+                np = np2;
+                ng = ng2;
+                ++qe;
+            }
+            std::sort(tw.begin(), tw.end());
+            std::sort(tv.begin(), tv.end());
+            for (size_t i = 0; i < tw.size(); ++i) posW[tw[i]] = (int32_t)i;
+            for (size_t i = 0; i < tv.size(); ++i) posV[tv[i]] = (int32_t)i;
+            for (int64_t e = prow[q]; e < prow[qe]; ++e) widx[e] = (uint16_t)posW[pcol[e]];
+            for (int64_t e = grow[q]; e < grow[qe]; ++e) gidx[e] = (uint16_t)posV[gcol[e]];
+            TileDesc d;
+            d.r0 = (int32_t)(kind ? 3 * nfull + 2 * (q - nfull) : 3 * q);
+            d.nrows = (int32_t)((qe - q) * ncomp);
+            d.base = grow[q];
+            d.n = (int32_t)ng;
+            d.pbase = prow[q];
+            d.npe = (int32_t)(2 * np);
+            d.woff = (int32_t)wlist.size();
+            d.nw = (int32_t)tw.size();
+            d.voff = (int32_t)vlist.size();
+            d.nv = (int32_t)tv.size();
+            NPG_REQUIRE(d.nw > 0, "build_window_tiles: a block tile without column nodes");
+            wlist.insert(wlist.end(), tw.begin(), tw.end());
+            vlist.insert(vlist.end(), tv.begin(), tv.end());
+            blk.push_back(d);
+            ghost.push_back(!tv.empty() && tv.back() >= A->m);          // (record columns are owned nodes by construction)
+            q = qe;
+        }
+    }
+    NPG_REQUIRE(wlist.size() < (size_t)INT32_MAX && vlist.size() < (size_t)INT32_MAX, "build_window_tiles: window lists exceed int32 offsets");
+    // the tiles of the rows behind the block rows, as build_tiles made (and ordered) them
+    std::vector<TileDesc> ord;
+    ord.reserve(blk.size() + A->h_tiles.size());
+    int32_t nint = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (size_t t = 0; t < blk.size(); ++t)
+            if ((ghost[t] != 0) == (pass == 1)) ord.push_back(blk[t]);
+        for (int32_t t = 0; t < A->ntiles; ++t)
+            if (A->h_tiles[t].r0 >= nbr && (t >= A->ntiles_interior) == (pass == 1)) ord.push_back(A->h_tiles[t]);
+        if (pass == 0) nint = (int32_t)ord.size();
+    }
+    auto up = [&](void **dst, const void *src, size_t bytes) -> int {
+        NPG_HIP(hipMalloc(dst, std::max<size_t>(bytes, 16)));
+        if (bytes) NPG_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return NPG_OK;
+    };
+    int rc = NPG_OK;
+    auto chk = [&](int r) { if (rc == NPG_OK) rc = r; };
+    chk(up((void **)&A->wtile_ptr, ord.data(), ord.size() * sizeof(TileDesc)));
+    chk(up((void **)&A->widx, widx.data(), widx.size() * sizeof(uint16_t)));
+    chk(up((void **)&A->gidx, gidx.data(), gidx.size() * sizeof(uint16_t)));
+    chk(up((void **)&A->wlist, wlist.data(), wlist.size() * sizeof(int32_t)));
+    chk(up((void **)&A->vlist, vlist.data(), vlist.size() * sizeof(int32_t)));
+    if (rc != NPG_OK) {
+        free_window_tiles(A);
+        return rc;
+    }
+    A->nwtiles = (int32_t)ord.size();
+    A->nwtiles_interior = nint;
+    A->nwlist = (int64_t)wlist.size();
+    A->nvlist = (int64_t)vlist.size();
+    // lanes per node in the segmented sums of a windowed tile: ~75 nodes per tile and a lane takes two slots per trip
+    const double mean = (double)(prow[nnode] / 2 + grow[nnode]) / (double)nnode;
+    A->wlanes = mean <= 40 ? 4 : 8;
+    if (getenv("NPG_SPMV_WLANES")) A->wlanes = atoi(getenv("NPG_SPMV_WLANES")) == 8 ? 8 : 4;
+    A->gen++;
     return NPG_OK;
 }
 
@@ -282,6 +424,10 @@ CsrDev csr_view(const npg_csr *A) {
     v.pk9 = A->pk9;
     v.pk9_32 = A->pk9_32;
     v.npk9 = A->npk9;
+    v.widx = A->widx;
+    v.gidx = A->gidx;
+    v.wlist = A->wlist;
+    v.vlist = A->vlist;
     return v;
 }
 
@@ -315,6 +461,10 @@ NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double
     nval.reserve((size_t)A->nnz / 2);
     // first DoF of column node c / node and component of a block column
     auto first = [&](int64_t c) { return c < nfull ? 3 * c : nf3 + 2 * (c - nfull); };
+    // windowed tile set (spmv_window.h; NPG_SPMV_WINDOW=0: none): every node's record list is padded to an even count
+    const char *we = getenv("NPG_SPMV_WINDOW");
+    const bool want_win = !(we && atoi(we) == 0);
+    int64_t nrec_real = 0;
     for (int64_t q = 0; q < nnode; ++q) {
         const bool qfull = q < nfull;
         const int64_t rx = first(q), ry = rx + 1, rz = rx + 2;
@@ -344,6 +494,12 @@ NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double
         // nothing of the block may be left in the y and z rows
         if (ib < b1 && col[ib] < nbr) return NPG_OK;
         if (qfull && iz < z1 && col[iz] < nbr) return NPG_OK;
+        nrec_real += (int64_t)pcol.size() - prow[q];
+        if (want_win && (((int64_t)pcol.size() - prow[q]) & 1)) {        // zero record on the node's last column node
+            pcol.push_back(pcol.back());
+            pkc.push_back(0.0);
+            pkc.push_back(0.0);
+        }
         prow[q + 1] = (int64_t)pcol.size();
         const int64_t lo[3] = {ia, ib, iz}, hi[3] = {a1, b1, z1};
         // what is left of the node's rows (columns outside the block): as column records {m, a_x, a_y, a_z} - a three-way
@@ -473,8 +629,10 @@ NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double
     A->rnnz = (int64_t)ncol.size();
     A->nfull = (int32_t)nfull;
     A->nsurf = (int32_t)nsurf;
+    A->nrec_real = nrec_real;
     int rc = build_tiles(A);
     if (rc) return rc;
+    if (want_win && colrec && (rc = build_window_tiles(A, pcol, gcolv))) return rc;
     *blocked = 1;
     return NPG_OK;
 }
@@ -746,6 +904,7 @@ NPG_API int npg_csr_destroy(npg_csr *A) {
     if (A->dcol) hipFree(A->dcol);
     if (A->dval) hipFree(A->dval);
     if (A->dval32) hipFree(A->dval32);
+    free_window_tiles(A);
     delete A;
     return NPG_OK;
 }
@@ -761,7 +920,7 @@ NPG_API int npg_csr_shape(const npg_csr *A, int64_t *m, int64_t *n, int64_t *nnz
 NPG_API int npg_csr_storage(const npg_csr *A, int64_t *npairs, int64_t *paired_records, int64_t *csr_entries) {
     NPG_REQUIRE(A, "npg_csr_storage: NULL matrix");
     if (npairs) *npairs = A->nnode();
-    if (paired_records) *paired_records = A->nnode() ? A->h_prow[A->nnode()] : 0;
+    if (paired_records) *paired_records = A->nnode() ? (A->pk9 ? A->h_prow[A->nnode()] : A->nrec_real) : 0;      // (without zero-record padding)
     if (csr_entries) *csr_entries = A->rnnz;
     return NPG_OK;
 }
@@ -775,6 +934,33 @@ NPG_API int npg_csr_spmv_bytes(const npg_csr *Ap, int64_t *matrix_bytes) {
     if (A->grow) b += 8 * (nnode + 1) + 28 * A->ngrec;
     if (A->drow) b += 8 * (A->m - A->block_rows() + 1) + 28 * A->ndrec;
     *matrix_bytes = b;
+    return NPG_OK;
+}
+
+NPG_API int npg_csr_window_info(const npg_csr *Ap, int64_t *tiles, int64_t *block_tiles, int64_t *distinct, int64_t *matrix_bytes) {
+    NPG_REQUIRE(Ap, "npg_csr_window_info: NULL matrix");
+    const npg_csr *A = spmv_form(Ap);
+    int64_t nblk = 0;
+    if (A->wtile_ptr) {
+        // (block tiles are the descriptors with a window: count them from the lists' owner - every block tile has nw > 0)
+        const int64_t nbr = A->block_rows();
+        int64_t behind = 0;
+        for (const npg::TileDesc &t : A->h_tiles) behind += t.r0 >= nbr;
+        nblk = A->nwtiles - behind;
+    }
+    if (tiles) *tiles = A->nwtiles;
+    if (block_tiles) *block_tiles = nblk;
+    if (distinct) *distinct = A->nwlist + A->nvlist;
+    if (matrix_bytes) {
+        int64_t b = 0;
+        if (A->wtile_ptr) {
+            const int64_t nnode = A->nnode(), nrec = A->h_prow[nnode];
+            b = 48 * (int64_t)A->nwtiles + 18 * nrec + 26 * A->ngrec + 4 * (A->nwlist + A->nvlist) + 16 * (nnode + 1) +
+                12 * A->rnnz + 8 * (A->m - A->block_rows() + 1);
+            if (A->drow) b += 8 * (A->m - A->block_rows() + 1) + 28 * A->ndrec;
+        }
+        *matrix_bytes = b;
+    }
     return NPG_OK;
 }
 
@@ -1051,6 +1237,83 @@ int spmv_raw(const npg_csr *A, const double *x, double *y, double alpha, double 
     return spmv_epi(A, x, e);
 }
 }  // namespace npg
+
+namespace npg {
+__global__ void k_fill_gather32(const double *__restrict__ x, GatherMap g, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        g.p[g.pos((int)i)] = (float)x[i];
+}
+
+// y = A x with x read from its fp32 gather-layout copy: the SpMV of the Krylov kernels' gather-layout instance, stand-alone.
+// WL > 0: the matrix's windowed tile set (block tiles gather every distinct column once into LDS); 0: its ordinary tiles.
+template <int L, int WL>
+__global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32(CsrDev A, const TileDesc *__restrict__ tiles, int ntiles, GatherMap g,
+                                                            double *__restrict__ y) {
+    __shared__ TileLds tl;
+    __shared__ double sw[kTileRows];
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    TileDesc td = tiles[t];
+    while (true) {
+        const int tn = t + gridDim.x;
+        TileDesc nd = td;
+        if (tn < ntiles) nd = tiles[tn];
+        if (WL != 0 && td.nw)
+            spmv_tile_win<kSpmvThreads, (WL ? WL : 4)>(A, PaddedX{g}, td, tl, sw);
+        else
+            spmv_tile<kSpmvThreads, L, PaddedX, kTileNnz, 2, NoProf, false, true, false>(A, PaddedX{g}, td, tl, sw);
+        for (int r = threadIdx.x; r < td.nrows; r += kSpmvThreads) y[td.r0 + r] = sw[r];
+        if (tn >= ntiles) break;
+        t = tn;
+        td = nd;
+    }
+}
+
+template <int L>
+static void launch_spmv_g32(const npg_csr *A, const GatherMap &g, double *y, bool win) {
+    const TileDesc *tiles = win ? A->wtile_ptr : A->tile_ptr;
+    const int nt = win ? A->nwtiles : A->ntiles;
+    const dim3 grid(std::max(1, std::min<int>(nt, 3 * A->ctx->num_cu))), blk(kSpmvThreads);
+    if (win && A->wlanes == 8)
+        hipLaunchKernelGGL((k_spmv_g32<L, 8>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y);
+    else if (win)
+        hipLaunchKernelGGL((k_spmv_g32<L, 4>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y);
+    else
+        hipLaunchKernelGGL((k_spmv_g32<L, 0>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y);
+}
+}  // namespace npg
+
+// y = A fl32(x): the product the Krylov kernels' gather-layout instance forms (npg_gmres_set_gather) as a call of its own - x
+// is first copied, rounded to fp32, into the gather layout of spmv_device.h (a node's components padded to 16 bytes), then
+// multiplied in fp64.  windowed != 0: on the matrix's windowed tile set (npg_csr_window_info; an error if it has none).
+// `reps` > 1 repeats the product (timing loops: the copy is made once).
+NPG_API int npg_spmv_gather32(const npg_csr *A, const npg_vec *x, npg_vec *y, int windowed, int reps) {
+    NPG_REQUIRE(A && x && y, "npg_spmv_gather32: NULL argument");
+    NPG_REQUIRE(x->n == A->n && y->n == A->m, "npg_spmv_gather32: A is %lld x %lld but x has %lld and y has %lld entries",
+                (long long)A->m, (long long)A->n, (long long)x->n, (long long)y->n);
+    NPG_REQUIRE(A->nnode() > 0 && !A->pk9 && !A->packed, "npg_spmv_gather32: the matrix is not stored by {c, K, C} node blocks");
+    NPG_REQUIRE(!windowed || A->wtile_ptr, "npg_spmv_gather32: the matrix has no windowed tile set");
+    NPG_HIP(hipSetDevice(A->ctx->device));
+    const int64_t nbr = A->block_rows(), need = 4 * A->nnode() + (A->n - nbr) + 8;
+    float *buf = nullptr;
+    NPG_HIP(hipMalloc((void **)&buf, (size_t)need * sizeof(float)));
+    NPG_HIP(hipMemsetAsync(buf, 0, (size_t)need * sizeof(float), A->ctx->stream));
+    const GatherMap g{buf, 3 * A->nfull, A->nfull, (int)nbr, (int)(4 * A->nnode() - nbr)};
+    hipLaunchKernelGGL(k_fill_gather32, dim3((unsigned)std::min<int64_t>(4096, (A->n + 255) / 256)), dim3(256), 0, A->ctx->stream, x->d, g,
+                       A->n);
+    for (int r = 0; r < std::max(1, reps); ++r) switch (A->lanes) {
+            case 4: launch_spmv_g32<4>(A, g, y->d, windowed != 0); break;
+            case 8: launch_spmv_g32<8>(A, g, y->d, windowed != 0); break;
+            case 16: launch_spmv_g32<16>(A, g, y->d, windowed != 0); break;
+            default: launch_spmv_g32<32>(A, g, y->d, windowed != 0); break;
+        }
+    hipError_t e = hipGetLastError();
+    hipError_t e2 = hipStreamSynchronize(A->ctx->stream);
+    hipFree(buf);
+    NPG_HIP(e);
+    NPG_HIP(e2);
+    return NPG_OK;
+}
 
 NPG_API int npg_spmv(const npg_csr *A, const npg_vec *x, npg_vec *y, double alpha, double beta) {
     NPG_REQUIRE(A && x && y, "npg_spmv: NULL argument");

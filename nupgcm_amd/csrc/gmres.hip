@@ -36,6 +36,7 @@
 
 #include "common.h"
 #include "spmv_device.h"
+#include "spmv_window.h"
 
 namespace npg {
 
@@ -62,6 +63,8 @@ struct GDev {
     const TileDesc *tile_ptr;
     int ntiles, n, mem;
     int nt_int;           // tiles [0, nt_int) read no ghost column (distributed row blocks; = ntiles otherwise)
+    const TileDesc *wt_ptr;   // windowed tile set (spmv_window.h) for the Arnoldi kernel's gather-layout instance; null: none
+    int nwt, nwt_int, wl; // wl: lanes per node in a windowed tile's segmented sums (4 or 8)
     int pkind;
     double pscalar;
     const double *pdiag;
@@ -307,8 +310,11 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_residual(GDev d) {
 // XG: the SpMV input is gathered from the fp32 gather-layout copy of wt (GDev::xg; no second Gram-Schmidt pass in that mode):
 // 1 = node-blocked matrix (records), 2 = plain CSR matrix (the copy is then simply the vector in fp32: 4-byte gathers).
 // N9: the matrix may hold FULL node records (spmv_device.h).
-template <int L, bool FUSED, int XG = 0, bool N9 = false>
+// WL > 0: the tiles come from the matrix's WINDOWED set (spmv_window.h; XG = 1 only): block tiles gather every distinct column
+// once into LDS, WL lanes per node in their segmented sums; the tiles of the other rows are the ordinary ones.
+template <int L, bool FUSED, int XG = 0, bool N9 = false, int WL = 0>
 __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, int j, int t0, int t1) {
+    static_assert(WL == 0 || (XG == 1 && !N9 && !FUSED), "windowed tiles serve the gather-layout instance of the split organisation");
     __shared__ KShared sh;
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
@@ -349,10 +355,11 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
     const bool ro = XG == 0 && sh.reorth != 0;        // (the gather-layout instance runs in fast mode: never a second pass)
     const double h2k = (ro && k < j) ? sh.h2[k] : 0.0;
     double acc = 0.0;
-    TileDesc nd = d.tile_ptr[t0 + (int)blockIdx.x < t1 ? t0 + (int)blockIdx.x : 0];
+    const TileDesc *__restrict__ tiles = WL ? d.wt_ptr : d.tile_ptr;
+    TileDesc nd = tiles[t0 + (int)blockIdx.x < t1 ? t0 + (int)blockIdx.x : 0];
     for (int t = t0 + blockIdx.x; t < t1; t += gridDim.x) {
         const TileDesc td = nd;
-        if (t + (int)gridDim.x < t1) nd = d.tile_ptr[t + gridDim.x];      // in flight during this tile
+        if (t + (int)gridDim.x < t1) nd = tiles[t + gridDim.x];      // in flight during this tile
         const int r0 = td.r0, r1 = td.r0 + td.nrows;
         // split mode: this thread's row of wt for the epilogue, fetched now so that its latency hides behind the tile
         // (a tile has at most kTileRows <= kKB rows: one row per thread)
@@ -362,7 +369,12 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
         // one instantiation for both cases: without a second pass the correction loop has no trips
         if constexpr (XG == 2)
             spmv_tile<kKB, L>(d.A, PaddedX{d.xg}, td, tl, sw);
-        else if constexpr (XG == 1)
+        else if constexpr (WL != 0) {
+            if (td.nw)
+                spmv_tile_win<kKB, WL>(d.A, PaddedX{d.xg}, td, tl, sw);
+            else
+                spmv_tile<kKB, L, PaddedX, kTileNnz, 2, NoProf, false, true, false>(d.A, PaddedX{d.xg}, td, tl, sw);
+        } else if constexpr (XG == 1)
             // (node-blocked by definition: hardly any CSR entries - two pairs per lane there keep the records' loops inside the
             //  register budget)
             spmv_tile<kKB, L, PaddedX, kTileNnz, 2, NoProf, false, true, N9>(d.A, PaddedX{d.xg}, td, tl, sw);
@@ -901,6 +913,11 @@ static void launch_arnoldi_split(const GDev &d, int grid, int j, int t0, int t1,
             hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 0, true>), g, b, 0, st, d, j, t0, t1);
     } else if (d.xg.p && d.xg.nbr == 0) {
         hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 2>), g, b, 0, st, d, j, t0, t1);
+    } else if (d.xg.p && d.wt_ptr) {
+        if (d.wl == 8)
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1, false, 8>), g, b, 0, st, d, j, t0, t1);
+        else
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1, false, 4>), g, b, 0, st, d, j, t0, t1);
     } else if (d.xg.p) {
         hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1>), g, b, 0, st, d, j, t0, t1);
     } else {
@@ -927,7 +944,9 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
     static const int overlap_env = getenv("NPG_HALO_OVERLAP") ? atoi(getenv("NPG_HALO_OVERLAP")) : -1;
     const bool kernel_only = dist && comm_is_kernel_only(ws->ctx);
     const int want = !dist ? 0 : ws->halo_overlap >= 0 ? ws->halo_overlap : (overlap_env >= 0 ? overlap_env : (kernel_only || ws->ctx->shm ? 1 : 0));
-    const bool overlap = dist && d.split && want && d.nt_int > 0 && d.nt_int < d.ntiles;
+    // tile range of the Arnoldi launches: the windowed set where the gather-layout instance has one
+    const int a_nt = d.wt_ptr ? d.nwt : d.ntiles, a_int = d.wt_ptr ? d.nwt_int : d.nt_int;
+    const bool overlap = dist && d.split && want && a_int > 0 && a_int < a_nt;
     const int maxg = ws ? std::min(kMaxG, 3 * ws->ctx->num_cu) : kMaxG;
     static const int reserve_env = getenv("NPG_HALO_RESERVE_CUS") ? atoi(getenv("NPG_HALO_RESERVE_CUS")) : 4;
     const int reserve = std::max(0, std::min(reserve_env, maxg / 6));
@@ -936,7 +955,7 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
         const int now = (overlap ? 2 : 0) + (d.split ? 1 : 0);
         if (now != last && (last = now, true))
             fprintf(stderr, "halo overlap %s: %d interior / %d boundary tiles per Arnoldi step (split %d)\n", overlap ? "on" : "off",
-                    d.nt_int, d.ntiles - d.nt_int, d.split);
+                    a_int, a_nt - a_int, d.split);
     }
     // distributed + gather-layout input: the ghosts of wt are also stored as floats behind the owned part of the copy
     float *g32 = (dist && d.xg.p) ? d.xg.p + d.xg.pos(d.n) : nullptr;
@@ -948,16 +967,16 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
             // tile) and RCCL's send/recv kernels on the other stream could otherwise not start before they are all done.  Peer
             // windows: nothing of ours runs beside it (the neighbours' stores need no CU here): full grid.
             const int gi = kernel_only ? maxg : maxg - 3 * reserve;
-            launch_arnoldi_split<L>(d, std::min(d.nt_int, gi), j, 0, d.nt_int, st);
+            launch_arnoldi_split<L>(d, std::min(a_int, gi), j, 0, a_int, st);
             if ((rc = halo_exchange_wait(ws->halo))) return rc;
-            launch_arnoldi_split<L>(d, std::min(d.ntiles - d.nt_int, maxg), j, d.nt_int, d.ntiles, st);
+            launch_arnoldi_split<L>(d, std::min(a_nt - a_int, maxg), j, a_int, a_nt, st);
             if (pev) hipEventRecord(pev[2 * j + 1], st);
             launch_rows_kernel(d, j, st, false);
         } else {
         if (dist && (rc = halo_exchange_raw(ws->halo, d.wt, g32))) return rc;
         if (pev) hipEventRecord(pev[2 * j], st);
         if (d.split) {
-            launch_arnoldi_split<L>(d, d.G1, j, 0, d.ntiles, st);
+            launch_arnoldi_split<L>(d, std::min(d.G1, std::max(1, a_nt)), j, 0, a_nt, st);
             if (pev) hipEventRecord(pev[2 * j + 1], st);
             launch_rows_kernel(d, j, st, false);
         } else {
@@ -1191,6 +1210,14 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A_in, int precond_kind
             ws->xg_key[2] = (int)A->n;
         }
         d.xg = GatherMap{ws->xg, 3 * A->nfull, A->nfull, (int)nbr, (int)(4 * A->nnode() - nbr)};
+        // windowed tile set of the block rows (spmv_window.h; NPG_GMRES_WINDOW=0: the ordinary tiles)
+        static const int win_env = getenv("NPG_GMRES_WINDOW") ? atoi(getenv("NPG_GMRES_WINDOW")) : 1;
+        if (win_env && ws->gather32 != 2 && d.split && A->wtile_ptr && !A->pk9 && nbr > 0) {
+            d.wt_ptr = A->wtile_ptr;
+            d.nwt = A->nwtiles;
+            d.nwt_int = A->nwtiles_interior;
+            d.wl = A->wlanes;
+        }
     }
     if (dist) {
         d.Q1 = ws->Rg;
@@ -1435,8 +1462,9 @@ NPG_API int npg_gmres_set_basis(npg_gmres *ws, int bits) {
 }
 
 NPG_API int npg_gmres_set_gather(npg_gmres *ws, int mode) {
-    NPG_REQUIRE(ws && mode >= -1 && mode <= 1, "npg_gmres_set_gather: mode must be -1 (default), 0 or 1");
+    NPG_REQUIRE(ws && mode >= -1 && mode <= 2, "npg_gmres_set_gather: mode must be -1 (default), 0, 1 or 2");
     ws->gather32 = mode;
+    ws->have_graph = false;
     return NPG_OK;
 }
 

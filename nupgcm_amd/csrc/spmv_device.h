@@ -79,6 +79,10 @@ struct CsrDev {
     const double *pk9;
     const float *pk9_32;
     int64_t npk9;
+    // windowed tile set (spmv_window.h): 16-bit window indices of the node records / column records and the per-tile lists
+    // of distinct column nodes / other columns (TileDesc::woff, voff index them); null without it
+    const uint16_t *widx, *gidx;
+    const int32_t *wlist, *vlist;
 };
 
 __device__ __forceinline__ int block_rows(const CsrDev &A) { return 3 * A.nfull + 2 * A.nsurf; }
@@ -131,6 +135,8 @@ struct PaddedX {
     GatherMap g;
     __device__ __forceinline__ double operator()(int c) const { return (double)g.p[g.pos(c)]; }
     __device__ __forceinline__ float4 node4(int c) const { return *reinterpret_cast<const float4 *>(g.p + 4 * (size_t)c); }
+    // entry i behind the block rows (pressure rows, a rank's ghosts) as stored
+    __device__ __forceinline__ float behind(int i) const { return g.p[i + g.off]; }
     __device__ __forceinline__ double2 two(int i) const { return make_double2((*this)(i), (*this)(i + 1)); }
     __device__ __forceinline__ double third(int i) const { return (*this)(i); }
 };
@@ -142,7 +148,7 @@ struct NoProf {
 
 template <int TNNZ>
 struct TileLdsT {
-    double prod[TNNZ + 2];           // +2: the CSR part of a tile may start on an odd entry
+    alignas(16) double prod[TNNZ + 2];           // +2: the CSR part of a tile may start on an odd entry
     int32_t rp[kTileRows + 1];       // CSR row offsets into prod
     int32_t prp[kTileRows / 2 + 1];  // node offsets into the block products / row offsets into the coupling-record sums
 };                                   // (a tile of rows with coupling records holds at most kTileRows / 2 rows)
@@ -521,6 +527,7 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, int r0, i
     td.n = (int)(A.rowptr[r1] - td.base);
     td.pbase = 0;
     td.npe = 0;
+    td.woff = td.voff = td.nw = td.nv = 0;
     if (r0 < block_rows(A)) {
         td.pbase = A.prow[node_of_row(A, r0)];
         td.npe = (int)(A.prow[node_of_row(A, r1)] - td.pbase);

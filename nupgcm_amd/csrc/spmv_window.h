@@ -1,0 +1,172 @@
+// Windowed block tiles: the block rows of a node-blocked matrix ({c, K, C} node records + {m, a_x, a_y, a_z} column records,
+// spmv_device.h) with every gather of the input vector served from LDS.
+//
+// Why.  The record-form SpMV is bound by the rate at which a CU's texture-address / L1 path accepts divergent gather lanes,
+// not by HBM (profiles/r02_spmv_experiments.txt section 6: with EVERY gather an L1 hit the kernel is 3 % faster,
+// section 7: gathers served by LDS reads cost 9 us per SpMV instead of 55).  A tile of ~75 row nodes holds ~2 000 node records
+// but only ~480 DISTINCT column nodes (RCM keeps a tile's columns close; measured on bowl3D h = 0.02: 4.2 records per distinct
+// node) and ~600 column records on ~100 distinct pressure columns.  So the host stores, per tile, the ascending list of distinct
+// column nodes (`wlist`) and of distinct other columns (`vlist`); the tile gathers each of them ONCE - adjacent lanes gather
+// ascending nodes - into an LDS window, and the records address the window through 16-bit indices (2 bytes per record instead of
+// the 4-byte column: the lists cost less than the indices save).  Texture-path gather lanes per SpMV of that matrix: 24.6 M ->
+// 5.6 M in the block rows.
+//
+// Pair sums.  Every node's record list is padded to an even count with a zero record, and a lane takes two ADJACENT records of
+// the same row node: their products are summed in registers before they reach LDS - half the product slots, half the LDS
+// traffic and half the segmented-sum trips for the node records; what the slots save pays for the window's LDS.
+//
+// One dependent chain per tile: list loads, then ALL record loads of the tile (at most three record pairs and two column
+// records per lane: the host sizes the tiles so), then the gathers of the lists' columns; by the time the window is in LDS the
+// records have arrived, and everything behind the barrier is LDS reads and arithmetic.  (The non-windowed tile function runs
+// two record loops of two dependent round trips each.)
+//
+// The input accessor must serve a node's components as one float4 (`node4`) and an entry behind the block rows as a float
+// (`behind`): the fp32 gather-layout copy of the Krylov vector (PaddedX).  Products and sums are fp64.
+#pragma once
+#include "spmv_device.h"
+
+namespace npg {
+
+constexpr int kWinPairs = 2;      // record pairs per lane a windowed tile may hold (npe <= 2 * kWinPairs * threads)
+constexpr int kWinCols = 1;       // column records per lane
+constexpr int kWinNodes = 2;      // distinct column nodes per lane (nw); distinct other columns: one per lane (nv)
+
+// One windowed tile.  On return (after the trailing barrier) out[r - r0] holds (A x)[r] for the tile's rows.
+template <int NT, int L, class XF, int TNNZ, class PROF = NoProf>
+__device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const XF x, const TileDesc &td, TileLdsT<TNNZ> &t,
+                                              double *__restrict__ out, PROF prof = PROF()) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));          // per-tile re-made lane offsets (spmv_tile's REMAT): keeps the stream bases out of the caller's loop
+    const bool full = td.r0 < 3 * A.nfull;
+    const int ncomp = full ? 3 : 2;
+    const int q0 = node_of_row(A, td.r0);
+    const int nnode = full ? (td.nrows * 21846) >> 16 : td.nrows >> 1;       // nrows / 3 for nrows < 2^15
+    const int npair = td.npe >> 1, n = td.n, nw = td.nw, nv = td.nv;
+    const int64_t pbase = td.pbase, base = td.base;
+    const int slot0 = ncomp * npair;                         // column-record products live behind the pair products
+    const int slots = slot0 + ncomp * n;
+    float4 *__restrict__ win = reinterpret_cast<float4 *>(t.prod + ((slots + 1) & ~1));
+    float *__restrict__ vwin = reinterpret_cast<float *>(win + nw);
+    // Every load below is unconditional, from an index clamped into the tile's range (a lane without work re-reads the last
+    // element and never uses it): no control flow between the loads, so they are all in flight together.
+    // ---- (1) the tile's distinct columns
+    int32_t wc[kWinNodes], vc;
+#pragma unroll
+    for (int u = 0; u < kWinNodes; ++u) wc[u] = __builtin_nontemporal_load(A.wlist + td.woff + min(tid + u * NT, nw - 1));
+    vc = __builtin_nontemporal_load(A.vlist + td.voff + min(tid, max(nv - 1, 0)));
+    // ---- (2) every record of the tile
+    uint32_t ip[kWinPairs];
+    double k0[kWinPairs], c0[kWinPairs], k1[kWinPairs], c1[kWinPairs];
+    {
+        const uint32_t *__restrict__ wp = reinterpret_cast<const uint32_t *>(A.widx + pbase);
+        const double *__restrict__ kp = reinterpret_cast<const double *>(A.pkc + pbase);
+#pragma unroll
+        for (int u = 0; u < kWinPairs; ++u) {
+            const int p = min(tid + u * NT, npair - 1);
+            ip[u] = __builtin_nontemporal_load(wp + p);
+            k0[u] = __builtin_nontemporal_load(kp + 4 * p);
+            c0[u] = __builtin_nontemporal_load(kp + 4 * p + 1);
+            k1[u] = __builtin_nontemporal_load(kp + 4 * p + 2);
+            c1[u] = __builtin_nontemporal_load(kp + 4 * p + 3);
+        }
+    }
+    uint32_t gi[kWinCols];
+    double ax[kWinCols], ay[kWinCols], az[kWinCols];
+    {
+        const double *__restrict__ gp = reinterpret_cast<const double *>(A.gxy + base);
+#pragma unroll
+        for (int u = 0; u < kWinCols; ++u) {
+            const int e = min(tid + u * NT, max(n - 1, 0));
+            gi[u] = __builtin_nontemporal_load(A.gidx + base + e);
+            ax[u] = __builtin_nontemporal_load(gp + 2 * e);
+            ay[u] = __builtin_nontemporal_load(gp + 2 * e + 1);
+            az[u] = __builtin_nontemporal_load(A.gz + base + e);
+        }
+    }
+    // node bookkeeping of the segmented sums (LDS writes: independent of everything in flight)
+    for (int q = threadIdx.x; q <= nnode; q += NT) {
+        t.rp[q] = (int32_t)(A.grow[q0 + q] - base);
+        t.prp[q] = (int32_t)((A.prow[q0 + q] - pbase) >> 1);
+    }
+    // ---- (3) ONE gather per distinct column, ascending along the lanes
+    {
+        float4 f[kWinNodes];
+#pragma unroll
+        for (int u = 0; u < kWinNodes; ++u) f[u] = x.node4(wc[u]);
+        const float v = x.behind(vc);
+#pragma unroll
+        for (int u = 0; u < kWinNodes; ++u) {
+            const int i = tid + u * NT;
+            if (i < nw) win[i] = f[u];
+        }
+        if (tid < nv) vwin[tid] = v;
+    }
+    prof.stamp(3);
+    __syncthreads();
+    // ---- (4) products: two adjacent records of one row node per lane, summed before they reach LDS
+#pragma unroll
+    for (int u = 0; u < kWinPairs; ++u) {
+        const int p = tid + u * NT;
+        if (p < npair) {
+            const float4 fa = win[ip[u] & 0xffffu], fb = win[ip[u] >> 16];
+            const double xa = (double)fa.x, ya = (double)fa.y, xb = (double)fb.x, yb = (double)fb.y;
+            t.prod[p] = (k0[u] * xa + c0[u] * ya) + (k1[u] * xb + c1[u] * yb);
+            t.prod[npair + p] = (k0[u] * ya - c0[u] * xa) + (k1[u] * yb - c1[u] * xb);
+            if (full) t.prod[2 * npair + p] = k0[u] * (double)fa.z + k1[u] * (double)fb.z;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kWinCols; ++u) {
+        const int e = tid + u * NT;
+        if (e < n) {
+            const double xv = (double)vwin[gi[u]];
+            t.prod[slot0 + e] = ax[u] * xv;
+            t.prod[slot0 + n + e] = ay[u] * xv;
+            if (full) t.prod[slot0 + 2 * n + e] = az[u] * xv;
+        }
+    }
+    prof.stamp(0);
+    __syncthreads();
+    prof.stamp(1);
+    // ---- (5) segmented sums: a lane group sums the two or three rows of a NODE together (spmv_tile's node-wise loop)
+    const int g = threadIdx.x / L, l = threadIdx.x % L;
+    for (int q = g; q < nnode; q += NT / L) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        const int cb = t.rp[q], ce = t.rp[q + 1];
+        for (int k = cb + 2 * l; k < ce; k += 2 * L) {
+            const bool two = k + 1 < ce;
+            const double a0 = t.prod[slot0 + k], b0 = t.prod[slot0 + k + 1];
+            const double a1 = t.prod[slot0 + n + k], b1 = t.prod[slot0 + n + k + 1];
+            s0 += a0 + (two ? b0 : 0.0);
+            s1 += a1 + (two ? b1 : 0.0);
+            if (full) {
+                const double a2 = t.prod[slot0 + 2 * n + k], b2 = t.prod[slot0 + 2 * n + k + 1];
+                s2 += a2 + (two ? b2 : 0.0);
+            }
+        }
+        const int pb = t.prp[q], pe = t.prp[q + 1];
+        for (int k = pb + 2 * l; k < pe; k += 2 * L) {
+            const bool two = k + 1 < pe;
+            const double a0 = t.prod[k], b0 = t.prod[k + 1];
+            const double a1 = t.prod[npair + k], b1 = t.prod[npair + k + 1];
+            s0 += a0 + (two ? b0 : 0.0);
+            s1 += a1 + (two ? b1 : 0.0);
+            if (full) {
+                const double a2 = t.prod[2 * npair + k], b2 = t.prod[2 * npair + k + 1];
+                s2 += a2 + (two ? b2 : 0.0);
+            }
+        }
+        s0 = group_sum_dpp<L>(s0);
+        s1 = group_sum_dpp<L>(s1);
+        if (full) s2 = group_sum_dpp<L>(s2);
+        if (l == 0) {
+            out[q * ncomp] = s0;
+            out[q * ncomp + 1] = s1;
+            if (full) out[q * ncomp + 2] = s2;
+        }
+    }
+    prof.stamp(2);
+    __syncthreads();
+}
+
+}  // namespace npg

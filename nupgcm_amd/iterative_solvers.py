@@ -83,7 +83,8 @@ class GmresWorkspace(_Workspace):
 
     def set_gather(self, mode):
         """Arnoldi kernel's SpMV input from the fp32 gather-layout copy of the Krylov vector (npg_gmres_set_gather):
-        -1 = default (on where it applies: one GPU, fp32-stored basis, node-blocked matrix), 0 = off, 1 = on where it applies"""
+        -1 = default (on where it applies: one GPU, fp32-stored basis, node-blocked matrix), 0 = off, 1 = on where it applies,
+        2 = on, without the matrix's windowed tile set (csrc/spmv_window.h)"""
         L.check(L.lib().npg_gmres_set_gather(self.h, int(mode)))
 
     def set_profile(self, on=True):

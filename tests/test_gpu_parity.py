@@ -358,6 +358,54 @@ def test_gmres_gather_layout_input(arch):
     assert not np.array_equal(out[1][1], out[0][1])               # (the switch really selects another kernel)
 
 
+def test_windowed_tiles(arch):
+    """Windowed tile set of a node-blocked matrix (csrc/spmv_window.h): every tile gathers its distinct columns once into LDS,
+    the records address the window by 16-bit indices, two adjacent records of a row node are summed before they reach LDS.
+    The product of the gather-layout instance - A applied to the fp32-rounded vector, in fp64 - equals the plain-CSR product of
+    the same rounded vector on the windowed tiles and on the ordinary ones; GMRES takes the same path either way."""
+    fed, prm, frc, dt, b0 = build_fe_data("bowl_mixing")
+    d = fed.dofs
+    A = npg.build_A_inversion(arch, fed, prm, 1.0)
+    ref = A.to_scipy_csr()
+    assert A.block_nodes(d.n_full, d.n_surf)
+    nodes, rec, ent = A.storage()
+    info = A.window_info()
+    assert info["tiles"] > info["block_tiles"] > 0
+    assert info["distinct"] < 0.75 * (rec + A.coupling_records() / 2)       # fewer gathers than records (small tiles here)
+    assert 0 < info["bytes"] < A.stored_spmv_bytes() * 1.05
+    rng = np.random.default_rng(7)
+    for trial in range(3):
+        x = rng.standard_normal(ref.shape[1]) * (1.0 if trial else 1e3)
+        want = ref @ x.astype(np.float32).astype(np.float64)
+        dx = npg.on_architecture(arch, x)
+        yw = A.mul_gather32(dx, windowed=True).to_host()
+        y0 = A.mul_gather32(dx, windowed=False).to_host()
+        assert rel(yw, want) < 1e-13 and rel(y0, want) < 1e-13
+    # a matrix built without the set (NPG_SPMV_WINDOW=0) refuses the windowed product and reports no tiles
+    os.environ["NPG_SPMV_WINDOW"] = "0"
+    try:
+        A0 = npg.build_A_inversion(arch, fed, prm, 1.0)
+        assert A0.block_nodes(d.n_full, d.n_surf) and A0.window_info()["tiles"] == 0 and A0.storage()[1] == rec
+        with pytest.raises(L.DeviceError):
+            A0.mul_gather32(npg.on_architecture(arch, x), windowed=True)
+    finally:
+        del os.environ["NPG_SPMV_WINDOW"]
+    # the solver on both tile sets: same iteration counts (the products differ by rounding of the sums only)
+    h = fed.mesh.median_edge_length()
+    y = ref @ np.cos(np.arange(ref.shape[1], dtype=float)) * 1e-3
+    out = {}
+    for mode in (1, 2):
+        ws = npg.GmresWorkspace(arch.ctx, ref.shape[0], memory=20)
+        ws.set_basis(32)
+        ws.set_gather(mode)
+        st = ws.solve(A, npg.on_architecture(arch, y), ws.x, npg.Diagonal(scalar=1 / h ** 3))
+        xs = ws.x.to_host()
+        assert st["solved"] == 1 and np.linalg.norm((y - ref @ xs) / h ** 3) <= 1.5 * (1e-6 + 1e-6 * st["rnorm0"])
+        out[mode] = (st["niter"], xs)
+    assert abs(out[1][0] - out[2][0]) <= 0.03 * out[2][0], (out[1][0], out[2][0])
+    assert rel(out[1][1], out[2][1]) < 2e-4
+
+
 def test_cg_evolution_system(arch, flux, golden_dir):
     z = np.load(f"{golden_dir}/state_bowl_surface_flux.npz")
     Am = (flux.M + flux.theta("BDF2") * (flux.Kh + flux.Kv)).tocsr()
@@ -1009,6 +1057,13 @@ def test_full_size_properties(arch):
     ax, ay = A_csr.mul(x).to_host(), A_csr.mul(y).to_host()
     bx = A_blk.mul(x).to_host()
     assert rel(bx, ax) < 1e-13                                             # node records == CSR entries
+    # the windowed tile set (csrc/spmv_window.h) at full size: A applied to the fp32-rounded vector, against plain CSR
+    info = A_blk.window_info()
+    assert info["block_tiles"] > 5000 and info["distinct"] < 0.35 * (rec + A_blk.coupling_records() / 2)
+    x32 = npg.DeviceVector.from_host(ctx, x.to_host().astype(np.float32).astype(np.float64))
+    ax32 = A_csr.mul(x32).to_host()
+    assert rel(A_blk.mul_gather32(x, windowed=True).to_host(), ax32) < 1e-13
+    assert rel(A_blk.mul_gather32(x, windowed=False).to_host(), ax32) < 1e-13
     z = x.copy()
     z.axpby(-0.75, y, 2.5)                                                 # z = 2.5 x - 0.75 y
     assert rel(A_blk.mul(z).to_host(), 2.5 * ax - 0.75 * ay) < 1e-13       # linearity
