@@ -50,14 +50,15 @@ def parse():
     return ap.parse_args()
 
 
-PMC_FILE = "profiles/r03_pmc.json"
+PMC_FILE = "profiles/r04_pmc.json"
 
 
 def pmc_traffic(workload, kernel="k_gmres_arnoldi"):
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (a builder run, not this run:
-    profiles/r03_pmc.json, made by tools/pmc_probe.py + tools/pmc_summary.py on this workload; FETCH_SIZE / WRITE_SIZE in
-    separate passes, gfx950 correction applied as described in profiles/README.md) - the line says so in `traffic_source`.
-    None when no counters were collected for the workload."""
+    profiles/r04_pmc.json, made by `tools/prof.sh pmc` = tools/pmc_probe.py + tools/pmc_summary.py on this workload with THIS
+    round's kernel; FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied as described in profiles/README.md) -
+    the line says so in `traffic_source`.  None when no counters were collected for the workload (the roofline is then priced
+    in the bytes the layout says must move, `stored_bytes_per_launch`)."""
     p = os.path.join(ROOT, PMC_FILE)
     if not os.path.exists(p):
         return None
@@ -202,8 +203,10 @@ def main():
         transport_check = "passed"
         if not model.verify_transport():
             was = ctx.comm_info()["in_cycle_transport"]
-            if was != "peer":
-                raise SystemExit(f"bench: the {was} transport failed the halo / all-reduce check")
+            if was != "peer" or os.environ.get("NPG_COMM_TRANSPORT") == "peer":
+                # (NPG_COMM_TRANSPORT=peer creates no RCCL communicator: there is nothing to fall back on)
+                raise SystemExit(f"bench: the {was} transport failed the halo / all-reduce check"
+                                 + (" and NPG_COMM_TRANSPORT=peer leaves no RCCL communicator to fall back on" if was == "peer" else ""))
             if rank == 0:
                 print("[bench] peer-window transport failed its end-to-end check: falling back on RCCL", file=sys.stderr)
             import gc
@@ -267,28 +270,35 @@ def main():
     roofline = None
     if launches > 0:
         avg_ms = ms_total / launches
-        ach = alg_bytes / (avg_ms * 1e-3) / 1e9
-        roofline = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+        # bytes the kernel's layout says must move per launch: the matrix in the form the Arnoldi kernel streams it (the
+        # windowed tile set where it has one, csrc/spmv_window.h), its input gathered once, + wt re-read + w and the new basis column
+        winfo = A.window_info() if hasattr(A, "window_info") and getattr(A, "paired", False) else {"tiles": 0}
+        windowed = bool(winfo["tiles"]) and os.environ.get("NPG_GMRES_WINDOW", "1") != "0"
+        stored = (winfo["bytes"] if windowed else A.stored_spmv_bytes()) + 2 * 8 * N
+        measured = pmc_traffic(a.workload) if world == 1 else None
+        real = measured or stored
+        real_gbps = real / (avg_ms * 1e-3) / 1e9
+        csr_gbps = alg_bytes / (avg_ms * 1e-3) / 1e9
+        # `achieved` / `frac`: bytes that really move (PMC-measured where a measurement of this round's kernel is on file, else
+        # the stored bytes) over the live HIP-event launch time, against the 8 TB/s HBM spec.  The rate in the ALGORITHMIC bytes
+        # of SURVEY 8(d) - what a plain-CSR SpMV of the same matrix would have had to stream in that time - is a separate key.
+        roofline = dict(bound="hbm", achieved=real_gbps, peak=HBM_PEAK_GBS, unit="GB/s", frac=real_gbps / HBM_PEAK_GBS,
                         scope="one GPU" if world == 1 else f"rank 0's row block ({N} of {N_glob} rows), one of {world} GPUs",
                         # (the committed counters are for the whole matrix on one GPU: no figure for a rank's row block)
-                        traffic=pmc_traffic(a.workload) if world == 1 else None,
-                        traffic_source=(f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier builder "
-                                        "run on this workload, not measured in this run)"
-                                        if world == 1 and pmc_traffic(a.workload) is not None else None), kernel="k_gmres_arnoldi (Givens prologue + CSR-stream SpMV"
-                        + (")" if N >= 8192 else " + fused Gram-Schmidt dots)"),
-                        avg_launch_us=avg_ms * 1e3, launches=launches, algorithmic_bytes_per_launch=alg_bytes,
-                        cache_resident=bool(alg_bytes < 256 * 2 ** 20))
-        # what actually moved, next to the algorithmic figure: bytes as laid out in HBM (node-block records stream 20 B
-        # where CSR streams 60) and, where a PMC measurement is on file, the measured traffic
-        stored = A.stored_spmv_bytes() + 2 * 8 * N           # SpMV bytes (matrix, x, y) + wt re-read + new basis column
-        roofline["stored_bytes_per_launch"] = int(stored)
-        real = roofline["traffic"] or stored
-        roofline["real_GBps"] = real / (avg_ms * 1e-3) / 1e9
-        roofline["real_frac"] = roofline["real_GBps"] / HBM_PEAK_GBS
-        roofline["note"] = ("`achieved` / `frac` price the launch in the ALGORITHMIC bytes of SURVEY 8(d) (12 B per stored CSR "
-                            "entry); the kernel streams the matrix in record form (`stored_bytes_per_launch`, PMC `traffic`), "
-                            "which is fewer bytes - that is how `frac` can pass the streaming ceiling, or 1; `real_frac` is "
-                            "the fraction of the HBM spec in bytes that really move")
+                        traffic=measured,
+                        traffic_source=(f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a builder run of this "
+                                        "round's kernel on this workload, not measured in this run)" if measured is not None else None),
+                        bytes_priced="traffic (PMC)" if measured is not None else "stored_bytes_per_launch (no PMC measurement on file)",
+                        kernel="k_gmres_arnoldi (Givens prologue + record-stream SpMV"
+                        + (", windowed tiles" if windowed else "") + (")" if N >= 8192 else " + fused Gram-Schmidt dots)"),
+                        avg_launch_us=avg_ms * 1e3, launches=launches, stored_bytes_per_launch=int(stored),
+                        algorithmic_bytes_per_launch=alg_bytes, csr_equivalent_GBps=csr_gbps,
+                        csr_equivalent_frac=csr_gbps / HBM_PEAK_GBS,
+                        cache_resident=bool(alg_bytes < 256 * 2 ** 20),
+                        window=({k: winfo[k] for k in ("tiles", "block_tiles", "distinct")} if windowed else None))
+        roofline["note"] = ("`achieved` / `frac` price the launch in the bytes that really move; the kernel streams the matrix "
+                            "in record form, fewer bytes than the 12 B per stored entry of a CSR SpMV - `csr_equivalent_GBps` "
+                            "is the rate in those algorithmic bytes of SURVEY 8(d) and may exceed the HBM peak")
     # stand-alone SpMV kernel (same tiles, no Krylov epilogue) for reference
     x = npg.DeviceVector.from_host(ctx, np.sin(np.arange(A.shape[1], dtype=float)))
     y = npg.DeviceVector(ctx, N)
@@ -321,7 +331,10 @@ def main():
         "metric": "timesteps/sec (evolve!+invert! loop; inversion SpMV GB/s in 'roofline')",
         "value": a.steps / elapsed, "unit": "timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": ("f64" if channel or a.preconditioner != "diagonal" or N < 8192 else
+                  "f64 arithmetic; fp32-STORED Krylov basis and fp32 gather-layout copy of the SpMV input (the library's default at "
+                  "rtol >= 1e-7; products, sums, x += V y and the restart residual are fp64 - the all-fp64 figure is `fp64_basis`)"),
+        "data": "synthetic",
         "config": {"workload": (f"{a.workload}: production parameters of scratch/run.jl (alpha=1/8, f=y, P1 buoyancy, nu(x) -> "
                                 f"full-stress form, convection + eddy closures, wind, BDF1 with the adaptive CFL step, "
                                 f"GMRES itmax=1000) on the x-periodic structured-to-tet channel-basin mesh; element kernels "
@@ -401,6 +414,38 @@ def main():
             "gmres_iterations_per_step": [x[1]["niter"] for x in st], "all_solved": all(x[1]["solved"] == 1 for x in st),
             "gmres_initial_residual_per_step": [float(f"{x[1]['rnorm0']:.4g}") for x in st], "setup_seconds": round(t_x, 1)}
         del ex
+    # ---- the like-for-like precision: the headline loop with the Krylov basis and the SpMV input stored in fp64 throughout, as
+    # Krylov.jl's CuVector{Float64} workspaces are (src/inversion.jl:84)
+    if rank == 0 and world == 1 and not channel and a.preconditioner == "diagonal" and not a.no_multigrid and N >= 8192:
+        t_x = time.time()
+        f64 = workloads.example_model(arch, mesh_model, dt=a.dt, fine_fe_data=model.fe_data)
+        if a.extrapolate_guess:
+            f64.extrapolate_guess = a.extrapolate_guess
+        w64 = f64.inversion.solver.workspace
+        w64.set_basis(64)
+        w64.set_gather(0)
+        npg.invert(f64)
+        ctx.sync()
+        t_x = time.time() - t_x
+        k = max(1, min(a.steps, 5))
+        npg.run(f64, n_steps=a.warmup)
+        ctx.sync()
+        t0 = time.perf_counter()
+        npg.run(f64, n_steps=k)
+        ctx.sync()
+        el = time.perf_counter() - t0
+        st = f64.stats[-k:]
+        w64.set_profile(True)
+        npg.run(f64, n_steps=1)
+        ms64, l64 = w64.get_profile()
+        w64.set_profile(False)
+        out["fp64_basis"] = {
+            "what": "the headline loop with the Krylov basis stored in fp64 and the SpMV input gathered from the fp64 vector "
+                    "(npg_gmres_set_basis(64), npg_gmres_set_gather(0)): every stored number fp64, as in the reference",
+            "value": k / el, "unit": "timesteps/s", "steps": k, "warmup": a.warmup, "ms_per_step": 1e3 * el / k,
+            "gmres_iterations_per_step": [x[1]["niter"] for x in st], "all_solved": all(x[1]["solved"] == 1 for x in st),
+            "arnoldi_avg_launch_us": (1e3 * ms64 / l64) if l64 else None, "setup_seconds": round(t_x, 1)}
+        del f64
     # ---- small meshes (the reference's own): the explicit inverse in HBM instead of latency-bound Krylov iterations
     if rank == 0 and world == 1 and not channel and a.preconditioner == "diagonal" and not a.no_multigrid and N <= 40000:
         t_d = time.time()

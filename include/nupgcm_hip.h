@@ -205,7 +205,8 @@ int npg_gmres_set_profile(npg_gmres *ws, int on);
  * latency-bound sizes), 1 = split (SpMV kernel + row-streaming dots/orthogonalisation kernels, column-major basis:
  * bandwidth-bound sizes), -1 = by size (split from 8192 rows; default).  Same arithmetic either way. */
 /* Stored Krylov basis of the split kernel organisation (n >= 8192): 64 = fp64, 32 = fp32 ("compressed basis": only the
- * stored copy used by the Gram-Schmidt sums and x += V y is rounded; SpMV inputs, sums, the restart residual stay fp64),
+ * stored copy used by the Gram-Schmidt sums and x += V y is rounded; sums, products and the restart residual stay fp64, and so
+ * does the SpMV input unless its fp32 gather-layout copy is in use - npg_gmres_set_gather below, the default wherever it applies),
  * 0 = by tolerance (fp32 when rtol >= 1e-7, the reference's 1e-6 included).  NPG_GMRES_BASIS=32|64 overrides the default. */
 int npg_gmres_set_basis(npg_gmres *ws, int bits);
 /* Where the basis is stored in fp32 (above), with a node-blocked matrix, the Arnoldi kernel gathers its SpMV input

@@ -139,6 +139,15 @@ struct npg_csr {
     uint16_t *gidx = nullptr;    // device, window index of every column record (same indexing as gcol)
     int32_t *wlist = nullptr;    // device, concatenated per-tile lists of distinct column nodes (ascending per tile)
     int32_t *vlist = nullptr;    // device, concatenated per-tile lists of distinct columns of the column records
+    double *pkc2 = nullptr;      // device, the {K, C} values split by position in the record pair: [npairs] firsts, [npairs] seconds
+    int64_t npairs = 0;
+    double *dxy2 = nullptr;      // device, the (d_x, d_y) of the coupling records split the same way: [ndpairs] firsts, [ndpairs] seconds
+    int64_t ndpairs = 0;
+    int32_t *wbk = nullptr;      // device, [nnode][2]: tile-local end offsets of node q's column records / record pairs
+    uint16_t *dwidx = nullptr;   // device, window index of every coupling record (windowed tiles of the rows behind the block rows)
+    int32_t *dbk = nullptr;      // device, per row behind the block rows: tile-local end offset of its coupling record PAIRS
+    int32_t nwrow_tiles = 0;     // windowed tiles of the rows behind the block rows (0: those rows keep their ordinary tiles)
+    int64_t ndrec_real = 0;      // coupling records without the zero records that pad a row's list to an even count
     int64_t nwlist = 0, nvlist = 0;
     int64_t nrec_real = 0;       // node records without the zero records that pad a node's list to an even count
     std::vector<npg::TileDesc> h_tiles;   // host copy of tile_ptr (final order)

@@ -131,11 +131,15 @@ int build_tiles(npg_csr *A) {
 }
 
 static void free_window_tiles(npg_csr *A) {
-    for (void *p : {(void *)A->wtile_ptr, (void *)A->widx, (void *)A->gidx, (void *)A->wlist, (void *)A->vlist})
+    for (void *p : {(void *)A->wtile_ptr, (void *)A->widx, (void *)A->gidx, (void *)A->wlist, (void *)A->vlist, (void *)A->wbk, (void *)A->dwidx, (void *)A->dbk, (void *)A->pkc2, (void *)A->dxy2})
         if (p) hipFree(p);
     A->wtile_ptr = nullptr;
     A->widx = A->gidx = nullptr;
     A->wlist = A->vlist = nullptr;
+    A->wbk = A->dbk = nullptr;
+    A->pkc2 = A->dxy2 = nullptr;
+    A->dwidx = nullptr;
+    A->nwrow_tiles = 0;
     A->nwtiles = A->nwtiles_interior = 0;
     A->nwlist = A->nvlist = 0;
 }
@@ -145,19 +149,21 @@ static void free_window_tiles(npg_csr *A) {
 // nodes (16 B each) and of distinct other columns (4 B each) - followed by the ordinary tiles of the rows behind the block
 // rows.  pcol / gcol: host copies of the record columns (every node's list already padded to an even count).
 // Leaves the matrix without a windowed set (no error) when some node's rows would not fit a tile.
-static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, const std::vector<int32_t> &gcol) {
+static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, const std::vector<int32_t> &gcol,
+                              const std::vector<int32_t> &dcol, const std::vector<double> &pkc, const std::vector<double> &dxy) {
     free_window_tiles(A);
     const int64_t nnode = A->nnode(), nfull = A->nfull, nbr = A->block_rows();
     if (nnode == 0 || !A->grow || A->pk9) return NPG_OK;
     const std::vector<int64_t> &prow = A->h_prow, &grow = A->h_grow;
     constexpr int NT = 512;
-    const int64_t hard = 8 * (int64_t)kTileNnz;
+    int64_t hard = 8 * (int64_t)kTileNnz;
+    if (getenv("NPG_WIN_BYTES")) hard = std::min<int64_t>(hard, std::max<int64_t>(8192, atoll(getenv("NPG_WIN_BYTES"))));    // tuning: smaller tiles
     // small matrices: about one tile per CU (as tile_boundaries does)
     const int64_t total = 8 * (3 * (prow[nfull] / 2 + grow[nfull]) + 2 * ((prow[nnode] - prow[nfull]) / 2 + grow[nnode] - grow[nfull]));
     const int64_t soft = std::min<int64_t>(hard, std::max<int64_t>(8 * 1024, total / std::max(1, A->ctx->num_cu)));
     std::vector<int32_t> stampW((size_t)nnode, -1), stampV((size_t)A->n, -1), posW((size_t)nnode, 0), posV((size_t)A->n, 0);
     std::vector<uint16_t> widx(pcol.size()), gidx(gcol.size());
-    std::vector<int32_t> wlist, vlist, tw, tv, nwl, nvl;
+    std::vector<int32_t> wlist, vlist, tw, tv, nwl, nvl, wbk((size_t)2 * nnode);
     std::vector<TileDesc> blk;
     std::vector<char> ghost;
     auto bytes_of = [](int ncomp, int64_t np, int64_t ng, int64_t nw, int64_t nv) {
@@ -209,6 +215,10 @@ static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, cons
             for (size_t i = 0; i < tv.size(); ++i) posV[tv[i]] = (int32_t)i;
             for (int64_t e = prow[q]; e < prow[qe]; ++e) widx[e] = (uint16_t)posW[pcol[e]];
             for (int64_t e = grow[q]; e < grow[qe]; ++e) gidx[e] = (uint16_t)posV[gcol[e]];
+            for (int64_t k = q; k < qe; ++k) {
+                wbk[2 * k] = (int32_t)(grow[k + 1] - grow[q]);
+                wbk[2 * k + 1] = (int32_t)((prow[k + 1] - prow[q]) >> 1);
+            }
             TileDesc d;
             d.r0 = (int32_t)(kind ? 3 * nfull + 2 * (q - nfull) : 3 * q);
             d.nrows = (int32_t)((qe - q) * ncomp);
@@ -228,16 +238,111 @@ static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, cons
             q = qe;
         }
     }
+    // The rows behind the block rows (the divergence rows) as windowed tiles too, when all they hold is coupling records: two
+    // adjacent records of a row per lane (every row's list is padded to an even count), at most kWinPairs pairs per lane and
+    // kWinNodes distinct column nodes per lane - small tiles, one dependent chain each (the ordinary tile function walks such
+    // a row block in four trips of two round trips).  NPG_WIN_ROWS=0: ordinary tiles for these rows.
+    std::vector<TileDesc> rowt;
+    std::vector<uint16_t> dwidx;
+    std::vector<int32_t> dbk;
+    const int64_t nbehind = A->m - nbr;
+    const bool rows_env = !(getenv("NPG_WIN_ROWS") && atoi(getenv("NPG_WIN_ROWS")) == 0);
+    if (rows_env && A->drow && nbehind > 0 && A->h_rowptr[A->m] - A->h_rowptr[nbr] == 0 && A->n == A->m) {
+        const std::vector<int64_t> &drow = A->h_drow;
+        dwidx.assign(dcol.size(), 0);
+        dbk.assign((size_t)nbehind, 0);
+        int64_t cap_pairs = kWinPairs * NT;
+        {       // small matrices: about as many tiles as the block rows got per byte
+            const int64_t want = std::max<int64_t>(1, (int64_t)blk.size() * (drow[nbehind] * 28) / std::max<int64_t>(1, total * 3));
+            cap_pairs = std::min<int64_t>(cap_pairs, std::max<int64_t>(64, drow[nbehind] / 2 / want));
+        }
+        int64_t r = 0;
+        bool ok = true;
+        while (r < nbehind && ok) {
+            const int32_t T = (int32_t)(blk.size() + rowt.size());
+            tw.clear();
+            int64_t np = 0, re = r;
+            while (re < nbehind) {
+                nwl.clear();
+                for (int64_t e = drow[re]; e < drow[re + 1]; ++e)
+                    if (stampW[dcol[e]] != T) {
+                        stampW[dcol[e]] = T;
+                        nwl.push_back(dcol[e]);
+                    }
+                const int64_t np2 = np + (drow[re + 1] - drow[re]) / 2, nw2 = (int64_t)(tw.size() + nwl.size());
+                const bool hardfit = re + 1 - r <= kTileRows / 2 && np2 <= kWinPairs * NT && nw2 <= kWinNodes * NT &&
+                                     8 * ((np2 + 1) & ~(int64_t)1) + 16 * nw2 <= hard;
+                if (re == r && !hardfit) {
+                    ok = false;
+                    break;
+                }
+                if (re > r && !(hardfit && np2 <= cap_pairs)) {
+                    for (int32_t c : nwl) stampW[c] = -1;
+                    break;
+                }
+                tw.insert(tw.end(), nwl.begin(), nwl.end());
+                np = np2;
+                ++re;
+            }
+            if (!ok) break;
+            std::sort(tw.begin(), tw.end());
+            for (size_t i = 0; i < tw.size(); ++i) posW[tw[i]] = (int32_t)i;
+            for (int64_t e = drow[r]; e < drow[re]; ++e) dwidx[e] = (uint16_t)posW[dcol[e]];
+            for (int64_t k = r; k < re; ++k) dbk[k] = (int32_t)((drow[k + 1] - drow[r]) >> 1);
+            TileDesc d;
+            d.r0 = (int32_t)(nbr + r);
+            d.nrows = (int32_t)(re - r);
+            d.base = 0;
+            d.n = 0;
+            d.pbase = drow[r];
+            d.npe = (int32_t)(2 * np);
+            d.woff = (int32_t)wlist.size();
+            d.nw = (int32_t)tw.size();
+            d.voff = (int32_t)vlist.size();
+            d.nv = 0;
+            if (d.nw == 0) {            // (a block of empty rows: nothing to window)
+                ok = false;
+                break;
+            }
+            wlist.insert(wlist.end(), tw.begin(), tw.end());
+            rowt.push_back(d);
+            r = re;
+        }
+        if (!ok) rowt.clear();
+    }
+    vlist.push_back((int32_t)nbr);           // sentinel: a tile without such columns still reads one entry at its offset
     NPG_REQUIRE(wlist.size() < (size_t)INT32_MAX && vlist.size() < (size_t)INT32_MAX, "build_window_tiles: window lists exceed int32 offsets");
-    // the tiles of the rows behind the block rows, as build_tiles made (and ordered) them
+    // the tiles of the rows behind the block rows: windowed (above), or as build_tiles made (and ordered) them
     std::vector<TileDesc> ord;
-    ord.reserve(blk.size() + A->h_tiles.size());
+    ord.reserve(blk.size() + A->h_tiles.size() + rowt.size());
     int32_t nint = 0;
+    // order within a pass (tuning, NPG_WIN_ORDER): 0 = block tiles, then the rows behind them; 1 = the other way round;
+    // 2 = the tiles of the rows behind the block rows spread evenly among the block tiles
+    const int order = getenv("NPG_WIN_ORDER") ? atoi(getenv("NPG_WIN_ORDER")) : 0;
     for (int pass = 0; pass < 2; ++pass) {
+        std::vector<TileDesc> a, b;
         for (size_t t = 0; t < blk.size(); ++t)
-            if ((ghost[t] != 0) == (pass == 1)) ord.push_back(blk[t]);
-        for (int32_t t = 0; t < A->ntiles; ++t)
-            if (A->h_tiles[t].r0 >= nbr && (t >= A->ntiles_interior) == (pass == 1)) ord.push_back(A->h_tiles[t]);
+            if ((ghost[t] != 0) == (pass == 1)) a.push_back(blk[t]);
+        if (!rowt.empty()) {
+            if (pass == 0) b = rowt;         // (only matrices without ghost columns get here)
+        } else {
+            for (int32_t t = 0; t < A->ntiles; ++t)
+                if (A->h_tiles[t].r0 >= nbr && (t >= A->ntiles_interior) == (pass == 1)) b.push_back(A->h_tiles[t]);
+        }
+        if (order == 1) {
+            ord.insert(ord.end(), b.begin(), b.end());
+            ord.insert(ord.end(), a.begin(), a.end());
+        } else if (order == 2 && !b.empty()) {
+            size_t ib = 0;
+            for (size_t ia = 0; ia < a.size(); ++ia) {
+                while (ib < b.size() && ib * a.size() <= ia * b.size()) ord.push_back(b[ib++]);
+                ord.push_back(a[ia]);
+            }
+            while (ib < b.size()) ord.push_back(b[ib++]);
+        } else {
+            ord.insert(ord.end(), a.begin(), a.end());
+            ord.insert(ord.end(), b.begin(), b.end());
+        }
         if (pass == 0) nint = (int32_t)ord.size();
     }
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
@@ -252,6 +357,35 @@ static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, cons
     chk(up((void **)&A->gidx, gidx.data(), gidx.size() * sizeof(uint16_t)));
     chk(up((void **)&A->wlist, wlist.data(), wlist.size() * sizeof(int32_t)));
     chk(up((void **)&A->vlist, vlist.data(), vlist.size() * sizeof(int32_t)));
+    chk(up((void **)&A->wbk, wbk.data(), wbk.size() * sizeof(int32_t)));
+    {       // the {K, C} values once more, split by position in the pair: [pairs] first records, then [pairs] second records -
+            // a lane's two 16-byte loads are then each part of a fully contiguous stream (the interleaved pkc gives 32-byte strides)
+        const size_t P = pcol.size() / 2;
+        std::vector<double> k2(4 * P);
+        for (size_t pr = 0; pr < P; ++pr) {
+            k2[2 * pr] = pkc[4 * pr];
+            k2[2 * pr + 1] = pkc[4 * pr + 1];
+            k2[2 * P + 2 * pr] = pkc[4 * pr + 2];
+            k2[2 * P + 2 * pr + 1] = pkc[4 * pr + 3];
+        }
+        chk(up((void **)&A->pkc2, k2.data(), k2.size() * sizeof(double)));
+        A->npairs = (int64_t)P;
+    }
+    if (!rowt.empty()) {
+        chk(up((void **)&A->dwidx, dwidx.data(), dwidx.size() * sizeof(uint16_t)));
+        chk(up((void **)&A->dbk, dbk.data(), dbk.size() * sizeof(int32_t)));
+        const size_t P = dcol.size() / 2;      // (d_x, d_y) split by position in the record pair, like pkc2
+        std::vector<double> d2(4 * P);
+        for (size_t pr = 0; pr < P; ++pr) {
+            d2[2 * pr] = dxy[4 * pr];
+            d2[2 * pr + 1] = dxy[4 * pr + 1];
+            d2[2 * P + 2 * pr] = dxy[4 * pr + 2];
+            d2[2 * P + 2 * pr + 1] = dxy[4 * pr + 3];
+        }
+        chk(up((void **)&A->dxy2, d2.data(), d2.size() * sizeof(double)));
+        A->ndpairs = (int64_t)P;
+    }
+    A->nwrow_tiles = (int32_t)rowt.size();
     if (rc != NPG_OK) {
         free_window_tiles(A);
         return rc;
@@ -428,6 +562,13 @@ CsrDev csr_view(const npg_csr *A) {
     v.gidx = A->gidx;
     v.wlist = A->wlist;
     v.vlist = A->vlist;
+    v.wbk = A->wbk;
+    v.pkc2 = reinterpret_cast<const double2 *>(A->pkc2);
+    v.npairs = A->npairs;
+    v.dxy2 = reinterpret_cast<const double2 *>(A->dxy2);
+    v.ndpairs = A->ndpairs;
+    v.dwidx = A->dwidx;
+    v.dbk = A->dbk;
     return v;
 }
 
@@ -545,6 +686,7 @@ NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double
     std::vector<int64_t> drow;
     std::vector<int32_t> dcol;
     std::vector<double> dxy, dz;
+    int64_t ndrec_real = 0;
     if (coupling) {
         drow.assign((size_t)(A->m - nbr) + 1, 0);
         for (int64_t r = nbr; r < A->m && coupling; ++r) {
@@ -558,6 +700,14 @@ NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double
                 dxy.push_back(d[0]);
                 dxy.push_back(d[1]);
                 dz.push_back(d[2]);
+                ++nrec;
+            }
+            ndrec_real += nrec;
+            if (want_win && (nrec & 1)) {          // zero record on the row's last column node (windowed tiles take records in pairs)
+                dcol.push_back(dcol.back());
+                dxy.push_back(0.0);
+                dxy.push_back(0.0);
+                dz.push_back(0.0);
                 ++nrec;
             }
             drow[r - nbr + 1] = (int64_t)dcol.size();
@@ -622,6 +772,7 @@ NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double
         NPG_HIP(hipMemcpy(A->dval, dxy.data(), 2 * nd * sizeof(double), hipMemcpyHostToDevice));
         NPG_HIP(hipMemcpy(A->dval + 2 * nd, dz.data(), nd * sizeof(double), hipMemcpyHostToDevice));
         A->ndrec = (int64_t)nd;
+        A->ndrec_real = ndrec_real;
         A->h_drow = std::move(drow);
     }
     A->h_rowptr = std::move(nrp);
@@ -632,7 +783,7 @@ NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double
     A->nrec_real = nrec_real;
     int rc = build_tiles(A);
     if (rc) return rc;
-    if (want_win && colrec && (rc = build_window_tiles(A, pcol, gcolv))) return rc;
+    if (want_win && colrec && (rc = build_window_tiles(A, pcol, gcolv, dcol, pkc, dxy))) return rc;
     *blocked = 1;
     return NPG_OK;
 }
@@ -944,8 +1095,9 @@ NPG_API int npg_csr_window_info(const npg_csr *Ap, int64_t *tiles, int64_t *bloc
     if (A->wtile_ptr) {
         // (block tiles are the descriptors with a window: count them from the lists' owner - every block tile has nw > 0)
         const int64_t nbr = A->block_rows();
-        int64_t behind = 0;
-        for (const npg::TileDesc &t : A->h_tiles) behind += t.r0 >= nbr;
+        int64_t behind = A->nwrow_tiles;
+        if (!behind)
+            for (const npg::TileDesc &t : A->h_tiles) behind += t.r0 >= nbr;
         nblk = A->nwtiles - behind;
     }
     if (tiles) *tiles = A->nwtiles;
@@ -955,9 +1107,9 @@ NPG_API int npg_csr_window_info(const npg_csr *Ap, int64_t *tiles, int64_t *bloc
         int64_t b = 0;
         if (A->wtile_ptr) {
             const int64_t nnode = A->nnode(), nrec = A->h_prow[nnode];
-            b = 48 * (int64_t)A->nwtiles + 18 * nrec + 26 * A->ngrec + 4 * (A->nwlist + A->nvlist) + 16 * (nnode + 1) +
+            b = 48 * (int64_t)A->nwtiles + 18 * nrec + 26 * A->ngrec + 4 * (A->nwlist + A->nvlist) + 8 * nnode +
                 12 * A->rnnz + 8 * (A->m - A->block_rows() + 1);
-            if (A->drow) b += 8 * (A->m - A->block_rows() + 1) + 28 * A->ndrec;
+            if (A->drow) b += A->nwrow_tiles ? 4 * (A->m - A->block_rows()) + 26 * A->ndrec : 8 * (A->m - A->block_rows() + 1) + 28 * A->ndrec;
         }
         *matrix_bytes = b;
     }
@@ -966,7 +1118,7 @@ NPG_API int npg_csr_window_info(const npg_csr *Ap, int64_t *tiles, int64_t *bloc
 
 NPG_API int npg_csr_coupling_records(const npg_csr *A, int64_t *records) {
     NPG_REQUIRE(A && records, "npg_csr_coupling_records: NULL argument");
-    *records = A->ndrec + A->ngrec;
+    *records = (A->pk9 || !A->drow ? A->ndrec : A->ndrec_real) + A->ngrec;      // (without zero-record padding)
     return NPG_OK;
 }
 
@@ -1246,22 +1398,96 @@ __global__ void k_fill_gather32(const double *__restrict__ x, GatherMap g, int64
 
 // y = A x with x read from its fp32 gather-layout copy: the SpMV of the Krylov kernels' gather-layout instance, stand-alone.
 // WL > 0: the matrix's windowed tile set (block tiles gather every distinct column once into LDS); 0: its ordinary tiles.
+// phase stamps of the windowed block tiles (NPG_WIN_DIAG=128, tools/window_ab.py): s_memtime at the marks of spmv_tile_win,
+// taken by thread 0's wave without waiting for memory
+struct WinProf {
+    unsigned long long *c;
+    __device__ __forceinline__ void stamp(int i) const {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+        c[i] = t;
+    }
+};
+
 template <int L, int WL>
+__global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32_timed(CsrDev A, const TileDesc *__restrict__ tiles, int ntiles, GatherMap g,
+                                                                  double *__restrict__ y, unsigned long long *acc) {
+    __shared__ TileLds tl;
+    __shared__ double sw[kTileRows];
+    unsigned long long a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, nt = 0, st[10];
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    TileDesc td = tiles[t];
+    WinPre pre;
+    bool have = false;
+    while (true) {
+        const int tn = t + gridDim.x;
+        TileDesc nd = td;
+        if (tn < ntiles) nd = tiles[tn];
+        if (td.nw && td.r0 < block_rows(A)) {
+            if (!have) win_first<kSpmvThreads>(A, PaddedX{g}, td, pre);
+            have = tn < ntiles && nd.nw != 0 && nd.r0 < block_rows(A);
+            spmv_tile_win<kSpmvThreads, WL, PaddedX, kTileNnz, WinProf>(A, PaddedX{g}, td, nd, have, pre, tl, sw, WinProf{st});
+            WinProf{st}.stamp(6);
+            for (int r = threadIdx.x; r < td.nrows; r += kSpmvThreads) y[td.r0 + r] = sw[r];
+            WinProf{st}.stamp(7);
+            a[0] += st[3] - st[9];      // bookkeeping waited for and written
+            a[8] += st[8] - st[4];      // window (gathered a tile ago) written
+            a[9] += st[9] - st[8];      // loads issued
+            a[1] += st[5] - st[3];      // barrier 1
+            a[2] += st[0] - st[5];      // gathers issued, records waited for, products
+            a[3] += st[1] - st[0];      // barrier 2
+            a[4] += st[2] - st[1];      // segmented sums
+            a[5] += st[6] - st[2];      // barrier 3
+            a[6] += st[7] - st[6];      // output stores issued
+            ++nt;
+        } else {
+            have = false;
+            pre = WinPre{};
+        }
+        if (tn >= ntiles) break;
+        t = tn;
+        td = nd;
+    }
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 10; ++i)
+            if (i != 7) atomicAdd(acc + i, a[i]);
+        atomicAdd(acc + 7, nt);
+    }
+}
+
+template <int L, int WL, int DIAG = 0>
 __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32(CsrDev A, const TileDesc *__restrict__ tiles, int ntiles, GatherMap g,
                                                             double *__restrict__ y) {
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
     int t = blockIdx.x;
     if (t >= ntiles) return;
+    if (DIAG & 64) {          // timing diagnostic: the workgroups of a CU start a third of a tile apart
+        const int k = blockIdx.x / 256;
+        for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(110);
+    }
     TileDesc td = tiles[t];
+    WinPre pre;
+    bool have = false;           // `pre` holds td's window
     while (true) {
         const int tn = t + gridDim.x;
         TileDesc nd = td;
         if (tn < ntiles) nd = tiles[tn];
-        if (WL != 0 && td.nw)
-            spmv_tile_win<kSpmvThreads, (WL ? WL : 4)>(A, PaddedX{g}, td, tl, sw);
-        else
+        if (WL != 0 && td.nw) {
+            if (!(DIAG & 16)) {
+                if (!have) win_first<kSpmvThreads>(A, PaddedX{g}, td, pre);
+                have = tn < ntiles && nd.nw != 0;
+                if (td.r0 < block_rows(A))
+                    spmv_tile_win<kSpmvThreads, (WL ? WL : 4), PaddedX, kTileNnz, NoProf, (DIAG & 7)>(A, PaddedX{g}, td, nd, have, pre, tl, sw);
+                else if (!(DIAG & 8))
+                    spmv_tile_winrows<kSpmvThreads, L>(A, PaddedX{g}, td, nd, have, pre, tl, sw);
+            }
+        } else if (!(DIAG & 8)) {
+            have = false;
             spmv_tile<kSpmvThreads, L, PaddedX, kTileNnz, 2, NoProf, false, true, false>(A, PaddedX{g}, td, tl, sw);
+            pre = WinPre{};              // (dead across the call above: nothing to keep in registers)
+        }
         for (int r = threadIdx.x; r < td.nrows; r += kSpmvThreads) y[td.r0 + r] = sw[r];
         if (tn >= ntiles) break;
         t = tn;
@@ -1274,6 +1500,41 @@ static void launch_spmv_g32(const npg_csr *A, const GatherMap &g, double *y, boo
     const TileDesc *tiles = win ? A->wtile_ptr : A->tile_ptr;
     const int nt = win ? A->nwtiles : A->ntiles;
     const dim3 grid(std::max(1, std::min<int>(nt, 3 * A->ctx->num_cu))), blk(kSpmvThreads);
+    static const int diag = getenv("NPG_WIN_DIAG") ? atoi(getenv("NPG_WIN_DIAG")) : 0;      // tools/window_ab.py: timing diagnostics
+    if (win && diag == 128) {
+        unsigned long long *acc = nullptr, h[10];
+        if (hipMalloc((void **)&acc, sizeof h) != hipSuccess) return;
+        hipMemsetAsync(acc, 0, sizeof h, A->ctx->stream);
+        hipLaunchKernelGGL((k_spmv_g32_timed<L, 4>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y, acc);
+        hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, A->ctx->stream);
+        hipStreamSynchronize(A->ctx->stream);
+        hipFree(acc);
+        static int said = 0;
+        if (said++ % 64 == 3)
+            fprintf(stderr, "windowed block tiles, s_memtime ticks per tile (thread 0's wave, %llu tiles): window write %.0f | loads issued %.0f | bookkeeping %.0f | barrier1 %.0f | gather+wait+products %.0f | "
+                    "barrier2 %.0f | sums %.0f | barrier3 %.0f | stores %.0f\n", h[7], (double)h[8] / h[7], (double)h[9] / h[7], (double)h[0] / h[7], (double)h[1] / h[7], (double)h[2] / h[7],
+                    (double)h[3] / h[7], (double)h[4] / h[7], (double)h[5] / h[7], (double)h[6] / h[7]);
+        return;
+    }
+    if (win && diag) {
+        switch (diag) {
+            case 1: hipLaunchKernelGGL((k_spmv_g32<L, 4, 1>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
+            case 2: hipLaunchKernelGGL((k_spmv_g32<L, 4, 2>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
+            case 3: hipLaunchKernelGGL((k_spmv_g32<L, 4, 3>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
+            case 4: hipLaunchKernelGGL((k_spmv_g32<L, 4, 4>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
+            case 8: hipLaunchKernelGGL((k_spmv_g32<L, 4, 8>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
+            case 16: hipLaunchKernelGGL((k_spmv_g32<L, 4, 16>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
+            case 9: hipLaunchKernelGGL((k_spmv_g32<L, 4, 9>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
+            case 10: hipLaunchKernelGGL((k_spmv_g32<L, 4, 10>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
+            case 11: hipLaunchKernelGGL((k_spmv_g32<L, 4, 11>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
+            case 12: hipLaunchKernelGGL((k_spmv_g32<L, 4, 12>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
+            case 15: hipLaunchKernelGGL((k_spmv_g32<L, 4, 15>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
+            case 64: hipLaunchKernelGGL((k_spmv_g32<L, 4, 64>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
+            case 72: hipLaunchKernelGGL((k_spmv_g32<L, 4, 72>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
+            default: hipLaunchKernelGGL((k_spmv_g32<L, 4, 7>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
+        }
+        return;
+    }
     if (win && A->wlanes == 8)
         hipLaunchKernelGGL((k_spmv_g32<L, 8>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y);
     else if (win)

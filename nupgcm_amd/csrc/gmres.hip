@@ -357,6 +357,8 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
     double acc = 0.0;
     const TileDesc *__restrict__ tiles = WL ? d.wt_ptr : d.tile_ptr;
     TileDesc nd = tiles[t0 + (int)blockIdx.x < t1 ? t0 + (int)blockIdx.x : 0];
+    WinPre pre;                  // (WL) a windowed tile's window, gathered during the tile before it
+    bool have = false;
     for (int t = t0 + blockIdx.x; t < t1; t += gridDim.x) {
         const TileDesc td = nd;
         if (t + (int)gridDim.x < t1) nd = tiles[t + gridDim.x];      // in flight during this tile
@@ -370,10 +372,18 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
         if constexpr (XG == 2)
             spmv_tile<kKB, L>(d.A, PaddedX{d.xg}, td, tl, sw);
         else if constexpr (WL != 0) {
-            if (td.nw)
-                spmv_tile_win<kKB, WL>(d.A, PaddedX{d.xg}, td, tl, sw);
-            else
+            if (td.nw) {
+                if (!have) win_first<kKB>(d.A, PaddedX{d.xg}, td, pre);
+                have = t + (int)gridDim.x < t1 && nd.nw != 0;
+                if (td.r0 < block_rows(d.A))
+                    spmv_tile_win<kKB, WL>(d.A, PaddedX{d.xg}, td, nd, have, pre, tl, sw);
+                else
+                    spmv_tile_winrows<kKB, L>(d.A, PaddedX{d.xg}, td, nd, have, pre, tl, sw);
+            } else {
+                have = false;
                 spmv_tile<kKB, L, PaddedX, kTileNnz, 2, NoProf, false, true, false>(d.A, PaddedX{d.xg}, td, tl, sw);
+                pre = WinPre{};          // (dead across the call above: nothing to keep in registers)
+            }
         } else if constexpr (XG == 1)
             // (node-blocked by definition: hardly any CSR entries - two pairs per lane there keep the records' loops inside the
             //  register budget)

@@ -83,6 +83,13 @@ struct CsrDev {
     // of distinct column nodes / other columns (TileDesc::woff, voff index them); null without it
     const uint16_t *widx, *gidx;
     const int32_t *wlist, *vlist;
+    const double2 *pkc2;      // {K, C} split by position in the record pair: [npairs] first records, [npairs] second records
+    int64_t npairs;
+    const double2 *dxy2;      // (d_x, d_y) of the coupling records, split the same way (windowed tiles of the rows behind the block rows)
+    int64_t ndpairs;
+    const int32_t *wbk;       // per block node q: {end of its column records, end of its record PAIRS} relative to its windowed tile
+    const uint16_t *dwidx;    // window indices of the coupling records / per row behind the block rows the tile-local end of its
+    const int32_t *dbk;       // coupling record pairs (windowed tiles of those rows; null: they keep their ordinary tiles)
 };
 
 __device__ __forceinline__ int block_rows(const CsrDev &A) { return 3 * A.nfull + 2 * A.nsurf; }

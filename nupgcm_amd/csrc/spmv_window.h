@@ -30,13 +30,51 @@ namespace npg {
 constexpr int kWinPairs = 2;      // record pairs per lane a windowed tile may hold (npe <= 2 * kWinPairs * threads)
 constexpr int kWinCols = 1;       // column records per lane
 constexpr int kWinNodes = 2;      // distinct column nodes per lane (nw); distinct other columns: one per lane (nv)
+// (three pairs and two column records per lane - tiles as large as the LDS allows - spill 25 VGPRs at the Arnoldi kernel's
+//  80-register cap: 2 + 1 needs 77)
 
-// One windowed tile.  On return (after the trailing barrier) out[r - r0] holds (A x)[r] for the tile's rows.
-template <int NT, int L, class XF, int TNNZ, class PROF = NoProf>
-__device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const XF x, const TileDesc &td, TileLdsT<TNNZ> &t,
-                                              double *__restrict__ out, PROF prof = PROF()) {
+// The window of a tile as gathered: held in registers from the middle of the PREVIOUS tile (below) to the start of its own.
+struct WinPre {
+    float4 f[kWinNodes];
+    float v;
+};
+
+// the two halves of a window prefetch: request the next tile's lists / gather their columns
+template <int NT>
+__device__ __forceinline__ void win_lists(const CsrDev &A, const TileDesc &next, int tid, int32_t (&wc)[kWinNodes], int32_t &vc) {
+#pragma unroll
+    for (int u = 0; u < kWinNodes; ++u) wc[u] = __builtin_nontemporal_load(A.wlist + next.woff + min(tid + u * NT, next.nw - 1));
+    vc = __builtin_nontemporal_load(A.vlist + next.voff + min(tid, max(next.nv - 1, 0)));
+}
+template <class XF, int DIAG = 0>
+__device__ __forceinline__ void win_gather(const XF &x, const int32_t (&wc)[kWinNodes], int32_t vc, WinPre &w) {
+#pragma unroll
+    for (int u = 0; u < kWinNodes; ++u) w.f[u] = (DIAG & 1) ? make_float4((float)wc[u], 1.f, 2.f, 0.f) : x.node4(wc[u]);
+    w.v = (DIAG & 1) ? (float)vc : x.behind(vc);
+}
+
+// lists -> gathers for a tile nobody prefetched (a workgroup's first windowed tile): two dependent round trips, once
+template <int NT, class XF>
+__device__ __forceinline__ void win_first(const CsrDev &A, const XF &x, const TileDesc &td, WinPre &w) {
+    const int tid = threadIdx.x;
+    int32_t wc[kWinNodes], vc;
+    win_lists<NT>(A, td, tid, wc, vc);
+    win_gather(x, wc, vc, w);
+}
+
+// One windowed BLOCK tile.  `w`: on entry this tile's window (win_first, or the previous call), on return - if `pre_next` - the window
+// of tile `next`: its lists are requested before this tile's records, its gathers are issued once the lists are in and are in
+// flight during this tile's products and segmented sums, so that the only global round trip a tile waits for is its own
+// record stream (hipcc's __syncthreads waits for LDS only: loads stay in flight across the barriers).
+// On return (after the trailing barrier) out[r - r0] holds (A x)[r] for the tile's rows.
+// DIAG (timing diagnostics of tools/window_ab.py only; results are then meaningless): bit 0 = the window is filled without
+// gathering, bit 1 = no segmented sums, bit 2 = no record loads (products of constants).
+template <int NT, int L, class XF, int TNNZ, class PROF = NoProf, int DIAG = 0>
+__device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const XF x, const TileDesc &td, const TileDesc &next, bool pre_next,
+                                              WinPre &w, TileLdsT<TNNZ> &t, double *__restrict__ out, PROF prof = PROF()) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));          // per-tile re-made lane offsets (spmv_tile's REMAT): keeps the stream bases out of the caller's loop
+    prof.stamp(4);
     const bool full = td.r0 < 3 * A.nfull;
     const int ncomp = full ? 3 : 2;
     const int q0 = node_of_row(A, td.r0);
@@ -47,27 +85,42 @@ __device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const XF x, const
     const int slots = slot0 + ncomp * n;
     float4 *__restrict__ win = reinterpret_cast<float4 *>(t.prod + ((slots + 1) & ~1));
     float *__restrict__ vwin = reinterpret_cast<float *>(win + nw);
+    // node bookkeeping of the segmented sums, tile-local and ready for LDS (requested FIRST: vmcnt counts in order, and a wait
+    // for these two words must not be a wait for the record stream behind them)
+    const int2 bk = *reinterpret_cast<const int2 *>(A.wbk + 2 * (size_t)(q0 + min(tid, nnode - 1)));
+    // ---- (1) this tile's window, gathered a tile ago
+#pragma unroll
+    for (int u = 0; u < kWinNodes; ++u) {
+        const int i = tid + u * NT;
+        if (i < nw) win[i] = w.f[u];
+    }
+    if (tid < nv) vwin[tid] = w.v;
+    prof.stamp(8);
     // Every load below is unconditional, from an index clamped into the tile's range (a lane without work re-reads the last
     // element and never uses it): no control flow between the loads, so they are all in flight together.
-    // ---- (1) the tile's distinct columns
-    int32_t wc[kWinNodes], vc;
-#pragma unroll
-    for (int u = 0; u < kWinNodes; ++u) wc[u] = __builtin_nontemporal_load(A.wlist + td.woff + min(tid + u * NT, nw - 1));
-    vc = __builtin_nontemporal_load(A.vlist + td.voff + min(tid, max(nv - 1, 0)));
-    // ---- (2) every record of the tile
+    // ---- (2) the NEXT tile's distinct columns
+    int32_t wc[kWinNodes], vc = 0;
+    if (pre_next) win_lists<NT>(A, next, tid, wc, vc);
+    // ---- (3) every record of this tile
     uint32_t ip[kWinPairs];
     double k0[kWinPairs], c0[kWinPairs], k1[kWinPairs], c1[kWinPairs];
     {
         const uint32_t *__restrict__ wp = reinterpret_cast<const uint32_t *>(A.widx + pbase);
-        const double *__restrict__ kp = reinterpret_cast<const double *>(A.pkc + pbase);
+        const double *__restrict__ ka = reinterpret_cast<const double *>(A.pkc2 + (pbase >> 1));
+        const double *__restrict__ kb = reinterpret_cast<const double *>(A.pkc2 + A.npairs + (pbase >> 1));
 #pragma unroll
         for (int u = 0; u < kWinPairs; ++u) {
             const int p = min(tid + u * NT, npair - 1);
+            if (DIAG & 4) {
+                ip[u] = (uint32_t)p & 0x00ff00ffu;
+                k0[u] = c0[u] = k1[u] = c1[u] = (double)p;
+                continue;
+            }
             ip[u] = __builtin_nontemporal_load(wp + p);
-            k0[u] = __builtin_nontemporal_load(kp + 4 * p);
-            c0[u] = __builtin_nontemporal_load(kp + 4 * p + 1);
-            k1[u] = __builtin_nontemporal_load(kp + 4 * p + 2);
-            c1[u] = __builtin_nontemporal_load(kp + 4 * p + 3);
+            k0[u] = __builtin_nontemporal_load(ka + 2 * p);
+            c0[u] = __builtin_nontemporal_load(ka + 2 * p + 1);
+            k1[u] = __builtin_nontemporal_load(kb + 2 * p);
+            c1[u] = __builtin_nontemporal_load(kb + 2 * p + 1);
         }
     }
     uint32_t gi[kWinCols];
@@ -77,33 +130,29 @@ __device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const XF x, const
 #pragma unroll
         for (int u = 0; u < kWinCols; ++u) {
             const int e = min(tid + u * NT, max(n - 1, 0));
+            if (DIAG & 4) {
+                gi[u] = (uint32_t)e & 31u;
+                ax[u] = ay[u] = az[u] = (double)e;
+                continue;
+            }
             gi[u] = __builtin_nontemporal_load(A.gidx + base + e);
             ax[u] = __builtin_nontemporal_load(gp + 2 * e);
             ay[u] = __builtin_nontemporal_load(gp + 2 * e + 1);
             az[u] = __builtin_nontemporal_load(A.gz + base + e);
         }
     }
-    // node bookkeeping of the segmented sums (LDS writes: independent of everything in flight)
-    for (int q = threadIdx.x; q <= nnode; q += NT) {
-        t.rp[q] = (int32_t)(A.grow[q0 + q] - base);
-        t.prp[q] = (int32_t)((A.prow[q0 + q] - pbase) >> 1);
+    prof.stamp(9);
+    if (tid < nnode) {
+        t.rp[tid + 1] = bk.x;
+        t.prp[tid + 1] = bk.y;
     }
-    // ---- (3) ONE gather per distinct column, ascending along the lanes
-    {
-        float4 f[kWinNodes];
-#pragma unroll
-        for (int u = 0; u < kWinNodes; ++u) f[u] = x.node4(wc[u]);
-        const float v = x.behind(vc);
-#pragma unroll
-        for (int u = 0; u < kWinNodes; ++u) {
-            const int i = tid + u * NT;
-            if (i < nw) win[i] = f[u];
-        }
-        if (tid < nv) vwin[tid] = v;
-    }
+    if (tid == 0) t.rp[0] = t.prp[0] = 0;
     prof.stamp(3);
     __syncthreads();
-    // ---- (4) products: two adjacent records of one row node per lane, summed before they reach LDS
+    prof.stamp(5);
+    // ---- (4) ONE gather per distinct column of the NEXT tile, ascending along the lanes: in flight until that tile starts
+    if (pre_next) win_gather<XF, DIAG>(x, wc, vc, w);
+    // ---- (5) products: two adjacent records of one row node per lane, summed before they reach LDS
 #pragma unroll
     for (int u = 0; u < kWinPairs; ++u) {
         const int p = tid + u * NT;
@@ -128,9 +177,9 @@ __device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const XF x, const
     prof.stamp(0);
     __syncthreads();
     prof.stamp(1);
-    // ---- (5) segmented sums: a lane group sums the two or three rows of a NODE together (spmv_tile's node-wise loop)
+    // ---- (6) segmented sums: a lane group sums the two or three rows of a NODE together (spmv_tile's node-wise loop)
     const int g = threadIdx.x / L, l = threadIdx.x % L;
-    for (int q = g; q < nnode; q += NT / L) {
+    for (int q = g; q < ((DIAG & 2) ? 0 : nnode); q += NT / L) {
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         const int cb = t.rp[q], ce = t.rp[q + 1];
         for (int k = cb + 2 * l; k < ce; k += 2 * L) {
@@ -166,6 +215,73 @@ __device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const XF x, const
         }
     }
     prof.stamp(2);
+    __syncthreads();
+}
+
+// One windowed tile of rows BEHIND the block rows (the divergence rows): coupling records {c, d_x, d_y, d_z} in pairs - two
+// adjacent records of one row per lane, their six products summed into ONE LDS slot - with every distinct column node gathered
+// once into the window, as in the block tiles; same prefetch protocol (`w`, `next`, `pre_next`).  These tiles hold no other
+// entries (the host keeps a matrix whose rows behind the block hold CSR entries on ordinary tiles).
+template <int NT, int L, class XF, int TNNZ>
+__device__ __forceinline__ void spmv_tile_winrows(const CsrDev &A, const XF x, const TileDesc &td, const TileDesc &next, bool pre_next,
+                                                  WinPre &w, TileLdsT<TNNZ> &t, double *__restrict__ out) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int nrows = td.nrows, npair = td.npe >> 1, nw = td.nw;
+    const int64_t pbase = td.pbase;
+    float4 *__restrict__ win = reinterpret_cast<float4 *>(t.prod + ((npair + 1) & ~1));
+    const int32_t bk = A.dbk[(td.r0 - block_rows(A)) + min(tid, nrows - 1)];
+#pragma unroll
+    for (int u = 0; u < kWinNodes; ++u) {
+        const int i = tid + u * NT;
+        if (i < nw) win[i] = w.f[u];
+    }
+    int32_t wc[kWinNodes], vc = 0;
+    if (pre_next) win_lists<NT>(A, next, tid, wc, vc);
+    uint32_t ip[kWinPairs];
+    double dx0[kWinPairs], dy0[kWinPairs], dx1[kWinPairs], dy1[kWinPairs], dz0[kWinPairs], dz1[kWinPairs];
+    {
+        const uint32_t *__restrict__ wp = reinterpret_cast<const uint32_t *>(A.dwidx + pbase);
+        const double *__restrict__ xa = reinterpret_cast<const double *>(A.dxy2 + (pbase >> 1));
+        const double *__restrict__ xb = reinterpret_cast<const double *>(A.dxy2 + A.ndpairs + (pbase >> 1));
+        const double *__restrict__ zz = A.dz + pbase;
+#pragma unroll
+        for (int u = 0; u < kWinPairs; ++u) {
+            const int p = min(tid + u * NT, npair - 1);
+            ip[u] = __builtin_nontemporal_load(wp + p);
+            dx0[u] = __builtin_nontemporal_load(xa + 2 * p);
+            dy0[u] = __builtin_nontemporal_load(xa + 2 * p + 1);
+            dx1[u] = __builtin_nontemporal_load(xb + 2 * p);
+            dy1[u] = __builtin_nontemporal_load(xb + 2 * p + 1);
+            dz0[u] = __builtin_nontemporal_load(zz + 2 * p);
+            dz1[u] = __builtin_nontemporal_load(zz + 2 * p + 1);
+        }
+    }
+    if (tid < nrows) t.prp[tid + 1] = bk;
+    if (tid == 0) t.prp[0] = 0;
+    __syncthreads();
+    if (pre_next) win_gather(x, wc, vc, w);
+#pragma unroll
+    for (int u = 0; u < kWinPairs; ++u) {
+        const int p = tid + u * NT;
+        if (p < npair) {
+            const float4 fa = win[ip[u] & 0xffffu], fb = win[ip[u] >> 16];
+            t.prod[p] = (dx0[u] * (double)fa.x + dy0[u] * (double)fa.y + dz0[u] * (double)fa.z) +
+                        (dx1[u] * (double)fb.x + dy1[u] * (double)fb.y + dz1[u] * (double)fb.z);
+        }
+    }
+    __syncthreads();
+    const int g = threadIdx.x / L, l = threadIdx.x % L;
+    for (int r = g; r < nrows; r += NT / L) {
+        double s = 0.0;
+        const int pe = t.prp[r + 1];
+        for (int k = t.prp[r] + 2 * l; k < pe; k += 2 * L) {
+            const double a = t.prod[k], b = t.prod[k + 1];
+            s += a + (k + 1 < pe ? b : 0.0);
+        }
+        s = group_sum_dpp<L>(s);
+        if (l == 0) out[r] = s;
+    }
     __syncthreads();
 }
 

@@ -459,8 +459,11 @@ class PartitionedModel(Model):
         n = ctx.nranks
         s = ctx.allreduce_sum(np.arange(1.0, 6.0) * (ctx.rank + 1))
         ok = ok and np.array_equal(s, np.arange(1.0, 6.0) * n * (n + 1) / 2)
-        bad = ctx.allreduce_sum([0.0 if ok else 1.0])[0]
-        return bad == 0.0
+        # the verdict travels over the BOOTSTRAP channel (torch.distributed object collectives), never over the transport under
+        # test: a broken all-reduce must not be able to hand different ranks different verdicts
+        verdicts = [None] * self.dist.get_world_size()
+        self.dist.all_gather_object(verdicts, bool(ok))
+        return all(verdicts)
 
     def reassemble_A(self):
         """the eddy closure's refresh (src/model.jl:160-170): full-stress A on the rank's cells into the rank's rows"""
