@@ -158,6 +158,8 @@ static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, cons
     constexpr int NT = 512;
     int64_t hard = 8 * (int64_t)kTileNnz;
     if (getenv("NPG_WIN_BYTES")) hard = std::min<int64_t>(hard, std::max<int64_t>(8192, atoll(getenv("NPG_WIN_BYTES"))));    // tuning: smaller tiles
+    const double scale = getenv("NPG_WIN_SCALE") ? std::min(1.0, std::max(0.25, atof(getenv("NPG_WIN_SCALE")))) : 1.0;       // tuning: all caps scaled
+    const int64_t cap_p = (int64_t)(scale * kWinPairs * NT), cap_c = (int64_t)(scale * kWinCols * NT);
     // small matrices: about one tile per CU (as tile_boundaries does)
     const int64_t total = 8 * (3 * (prow[nfull] / 2 + grow[nfull]) + 2 * ((prow[nnode] - prow[nfull]) / 2 + grow[nnode] - grow[nfull]));
     const int64_t soft = std::min<int64_t>(hard, std::max<int64_t>(8 * 1024, total / std::max(1, A->ctx->num_cu)));
@@ -195,8 +197,7 @@ static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, cons
                 const int64_t np2 = np + (prow[qe + 1] - prow[qe]) / 2, ng2 = ng + (grow[qe + 1] - grow[qe]);
                 const int64_t nw2 = (int64_t)(tw.size() + nwl.size()), nv2 = (int64_t)(tv.size() + nvl.size());
                 const int64_t by = bytes_of(ncomp, np2, ng2, nw2, nv2);
-                const bool shape = (qe + 1 - q) * ncomp <= kTileRows && np2 <= kWinPairs * NT && ng2 <= kWinCols * NT &&
-                                   nw2 <= kWinNodes * NT && nv2 <= NT;
+                const bool shape = (qe + 1 - q) * ncomp <= kTileRows && np2 <= cap_p && ng2 <= cap_c && nw2 <= kWinNodes * NT && nv2 <= NT;
                 if (qe == q && !(shape && by <= hard)) return NPG_OK;       // one node's rows do not fit: no windowed set
                 if (qe > q && !(shape && by <= soft)) {
                     for (int32_t c : nwl) stampW[c] = -1;
@@ -251,7 +252,7 @@ static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, cons
         const std::vector<int64_t> &drow = A->h_drow;
         dwidx.assign(dcol.size(), 0);
         dbk.assign((size_t)nbehind, 0);
-        int64_t cap_pairs = kWinPairs * NT;
+        int64_t cap_pairs = cap_p;
         {       // small matrices: about as many tiles as the block rows got per byte
             const int64_t want = std::max<int64_t>(1, (int64_t)blk.size() * (drow[nbehind] * 28) / std::max<int64_t>(1, total * 3));
             cap_pairs = std::min<int64_t>(cap_pairs, std::max<int64_t>(64, drow[nbehind] / 2 / want));
@@ -394,9 +395,10 @@ static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, cons
     A->nwtiles_interior = nint;
     A->nwlist = (int64_t)wlist.size();
     A->nvlist = (int64_t)vlist.size();
-    // lanes per node in the segmented sums of a windowed tile: ~75 nodes per tile and a lane takes two slots per trip
+    // lanes per node in the segmented sums of a windowed tile (a lane takes two slots per trip): measured on bowl3D h = 0.02
+    // (14 pair slots + 8 column-record slots per row, 64 nodes per tile) 8 lanes 136.9 us per product against 142.6 with 4
     const double mean = (double)(prow[nnode] / 2 + grow[nnode]) / (double)nnode;
-    A->wlanes = mean <= 40 ? 4 : 8;
+    A->wlanes = mean <= 12 ? 4 : 8;
     if (getenv("NPG_SPMV_WLANES")) A->wlanes = atoi(getenv("NPG_SPMV_WLANES")) == 8 ? 8 : 4;
     A->gen++;
     return NPG_OK;

@@ -65,6 +65,8 @@ struct GDev {
     int nt_int;           // tiles [0, nt_int) read no ghost column (distributed row blocks; = ntiles otherwise)
     const TileDesc *wt_ptr;   // windowed tile set (spmv_window.h) for the Arnoldi kernel's gather-layout instance; null: none
     int nwt, nwt_int, wl; // wl: lanes per node in a windowed tile's segmented sums (4 or 8)
+    int word;             // the windowed set also holds ordinary tiles
+    int wpre;             // request the first tile's window before the prologue (tuning switch NPG_WIN_PRE)
     int pkind;
     double pscalar;
     const double *pdiag;
@@ -312,13 +314,26 @@ __global__ void __launch_bounds__(kKB, 6) k_gmres_residual(GDev d) {
 // N9: the matrix may hold FULL node records (spmv_device.h).
 // WL > 0: the tiles come from the matrix's WINDOWED set (spmv_window.h; XG = 1 only): block tiles gather every distinct column
 // once into LDS, WL lanes per node in their segmented sums; the tiles of the other rows are the ordinary ones.
-template <int L, bool FUSED, int XG = 0, bool N9 = false, int WL = 0>
+// ORD: that set also holds ordinary tiles (rows behind the block rows with CSR entries, e.g. a rank's ghost columns); the instance
+// without them carries less code through its register budget.
+template <int L, bool FUSED, int XG = 0, bool N9 = false, int WL = 0, bool ORD = true>
 __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, int j, int t0, int t1) {
     static_assert(WL == 0 || (XG == 1 && !N9 && !FUSED), "windowed tiles serve the gather-layout instance of the split organisation");
     __shared__ KShared sh;
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
     double *tmp = tl.prod;                // scratch of the prologue / final block reduction, outside the tile loop
+    // (WL) the first tile's window is requested before the prologue: its two dependent round trips pass behind the Givens work
+    const TileDesc *__restrict__ tiles = WL ? d.wt_ptr : d.tile_ptr;
+    TileDesc nd = tiles[t0 + (int)blockIdx.x < t1 ? t0 + (int)blockIdx.x : 0];
+    WinPre pre;                  // (WL) a windowed tile's window, gathered during the tile before it
+    bool have = false;
+    if constexpr (WL != 0) {
+        if (d.wpre && t0 + (int)blockIdx.x < t1 && nd.nw) {
+            win_first<kKB>(d.A, PaddedX{d.xg}, nd, pre);
+            have = true;
+        }
+    }
     if (j == 0) {
         const Snap c = *d.C;
         reduce_partials<kNS, kMaxI>(d.QR, d.nQR, 1, tmp, sh.red);
@@ -355,10 +370,6 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
     const bool ro = XG == 0 && sh.reorth != 0;        // (the gather-layout instance runs in fast mode: never a second pass)
     const double h2k = (ro && k < j) ? sh.h2[k] : 0.0;
     double acc = 0.0;
-    const TileDesc *__restrict__ tiles = WL ? d.wt_ptr : d.tile_ptr;
-    TileDesc nd = tiles[t0 + (int)blockIdx.x < t1 ? t0 + (int)blockIdx.x : 0];
-    WinPre pre;                  // (WL) a windowed tile's window, gathered during the tile before it
-    bool have = false;
     for (int t = t0 + blockIdx.x; t < t1; t += gridDim.x) {
         const TileDesc td = nd;
         if (t + (int)gridDim.x < t1) nd = tiles[t + gridDim.x];      // in flight during this tile
@@ -379,7 +390,7 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
                     spmv_tile_win<kKB, WL>(d.A, PaddedX{d.xg}, td, nd, have, pre, tl, sw);
                 else
                     spmv_tile_winrows<kKB, L>(d.A, PaddedX{d.xg}, td, nd, have, pre, tl, sw);
-            } else {
+            } else if constexpr (ORD) {
                 have = false;
                 spmv_tile<kKB, L, PaddedX, kTileNnz, 2, NoProf, false, true, false>(d.A, PaddedX{d.xg}, td, tl, sw);
                 pre = WinPre{};          // (dead across the call above: nothing to keep in registers)
@@ -924,10 +935,14 @@ static void launch_arnoldi_split(const GDev &d, int grid, int j, int t0, int t1,
     } else if (d.xg.p && d.xg.nbr == 0) {
         hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 2>), g, b, 0, st, d, j, t0, t1);
     } else if (d.xg.p && d.wt_ptr) {
-        if (d.wl == 8)
-            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1, false, 8>), g, b, 0, st, d, j, t0, t1);
+        if (d.wl == 8 && !d.word)
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1, false, 8, false>), g, b, 0, st, d, j, t0, t1);
+        else if (d.wl == 8)
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1, false, 8, true>), g, b, 0, st, d, j, t0, t1);
+        else if (!d.word)
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1, false, 4, false>), g, b, 0, st, d, j, t0, t1);
         else
-            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1, false, 4>), g, b, 0, st, d, j, t0, t1);
+            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1, false, 4, true>), g, b, 0, st, d, j, t0, t1);
     } else if (d.xg.p) {
         hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1>), g, b, 0, st, d, j, t0, t1);
     } else {
@@ -1227,6 +1242,10 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A_in, int precond_kind
             d.nwt = A->nwtiles;
             d.nwt_int = A->nwtiles_interior;
             d.wl = A->wlanes;
+            static const int ord_env = getenv("NPG_WIN_ORD") ? atoi(getenv("NPG_WIN_ORD")) : 0;
+            static const int pre_env = getenv("NPG_WIN_PRE") ? atoi(getenv("NPG_WIN_PRE")) : 1;
+            d.word = ord_env || (A->nwrow_tiles == 0 && A->m > A->block_rows());
+            d.wpre = pre_env;
         }
     }
     if (dist) {

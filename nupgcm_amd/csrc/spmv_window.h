@@ -1,24 +1,29 @@
-// Windowed block tiles: the block rows of a node-blocked matrix ({c, K, C} node records + {m, a_x, a_y, a_z} column records,
-// spmv_device.h) with every gather of the input vector served from LDS.
+// Windowed tiles: the rows of a node-blocked matrix ({c, K, C} node records + {m, a_x, a_y, a_z} column records in the block
+// rows, {c, d_x, d_y, d_z} coupling records behind them; spmv_device.h) with every gather of the input vector served from LDS.
 //
-// Why.  The record-form SpMV is bound by the rate at which a CU's texture-address / L1 path accepts divergent gather lanes,
-// not by HBM (profiles/r02_spmv_experiments.txt section 6: with EVERY gather an L1 hit the kernel is 3 % faster,
-// section 7: gathers served by LDS reads cost 9 us per SpMV instead of 55).  A tile of ~75 row nodes holds ~2 000 node records
-// but only ~480 DISTINCT column nodes (RCM keeps a tile's columns close; measured on bowl3D h = 0.02: 4.2 records per distinct
-// node) and ~600 column records on ~100 distinct pressure columns.  So the host stores, per tile, the ascending list of distinct
-// column nodes (`wlist`) and of distinct other columns (`vlist`); the tile gathers each of them ONCE - adjacent lanes gather
-// ascending nodes - into an LDS window, and the records address the window through 16-bit indices (2 bytes per record instead of
-// the 4-byte column: the lists cost less than the indices save).  Texture-path gather lanes per SpMV of that matrix: 24.6 M ->
-// 5.6 M in the block rows.
+// Why.  The record-form SpMV is bound by the rate at which a CU's texture-address / L1 path accepts vector-memory lanes, not by
+// HBM (profiles/r02_spmv_experiments.txt section 6: with EVERY gather an L1 hit the kernel is 3 % faster,
+// section 7: gathers served by LDS reads cost 9 us per SpMV instead of 55).  A tile of ~64 row nodes holds ~1 800 node records
+// but only ~430 DISTINCT column nodes (RCM keeps a tile's columns close; bowl3D h = 0.02: 4.2 records per distinct node) and
+// ~500 column records on ~90 distinct pressure columns.  So the host stores, per tile, the ascending list of distinct column
+// nodes (`wlist`) and of distinct other columns (`vlist`); the tile gathers each of them ONCE - adjacent lanes gather ascending
+// nodes - into an LDS window, and the records address the window through 16-bit indices (2 bytes per record instead of the
+// 4-byte column: the lists cost less than the indices save).  Divergent gather lanes per SpMV of that matrix: 30 M -> 8.3 M.
 //
-// Pair sums.  Every node's record list is padded to an even count with a zero record, and a lane takes two ADJACENT records of
-// the same row node: their products are summed in registers before they reach LDS - half the product slots, half the LDS
-// traffic and half the segmented-sum trips for the node records; what the slots save pays for the window's LDS.
+// Pair sums.  Every node's (every row's) record list is padded to an even count with a zero record, and a lane takes two ADJACENT
+// records of the same row node: their products are summed in registers before they reach LDS - half the product slots, half the
+// LDS traffic and half the segmented-sum trips; what the slots save pays for the window's LDS.  The values of a pair are stored
+// SPLIT by position in the pair (pkc2 / dxy2: all first records, then all second records), so that each of a lane's two 16-byte
+// loads belongs to a fully contiguous stream: with the interleaved array (32-byte lane stride, every 128-byte line touched by
+// two instructions) the same kernel took 164 us instead of 143 (profiles/r04_windowed_tiles.txt).
 //
-// One dependent chain per tile: list loads, then ALL record loads of the tile (at most three record pairs and two column
-// records per lane: the host sizes the tiles so), then the gathers of the lists' columns; by the time the window is in LDS the
-// records have arrived, and everything behind the barrier is LDS reads and arithmetic.  (The non-windowed tile function runs
-// two record loops of two dependent round trips each.)
+// One dependent chain per tile, and the window is not on it: a tile requests the NEXT tile's lists before its own records,
+// gathers the next tile's columns once the lists are in (in flight during its own products and segmented sums; hipcc's
+// __syncthreads waits for LDS only, loads stay in flight across barriers) and hands the gathered window on in registers
+// (WinPre); the node bookkeeping of the segmented sums is precomputed per node (`wbk`) and requested first, because vmcnt counts
+// in order and a wait for two words must not be a wait for the record stream.  What a tile waits for is its own record stream:
+// at most kWinPairs record pairs and kWinCols column records per lane, all requested at once (more per lane - tiles as large as
+// the LDS would allow - spill at the Arnoldi kernel's 80-register cap: 3 + 2 spills 25 VGPRs, 2 + 1 needs 76).
 //
 // The input accessor must serve a node's components as one float4 (`node4`) and an entry behind the block rows as a float
 // (`behind`): the fp32 gather-layout copy of the Krylov vector (PaddedX).  Products and sums are fp64.
@@ -30,8 +35,6 @@ namespace npg {
 constexpr int kWinPairs = 2;      // record pairs per lane a windowed tile may hold (npe <= 2 * kWinPairs * threads)
 constexpr int kWinCols = 1;       // column records per lane
 constexpr int kWinNodes = 2;      // distinct column nodes per lane (nw); distinct other columns: one per lane (nv)
-// (three pairs and two column records per lane - tiles as large as the LDS allows - spill 25 VGPRs at the Arnoldi kernel's
-//  80-register cap: 2 + 1 needs 77)
 
 // The window of a tile as gathered: held in registers from the middle of the PREVIOUS tile (below) to the start of its own.
 struct WinPre {
