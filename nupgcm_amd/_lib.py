@@ -11,7 +11,8 @@ import re
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnupgcm_hip.so")
+# NPG_LIB_NAME: another build of the SAME library beside it (A/B timing of two builds on one GPU box; tools only)
+LIB_PATH = os.path.join(_HERE, os.environ.get("NPG_LIB_NAME", "libnupgcm_hip.so"))
 HEADER_PATH = os.path.join(_HERE, "..", "include", "nupgcm_hip.h")
 
 
@@ -117,6 +118,8 @@ def _declare(L):
         "npg_halo_exchange": [P, P], "npg_gmres_set_halo": [P, P], "npg_gmres_set_dist_options": [P, C.c_int, C.c_int], "npg_cg_set_halo": [P, P],
     }
     for name, args in sig.items():
+        if "NPG_LIB_NAME" in os.environ and not hasattr(L, name):
+            continue            # (an older build timed beside the current one: entry points it lacks stay unbound)
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int

@@ -44,13 +44,19 @@ constexpr int kTileRows = 256;     // most rows in one SpMV tile
 constexpr int kMaxMem = 30;        // largest GMRES memory supported (partial rows hold mem + 2 values)
 
 // one SpMV tile: rows [r0, r0 + nrows), its n CSR entries from `base` and (node-block rows) npe records from `pbase`.
-// Kernels fetch the next tile's descriptor while they work on the current one.
-// Windowed block tiles (spmv_window.h; nw > 0): the tile's distinct column nodes wlist[woff .. woff + nw) and distinct other
-// columns vlist[voff .. voff + nv) are gathered ONCE into LDS; the records address them by 16-bit window indices.
+// 32 bytes = one scalar load; kernels fetch the next tile's descriptor while they work on the current one.
 struct TileDesc {
     int64_t base, pbase;
     int32_t r0, nrows, n, npe;
-    int32_t woff, voff, nw, nv;      // zero in ordinary tiles
+};
+// a tile of the WINDOWED set (spmv_window.h): the same, plus (nw > 0) the tile's distinct column nodes wlist[woff .. woff + nw) and
+// distinct other columns vlist[voff .. voff + nv), gathered ONCE into LDS and addressed by the records through 16-bit window
+// indices; nw = 0: an ordinary tile.  (A type of its own: the twelve more bytes, carried by every kernel's tile loop, cost the
+// ordinary kernels spilled scalar registers - k_spmv 191 -> 256 us when TileDesc itself had grown.)
+struct WTileDesc {
+    int64_t base, pbase;
+    int32_t r0, nrows, n, npe;
+    int32_t woff, voff, nw, nv;
 };
 
 }  // namespace npg
@@ -132,7 +138,7 @@ struct npg_csr {
     // windowed tile set of the block rows (spmv_window.h, build_window_tiles): a SECOND tiling of the same matrix for the
     // kernels that gather from the fp32 gather-layout copy of their input - every node's record list padded to an even
     // count (zero records), 16-bit window indices beside pcol / gcol, per-tile lists of distinct columns
-    npg::TileDesc *wtile_ptr = nullptr; // device, nwtiles descriptors: windowed block tiles, then the ordinary tiles of the other rows
+    npg::WTileDesc *wtile_ptr = nullptr; // device, nwtiles descriptors: windowed block tiles, then the ordinary tiles of the other rows
     int32_t nwtiles = 0, nwtiles_interior = 0;
     int32_t wlanes = 8;
     uint16_t *widx = nullptr;    // device, window index of every node record (same indexing as pcol)
@@ -210,6 +216,8 @@ NPG_SHARED int csr_repack(const npg_csr *A);
 NPG_SHARED int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp, int max_rows = kTileRows);
 struct CsrDev;
 NPG_SHARED CsrDev csr_view(const npg_csr *A);
+struct WinDev;
+WinDev win_view(const npg_csr *A);
 // epilogue of the tiled SpMV kernel: y = alpha (A x) + beta c   [c may be y itself; not read when beta == 0]
 //                           and, if z:  z = zc zin + w dg .* y  [zin may be null]
 struct SpmvEpi {

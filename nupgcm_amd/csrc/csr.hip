@@ -86,7 +86,6 @@ int build_tiles(npg_csr *A) {
         q.n = (int32_t)(rp[r1] - rp[r0]);
         q.pbase = 0;
         q.npe = 0;
-        q.woff = q.voff = q.nw = q.nv = 0;
         if (r0 < nbr) {
             q.pbase = A->h_prow[node(r0)];
             q.npe = (int32_t)(A->h_prow[node(r1)] - q.pbase);
@@ -166,7 +165,7 @@ static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, cons
     std::vector<int32_t> stampW((size_t)nnode, -1), stampV((size_t)A->n, -1), posW((size_t)nnode, 0), posV((size_t)A->n, 0);
     std::vector<uint16_t> widx(pcol.size()), gidx(gcol.size());
     std::vector<int32_t> wlist, vlist, tw, tv, nwl, nvl, wbk((size_t)2 * nnode);
-    std::vector<TileDesc> blk;
+    std::vector<WTileDesc> blk;
     std::vector<char> ghost;
     auto bytes_of = [](int ncomp, int64_t np, int64_t ng, int64_t nw, int64_t nv) {
         const int64_t slots = ncomp * (np + ng);
@@ -220,7 +219,7 @@ static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, cons
                 wbk[2 * k] = (int32_t)(grow[k + 1] - grow[q]);
                 wbk[2 * k + 1] = (int32_t)((prow[k + 1] - prow[q]) >> 1);
             }
-            TileDesc d;
+            WTileDesc d;
             d.r0 = (int32_t)(kind ? 3 * nfull + 2 * (q - nfull) : 3 * q);
             d.nrows = (int32_t)((qe - q) * ncomp);
             d.base = grow[q];
@@ -243,7 +242,7 @@ static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, cons
     // adjacent records of a row per lane (every row's list is padded to an even count), at most kWinPairs pairs per lane and
     // kWinNodes distinct column nodes per lane - small tiles, one dependent chain each (the ordinary tile function walks such
     // a row block in four trips of two round trips).  NPG_WIN_ROWS=0: ordinary tiles for these rows.
-    std::vector<TileDesc> rowt;
+    std::vector<WTileDesc> rowt;
     std::vector<uint16_t> dwidx;
     std::vector<int32_t> dbk;
     const int64_t nbehind = A->m - nbr;
@@ -290,7 +289,7 @@ static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, cons
             for (size_t i = 0; i < tw.size(); ++i) posW[tw[i]] = (int32_t)i;
             for (int64_t e = drow[r]; e < drow[re]; ++e) dwidx[e] = (uint16_t)posW[dcol[e]];
             for (int64_t k = r; k < re; ++k) dbk[k] = (int32_t)((drow[k + 1] - drow[r]) >> 1);
-            TileDesc d;
+            WTileDesc d;
             d.r0 = (int32_t)(nbr + r);
             d.nrows = (int32_t)(re - r);
             d.base = 0;
@@ -314,21 +313,22 @@ static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, cons
     vlist.push_back((int32_t)nbr);           // sentinel: a tile without such columns still reads one entry at its offset
     NPG_REQUIRE(wlist.size() < (size_t)INT32_MAX && vlist.size() < (size_t)INT32_MAX, "build_window_tiles: window lists exceed int32 offsets");
     // the tiles of the rows behind the block rows: windowed (above), or as build_tiles made (and ordered) them
-    std::vector<TileDesc> ord;
+    std::vector<WTileDesc> ord;
     ord.reserve(blk.size() + A->h_tiles.size() + rowt.size());
+    auto widen = [](const TileDesc &t) { return WTileDesc{t.base, t.pbase, t.r0, t.nrows, t.n, t.npe, 0, 0, 0, 0}; };
     int32_t nint = 0;
     // order within a pass (tuning, NPG_WIN_ORDER): 0 = block tiles, then the rows behind them; 1 = the other way round;
     // 2 = the tiles of the rows behind the block rows spread evenly among the block tiles
     const int order = getenv("NPG_WIN_ORDER") ? atoi(getenv("NPG_WIN_ORDER")) : 0;
     for (int pass = 0; pass < 2; ++pass) {
-        std::vector<TileDesc> a, b;
+        std::vector<WTileDesc> a, b;
         for (size_t t = 0; t < blk.size(); ++t)
             if ((ghost[t] != 0) == (pass == 1)) a.push_back(blk[t]);
         if (!rowt.empty()) {
             if (pass == 0) b = rowt;         // (only matrices without ghost columns get here)
         } else {
             for (int32_t t = 0; t < A->ntiles; ++t)
-                if (A->h_tiles[t].r0 >= nbr && (t >= A->ntiles_interior) == (pass == 1)) b.push_back(A->h_tiles[t]);
+                if (A->h_tiles[t].r0 >= nbr && (t >= A->ntiles_interior) == (pass == 1)) b.push_back(widen(A->h_tiles[t]));
         }
         if (order == 1) {
             ord.insert(ord.end(), b.begin(), b.end());
@@ -353,7 +353,7 @@ static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, cons
     };
     int rc = NPG_OK;
     auto chk = [&](int r) { if (rc == NPG_OK) rc = r; };
-    chk(up((void **)&A->wtile_ptr, ord.data(), ord.size() * sizeof(TileDesc)));
+    chk(up((void **)&A->wtile_ptr, ord.data(), ord.size() * sizeof(WTileDesc)));
     chk(up((void **)&A->widx, widx.data(), widx.size() * sizeof(uint16_t)));
     chk(up((void **)&A->gidx, gidx.data(), gidx.size() * sizeof(uint16_t)));
     chk(up((void **)&A->wlist, wlist.data(), wlist.size() * sizeof(int32_t)));
@@ -560,18 +560,23 @@ CsrDev csr_view(const npg_csr *A) {
     v.pk9 = A->pk9;
     v.pk9_32 = A->pk9_32;
     v.npk9 = A->npk9;
-    v.widx = A->widx;
-    v.gidx = A->gidx;
-    v.wlist = A->wlist;
-    v.vlist = A->vlist;
-    v.wbk = A->wbk;
-    v.pkc2 = reinterpret_cast<const double2 *>(A->pkc2);
-    v.npairs = A->npairs;
-    v.dxy2 = reinterpret_cast<const double2 *>(A->dxy2);
-    v.ndpairs = A->ndpairs;
-    v.dwidx = A->dwidx;
-    v.dbk = A->dbk;
     return v;
+}
+
+WinDev win_view(const npg_csr *A) {
+    WinDev w;
+    w.widx = A->widx;
+    w.gidx = A->gidx;
+    w.wlist = A->wlist;
+    w.vlist = A->vlist;
+    w.pkc2 = reinterpret_cast<const double2 *>(A->pkc2);
+    w.npairs = A->npairs;
+    w.wbk = A->wbk;
+    w.dwidx = A->dwidx;
+    w.dbk = A->dbk;
+    w.dxy2 = reinterpret_cast<const double2 *>(A->dxy2);
+    w.ndpairs = A->ndpairs;
+    return w;
 }
 
 }  // namespace npg
@@ -1412,24 +1417,24 @@ struct WinProf {
 };
 
 template <int L, int WL>
-__global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32_timed(CsrDev A, const TileDesc *__restrict__ tiles, int ntiles, GatherMap g,
+__global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32_timed(CsrDev A, WinDev W, const WTileDesc *__restrict__ tiles, int ntiles, GatherMap g,
                                                                   double *__restrict__ y, unsigned long long *acc) {
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
     unsigned long long a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, nt = 0, st[10];
     int t = blockIdx.x;
     if (t >= ntiles) return;
-    TileDesc td = tiles[t];
+    WTileDesc td = tiles[t];
     WinPre pre;
     bool have = false;
     while (true) {
         const int tn = t + gridDim.x;
-        TileDesc nd = td;
+        WTileDesc nd = td;
         if (tn < ntiles) nd = tiles[tn];
         if (td.nw && td.r0 < block_rows(A)) {
-            if (!have) win_first<kSpmvThreads>(A, PaddedX{g}, td, pre);
+            if (!have) win_first<kSpmvThreads>(W, PaddedX{g}, td, pre);
             have = tn < ntiles && nd.nw != 0 && nd.r0 < block_rows(A);
-            spmv_tile_win<kSpmvThreads, WL, PaddedX, kTileNnz, WinProf>(A, PaddedX{g}, td, nd, have, pre, tl, sw, WinProf{st});
+            spmv_tile_win<kSpmvThreads, WL, PaddedX, kTileNnz, WinProf>(A, W, PaddedX{g}, td, nd, have, pre, tl, sw, WinProf{st});
             WinProf{st}.stamp(6);
             for (int r = threadIdx.x; r < td.nrows; r += kSpmvThreads) y[td.r0 + r] = sw[r];
             WinProf{st}.stamp(7);
@@ -1459,7 +1464,7 @@ __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32_timed(CsrDev A, co
 }
 
 template <int L, int WL, int DIAG = 0>
-__global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32(CsrDev A, const TileDesc *__restrict__ tiles, int ntiles, GatherMap g,
+__global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32(CsrDev A, WinDev W, const void *__restrict__ tiles_, int ntiles, GatherMap g,
                                                             double *__restrict__ y) {
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
@@ -1469,45 +1474,62 @@ __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32(CsrDev A, const Ti
         const int k = blockIdx.x / 256;
         for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(110);
     }
-    TileDesc td = tiles[t];
-    WinPre pre;
-    bool have = false;           // `pre` holds td's window
-    while (true) {
-        const int tn = t + gridDim.x;
-        TileDesc nd = td;
-        if (tn < ntiles) nd = tiles[tn];
-        if (WL != 0 && td.nw) {
-            if (!(DIAG & 16)) {
-                if (!have) win_first<kSpmvThreads>(A, PaddedX{g}, td, pre);
-                have = tn < ntiles && nd.nw != 0;
-                if (td.r0 < block_rows(A))
-                    spmv_tile_win<kSpmvThreads, (WL ? WL : 4), PaddedX, kTileNnz, NoProf, (DIAG & 7)>(A, PaddedX{g}, td, nd, have, pre, tl, sw);
-                else if (!(DIAG & 8))
-                    spmv_tile_winrows<kSpmvThreads, L>(A, PaddedX{g}, td, nd, have, pre, tl, sw);
-            }
-        } else if (!(DIAG & 8)) {
-            have = false;
+    if constexpr (WL == 0) {          // the matrix's ordinary tiles
+        const TileDesc *__restrict__ tiles = static_cast<const TileDesc *>(tiles_);
+        TileDesc td = tiles[t];
+        while (true) {
+            const int tn = t + gridDim.x;
+            TileDesc nd = td;
+            if (tn < ntiles) nd = tiles[tn];
             spmv_tile<kSpmvThreads, L, PaddedX, kTileNnz, 2, NoProf, false, true, false>(A, PaddedX{g}, td, tl, sw);
-            pre = WinPre{};              // (dead across the call above: nothing to keep in registers)
+            for (int r = threadIdx.x; r < td.nrows; r += kSpmvThreads) y[td.r0 + r] = sw[r];
+            if (tn >= ntiles) break;
+            t = tn;
+            td = nd;
         }
-        for (int r = threadIdx.x; r < td.nrows; r += kSpmvThreads) y[td.r0 + r] = sw[r];
-        if (tn >= ntiles) break;
-        t = tn;
-        td = nd;
+    } else {
+        const WTileDesc *__restrict__ tiles = static_cast<const WTileDesc *>(tiles_);
+        WTileDesc td = tiles[t];
+        WinPre pre;
+        bool have = false;           // `pre` holds td's window
+        while (true) {
+            const int tn = t + gridDim.x;
+            WTileDesc nd = td;
+            if (tn < ntiles) nd = tiles[tn];
+            if (td.nw) {
+                if (!(DIAG & 16)) {
+                    if (!have) win_first<kSpmvThreads>(W, PaddedX{g}, td, pre);
+                    have = tn < ntiles && nd.nw != 0;
+                    if (td.r0 < block_rows(A))
+                        spmv_tile_win<kSpmvThreads, WL, PaddedX, kTileNnz, NoProf, (DIAG & 7)>(A, W, PaddedX{g}, td, nd, have, pre, tl, sw);
+                    else if (!(DIAG & 8))
+                        spmv_tile_winrows<kSpmvThreads, L>(A, W, PaddedX{g}, td, nd, have, pre, tl, sw);
+                }
+            } else if (!(DIAG & 8)) {
+                have = false;
+                spmv_tile<kSpmvThreads, L, PaddedX, kTileNnz, 2, NoProf, false, true, false>(A, PaddedX{g}, ordinary(td), tl, sw);
+                pre = WinPre{};              // (dead across the call above: nothing to keep in registers)
+            }
+            for (int r = threadIdx.x; r < td.nrows; r += kSpmvThreads) y[td.r0 + r] = sw[r];
+            if (tn >= ntiles) break;
+            t = tn;
+            td = nd;
+        }
     }
 }
 
 template <int L>
 static void launch_spmv_g32(const npg_csr *A, const GatherMap &g, double *y, bool win) {
-    const TileDesc *tiles = win ? A->wtile_ptr : A->tile_ptr;
+    const void *tiles = win ? (const void *)A->wtile_ptr : (const void *)A->tile_ptr;
     const int nt = win ? A->nwtiles : A->ntiles;
+    const WinDev W = win_view(A);
     const dim3 grid(std::max(1, std::min<int>(nt, 3 * A->ctx->num_cu))), blk(kSpmvThreads);
     static const int diag = getenv("NPG_WIN_DIAG") ? atoi(getenv("NPG_WIN_DIAG")) : 0;      // tools/window_ab.py: timing diagnostics
     if (win && diag == 128) {
         unsigned long long *acc = nullptr, h[10];
         if (hipMalloc((void **)&acc, sizeof h) != hipSuccess) return;
         hipMemsetAsync(acc, 0, sizeof h, A->ctx->stream);
-        hipLaunchKernelGGL((k_spmv_g32_timed<L, 4>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y, acc);
+        hipLaunchKernelGGL((k_spmv_g32_timed<L, 4>), grid, blk, 0, A->ctx->stream, csr_view(A), W, A->wtile_ptr, nt, g, y, acc);
         hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, A->ctx->stream);
         hipStreamSynchronize(A->ctx->stream);
         hipFree(acc);
@@ -1520,29 +1542,29 @@ static void launch_spmv_g32(const npg_csr *A, const GatherMap &g, double *y, boo
     }
     if (win && diag) {
         switch (diag) {
-            case 1: hipLaunchKernelGGL((k_spmv_g32<L, 4, 1>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
-            case 2: hipLaunchKernelGGL((k_spmv_g32<L, 4, 2>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
-            case 3: hipLaunchKernelGGL((k_spmv_g32<L, 4, 3>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
-            case 4: hipLaunchKernelGGL((k_spmv_g32<L, 4, 4>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
-            case 8: hipLaunchKernelGGL((k_spmv_g32<L, 4, 8>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
-            case 16: hipLaunchKernelGGL((k_spmv_g32<L, 4, 16>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
-            case 9: hipLaunchKernelGGL((k_spmv_g32<L, 4, 9>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
-            case 10: hipLaunchKernelGGL((k_spmv_g32<L, 4, 10>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
-            case 11: hipLaunchKernelGGL((k_spmv_g32<L, 4, 11>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
-            case 12: hipLaunchKernelGGL((k_spmv_g32<L, 4, 12>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
-            case 15: hipLaunchKernelGGL((k_spmv_g32<L, 4, 15>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
-            case 64: hipLaunchKernelGGL((k_spmv_g32<L, 4, 64>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
-            case 72: hipLaunchKernelGGL((k_spmv_g32<L, 4, 72>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
-            default: hipLaunchKernelGGL((k_spmv_g32<L, 4, 7>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y); break;
+            case 1: hipLaunchKernelGGL((k_spmv_g32<L, 4, 1>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
+            case 2: hipLaunchKernelGGL((k_spmv_g32<L, 4, 2>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
+            case 3: hipLaunchKernelGGL((k_spmv_g32<L, 4, 3>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
+            case 4: hipLaunchKernelGGL((k_spmv_g32<L, 4, 4>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
+            case 8: hipLaunchKernelGGL((k_spmv_g32<L, 4, 8>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
+            case 16: hipLaunchKernelGGL((k_spmv_g32<L, 4, 16>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
+            case 9: hipLaunchKernelGGL((k_spmv_g32<L, 4, 9>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
+            case 10: hipLaunchKernelGGL((k_spmv_g32<L, 4, 10>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
+            case 11: hipLaunchKernelGGL((k_spmv_g32<L, 4, 11>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
+            case 12: hipLaunchKernelGGL((k_spmv_g32<L, 4, 12>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
+            case 15: hipLaunchKernelGGL((k_spmv_g32<L, 4, 15>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
+            case 64: hipLaunchKernelGGL((k_spmv_g32<L, 4, 64>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
+            case 72: hipLaunchKernelGGL((k_spmv_g32<L, 4, 72>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
+            default: hipLaunchKernelGGL((k_spmv_g32<L, 4, 7>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
         }
         return;
     }
     if (win && A->wlanes == 8)
-        hipLaunchKernelGGL((k_spmv_g32<L, 8>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y);
+        hipLaunchKernelGGL((k_spmv_g32<L, 8>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y);
     else if (win)
-        hipLaunchKernelGGL((k_spmv_g32<L, 4>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y);
+        hipLaunchKernelGGL((k_spmv_g32<L, 4>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y);
     else
-        hipLaunchKernelGGL((k_spmv_g32<L, 0>), grid, blk, 0, A->ctx->stream, csr_view(A), tiles, nt, g, y);
+        hipLaunchKernelGGL((k_spmv_g32<L, 0>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y);
 }
 }  // namespace npg
 

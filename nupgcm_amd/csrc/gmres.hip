@@ -33,6 +33,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "spmv_device.h"
@@ -63,7 +64,8 @@ struct GDev {
     const TileDesc *tile_ptr;
     int ntiles, n, mem;
     int nt_int;           // tiles [0, nt_int) read no ghost column (distributed row blocks; = ntiles otherwise)
-    const TileDesc *wt_ptr;   // windowed tile set (spmv_window.h) for the Arnoldi kernel's gather-layout instance; null: none
+    const WTileDesc *wt_ptr;  // windowed tile set (spmv_window.h) for the Arnoldi kernel's gather-layout instance; null: none
+    WinDev W;
     int nwt, nwt_int, wl; // wl: lanes per node in a windowed tile's segmented sums (4 or 8)
     int word;             // the windowed set also holds ordinary tiles
     int wpre;             // request the first tile's window before the prologue (tuning switch NPG_WIN_PRE)
@@ -324,13 +326,15 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
     __shared__ double sw[kTileRows];
     double *tmp = tl.prod;                // scratch of the prologue / final block reduction, outside the tile loop
     // (WL) the first tile's window is requested before the prologue: its two dependent round trips pass behind the Givens work
-    const TileDesc *__restrict__ tiles = WL ? d.wt_ptr : d.tile_ptr;
-    TileDesc nd = tiles[t0 + (int)blockIdx.x < t1 ? t0 + (int)blockIdx.x : 0];
+    using TD = std::conditional_t<WL != 0, WTileDesc, TileDesc>;
+    const TD *__restrict__ tiles;
+    if constexpr (WL != 0) tiles = d.wt_ptr; else tiles = d.tile_ptr;
+    TD nd = tiles[t0 + (int)blockIdx.x < t1 ? t0 + (int)blockIdx.x : 0];
     WinPre pre;                  // (WL) a windowed tile's window, gathered during the tile before it
     bool have = false;
     if constexpr (WL != 0) {
         if (d.wpre && t0 + (int)blockIdx.x < t1 && nd.nw) {
-            win_first<kKB>(d.A, PaddedX{d.xg}, nd, pre);
+            win_first<kKB>(d.W, PaddedX{d.xg}, nd, pre);
             have = true;
         }
     }
@@ -371,7 +375,7 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
     const double h2k = (ro && k < j) ? sh.h2[k] : 0.0;
     double acc = 0.0;
     for (int t = t0 + blockIdx.x; t < t1; t += gridDim.x) {
-        const TileDesc td = nd;
+        const TD td = nd;
         if (t + (int)gridDim.x < t1) nd = tiles[t + gridDim.x];      // in flight during this tile
         const int r0 = td.r0, r1 = td.r0 + td.nrows;
         // split mode: this thread's row of wt for the epilogue, fetched now so that its latency hides behind the tile
@@ -380,22 +384,22 @@ __global__ void __launch_bounds__(kKB, FUSED ? 4 : 6) k_gmres_arnoldi(GDev d, in
         double wt_row = 0.0;
         if (!FUSED && (int)threadIdx.x < td.nrows) wt_row = d.wt[td.r0 + threadIdx.x];
         // one instantiation for both cases: without a second pass the correction loop has no trips
-        if constexpr (XG == 2)
-            spmv_tile<kKB, L>(d.A, PaddedX{d.xg}, td, tl, sw);
-        else if constexpr (WL != 0) {
+        if constexpr (WL != 0) {
             if (td.nw) {
-                if (!have) win_first<kKB>(d.A, PaddedX{d.xg}, td, pre);
+                if (!have) win_first<kKB>(d.W, PaddedX{d.xg}, td, pre);
                 have = t + (int)gridDim.x < t1 && nd.nw != 0;
                 if (td.r0 < block_rows(d.A))
-                    spmv_tile_win<kKB, WL>(d.A, PaddedX{d.xg}, td, nd, have, pre, tl, sw);
+                    spmv_tile_win<kKB, WL>(d.A, d.W, PaddedX{d.xg}, td, nd, have, pre, tl, sw);
                 else
-                    spmv_tile_winrows<kKB, L>(d.A, PaddedX{d.xg}, td, nd, have, pre, tl, sw);
+                    spmv_tile_winrows<kKB, L>(d.A, d.W, PaddedX{d.xg}, td, nd, have, pre, tl, sw);
             } else if constexpr (ORD) {
                 have = false;
-                spmv_tile<kKB, L, PaddedX, kTileNnz, 2, NoProf, false, true, false>(d.A, PaddedX{d.xg}, td, tl, sw);
+                spmv_tile<kKB, L, PaddedX, kTileNnz, 2, NoProf, false, true, false>(d.A, PaddedX{d.xg}, ordinary(td), tl, sw);
                 pre = WinPre{};          // (dead across the call above: nothing to keep in registers)
             }
-        } else if constexpr (XG == 1)
+        } else if constexpr (XG == 2)
+            spmv_tile<kKB, L>(d.A, PaddedX{d.xg}, td, tl, sw);
+        else if constexpr (XG == 1)
             // (node-blocked by definition: hardly any CSR entries - two pairs per lane there keep the records' loops inside the
             //  register budget)
             spmv_tile<kKB, L, PaddedX, kTileNnz, 2, NoProf, false, true, N9>(d.A, PaddedX{d.xg}, td, tl, sw);
@@ -1239,6 +1243,7 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A_in, int precond_kind
         static const int win_env = getenv("NPG_GMRES_WINDOW") ? atoi(getenv("NPG_GMRES_WINDOW")) : 1;
         if (win_env && ws->gather32 != 2 && d.split && A->wtile_ptr && !A->pk9 && nbr > 0) {
             d.wt_ptr = A->wtile_ptr;
+            d.W = win_view(A);
             d.nwt = A->nwtiles;
             d.nwt_int = A->nwtiles_interior;
             d.wl = A->wlanes;

@@ -79,17 +79,6 @@ struct CsrDev {
     const double *pk9;
     const float *pk9_32;
     int64_t npk9;
-    // windowed tile set (spmv_window.h): 16-bit window indices of the node records / column records and the per-tile lists
-    // of distinct column nodes / other columns (TileDesc::woff, voff index them); null without it
-    const uint16_t *widx, *gidx;
-    const int32_t *wlist, *vlist;
-    const double2 *pkc2;      // {K, C} split by position in the record pair: [npairs] first records, [npairs] second records
-    int64_t npairs;
-    const double2 *dxy2;      // (d_x, d_y) of the coupling records, split the same way (windowed tiles of the rows behind the block rows)
-    int64_t ndpairs;
-    const int32_t *wbk;       // per block node q: {end of its column records, end of its record PAIRS} relative to its windowed tile
-    const uint16_t *dwidx;    // window indices of the coupling records / per row behind the block rows the tile-local end of its
-    const int32_t *dbk;       // coupling record pairs (windowed tiles of those rows; null: they keep their ordinary tiles)
 };
 
 __device__ __forceinline__ int block_rows(const CsrDev &A) { return 3 * A.nfull + 2 * A.nsurf; }
@@ -534,7 +523,6 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, int r0, i
     td.n = (int)(A.rowptr[r1] - td.base);
     td.pbase = 0;
     td.npe = 0;
-    td.woff = td.voff = td.nw = td.nv = 0;
     if (r0 < block_rows(A)) {
         td.pbase = A.prow[node_of_row(A, r0)];
         td.npe = (int)(A.prow[node_of_row(A, r1)] - td.pbase);

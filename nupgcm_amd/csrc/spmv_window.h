@@ -32,6 +32,21 @@
 
 namespace npg {
 
+// device view of a matrix's windowed tile set (npg_csr, build_window_tiles); passed beside CsrDev to the kernels that use it
+struct WinDev {
+    const uint16_t *widx, *gidx;   // 16-bit window indices of the node records / column records (indexed like pcol / gcol)
+    const int32_t *wlist, *vlist;  // per-tile lists of distinct column nodes / other columns (WTileDesc::woff, voff index them)
+    const double2 *pkc2;           // {K, C} split by position in the record pair: [npairs] first records, [npairs] second records
+    int64_t npairs;
+    const int32_t *wbk;            // per block node q: {end of its column records, end of its record PAIRS} relative to its tile
+    const uint16_t *dwidx;         // windowed tiles of the rows behind the block rows: window indices of the coupling records,
+    const int32_t *dbk;            // per such row the tile-local end of its coupling record pairs (null: those rows keep
+    const double2 *dxy2;           // ordinary tiles), (d_x, d_y) split like pkc2
+    int64_t ndpairs;
+};
+
+__device__ __forceinline__ TileDesc ordinary(const WTileDesc &w) { return TileDesc{w.base, w.pbase, w.r0, w.nrows, w.n, w.npe}; }
+
 constexpr int kWinPairs = 2;      // record pairs per lane a windowed tile may hold (npe <= 2 * kWinPairs * threads)
 constexpr int kWinCols = 1;       // column records per lane
 constexpr int kWinNodes = 2;      // distinct column nodes per lane (nw); distinct other columns: one per lane (nv)
@@ -43,26 +58,34 @@ struct WinPre {
 };
 
 // the two halves of a window prefetch: request the next tile's lists / gather their columns
+// (most tiles have at most NT distinct column nodes: the second list load and gather are skipped for them, wave-uniformly - the
+//  tile is bound by the vector-memory instructions its waves issue)
 template <int NT>
-__device__ __forceinline__ void win_lists(const CsrDev &A, const TileDesc &next, int tid, int32_t (&wc)[kWinNodes], int32_t &vc) {
+__device__ __forceinline__ void win_lists(const WinDev &A, const WTileDesc &next, int tid, int32_t (&wc)[kWinNodes], int32_t &vc) {
+    wc[0] = __builtin_nontemporal_load(A.wlist + next.woff + min(tid, next.nw - 1));
 #pragma unroll
-    for (int u = 0; u < kWinNodes; ++u) wc[u] = __builtin_nontemporal_load(A.wlist + next.woff + min(tid + u * NT, next.nw - 1));
+    for (int u = 1; u < kWinNodes; ++u) {
+        wc[u] = 0;
+        if (next.nw > u * NT) wc[u] = __builtin_nontemporal_load(A.wlist + next.woff + min(tid + u * NT, next.nw - 1));
+    }
     vc = __builtin_nontemporal_load(A.vlist + next.voff + min(tid, max(next.nv - 1, 0)));
 }
-template <class XF, int DIAG = 0>
-__device__ __forceinline__ void win_gather(const XF &x, const int32_t (&wc)[kWinNodes], int32_t vc, WinPre &w) {
+template <int NT, class XF, int DIAG = 0>
+__device__ __forceinline__ void win_gather(const XF &x, const WTileDesc &next, const int32_t (&wc)[kWinNodes], int32_t vc, WinPre &w) {
+    w.f[0] = (DIAG & 1) ? make_float4((float)wc[0], 1.f, 2.f, 0.f) : x.node4(wc[0]);
 #pragma unroll
-    for (int u = 0; u < kWinNodes; ++u) w.f[u] = (DIAG & 1) ? make_float4((float)wc[u], 1.f, 2.f, 0.f) : x.node4(wc[u]);
+    for (int u = 1; u < kWinNodes; ++u)
+        if (next.nw > u * NT) w.f[u] = (DIAG & 1) ? make_float4((float)wc[u], 1.f, 2.f, 0.f) : x.node4(wc[u]);
     w.v = (DIAG & 1) ? (float)vc : x.behind(vc);
 }
 
 // lists -> gathers for a tile nobody prefetched (a workgroup's first windowed tile): two dependent round trips, once
 template <int NT, class XF>
-__device__ __forceinline__ void win_first(const CsrDev &A, const XF &x, const TileDesc &td, WinPre &w) {
+__device__ __forceinline__ void win_first(const WinDev &W, const XF &x, const WTileDesc &td, WinPre &w) {
     const int tid = threadIdx.x;
     int32_t wc[kWinNodes], vc;
-    win_lists<NT>(A, td, tid, wc, vc);
-    win_gather(x, wc, vc, w);
+    win_lists<NT>(W, td, tid, wc, vc);
+    win_gather<NT>(x, td, wc, vc, w);
 }
 
 // One windowed BLOCK tile.  `w`: on entry this tile's window (win_first, or the previous call), on return - if `pre_next` - the window
@@ -73,7 +96,7 @@ __device__ __forceinline__ void win_first(const CsrDev &A, const XF &x, const Ti
 // DIAG (timing diagnostics of tools/window_ab.py only; results are then meaningless): bit 0 = the window is filled without
 // gathering, bit 1 = no segmented sums, bit 2 = no record loads (products of constants).
 template <int NT, int L, class XF, int TNNZ, class PROF = NoProf, int DIAG = 0>
-__device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const XF x, const TileDesc &td, const TileDesc &next, bool pre_next,
+__device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const WinDev &W, const XF x, const WTileDesc &td, const WTileDesc &next, bool pre_next,
                                               WinPre &w, TileLdsT<TNNZ> &t, double *__restrict__ out, PROF prof = PROF()) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));          // per-tile re-made lane offsets (spmv_tile's REMAT): keeps the stream bases out of the caller's loop
@@ -90,27 +113,27 @@ __device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const XF x, const
     float *__restrict__ vwin = reinterpret_cast<float *>(win + nw);
     // node bookkeeping of the segmented sums, tile-local and ready for LDS (requested FIRST: vmcnt counts in order, and a wait
     // for these two words must not be a wait for the record stream behind them)
-    const int2 bk = *reinterpret_cast<const int2 *>(A.wbk + 2 * (size_t)(q0 + min(tid, nnode - 1)));
+    int2 bk = make_int2(0, 0);          // (only the waves that hold nodes issue the load)
+    if (tid < nnode) bk = *reinterpret_cast<const int2 *>(W.wbk + 2 * (size_t)(q0 + tid));
     // ---- (1) this tile's window, gathered a tile ago
+    if (tid < nw) win[tid] = w.f[0];
 #pragma unroll
-    for (int u = 0; u < kWinNodes; ++u) {
-        const int i = tid + u * NT;
-        if (i < nw) win[i] = w.f[u];
-    }
+    for (int u = 1; u < kWinNodes; ++u)
+        if (nw > u * NT && tid + u * NT < nw) win[tid + u * NT] = w.f[u];
     if (tid < nv) vwin[tid] = w.v;
     prof.stamp(8);
     // Every load below is unconditional, from an index clamped into the tile's range (a lane without work re-reads the last
     // element and never uses it): no control flow between the loads, so they are all in flight together.
     // ---- (2) the NEXT tile's distinct columns
     int32_t wc[kWinNodes], vc = 0;
-    if (pre_next) win_lists<NT>(A, next, tid, wc, vc);
+    if (pre_next) win_lists<NT>(W, next, tid, wc, vc);
     // ---- (3) every record of this tile
     uint32_t ip[kWinPairs];
     double k0[kWinPairs], c0[kWinPairs], k1[kWinPairs], c1[kWinPairs];
     {
-        const uint32_t *__restrict__ wp = reinterpret_cast<const uint32_t *>(A.widx + pbase);
-        const double *__restrict__ ka = reinterpret_cast<const double *>(A.pkc2 + (pbase >> 1));
-        const double *__restrict__ kb = reinterpret_cast<const double *>(A.pkc2 + A.npairs + (pbase >> 1));
+        const uint32_t *__restrict__ wp = reinterpret_cast<const uint32_t *>(W.widx + pbase);
+        const double *__restrict__ ka = reinterpret_cast<const double *>(W.pkc2 + (pbase >> 1));
+        const double *__restrict__ kb = reinterpret_cast<const double *>(W.pkc2 + W.npairs + (pbase >> 1));
 #pragma unroll
         for (int u = 0; u < kWinPairs; ++u) {
             const int p = min(tid + u * NT, npair - 1);
@@ -138,7 +161,7 @@ __device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const XF x, const
                 ax[u] = ay[u] = az[u] = (double)e;
                 continue;
             }
-            gi[u] = __builtin_nontemporal_load(A.gidx + base + e);
+            gi[u] = __builtin_nontemporal_load(W.gidx + base + e);
             ax[u] = __builtin_nontemporal_load(gp + 2 * e);
             ay[u] = __builtin_nontemporal_load(gp + 2 * e + 1);
             az[u] = __builtin_nontemporal_load(A.gz + base + e);
@@ -154,7 +177,7 @@ __device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const XF x, const
     __syncthreads();
     prof.stamp(5);
     // ---- (4) ONE gather per distinct column of the NEXT tile, ascending along the lanes: in flight until that tile starts
-    if (pre_next) win_gather<XF, DIAG>(x, wc, vc, w);
+    if (pre_next) win_gather<NT, XF, DIAG>(x, next, wc, vc, w);
     // ---- (5) products: two adjacent records of one row node per lane, summed before they reach LDS
 #pragma unroll
     for (int u = 0; u < kWinPairs; ++u) {
@@ -226,27 +249,27 @@ __device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const XF x, const
 // once into the window, as in the block tiles; same prefetch protocol (`w`, `next`, `pre_next`).  These tiles hold no other
 // entries (the host keeps a matrix whose rows behind the block hold CSR entries on ordinary tiles).
 template <int NT, int L, class XF, int TNNZ>
-__device__ __forceinline__ void spmv_tile_winrows(const CsrDev &A, const XF x, const TileDesc &td, const TileDesc &next, bool pre_next,
+__device__ __forceinline__ void spmv_tile_winrows(const CsrDev &A, const WinDev &W, const XF x, const WTileDesc &td, const WTileDesc &next, bool pre_next,
                                                   WinPre &w, TileLdsT<TNNZ> &t, double *__restrict__ out) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int nrows = td.nrows, npair = td.npe >> 1, nw = td.nw;
     const int64_t pbase = td.pbase;
     float4 *__restrict__ win = reinterpret_cast<float4 *>(t.prod + ((npair + 1) & ~1));
-    const int32_t bk = A.dbk[(td.r0 - block_rows(A)) + min(tid, nrows - 1)];
+    int32_t bk = 0;
+    if (tid < nrows) bk = W.dbk[(td.r0 - block_rows(A)) + tid];
+    if (tid < nw) win[tid] = w.f[0];
 #pragma unroll
-    for (int u = 0; u < kWinNodes; ++u) {
-        const int i = tid + u * NT;
-        if (i < nw) win[i] = w.f[u];
-    }
+    for (int u = 1; u < kWinNodes; ++u)
+        if (nw > u * NT && tid + u * NT < nw) win[tid + u * NT] = w.f[u];
     int32_t wc[kWinNodes], vc = 0;
-    if (pre_next) win_lists<NT>(A, next, tid, wc, vc);
+    if (pre_next) win_lists<NT>(W, next, tid, wc, vc);
     uint32_t ip[kWinPairs];
     double dx0[kWinPairs], dy0[kWinPairs], dx1[kWinPairs], dy1[kWinPairs], dz0[kWinPairs], dz1[kWinPairs];
     {
-        const uint32_t *__restrict__ wp = reinterpret_cast<const uint32_t *>(A.dwidx + pbase);
-        const double *__restrict__ xa = reinterpret_cast<const double *>(A.dxy2 + (pbase >> 1));
-        const double *__restrict__ xb = reinterpret_cast<const double *>(A.dxy2 + A.ndpairs + (pbase >> 1));
+        const uint32_t *__restrict__ wp = reinterpret_cast<const uint32_t *>(W.dwidx + pbase);
+        const double *__restrict__ xa = reinterpret_cast<const double *>(W.dxy2 + (pbase >> 1));
+        const double *__restrict__ xb = reinterpret_cast<const double *>(W.dxy2 + W.ndpairs + (pbase >> 1));
         const double *__restrict__ zz = A.dz + pbase;
 #pragma unroll
         for (int u = 0; u < kWinPairs; ++u) {
@@ -263,7 +286,7 @@ __device__ __forceinline__ void spmv_tile_winrows(const CsrDev &A, const XF x, c
     if (tid < nrows) t.prp[tid + 1] = bk;
     if (tid == 0) t.prp[0] = 0;
     __syncthreads();
-    if (pre_next) win_gather(x, wc, vc, w);
+    if (pre_next) win_gather<NT>(x, next, wc, vc, w);
 #pragma unroll
     for (int u = 0; u < kWinPairs; ++u) {
         const int p = tid + u * NT;
