@@ -18,7 +18,18 @@
 #                               as one copy + one SpMV (no device broadcast machinery needed)
 #   * evolve!(model, ...) ..... method for models whose inversion lives on the HIP device (src/model.jl:213-285): the
 #                               advection assembly + right-hand-side combination of :269-278 - a serial Gridap loop on the
-#                               host in the reference, also in GPU mode - becomes one call of npg_fe_evolution_rhs
+#                               host in the reference, also in GPU mode - becomes one call of npg_fe_evolution_rhs; the
+#                               convection closure (:229-247: kappa_v from b, K_v and its lift, rhs_diff) and the LHS /
+#                               Jacobi refresh (:251-261) run on the device too (npg_fe_update_kappa_convection,
+#                               npg_fe_assemble_matrix, npg_fe_assemble_rhs_diff, npg_csr_combine, npg_csr_inv_diag)
+#   * update_Δt! .............. src/timesteppers.jl:108-119 for the model this extension serves: the per-cell maximum of |u|
+#                               over the quadrature points and the minimum over the cells are ONE device reduction over the
+#                               inversion solution already in HBM (npg_fe_cfl_ratio)
+#   * Model(...) .............. the constructor (src/model.jl:18-62) is where fe_data and the device matrix meet: the method
+#                               below hands A_inversion - uploaded in the reference's own order, src/dofs.jl:27-41 - to
+#                               npg_csr_block_nodes_dofs with Gridap's (node, component) of every velocity DoF, so that
+#                               the solves run on the library's record / windowed-tile layout while every vector keeps the
+#                               reference's order (the permutation lives inside the matrix handle)
 module nuPGCMHIPExt
 
 using nuPGCM
@@ -275,6 +286,54 @@ function hip_fe(fe_data)
     end
 end
 
+# ---- node-block storage from the reference's DoF order ------------------------------------------------------------------------
+"(node, component) of every free velocity DoF in Gridap's native numbering: a cell's local DoF l (1..30) is component (l-1)%3 of
+its local node (l-1)÷3+1 (node-major local numbering, SURVEY 8c); the node's label is that local node's DoF id in an
+unconstrained scalar P2 space on the same triangulation."
+function velocity_dof_nodes(fe_data)
+    U = fe_data.spaces.X_trial[1]
+    S = Gridap.FESpaces.TestFESpace(fe_data.mesh.model, Gridap.ReferenceFEs.ReferenceFE(Gridap.ReferenceFEs.lagrangian, Float64, 2))
+    idsu, idsn = Gridap.FESpaces.get_cell_dof_ids(U), Gridap.FESpaces.get_cell_dof_ids(S)
+    nu = fe_data.dofs.nu
+    node, comp = fill(Int64(-1), nu), zeros(Int32, nu)
+    for c in 1:length(idsu), l in 1:30
+        id = idsu[c][l]
+        if id > 0
+            node[id] = idsn[c][(l - 1) ÷ 3 + 1] - 1
+            comp[id] = (l - 1) % 3
+        end
+    end
+    return node, comp
+end
+
+"npg_csr_block_nodes_dofs on A_inversion as the reference uploaded it (rows / columns in p_inversion order, src/inversion.jl:37)"
+function block_nodes!(A::HIPSparseMatrixCSR, fe_data; rtol = 1e-12)
+    dofs = fe_data.dofs
+    node_native, comp_native = velocity_dof_nodes(fe_data)
+    N = dofs.nu + dofs.np
+    node, comp = fill(Int64(-1), N), zeros(Int32, N)
+    for i in 1:dofs.nu                                                   # p_inversion = [p_u; nu .+ p_p]: row i is native DoF p_u[i]
+        node[i] = node_native[dofs.p_inversion[i]]
+        comp[i] = comp_native[dofs.p_inversion[i]]
+    end
+    blocked = Ref{Cint}(0)
+    check(@ccall lib.npg_csr_block_nodes_dofs(A.h::Ptr{Cvoid}, node::Ptr{Int64}, comp::Ptr{Int32}, rtol::Float64, blocked::Ptr{Cint})::Cint)
+    return blocked[] != 0
+end
+
+const ACTIVE = Ref{Any}(nothing)        # the model this extension serves (update_Δt! has no argument that says so)
+function nuPGCM.Model(arch::GPU, params, forcings, fe_data, inversion::nuPGCM.InversionToolkit{<:HIPSparseMatrixCSR}, args...)
+    # constant viscosity only: the full-stress form (function-valued ν, eddy closure) has no {K, C} structure and the eddy
+    # refresh of src/model.jl:160-170 replaces solver.A anyway
+    if !(forcings.ν isa Function) && !forcings.eddy_param.is_on && size(inversion.solver.A, 1) >= 100_000
+        block_nodes!(inversion.solver.A, fe_data)
+    end
+    model = invoke(nuPGCM.Model, Tuple{nuPGCM.AbstractArchitecture, Any, Any, Any, Any, Vararg{Any}}, arch, params, forcings, fe_data,
+                   inversion, args...)
+    ACTIVE[] = model
+    return model
+end
+
 upload_perm(a::Vector{Float64}, perm::Vector{Int}) = begin               # on_architecture(arch, a[perm]) in one call
     v = HIPVector{Float64}(undef, length(perm))
     check(@ccall lib.npg_vec_upload_perm(v.h::Ptr{Cvoid}, a::Ptr{Float64}, (perm .- 1)::Ptr{Int64})::Cint)
@@ -287,17 +346,26 @@ function nuPGCM.evolve!(model::HIPModel, u_prev, b_prev)
     dofs, ev, ts = model.fe_data.dofs, model.evolution, model.timestepper
     solver = ev.solver
     θ = nuPGCM.evolution_parameter(model.params, ts)
-    if model.forcings.conv_param.is_on || ts.adaptive
-        # closures and the LHS refresh stay on the reference's (host) path, src/model.jl:229-261; only array conversions of
-        # this extension are involved.  (npg_fe_update_kappa_convection / npg_fe_assemble_matrix move them to the device too:
-        # see nupgcm_amd/model.py evolve.)
-        invoke(nuPGCM.evolve!, Tuple{nuPGCM.Model, Any, Any}, model, u_prev, b_prev)
-        return model
-    end
     fe = hip_fe(model.fe_data)
+    bv(b) = upload_perm(Vector{Float64}(b.free_values), dofs.p_b)
+    if model.forcings.conv_param.is_on || ts.adaptive
+        dm = device_evolution_matrices(ev, model)                         # M, Kₕ, Kᵥ on the device, one common pattern
+        if model.forcings.conv_param.is_on                                # src/model.jl:229-247
+            cp = model.forcings.conv_param
+            check(@ccall lib.npg_fe_update_kappa_convection(fe.h::Ptr{Cvoid}, C_NULL::Ptr{Float64}, Float64(cp.κᶜ)::Float64,
+                                                            Float64(cp.N²min)::Float64, Float64(model.params.α)::Float64,
+                                                            Float64(model.params.N²)::Float64, bv(model.state.b).h::Ptr{Cvoid})::Cint)
+            check(@ccall lib.npg_fe_assemble_matrix(fe.h::Ptr{Cvoid}, 3::Cint, 1.0::Float64, 0::Cint, dm.Kv.h::Ptr{Cvoid},
+                                                    ev.rhsᵥ.h::Ptr{Cvoid})::Cint)                     # NPG_MAT_KV, lift = rhsᵥ
+            check(@ccall lib.npg_fe_assemble_rhs_diff(fe.h::Ptr{Cvoid}, Float64(model.params.N²)::Float64, ev.rhs_diff.h::Ptr{Cvoid})::Cint)
+        end
+        # A = M + θ (Kₕ + Kᵥ), P = Diagonal(1 ./ diag(A)) - src/model.jl:251-261, on the device, in place
+        check(@ccall lib.npg_csr_combine(solver.A.h::Ptr{Cvoid}, 1.0::Float64, dm.M.h::Ptr{Cvoid}, θ::Float64, dm.Kh.h::Ptr{Cvoid},
+                                         dm.Kv.h::Ptr{Cvoid})::Cint)
+        check(@ccall lib.npg_csr_inv_diag(solver.A.h::Ptr{Cvoid}, solver.P.diag.h::Ptr{Cvoid})::Cint)
+    end
     # state in the solvers' orderings: [u; p] by p_inversion (the pressure part is not read by the advection form), b by p_b
     xi(u) = upload_perm(vcat(Vector{Float64}(u.free_values), zeros(dofs.np)), dofs.p_inversion)
-    bv(b) = upload_perm(Vector{Float64}(b.free_values), dofs.p_b)
     scheme = ts isa nuPGCM.BDF1 ? Cint(1) : Cint(2)
     check(@ccall lib.npg_fe_evolution_rhs(fe.h::Ptr{Cvoid}, scheme::Cint, ts.Δt[]::Float64, Float64(model.params.N²)::Float64,
                                           θ::Float64, bv(model.state.b).h::Ptr{Cvoid}, bv(b_prev).h::Ptr{Cvoid},
@@ -307,6 +375,50 @@ function nuPGCM.evolve!(model::HIPModel, u_prev, b_prev)
     nuPGCM.iterative_solve!(solver)
     model.state.b.free_values .= solver.x[dofs.inv_p_b]                  # src/model.jl:282
     return model
+end
+
+# device copies of the evolution matrices on ONE pattern (Gridap's structural pattern: explicit zeros kept, drop_zeros = 0), so
+# that K_v can be re-assembled in place and the LHS combined on the device; the coefficient tables the closures start from
+const EVO_CACHE = IdDict{Any, Any}()
+function device_evolution_matrices(ev, model)
+    get!(EVO_CACHE, ev) do
+        up(A) = begin
+            out = Ref{Ptr{Cvoid}}()
+            check(@ccall lib.npg_csr_create_from_csc(ctx()::Ptr{Cvoid}, size(A, 1)::Int64, size(A, 2)::Int64, (A.colptr .- 1)::Ptr{Int64},
+                                                      (A.rowval .- 1)::Ptr{Int64}, A.nzval::Ptr{Float64}, 0::Cint, out::Ptr{Ptr{Cvoid}})::Cint)
+            M = HIPSparseMatrixCSR{Float64}(out[], size(A)...)
+            finalizer(x -> @ccall(lib.npg_csr_destroy(x.h::Ptr{Cvoid})::Cint), M)
+        end
+        pattern = ev.M + ev.Kₕ + ev.Kᵥ                                     # union of the three patterns
+        onpat(A) = (B = copy(pattern); fill!(B.nzval, 0.0); B .+ A)       # A's values on the common pattern
+        fe = hip_fe(model.fe_data)
+        # background kappa_v at the quadrature points, [ncell][nq] (the closure adds the convective part to it)
+        xq = Gridap.CellData.get_cell_points(model.fe_data.mesh.dΩ)
+        κv = model.forcings.κᵥ
+        tab = κv isa Function ? reduce(vcat, [Float64.(κv.(p)) for p in Gridap.CellData.get_array(xq)]) :
+              fill(Float64(κv), length(Gridap.CellData.get_array(xq)) * length(first(Gridap.CellData.get_array(xq))))
+        check(@ccall lib.npg_fe_set_coeff(fe.h::Ptr{Cvoid}, "kappa_v"::Cstring, tab::Ptr{Float64})::Cint)
+        # the solver's own A must live on the same pattern for npg_csr_combine to write into it
+        model.evolution.solver.A = up(onpat(on_architecture(CPU(), model.evolution.solver.A)))
+        (M = up(onpat(ev.M)), Kh = up(onpat(ev.Kₕ)), Kv = up(onpat(ev.Kᵥ)))
+    end
+end
+
+# ---- update_Δt!: src/timesteppers.jl:108-119 as one device reduction --------------------------------------------------------------
+# (More specific than the reference's untyped method in its last argument, so dispatch prefers it; it serves the model of this
+#  extension - recognised by its measure - and defers to the reference's host evaluation otherwise.  `u` is model.state.u, whose
+#  values sync_flow! copied from inversion.solver.x after the last invert!: the device vector holds the same numbers.)
+function nuPGCM.update_Δt!(ts::nuPGCM.BDF1, u, dΩ, h_cells::Vector{Float64}; u_min = 0.01)
+    model = ACTIVE[]
+    if model === nothing || model.fe_data.mesh.dΩ !== dΩ
+        return invoke(nuPGCM.update_Δt!, Tuple{nuPGCM.BDF1, Any, Any, Any}, ts, u, dΩ, h_cells; u_min = u_min)
+    end
+    fe = hip_fe(model.fe_data)
+    out = Ref{Float64}()
+    check(@ccall lib.npg_fe_cfl_ratio(fe.h::Ptr{Cvoid}, h_cells::Ptr{Float64}, Float64(u_min)::Float64,
+                                      model.inversion.solver.x.h::Ptr{Cvoid}, out::Ptr{Float64})::Cint)
+    ts.Δt[] = ts.CFL_factor * out[]
+    return ts
 end
 
 end # module

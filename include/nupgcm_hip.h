@@ -112,6 +112,17 @@ int npg_csr_combine(npg_csr *out, double a, const npg_csr *X, double b, const np
  * matrix is untouched if it does not hold (e.g. function-valued nu).  A node-blocked matrix can be multiplied and solved
  * with, but not downloaded, cloned or re-assembled. */
 int npg_csr_block_nodes(npg_csr *A, int64_t n_full, int64_t n_surf, double rtol, int *blocked);
+/* The same for a matrix in ANY DoF order - the reference's own RCM of the velocity mass-matrix graph comes out component by
+ * component (src/dofs.jl:27-41,70-100), not node by node.  node_of_dof[i] >= 0: DoF i is component comp_of_dof[i] (0, 1, 2) of
+ * the velocity node with that label (any non-negative labels: Gridap's node ids); < 0: not a velocity DoF.  The library
+ * renumbers internally ([x, y, z of every node with three free components | x, y of every node with those two | other velocity
+ * DoFs | the rest], nodes in the order of their first DoF in the caller's numbering), permutes the matrix, blocks it as
+ * npg_csr_block_nodes does (windowed tile set included) and KEEPS THE PERMUTATION IN THE HANDLE: npg_spmv and npg_gmres_solve
+ * go on taking and returning vectors in the caller's order (right-hand side, warm start / solution and a vector preconditioner
+ * are gathered / scattered on the device, four vector passes per solve), so npg_vec_upload_perm / npg_vec_download_perm with
+ * the caller's own permutations stay what they were.  Other solvers refuse such a matrix.  *blocked = 0 and the matrix
+ * untouched if the structure does not hold. */
+int npg_csr_block_nodes_dofs(npg_csr *A, const int64_t *node_of_dof, const int32_t *comp_of_dof, double rtol, int *blocked);
 /* the two-component special case: npg_csr_block_nodes(A, 0, npairs, ...) */
 int npg_csr_pair_xy(npg_csr *A, int64_t npairs, double rtol, int *paired);
 /* how the matrix is laid out in HBM: number of block nodes, {c, K, C} records (20 bytes each, standing for 4 or 5 CSR

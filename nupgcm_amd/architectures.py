@@ -328,6 +328,20 @@ class DeviceCSR:
         self.packed = bool(flag.value)
         return self.packed
 
+    def block_nodes_dofs(self, node_of_dof, comp_of_dof, rtol=1e-12):
+        """npg_csr_block_nodes_dofs: node-block storage of a matrix in ANY DoF order (node_of_dof[i] < 0: not a velocity DoF);
+        the library renumbers internally and keeps the permutation in the handle - mul and GmresWorkspace.solve keep taking
+        vectors in this matrix's own order."""
+        nd = np.ascontiguousarray(node_of_dof, dtype=np.int64)
+        cd = np.ascontiguousarray(comp_of_dof, dtype=np.int32)
+        if nd.shape != (self.shape[0],) or cd.shape != nd.shape:
+            raise ValueError("block_nodes_dofs: one node label and one component per row")
+        flag = C.c_int()
+        L.check(L.lib().npg_csr_block_nodes_dofs(self.h, nd.ctypes.data_as(C.c_void_p), cd.ctypes.data_as(C.c_void_p), float(rtol),
+                                                 C.byref(flag)))
+        self.paired = bool(flag.value)
+        return self.paired
+
     def pair_xy(self, npairs, rtol=1e-12):
         """two-component special case of block_nodes: rows 2q, 2q+1 for q < npairs"""
         return self.block_nodes(0, npairs, rtol)

@@ -299,6 +299,7 @@ NPG_API int npg_cg_solve(npg_cg *ws, const npg_csr *A_in, int precond_kind, doub
                          int64_t itmax, npg_solve_stats *stats) {
     NPG_REQUIRE(ws && A_in && y && x, "npg_cg_solve: NULL argument");
     NPG_REQUIRE(!A_in->packed && !A_in->pk9, "npg_cg_solve: matrices with full node records are not served by the CG kernels");
+    NPG_REQUIRE(!A_in->uperm, "npg_cg_solve: the matrix carries an internal renumbering (npg_csr_block_nodes_dofs): npg_spmv and npg_gmres_solve only");
     const npg_csr *A = A_in;
     const int64_t nloc = ws->n + ws->n_ghost;     // distributed: vectors the SpMV reads hold [owned | ghosts]
     NPG_REQUIRE(A->m == ws->n && A->n == nloc && y->n == ws->n && x->n == nloc,

@@ -157,6 +157,12 @@ struct npg_csr {
     int64_t nwlist = 0, nvlist = 0;
     int64_t nrec_real = 0;       // node records without the zero records that pad a node's list to an even count
     std::vector<npg::TileDesc> h_tiles;   // host copy of tile_ptr (final order)
+    // npg_csr_block_nodes_dofs: the matrix was handed over in the CALLER's DoF order and is stored in the library's node-block
+    // order; uperm[i] = caller index of internal row / column i.  npg_spmv and npg_gmres_solve take and return vectors in the
+    // caller's order (one gather / scatter pass each way through the three scratch vectors); every other entry point refuses it
+    int32_t *uperm = nullptr;    // device, m entries; null: no internal renumbering
+    double *uvec[3] = {nullptr, nullptr, nullptr};      // device scratch, m doubles each: right-hand side, iterate, diagonal
+    bool uperm_active = false;   // set while npg_gmres_solve runs on the internally ordered vectors
     // optional fp32 copies of the values (csr_refresh_fp32): read instead of val / pkc by SpMVs that ask for them
     // (SpmvEpi::f32 - the multigrid preconditioner's; results are still accumulated and returned in fp64)
     float *val32 = nullptr, *pkc32 = nullptr;
@@ -231,6 +237,9 @@ struct SpmvEpi {
 };
 int spmv_epi(const npg_csr *A, const double *x, const SpmvEpi &e);
 int spmv_raw(const npg_csr *A, const double *x, double *y, double alpha, double beta, int f32 = 0);
+// vectors of a matrix with an internal renumbering (npg_csr::uperm): dst[i] = src[uperm[i]] / dst[uperm[i]] = src[i]
+void perm_gather(const npg_csr *A, double *dst, const double *src);
+void perm_scatter(const npg_csr *A, double *dst, const double *src);
 // (re)build the fp32 copies of A's values from val / pkc (enqueued on the context's stream)
 int csr_refresh_fp32(const npg_csr *A);
 // reductions that return a scalar to the host (synchronous)

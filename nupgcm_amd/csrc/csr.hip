@@ -983,6 +983,131 @@ NPG_API int npg_csr_pack_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, int *pa
     return NPG_OK;
 }
 
+namespace npg {
+__global__ void k_perm_gather(double *__restrict__ dst, const double *__restrict__ src, const int32_t *__restrict__ perm, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[perm[i]];
+}
+__global__ void k_perm_scatter(double *__restrict__ dst, const double *__restrict__ src, const int32_t *__restrict__ perm, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[perm[i]] = src[i];
+}
+void perm_gather(const npg_csr *A, double *dst, const double *src) {
+    hipLaunchKernelGGL(k_perm_gather, dim3((unsigned)std::min<int64_t>(4096, (A->m + 255) / 256)), dim3(256), 0, A->ctx->stream, dst, src,
+                       (const int32_t *)A->uperm, A->m);
+}
+void perm_scatter(const npg_csr *A, double *dst, const double *src) {
+    hipLaunchKernelGGL(k_perm_scatter, dim3((unsigned)std::min<int64_t>(4096, (A->m + 255) / 256)), dim3(256), 0, A->ctx->stream, dst, src,
+                       (const int32_t *)A->uperm, A->m);
+}
+}  // namespace npg
+
+// npg_csr_block_nodes for a matrix in ANY DoF order.  node_of_dof[i] >= 0: DoF i is component comp_of_dof[i] (0, 1, 2) of the
+// velocity node with that label (any non-negative labels: Gridap's node ids do); < 0: not a velocity DoF (pressure).  The
+// library renumbers internally - [x, y, z of every node with three components | x, y of every node with exactly those two | the
+// other velocity DoFs | the rest], nodes in the order of their first DoF in the caller's numbering (so a caller's RCM locality is
+// kept) - permutes the matrix on the host, blocks it, and keeps the permutation in the handle.
+NPG_API int npg_csr_block_nodes_dofs(npg_csr *A, const int64_t *node_of_dof, const int32_t *comp_of_dof, double rtol, int *blocked) {
+    NPG_REQUIRE(A && node_of_dof && comp_of_dof && blocked, "npg_csr_block_nodes_dofs: NULL argument");
+    NPG_REQUIRE(A->m == A->n, "npg_csr_block_nodes_dofs: the matrix must be square (%lld x %lld)", (long long)A->m, (long long)A->n);
+    NPG_REQUIRE(A->nnode() == 0 && !A->packed && !A->uperm, "npg_csr_block_nodes_dofs: the matrix is in record form already");
+    NPG_REQUIRE(A->owns_pattern, "npg_csr_block_nodes_dofs: the matrix shares its pattern with another (npg_csr_clone)");
+    *blocked = 0;
+    const int64_t N = A->m;
+    // nodes in the order of their first DoF; per node the DoF of each component
+    std::vector<int64_t> labels;
+    labels.reserve((size_t)N);
+    for (int64_t i = 0; i < N; ++i)
+        if (node_of_dof[i] >= 0) {
+            NPG_REQUIRE(comp_of_dof[i] >= 0 && comp_of_dof[i] < 3, "npg_csr_block_nodes_dofs: component %d of DoF %lld", (int)comp_of_dof[i], (long long)i);
+            labels.push_back(node_of_dof[i]);
+        }
+    if (labels.empty()) return NPG_OK;
+    std::vector<int64_t> uniq(labels);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    const int64_t nn = (int64_t)uniq.size();
+    std::vector<int64_t> dof((size_t)3 * nn, -1), first((size_t)nn, INT64_MAX);
+    for (int64_t i = 0; i < N; ++i)
+        if (node_of_dof[i] >= 0) {
+            const int64_t q = std::lower_bound(uniq.begin(), uniq.end(), node_of_dof[i]) - uniq.begin();
+            NPG_REQUIRE(dof[3 * q + comp_of_dof[i]] < 0, "npg_csr_block_nodes_dofs: node %lld has two DoFs for component %d",
+                        (long long)node_of_dof[i], (int)comp_of_dof[i]);
+            dof[3 * q + comp_of_dof[i]] = i;
+            first[q] = std::min(first[q], i);
+        }
+    std::vector<int64_t> order((size_t)nn);
+    for (int64_t q = 0; q < nn; ++q) order[q] = q;
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return first[a] < first[b]; });
+    std::vector<int32_t> perm;          // internal -> caller
+    perm.reserve((size_t)N);
+    std::vector<char> used((size_t)N, 0);
+    int64_t nfull = 0, nsurf = 0;
+    for (int64_t q : order)
+        if (dof[3 * q] >= 0 && dof[3 * q + 1] >= 0 && dof[3 * q + 2] >= 0) {
+            for (int a = 0; a < 3; ++a) {
+                perm.push_back((int32_t)dof[3 * q + a]);
+                used[dof[3 * q + a]] = 1;
+            }
+            ++nfull;
+        }
+    for (int64_t q : order)
+        if (dof[3 * q] >= 0 && dof[3 * q + 1] >= 0 && dof[3 * q + 2] < 0) {
+            for (int a = 0; a < 2; ++a) {
+                perm.push_back((int32_t)dof[3 * q + a]);
+                used[dof[3 * q + a]] = 1;
+            }
+            ++nsurf;
+        }
+    if (nfull + nsurf == 0) return NPG_OK;
+    for (int64_t i = 0; i < N; ++i)
+        if (!used[i]) perm.push_back((int32_t)i);
+    std::vector<int32_t> iperm((size_t)N);
+    for (int64_t i = 0; i < N; ++i) iperm[perm[i]] = (int32_t)i;
+    // A' = A[perm, perm] on the host, rows sorted
+    NPG_HIP(hipSetDevice(A->ctx->device));
+    NPG_HIP(hipStreamSynchronize(A->ctx->stream));
+    std::vector<int32_t> col((size_t)A->nnz), ncol((size_t)A->nnz);
+    std::vector<double> val((size_t)A->nnz), nval((size_t)A->nnz);
+    NPG_HIP(hipMemcpy(col.data(), A->col, col.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    NPG_HIP(hipMemcpy(val.data(), A->val, val.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const std::vector<int64_t> orp = A->h_rowptr;
+    std::vector<int64_t> nrp((size_t)N + 1, 0);
+    std::vector<std::pair<int32_t, double>> row;
+    for (int64_t i = 0; i < N; ++i) {
+        const int64_t r = perm[i];
+        row.clear();
+        for (int64_t k = orp[r]; k < orp[r + 1]; ++k) row.emplace_back(iperm[col[k]], val[k]);
+        std::sort(row.begin(), row.end(), [](const std::pair<int32_t, double> &a, const std::pair<int32_t, double> &b) { return a.first < b.first; });
+        int64_t o = nrp[i];
+        for (const auto &e : row) {
+            ncol[o] = e.first;
+            nval[o++] = e.second;
+        }
+        nrp[i + 1] = o;
+    }
+    auto put = [&](const std::vector<int64_t> &rp, const std::vector<int32_t> &c, const std::vector<double> &v) -> int {
+        NPG_HIP(hipMemcpy(A->rowptr, rp.data(), rp.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        if (!c.empty()) {
+            NPG_HIP(hipMemcpy(A->col, c.data(), c.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            NPG_HIP(hipMemcpy(A->val, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        A->h_rowptr = rp;
+        return build_tiles(A);
+    };
+    int rc = put(nrp, ncol, nval);
+    if (rc == NPG_OK) rc = npg_csr_block_nodes(A, nfull, nsurf, rtol, blocked);
+    if (rc != NPG_OK || !*blocked) {              // not the structure (or an error): the caller's matrix again, untouched
+        if (A->nnode() == 0) {
+            const int rc2 = put(orp, col, val);
+            if (rc == NPG_OK) rc = rc2;
+        }
+        return rc;
+    }
+    NPG_HIP(hipMalloc((void **)&A->uperm, (size_t)N * sizeof(int32_t)));
+    NPG_HIP(hipMemcpy(A->uperm, perm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
+    for (int k = 0; k < 3; ++k) NPG_HIP(hipMalloc((void **)&A->uvec[k], (size_t)N * sizeof(double)));
+    return NPG_OK;
+}
+
 // the (x, y)-only special case kept for callers that interleave two components: rows 2q, 2q+1 for q < npairs
 NPG_API int npg_csr_pair_xy(npg_csr *A, int64_t npairs, double rtol, int *paired) {
     return npg_csr_block_nodes(A, 0, npairs, rtol, paired);
@@ -1063,6 +1188,9 @@ NPG_API int npg_csr_destroy(npg_csr *A) {
     if (A->dval) hipFree(A->dval);
     if (A->dval32) hipFree(A->dval32);
     free_window_tiles(A);
+    if (A->uperm) hipFree(A->uperm);
+    for (double *p : A->uvec)
+        if (p) hipFree(p);
     delete A;
     return NPG_OK;
 }
@@ -1577,6 +1705,7 @@ NPG_API int npg_spmv_gather32(const npg_csr *A, const npg_vec *x, npg_vec *y, in
     NPG_REQUIRE(x->n == A->n && y->n == A->m, "npg_spmv_gather32: A is %lld x %lld but x has %lld and y has %lld entries",
                 (long long)A->m, (long long)A->n, (long long)x->n, (long long)y->n);
     NPG_REQUIRE(A->nnode() > 0 && !A->pk9 && !A->packed, "npg_spmv_gather32: the matrix is not stored by {c, K, C} node blocks");
+    NPG_REQUIRE(!A->uperm, "npg_spmv_gather32: the matrix carries an internal renumbering (npg_csr_block_nodes_dofs)");
     NPG_REQUIRE(!windowed || A->wtile_ptr, "npg_spmv_gather32: the matrix has no windowed tile set");
     NPG_HIP(hipSetDevice(A->ctx->device));
     const int64_t nbr = A->block_rows(), need = 4 * A->nnode() + (A->n - nbr) + 8;
@@ -1605,5 +1734,14 @@ NPG_API int npg_spmv(const npg_csr *A, const npg_vec *x, npg_vec *y, double alph
     NPG_REQUIRE(x->n == A->n && y->n == A->m, "npg_spmv: A is %lld x %lld but x has %lld and y has %lld entries",
                 (long long)A->m, (long long)A->n, (long long)x->n, (long long)y->n);
     NPG_REQUIRE(x->d != y->d, "npg_spmv: x and y must not alias");
+    if (A->uperm) {         // npg_csr_block_nodes_dofs: vectors come and go in the caller's DoF order
+        perm_gather(A, A->uvec[0], x->d);
+        if (beta != 0.0) perm_gather(A, A->uvec[1], y->d);
+        const int rc = spmv_raw(A, A->uvec[0], A->uvec[1], alpha, beta);
+        if (rc) return rc;
+        perm_scatter(A, y->d, A->uvec[1]);
+        NPG_HIP(hipGetLastError());
+        return NPG_OK;
+    }
     return spmv_raw(A, x->d, y->d, alpha, beta);
 }

@@ -1135,6 +1135,35 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A_in, int precond_kind
                             const npg_vec *precond_diag, const npg_vec *y, npg_vec *x, double atol, double rtol,
                             int64_t itmax, double reorth_eta, npg_solve_stats *stats) {
     NPG_REQUIRE(ws && A_in && y && x, "npg_gmres_solve: NULL argument");
+    if (A_in->uperm && !A_in->uperm_active) {
+        // npg_csr_block_nodes_dofs: right-hand side, iterate (warm start in, solution out) and a vector preconditioner come and go
+        // in the CALLER's DoF order - three gather passes in, one scatter pass out, then the solve proper on the library's order
+        NPG_REQUIRE(!ws->halo, "npg_gmres_solve: a matrix with an internal renumbering cannot be a distributed row block");
+        NPG_REQUIRE(y->n == A_in->m && x->n == A_in->m, "npg_gmres_solve: vector lengths do not match the matrix");
+        npg_csr *Am = const_cast<npg_csr *>(A_in);
+        npg_vec yi = *y, xi = *x, di;
+        yi.d = Am->uvec[0];
+        xi.d = Am->uvec[1];
+        yi.owns = xi.owns = false;
+        perm_gather(A_in, yi.d, y->d);
+        perm_gather(A_in, xi.d, x->d);
+        const npg_vec *dp = precond_diag;
+        if (precond_kind == NPG_PRECOND_DIAG && precond_diag) {
+            NPG_REQUIRE(precond_diag->n == A_in->m, "npg_gmres_solve: bad preconditioner");
+            di = *precond_diag;
+            di.d = Am->uvec[2];
+            di.owns = false;
+            perm_gather(A_in, di.d, precond_diag->d);
+            dp = &di;
+        }
+        Am->uperm_active = true;
+        const int rc = npg_gmres_solve(ws, A_in, precond_kind, precond_scalar, dp, &yi, &xi, atol, rtol, itmax, reorth_eta, stats);
+        Am->uperm_active = false;
+        if (rc) return rc;
+        perm_scatter(A_in, x->d, xi.d);
+        NPG_HIP(hipStreamSynchronize(ws->ctx->stream));
+        return NPG_OK;
+    }
     const npg_csr *A = spmv_form(A_in);           // (the record-form companion of a plain matrix, if it has one)
     const int64_t nloc = ws->n + ws->n_ghost;     // distributed: vectors the SpMV reads hold [owned | ghosts]
     NPG_REQUIRE(A->m == ws->n && A->n == nloc && y->n == ws->n && x->n == nloc,

@@ -844,6 +844,7 @@ static void by_groups(int k, F f) {
 NPG_API int npg_fgmres_solve(npg_fgmres *ws, const npg_csr *A, npg_precond *pc, const npg_vec *y, npg_vec *x,
                              double scale, double atol, double rtol, int64_t itmax, npg_solve_stats *stats) {
     NPG_REQUIRE(ws && A && y && x && stats, "npg_fgmres_solve: NULL argument");
+    NPG_REQUIRE(!A->uperm, "npg_fgmres_solve: the matrix carries an internal renumbering (npg_csr_block_nodes_dofs): npg_spmv and npg_gmres_solve only");
     const int64_t n = ws->n, ld = ws->ld;
     const int64_t nloc = n + ws->n_ghost;
     NPG_REQUIRE(A->m == n && A->n == nloc && y->n == n && x->n == nloc, "npg_fgmres_solve: system must be %lld x %lld (+%lld ghosts)",

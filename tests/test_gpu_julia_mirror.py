@@ -141,13 +141,76 @@ class Ext:
         L.check(lib().npg_fe_create(self.ctx, C.byref(d), C.byref(out)))
         return out
 
+    def block_nodes(self, A, node, comp, rtol=1e-12):                        # block_nodes!(A::HIPSparseMatrixCSR, fe_data)
+        node = np.ascontiguousarray(node, dtype=np.int64)
+        comp = np.ascontiguousarray(comp, dtype=np.int32)
+        flag = C.c_int()
+        L.check(lib().npg_csr_block_nodes_dofs(A, P64(node), P64(comp), rtol, C.byref(flag)))
+        return flag.value != 0
+
+    def upload_csc0(self, A):                                                # `up` of device_evolution_matrices: drop_zeros = 0
+        cp1, rv1, nz, m, n = _csc1(A)
+        out = C.c_void_p()
+        cp, rv = np.ascontiguousarray(cp1 - 1), np.ascontiguousarray(rv1 - 1)
+        L.check(lib().npg_csr_create_from_csc(self.ctx, m, n, P64(cp), P64(rv), P64(np.ascontiguousarray(nz)), 0, C.byref(out)))
+        return out
+
+    def device_evolution_matrices(self, model):                              # device_evolution_matrices(ev, model)
+        ev = model["evolution"]
+        if "dm" not in ev:
+            pattern = (abs(ev["M_host"]) + abs(ev["Kh_host"]) + abs(ev["Kv_host"])).tocsc()
+            pattern.data[:] = 1.0
+
+            def onpat(A):                                                    # A's values on the common pattern (explicit zeros kept)
+                B = pattern.copy()
+                B.data[:] = 0.0
+                B = (B + sp.csc_matrix(A)).tocsc()
+                out = pattern.copy().tocsc()
+                out.sort_indices()
+                B.sort_indices()
+                full = sp.csc_matrix((np.zeros(out.nnz), out.indices, out.indptr), shape=out.shape)
+                # scatter B's entries into the pattern's slots
+                pos = {}
+                for j in range(out.shape[1]):
+                    lo, hi = out.indptr[j], out.indptr[j + 1]
+                    pos.update({(int(i), j): lo + k for k, i in enumerate(out.indices[lo:hi])})
+                for j in range(B.shape[1]):
+                    for k in range(B.indptr[j], B.indptr[j + 1]):
+                        full.data[pos[(int(B.indices[k]), j)]] = B.data[k]
+                return full
+            kv = np.ascontiguousarray(model["kappa_v0_q"], dtype=np.float64)
+            L.check(lib().npg_fe_set_coeff(model["fe"], b"kappa_v", P64(kv)))
+            ev["solver"]["A"] = self.upload_csc0(onpat(ev["A_host"]))
+            ev["dm"] = dict(M=self.upload_csc0(onpat(ev["M_host"])), Kh=self.upload_csc0(onpat(ev["Kh_host"])),
+                            Kv=self.upload_csc0(onpat(ev["Kv_host"])))
+        return ev["dm"]
+
+    def update_dt(self, model, h_cells, u_min=0.01):                         # update_Δt!(ts::BDF1, u, dΩ, h_cells::Vector{Float64})
+        out = C.c_double()
+        hc = np.ascontiguousarray(h_cells, dtype=np.float64)
+        L.check(lib().npg_fe_cfl_ratio(model["fe"], P64(hc), u_min, model["inversion"]["solver"]["x"], C.byref(out)))
+        model["dt"] = model["CFL_factor"] * out.value
+        return model
+
     def evolve(self, model, u_prev, b_prev):                                 # evolve!(model::HIPModel, u_prev, b_prev)
         dofs, ev = model["dofs"], model["evolution"]
         solver = ev["solver"]
         fe = model["fe"]
         xi = lambda u: self.upload_perm(np.concatenate([u, np.zeros(dofs["np"])]), dofs["p_inversion"])
         bv = lambda b: self.upload_perm(b, dofs["p_b"])
-        L.check(lib().npg_fe_evolution_rhs(fe, 2, model["dt"], model["N2"], model["theta"], bv(model["b"]), bv(b_prev),
+        scheme = model.get("scheme", 2)
+        if model.get("conv") is not None or model.get("adaptive"):
+            theta = model["theta_of_dt"](model["dt"])
+            model["theta"] = theta
+            dm = self.device_evolution_matrices(model)
+            if model.get("conv") is not None:
+                kc, n2min = model["conv"]
+                L.check(lib().npg_fe_update_kappa_convection(fe, None, kc, n2min, model["alpha"], model["N2"], bv(model["b"])))
+                L.check(lib().npg_fe_assemble_matrix(fe, L.NPG_MAT_KV, 1.0, 0, dm["Kv"], ev["rhs_v"]))
+                L.check(lib().npg_fe_assemble_rhs_diff(fe, model["N2"], ev["rhs_diff"]))
+            L.check(lib().npg_csr_combine(solver["A"], 1.0, dm["M"], theta, dm["Kh"], dm["Kv"]))
+            L.check(lib().npg_csr_inv_diag(solver["A"], solver["P"]))
+        L.check(lib().npg_fe_evolution_rhs(fe, scheme, model["dt"], model["N2"], model["theta"], bv(model["b"]), bv(b_prev),
                                            xi(model["u"]), xi(u_prev), ev["rhs_diff"], ev["rhs_flux"], ev["rhs_M"],
                                            ev["rhs_h"], ev["rhs_v"], solver["y"]))
         self.iterative_solve(solver)
@@ -244,4 +307,141 @@ def test_three_timesteps_through_the_julia_binding_sequence():
     u, pr, b = rc.run(S, 3, solver="direct")
     rel = lambda a, c: np.linalg.norm(a - c) / np.linalg.norm(c)
     assert rel(model["b"], b) < 1e-8 and rel(model["u"], u) < 1e-6 and rel(p, pr) < 1e-6, \
+        (rel(model["b"], b), rel(model["u"], u), rel(p, pr))
+
+
+def _velocity_dof_nodes(s):
+    """velocity_dof_nodes(fe_data): (node, component) of every free velocity DoF in the native numbering"""
+    nodes, comps = np.nonzero(s.u_dof >= 0)
+    node = np.full(s.nu, -1, dtype=np.int64)
+    comp = np.zeros(s.nu, dtype=np.int32)
+    node[s.u_dof[nodes, comps]] = nodes
+    comp[s.u_dof[nodes, comps]] = comps
+    return node, comp
+
+
+def test_node_blocks_and_windowed_tiles_from_the_reference_order():
+    """Model(arch::GPU, ...) of the extension: A_inversion arrives as the reference uploads it - CSC, rows and columns in ITS
+    p_inversion (an RCM that comes out component by component, src/dofs.jl:70-100) - and npg_csr_block_nodes_dofs, given
+    Gridap's (node, component) of every velocity DoF, stores it by node blocks with a windowed tile set while every vector keeps
+    the caller's order: npg_spmv equals the host product, npg_gmres_solve the plain matrix's solve.  At 135 k unknowns, where
+    the record layouts are in play (they start at 100 k rows)."""
+    from nupgcm_amd import workloads                                         # (mesh only: refine.py; the FE side is the oracle's)
+    S = rc.setup("example", model=workloads.bowl_mesh_model("bowl3D_h0.05"))
+    o, s = S.orc, S.orc.sp
+    nu, N = s.nu, s.nu + s.np_
+    assert N >= 100000
+    p_inv0, _ = rc.rcm_perms(S)
+    A_host = sp.csr_matrix(S.A[p_inv0][:, p_inv0])
+    ext = Ext()
+    A = ext.on_architecture_GPU_SparseMatrixCSC(*_csc1(A_host))
+    A_plain = ext.on_architecture_GPU_SparseMatrixCSC(*_csc1(A_host))
+    node_native, comp_native = _velocity_dof_nodes(s)
+    node, comp = np.full(N, -1, dtype=np.int64), np.zeros(N, dtype=np.int32)
+    node[:nu], comp[:nu] = node_native[p_inv0[:nu]], comp_native[p_inv0[:nu]]
+    # the caller's order is NOT node-blocked: hardly any node has its x, y, z rows next to each other
+    together = (node[:nu - 2] == node[1:nu - 1]) & (node[:nu - 2] == node[2:nu]) & (comp[:nu - 2] == 0) & (comp[1:nu - 1] == 1) & (comp[2:nu] == 2)
+    assert together.sum() < 0.05 * len(s.u_dof)
+    assert ext.block_nodes(A, node, comp)
+    a, b_, c = C.c_int64(), C.c_int64(), C.c_int64()
+    L.check(lib().npg_csr_storage(A, C.byref(a), C.byref(b_), C.byref(c)))
+    assert a.value > 0.9 * len(s.u_dof) * 0.8 and b_.value > 10 * a.value and c.value < 0.01 * A_host.nnz
+    wt = [C.c_int64() for _ in range(4)]
+    L.check(lib().npg_csr_window_info(A, *[C.byref(w) for w in wt]))
+    assert wt[0].value > 0 and wt[1].value > 0
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(N)
+    dx, dy, dy0 = ext.on_architecture_GPU_Array(x), ext.HIPVector(N), ext.HIPVector(N)
+    L.check(lib().npg_spmv(A, dx, dy, 1.0, 0.0))
+    L.check(lib().npg_spmv(A_plain, dx, dy0, 1.0, 0.0))
+    want = A_host @ x
+    rel = lambda u, v: np.linalg.norm(u - v) / np.linalg.norm(v)
+    y1 = ext.on_architecture_CPU_HIPVector(dy)
+    assert rel(y1, want) < 1e-13 and rel(ext.on_architecture_CPU_HIPVector(dy0), want) < 1e-13
+    L.check(lib().npg_spmv(A, dx, dy, -0.5, 2.0))                           # mul!(y, A, x, alpha, beta) in the caller's order
+    assert rel(ext.on_architecture_CPU_HIPVector(dy), 2.0 * y1 - 0.5 * want) < 1e-13
+    # the solve, through the binding sequence: same iterations (to the few per cent any perturbation moves them), same answer
+    h, _ = o.precond_h()
+    rhs = A_host @ np.cos(np.arange(N, dtype=float)) * 1e-3
+    out = {}
+    for name, M in (("blocked", A), ("plain", A_plain)):
+        Pinv = ext.on_architecture_GPU_Array(np.full(N, 1 / h ** 3))
+        inv = ext.InversionToolkit(M, Pinv, None, None, N)
+        tk = inv["solver"]
+        L.check(lib().npg_vec_upload(tk["y"], P64(np.ascontiguousarray(rhs))))
+        ext.iterative_solve(tk)
+        st = tk["workspace"]["stats"]
+        xs = ext.on_architecture_CPU_HIPVector(tk["x"])
+        assert st["solved"] == 1 and np.linalg.norm((rhs - A_host @ xs) / h ** 3) <= 1.5 * (1e-6 + 1e-6 * st["rnorm0"])
+        L.check(lib().npg_vec_upload(tk["y"], P64(np.ascontiguousarray(1.01 * rhs))))
+        ext.iterative_solve(tk)                                              # warm start from workspace.x, in the caller's order
+        st2 = tk["workspace"]["stats"]
+        assert st2["solved"] == 1 and st2["niter"] < st["niter"]
+        out[name] = (st["niter"], xs)
+    assert abs(out["blocked"][0] - out["plain"][0]) <= 0.08 * out["plain"][0], (out["blocked"][0], out["plain"][0])
+    assert rel(out["blocked"][1], out["plain"][1]) < 5e-4
+
+
+def test_closures_and_cfl_step_through_the_julia_binding_sequence():
+    """evolve!(model::HIPModel) with the convection closure and update_Δt! of the extension: kappa_v from the current buoyancy,
+    K_v + lift, rhs_diff, the LHS M + theta (K_h + K_v) and its Jacobi diagonal, and the CFL step are device calls (raw
+    ctypes, the extension's sequence); four BDF1 steps with the adaptive step against the oracle's restatement of
+    src/model.jl:229-261 + src/timesteppers.jl:108-119."""
+    S = rc.setup("bowl_diri")
+    o, s = S.orc, S.orc.sp
+    nu, np_, nb = s.nu, s.np_, s.nb
+    N = nu + np_
+    conv, cfl = (0.5, 0.5), 0.5
+    p_inv0, p_b0 = rc.rcm_perms(S)
+    p_inversion, p_b = p_inv0 + 1, p_b0 + 1
+    inv_p_inversion, inv_p_b = np.argsort(p_inv0) + 1, np.argsort(p_b0) + 1
+    ext = Ext()
+    A = ext.on_architecture_GPU_SparseMatrixCSC(*_csc1(S.A[p_inv0][:, p_inv0]))
+    B = ext.on_architecture_GPU_SparseMatrixCSC(*_csc1(S.B[p_inv0]))
+    b0 = ext.on_architecture_GPU_Array(S.b0[p_inv0])
+    h, _ = o.precond_h()
+    inversion = ext.InversionToolkit(A, ext.on_architecture_GPU_Array(np.full(N, 1 / h ** 3)), B, b0, N, atol=1e-10, rtol=1e-10)
+    perm = lambda Mx: sp.csc_matrix(Mx)[p_b0][:, p_b0]
+    th1 = S.theta("BDF1")
+    Ah = (perm(S.M) + th1 * (perm(S.Kh) + perm(S.Kv))).tocsc()
+    up = ext.on_architecture_GPU_Array
+    ws = ext.CgWorkspace(nb)
+    evo = dict(rhs_diff=up(S.rhs_diff[p_b0]), rhs_flux=up(S.rhs_flux[p_b0]), rhs_M=up(S.rhs_M[p_b0]), rhs_h=up(S.rhs_h[p_b0]),
+               rhs_v=up(S.rhs_v[p_b0]), M_host=perm(S.M), Kh_host=perm(S.Kh), Kv_host=perm(S.Kv), A_host=Ah,
+               solver=ext.IterativeSolverToolkit(ext.on_architecture_GPU_SparseMatrixCSC(*_csc1(Ah)), up(1.0 / Ah.diagonal()),
+                                                 up(np.zeros(nb)), ws, dict(atol=1e-12, rtol=1e-12, itmax=0), "Evolution"))
+    t = _gridap_tables(S)
+    _, dN = fo.p2_basis(o.geo.lam, fo.TET_EDGES)
+    g = dict(nc=len(o.topo.cells), G=np.ascontiguousarray(o.geo.G.reshape(-1)), wdet=np.ascontiguousarray(o.geo.detJ),
+             qw=np.ascontiguousarray(o.geo.w), lam=np.ascontiguousarray(o.geo.lam), N2=np.ascontiguousarray(o.N2q),
+             dN2=np.ascontiguousarray(dN), n_inv=N, n_b=nb,
+             cu=np.ascontiguousarray(Ext.devidx(t["cell_u"], inv_p_inversion)),
+             cp=np.ascontiguousarray(np.where(t["cell_p"] > 0, inv_p_inversion[nu + np.maximum(t["cell_p"], 1) - 1] - 1, -1)
+                                     .astype(np.int32)),
+             cb=np.ascontiguousarray(Ext.devidx(t["cell_b"], inv_p_b)),
+             ud=np.ascontiguousarray(t["u_diri"]), bd=np.ascontiguousarray(t["b_diri"]))
+    fe = ext.hip_fe(g)
+    dt0 = S.dt
+    c = S.c
+    model = dict(dofs=dict(np=np_, p_inversion=p_inversion, p_b=p_b, inv_p_b=inv_p_b), evolution=evo, inversion=inversion, fe=fe,
+                 dt=dt0, N2=o.N2, alpha=o.alpha, theta=th1, theta_of_dt=lambda dt: dt * c, scheme=1, conv=conv, adaptive=True,
+                 CFL_factor=cfl, kappa_v0_q=fo._const_or_fn(o.kappa_v, o.geo.xq), b=o.interpolate_b(S.cfg["b0"]), u=np.zeros(nu))
+    u_prev, b_prev = model["u"].copy(), model["b"].copy()
+    h_cells = o.h_cells()
+    dts = []
+    for i in range(1, 5):
+        ext.update_dt(model, h_cells)                                        # src/model.jl:131
+        dts.append(model["dt"])
+        u_curr, b_curr = model["u"].copy(), model["b"].copy()
+        ext.evolve(model, u_prev, b_prev)
+        ext.invert(inversion, model["b"])
+        x = ext.getindex_perm(inversion["solver"]["x"], inv_p_inversion)
+        model["u"], p = x[:nu], x[nu:]
+        u_prev, b_prev = u_curr, b_curr
+        assert inversion["solver"]["workspace"]["stats"]["solved"] == 1 and ws["stats"]["solved"] == 1
+    S2 = rc.setup("bowl_diri")
+    u, pr, b = rc.run(S2, 4, solver="direct", scheme="BDF1", cfl_factor=cfl, adaptive=True, conv=conv)
+    rel = lambda a, c_: np.linalg.norm(a - c_) / np.linalg.norm(c_)
+    assert abs(dts[-1] - S2.dt) <= 1e-6 * S2.dt and len(set(np.round(dts, 12))) > 1      # the step really adapted
+    assert rel(model["b"], b) < 1e-7 and rel(model["u"], u) < 1e-5 and rel(p, pr) < 1e-5, \
         (rel(model["b"], b), rel(model["u"], u), rel(p, pr))

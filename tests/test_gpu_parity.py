@@ -96,6 +96,40 @@ def test_abi_argument_errors(arch):
     cg = npg.CgWorkspace(ctx, 12)
     with pytest.raises(L.DeviceError):
         cg.solve(A, y, cg.x, None)
+    # npg_csr_block_nodes_dofs: arguments are checked before anything is permuted; a matrix without the structure comes back intact
+    with pytest.raises(L.DeviceError):
+        A.block_nodes_dofs(np.zeros(12, np.int64), np.zeros(12, np.int32))          # twelve DoFs claim component 0 of node 0
+    with pytest.raises(L.DeviceError):
+        A.block_nodes_dofs(np.arange(12) // 3, np.full(12, 5, np.int32))            # component out of range
+    with pytest.raises(ValueError):
+        A.block_nodes_dofs(np.zeros(5, np.int64), np.zeros(5, np.int32))            # one label per row
+    assert not A.block_nodes_dofs(np.arange(12) // 3, (np.arange(12) % 3).astype(np.int32))     # identity: no [K -C; C K] couplings
+    assert abs(A.to_scipy_csr() - sp.eye(12)).max() == 0
+    R = npg.on_architecture(arch, sp.csr_matrix(np.ones((3, 4))))
+    with pytest.raises(L.DeviceError):
+        R.block_nodes_dofs(np.zeros(3, np.int64), np.arange(3, dtype=np.int32))     # not square
+    # a matrix that carries an internal renumbering is served by npg_spmv / npg_gmres_solve only
+    rng = np.random.default_rng(0)
+    nq = 40
+    Kp = sp.random(nq, nq, 0.1, random_state=1, format="csr") + sp.eye(nq)
+    Kp.data[:] = rng.standard_normal(Kp.nnz)
+    Cp = Kp.copy()
+    Cp.data[:] = rng.standard_normal(Cp.nnz)
+    blk = sp.kron(Kp, np.eye(2)) + sp.kron(Cp, np.array([[0.0, 1.0], [-1.0, 0.0]]))
+    full = sp.csr_matrix(sp.bmat([[blk, None], [None, sp.eye(7)]]))
+    shuffle = rng.permutation(full.shape[0])
+    Ms = sp.csr_matrix(full[shuffle][:, shuffle])
+    node = np.where(shuffle < 2 * nq, shuffle // 2, -1)
+    comp = np.where(shuffle < 2 * nq, shuffle % 2, 0).astype(np.int32)
+    dM = npg.on_architecture(arch, Ms)
+    assert dM.block_nodes_dofs(node, comp) and dM.storage()[0] == nq
+    xs = rng.standard_normal(Ms.shape[1])
+    assert rel(dM.mul(npg.on_architecture(arch, xs)).to_host(), Ms @ xs) < 1e-13              # vectors in the CALLER's order
+    cg2 = npg.CgWorkspace(ctx, Ms.shape[0])
+    with pytest.raises(L.DeviceError):
+        cg2.solve(dM, npg.on_architecture(arch, xs), cg2.x, None)
+    with pytest.raises(L.DeviceError):
+        dM.block_nodes_dofs(node, comp)                                                 # already in record form
     # out-of-range column index at construction
     bad = sp.csr_matrix(sp.eye(4))
     h = C.c_void_p()
