@@ -926,7 +926,10 @@ int npg::halo_exchange_async(npg_halo *h, double *x, float *g32) {
     h->pending_x = x;
     h->pending_g32 = g32;
     if (ctx->shm) return NPG_OK;          // host-driven loop-back transport: the exchange happens in halo_exchange_wait()
-    if (h->pw) {
+    // NPG_HALO_TWO_STREAM=1 (diagnostic; profiles/r04_overlap_rerun.txt): the peer exchange as ONE kernel on the plan's own stream,
+    // ordered against the context's stream by two events - round 2's arrangement, which is what RCCL's overlap still uses
+    static const int two_stream = getenv("NPG_HALO_TWO_STREAM") ? atoi(getenv("NPG_HALO_TWO_STREAM")) : 0;
+    if (h->pw && !two_stream) {
         // peer windows: push now, on the context's own stream; whatever the caller enqueues next runs while the neighbours'
         // stores arrive in this rank's window; halo_exchange_wait() enqueues the wait + unpack half behind it
         HaloPeer *w = (HaloPeer *)h->pw;
@@ -956,7 +959,8 @@ int npg::halo_exchange_wait(npg_halo *h) {
     npg_ctx *ctx = h->ctx;
     if (h->npeers == 0 && !ctx->shm) return NPG_OK;
     if (ctx->shm) return halo_exchange_on(h, h->pending_x, ctx->stream, h->pending_g32);
-    if (h->pw) {
+    static const int two_stream = getenv("NPG_HALO_TWO_STREAM") ? atoi(getenv("NPG_HALO_TWO_STREAM")) : 0;
+    if (h->pw && !two_stream) {
         HaloPeer *w = (HaloPeer *)h->pw;
         hipLaunchKernelGGL(k_halo_exchange, dim3(w->nwg_wait), dim3(256), 0, ctx->stream, h->pending_x, (const int32_t *)h->send_idx,
                            h->n_owned, w->nwg_push, w->nwg_wait, 2, w->dev, h->pending_g32);

@@ -972,7 +972,18 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
     // two events, never run between two physical GPUs) only when asked for - NPG_HALO_OVERLAP=1 / npg_gmres_set_dist_options
     static const int overlap_env = getenv("NPG_HALO_OVERLAP") ? atoi(getenv("NPG_HALO_OVERLAP")) : -1;
     const bool kernel_only = dist && comm_is_kernel_only(ws->ctx);
-    const int want = !dist ? 0 : ws->halo_overlap >= 0 ? ws->halo_overlap : (overlap_env >= 0 ? overlap_env : (kernel_only || ws->ctx->shm ? 1 : 0));
+    int want = !dist ? 0 : ws->halo_overlap >= 0 ? ws->halo_overlap : (overlap_env >= 0 ? overlap_env : (kernel_only || ws->ctx->shm ? 1 : 0));
+    // RCCL's two-stream overlap has never run between two physical GPUs: REFUSED (not merely off by default) unless the caller
+    // states that it knows - NPG_HALO_OVERLAP_UNVERIFIED=1.  (The two-event arrangement itself is sound: rerun with the peer
+    // kernel on a second stream after the epoch fix, profiles/r04_overlap_rerun.txt.)
+    static const int unverified_ok = getenv("NPG_HALO_OVERLAP_UNVERIFIED") ? atoi(getenv("NPG_HALO_OVERLAP_UNVERIFIED")) : 0;
+    if (want && dist && !kernel_only && !ws->ctx->shm && !unverified_ok) {
+        static bool told = false;
+        if (!told && (told = true))
+            fprintf(stderr, "[npg] halo overlap on the RCCL transport was asked for but has never been verified on two physical GPUs: "
+                            "running the exchange before the Arnoldi launch instead (NPG_HALO_OVERLAP_UNVERIFIED=1 overrides)\n");
+        want = 0;
+    }
     // tile range of the Arnoldi launches: the windowed set where the gather-layout instance has one
     const int a_nt = d.wt_ptr ? d.nwt : d.ntiles, a_int = d.wt_ptr ? d.nwt_int : d.nt_int;
     const bool overlap = dist && d.split && want && a_int > 0 && a_int < a_nt;
