@@ -486,7 +486,10 @@ def main():
     if dist is not None:
         # evidence of the communicator the timed region used: ncclCommCount / rank / device as RCCL reports them, the
         # transport of the in-cycle halo and all-reduce, and every rank's share of the system
-        mine = dict(ctx.comm_info(), **getattr(model, "comm_layout", {}))
+        import resource
+        mine = dict(ctx.comm_info(), **getattr(model, "comm_layout", {}),
+                    host_maxrss_mb=round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0, 1),
+                    setup_seconds=round(t_setup, 1))
         infos = [None] * world
         dist.all_gather_object(infos, mine)
         out["comm"] = {"rccl_ranks": infos[0].get("rccl_ranks"), "in_cycle_transport": infos[0].get("in_cycle_transport"),

@@ -536,8 +536,9 @@ NPG_API int npg_precond_mg_update_level(npg_precond *pc, int level, const npg_cs
                 level);
     NPG_REQUIRE(A && G && D && Dinv && S, "npg_precond_mg_update_level: NULL operator");
     MgLevel &l = pc->L[level];
-    NPG_REQUIRE(A->m == l.n && A->n == l.n && G->m == l.nu && G->n == l.np && D->m == l.np && D->n == l.nu &&
-                    Dinv->m == l.nu && Dinv->n == l.nu && S->m == l.np && S->n == l.np,
+    // (a distributed level's operators are row blocks with [owned | ghost] column spaces: compare with what the level holds)
+    NPG_REQUIRE(A->m == l.n && A->n == l.A->n && G->m == l.nu && G->n == l.G->n && D->m == l.np && D->n == l.D->n &&
+                    Dinv->m == l.nu && Dinv->n == l.nu && S->m == l.np && S->n == l.S->n,
                 "npg_precond_mg_update_level: shapes differ from the level's");
     NPG_HIP(hipStreamSynchronize(pc->ctx->stream));
     drop_graphs(pc);

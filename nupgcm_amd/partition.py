@@ -488,18 +488,19 @@ def example_model(arch, mesh_model, dist, dt=1e-3, t_stop=1e9, preconditioner="d
 
 
 def channel_basin_model(arch, mesh_model, dist, surface="flux", itmax=1000, CFL_factor=0.8, element_precision="fp32",
-                        atol=1e-6, rtol=1e-6, **kw):
+                        atol=1e-6, rtol=1e-6, fe_data=None, invert_now=True, **kw):
     """workloads.channel_basin_model (scratch/run.jl:146-172: BASELINE configs[4]) with the mesh partitioned over the ranks
     of `dist`: x-periodic mesh, P1 buoyancy, full-stress A, BDF1 with the CFL step, both closures - each re-evaluated and
     re-assembled on the rank's own cells."""
     from . import workloads
     from .model import invert
-    fed = workloads.channel_basin_fe_data(mesh_model, surface)
+    fed = fe_data if fe_data is not None else workloads.channel_basin_fe_data(mesh_model, surface)   # (fe_data: the caller's FEData of this mesh)
     prm, frc, _, _, dt, b0 = workloads.channel_basin_parameters(surface)
     ts = BDF1(t_start=0.0, t_stop=prm.mu_rho / prm.eps ** 2, dt=dt, adaptive=True, CFL_factor=CFL_factor)
     model = partitioned_model(arch, fed, prm, frc, ts, dist, atol=atol, rtol=rtol, itmax=itmax,
                               element_precision=element_precision, b0=b0, **kw)
-    invert(model)
+    if invert_now:          # (a caller that swaps the inversion solver first - use_multigrid - inverts afterwards)
+        invert(model)
     return model
 
 
@@ -511,8 +512,9 @@ class DistributedMultigridPreconditioner:
     Braess-Sarazin step needs the ghosts of three kinds of vectors (whole vectors for A, velocity parts for D, pressure parts
     for G and S) - three halo plans - and ONE operator that is not a row block of something local: S = D Dinv G, whose rows
     reach through ghost velocity nodes.  T = Dinv G is formed on the owned rows, the rows a neighbour needs travel once at
-    set-up, and S_own = D_own T follows (host-side scipy on the rank's block here: static viscosity only - the eddy closure's
-    refresh of a distributed level is not implemented)."""
+    set-up, and S_own = D_own T follows.  The set-up of the distributed level is host-side scipy on the rank's block; with the
+    eddy closure `refresh` repeats it on the re-assembled matrix (same layouts, new values; the replicated levels are
+    re-assembled on the device with the injected buoyancy's viscosity, as on one GPU)."""
 
     def __init__(self, arch, params, forcings, hierarchy, model, omega=2.5, jacobi_weight=0.7, schur_sweeps=3, nu1=2, nu2=2,
                  coarse_sweeps=20, cycle="V", coarse_dense=None):
@@ -521,16 +523,17 @@ class DistributedMultigridPreconditioner:
         from .inversion import build_A_inversion
         if len(hierarchy) < 2:
             raise ValueError("DistributedMultigridPreconditioner: needs a refinement hierarchy (>= 2 levels)")
-        if forcings.eddy_param.is_on:
-            raise NotImplementedError("distributed multigrid: the eddy closure's refresh of the distributed level is not implemented")
         ctx = arch.ctx
         self.ctx, self.arch = ctx, arch
+        self.prm, self.frc, self.hierarchy = params, forcings, hierarchy
         h = C.c_void_p()
         L.check(L.lib().npg_precond_create(ctx.h, L.NPG_PC_MG, len(hierarchy), C.byref(h)))
         self.h, self._keep, self.levels = h, [], []
-        full = callable(forcings.nu)
+        full = callable(forcings.nu) or forcings.eddy_param.is_on      # (the eddy closure re-assembles A in the full-stress form)
+        self._full = full
         # ---- replicated coarse levels: exactly MultigridPreconditioner's set-up --------------------------------------
         prev = None
+        self.cA, self.cops = [], []
         for lev, fed in enumerate(hierarchy[:-1]):
             d = fed.dofs
             A = build_A_inversion(arch, fed, params, forcings.nu, structural=full)
@@ -541,14 +544,49 @@ class DistributedMultigridPreconditioner:
             if prev is not None:
                 P = mgm.prolongation(prev, fed)
                 Pd, Rd = DeviceCSR.from_scipy(ctx, P), DeviceCSR.from_scipy(ctx, sp.csr_matrix(P.T))
-            self._keep += [A, ops, Pd, Rd]
+            self._keep += [Pd, Rd]
+            self.cA.append(A)
+            self.cops.append(ops)
             L.check(L.lib().npg_precond_mg_set_level(self.h, lev, A.h, int(d.nu), ops.G.h, ops.D.h, ops.Dinv.h, ops.S.h,
                                                      None if Pd is None else Pd.h, None if Rd is None else Rd.h))
             self.levels.append(d.nu + d.np)
             prev = fed
         # ---- the distributed finest level ------------------------------------------------------------------------------
+        fed, lay = hierarchy[-1], model.layout
+        f = lay.inv
+        Gl, Dh, Dinv, Sl = self._fine_operators(model, first=True)
+        Pg = mgm.prolongation(hierarchy[-2], fed)
+        Pl = sp.csr_matrix(Pg[f.owned])
+        ops = [DeviceCSR.from_scipy(ctx, M) for M in (Gl, Dh, sp.csr_matrix(Dinv), Sl, Pl, sp.csr_matrix(Pl.T))]
+        self._fine_ops = ops
+        A_sol = model.inversion.solver.A
+        L.check(L.lib().npg_precond_mg_set_level_dist(self.h, len(hierarchy) - 1, A_sol.h, int(lay.n_own_u), ops[0].h, ops[1].h,
+                                                      ops[2].h, ops[3].h, ops[4].h, ops[5].h, self.hx.h, self.hu.h, self.hp.h))
+        self.levels.append(fed.dofs.nu + fed.dofs.np)
+        L.check(L.lib().npg_precond_mg_set_params(self.h, float(omega), float(jacobi_weight), int(schur_sweeps), int(nu1),
+                                                  int(nu2), int(coarse_sweeps)))
+        L.check(L.lib().npg_precond_mg_set_cycle(self.h, {"V": 1, "W": 2}[cycle]))
+        if coarse_dense is None:
+            coarse_dense = self.levels[0] <= 40000
+        self._dense_mode = 0 if not coarse_dense else (1 if coarse_dense == "fp64" else 2)
+        if self._dense_mode:
+            L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, self._dense_mode))
+        self.coarse_dense = bool(coarse_dense)
+        self.params = dict(omega=omega, jacobi_weight=jacobi_weight, schur_sweeps=schur_sweeps, nu1=nu1, nu2=nu2,
+                           coarse_sweeps=coarse_sweeps, cycle=cycle)
+        self.layout_mg = dict(ghost_u=int(len(self._want)), ghost_p=int(len(self._gp)), S_nnz=int(Sl.nnz))
+        self._inj = None
+
+    def _fine_operators(self, model, first):
+        """(G, D, Dinv, S) of the distributed level as host matrices in the level's local layouts, from the rank's rows of the
+        CURRENT inversion matrix (assembled afresh into a plain-CSR copy with whatever viscosity table the engine holds).
+        Collective: the rows of T = Dinv G that belong to a neighbour's ghost velocity DoFs travel between the ranks.  The first
+        call also fixes the layouts - ghost velocity / pressure lists, halo plans - which later calls reuse."""
+        from . import multigrid as mgm
+        ctx, params, hierarchy = self.ctx, self.prm, self.hierarchy
         fed, lay, part, dist = hierarchy[-1], model.layout, model.partition, model.dist
         rank, world = dist.get_rank(), dist.get_world_size()
+        full = self._full
         f = lay.inv
         nu_g = fed.dofs.nu
         nu_o, n_own, n_sol = lay.n_own_u, f.n_own, f.n_sol
@@ -586,7 +624,6 @@ class DistributedMultigridPreconditioner:
                 replies[q] = (mine, rows.indptr, rows.indices, rows.data)
         allrep = [None] * world
         dist.all_gather_object(allrep, replies)
-        ip, ix, dv = [np.zeros(1, dtype=np.int64)], [], []
         pos = {}
         for q in range(world):
             rep = allrep[q].get(rank) if q != rank else None
@@ -608,53 +645,72 @@ class DistributedMultigridPreconditioner:
             Text_rows.append(Tg)
         Text = sp.vstack(Text_rows, format="csr")                             # rows [own_u | ghost u], global columns
         Sg = sp.csr_matrix(Dh @ Text)                                         # own_p x global ids
-        # pressure layout [own_p | ghost p]: everything G and S touch
         own_p = f.owned[nu_o:]
-        cols_used = np.union1d(np.unique(Sg.indices), g[p_cols_A])
-        gp = cols_used[lay.owner_inv[cols_used] != rank]
-        gp = gp[np.lexsort((gp, lay.owner_inv[gp]))]
-        lut_p = np.full(fed.dofs.nu + fed.dofs.np, -1, dtype=np.int64)
-        lut_p[own_p] = np.arange(len(own_p))
-        lut_p[gp] = len(own_p) + np.arange(len(gp))
-        npl = len(own_p) + len(gp)
+        G0g = sp.csr_matrix((G0.data, g[p_cols_A][G0.indices], G0.indptr), shape=(nu_o, fed.dofs.nu + fed.dofs.np))
+        if first:
+            # pressure layout [own_p | ghost p]: everything G and S touch
+            cols_used = np.union1d(np.unique(Sg.indices), g[p_cols_A])
+            gp = cols_used[lay.owner_inv[cols_used] != rank]
+            gp = gp[np.lexsort((gp, lay.owner_inv[gp]))]
+            lut_p = np.full(fed.dofs.nu + fed.dofs.np, -1, dtype=np.int64)
+            lut_p[own_p] = np.arange(len(own_p))
+            lut_p[gp] = len(own_p) + np.arange(len(gp))
+            self._lut_p, self._npl, self._want, self._gp = lut_p, len(own_p) + len(gp), want, gp
+            # halo plans of the velocity-part and pressure-part vectors
+            allg = [None] * world
+            dist.all_gather_object(allg, (want, gp))
+            own_u = f.owned[:nu_o]
+            plan_u = halo_plan(rank, own_u, lay.owner_inv, [a[0] for a in allg])
+            plan_p = halo_plan(rank, own_p, lay.owner_inv, [a[1] for a in allg])
+            self.hu = Halo(ctx, nu_o, len(want), plan_u)
+            self.hp = Halo(ctx, len(own_p), len(gp), plan_p)
+            self.hx = model.inversion.solver.halo
 
-        def to_p_layout(M_global_cols):
+        def to_p_layout(M_global_cols, pattern=None):
             M = sp.csr_matrix(M_global_cols)
-            lc = lut_p[M.indices]
-            assert (lc >= 0).all()
-            Q = sp.csr_matrix((M.data, lc, M.indptr), shape=(M.shape[0], npl))
+            lc = self._lut_p[M.indices]
+            if not (lc >= 0).all():
+                raise RuntimeError("distributed multigrid: a re-assembled operator reaches a pressure column outside the level's layout")
+            Q = sp.csr_matrix((M.data, lc, M.indptr), shape=(M.shape[0], self._npl))
             Q.sort_indices()
             return Q
-        Sl = to_p_layout(Sg)
-        Gl = to_p_layout(sp.csr_matrix((G0.data, g[p_cols_A][G0.indices], G0.indptr), shape=(nu_o, fed.dofs.nu + fed.dofs.np)))
-        # halo plans of the velocity-part and pressure-part vectors
-        allg = [None] * world
-        dist.all_gather_object(allg, (want, gp))
-        own_u = f.owned[:nu_o]
-        plan_u = halo_plan(rank, own_u, lay.owner_inv, [a[0] for a in allg])
-        plan_p = halo_plan(rank, own_p, lay.owner_inv, [a[1] for a in allg])
-        self.hu = Halo(ctx, nu_o, len(want), plan_u)
-        self.hp = Halo(ctx, len(own_p), len(gp), plan_p)
-        self.hx = model.inversion.solver.halo
-        Pg = mgm.prolongation(hierarchy[-2], fed)
-        Pl = sp.csr_matrix(Pg[f.owned])
-        ops = [DeviceCSR.from_scipy(ctx, M) for M in (Gl, Dh, sp.csr_matrix(Dinv), Sl, Pl, sp.csr_matrix(Pl.T))]
-        self._keep += ops
-        A_sol = model.inversion.solver.A
-        L.check(L.lib().npg_precond_mg_set_level_dist(self.h, len(hierarchy) - 1, A_sol.h, int(nu_o), ops[0].h, ops[1].h,
-                                                      ops[2].h, ops[3].h, ops[4].h, ops[5].h, self.hx.h, self.hu.h, self.hp.h))
-        self.levels.append(fed.dofs.nu + fed.dofs.np)
-        L.check(L.lib().npg_precond_mg_set_params(self.h, float(omega), float(jacobi_weight), int(schur_sweeps), int(nu1),
-                                                  int(nu2), int(coarse_sweeps)))
-        L.check(L.lib().npg_precond_mg_set_cycle(self.h, {"V": 1, "W": 2}[cycle]))
-        if coarse_dense is None:
-            coarse_dense = self.levels[0] <= 40000
-        if coarse_dense:
-            L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, 1 if coarse_dense == "fp64" else 2))
-        self.coarse_dense = bool(coarse_dense)
-        self.params = dict(omega=omega, jacobi_weight=jacobi_weight, schur_sweeps=schur_sweeps, nu1=nu1, nu2=nu2,
-                           coarse_sweeps=coarse_sweeps, cycle=cycle)
-        self.layout_mg = dict(ghost_u=int(len(want)), ghost_p=int(len(gp)), S_nnz=int(Sl.nnz))
+        return to_p_layout(G0g), Dh, Dinv, to_p_layout(Sg)
+
+    def refresh(self, A, model=None):
+        """the solver's matrix has been re-assembled on every rank (eddy closure, src/model.jl:160-170): recompute the distributed
+        level's smoother from it (same layouts, new values) and re-assemble the replicated coarser levels with the eddy viscosity of
+        the buoyancy injected into their meshes - what MultigridPreconditioner.refresh does on one GPU.  Collective."""
+        from . import multigrid as mgm
+        from .inversion import build_A_inversion, device_fe
+        if model is None:
+            raise ValueError("DistributedMultigridPreconditioner.refresh needs the model (its engine holds the viscosity table)")
+        top = len(self.hierarchy) - 1
+        Gl, Dh, Dinv, Sl = self._fine_operators(model, first=False)
+        new = [DeviceCSR.from_scipy(self.ctx, M) for M in (Gl, Dh, sp.csr_matrix(Dinv), Sl)]
+        L.check(L.lib().npg_precond_mg_update_level(self.h, top, A.h, new[0].h, new[1].h, new[2].h, new[3].h))
+        self._fine_ops[:4] = new
+        ep = self.frc.eddy_param
+        if ep.is_on:
+            fine = self.hierarchy[-1]
+            if self._inj is None:
+                p1 = fine.spaces.b_order == 1
+                self._inj = [mgm.injection(self.hierarchy[k].mesh, self.hierarchy[k + 1].mesh, p1) for k in range(top)]
+            s_f = fine.spaces
+            b_glob = model.state.b                                            # collective gather of the owned slices, native order
+            nodal = np.where(s_f.b_dof >= 0, b_glob[np.maximum(s_f.b_dof, 0)], s_f.b_diri_val)
+            for lev in range(top - 1, -1, -1):
+                fed = self.hierarchy[lev]
+                nodal = nodal[self._inj[lev]]
+                s = fed.spaces
+                fe = device_fe(self.arch, fed)
+                bl = DeviceVector.from_host(self.ctx, nodal[s.b_dof >= 0], fed.dofs.p_b)
+                fe.update_nu_eddy(ep.N2min, self.prm.alpha, self.prm.N2, bl)
+                build_A_inversion(self.arch, fed, self.prm, None, A=self.cA[lev])
+                ops = self.cops[lev].update(self.cA[lev])
+                L.check(L.lib().npg_precond_mg_update_level(self.h, lev, self.cA[lev].h, ops.G.h, ops.D.h, ops.Dinv.h, ops.S.h))
+            if self._dense_mode:
+                L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, self._dense_mode))
+        return self
 
     def counters(self):
         import ctypes as C

@@ -17,11 +17,21 @@ def main():
     dist.init_process_group("gloo")
     rank = dist.get_rank()
     arch = npg.GPU(int(os.environ.get("NPG_FORCE_DEVICE", 0)))
-    hier = [workloads.example_fe_data(m) for m in workloads.bowl_hierarchy_models(label)]
-    prm, frc = workloads.example_parameters()
-    m = partition.partitioned_model(arch, hier[-1], prm, frc, npg.BDF2(t_start=0.0, t_stop=1e9, dt=1e-3), dist)
-    partition.use_multigrid(m, hier)
-    assert m.verify_transport()
+    if label.startswith("channel_basin"):
+        # BASELINE configs[4] with converged inversions: x-periodic channel basin, both closures (the eddy closure re-assembles A
+        # in the full-stress form at step 10 and the preconditioner follows), two-level hierarchy, finest level partitioned
+        hh = float(label.split("_h")[1])
+        models = workloads.channel_basin_hierarchy_models(hh, 1)
+        hier = [workloads.channel_basin_fe_data(mm) for mm in models]
+        m = partition.channel_basin_model(arch, models[-1], dist, element_precision="fp64", itmax=0, fe_data=hier[-1], invert_now=False)
+        partition.use_multigrid(m, hier, omega=2.0)
+        assert m.verify_transport()
+    else:
+        hier = [workloads.example_fe_data(m) for m in workloads.bowl_hierarchy_models(label)]
+        prm, frc = workloads.example_parameters()
+        m = partition.partitioned_model(arch, hier[-1], prm, frc, npg.BDF2(t_start=0.0, t_stop=1e9, dt=1e-3), dist)
+        partition.use_multigrid(m, hier)
+        assert m.verify_transport()
     npg.invert(m)
     npg.run(m, n_steps=nsteps)
     arch.ctx.sync()
