@@ -301,6 +301,7 @@ NPG_API int npg_cg_solve(npg_cg *ws, const npg_csr *A_in, int precond_kind, doub
     NPG_REQUIRE(!A_in->packed && !A_in->pk9, "npg_cg_solve: matrices with full node records are not served by the CG kernels");
     NPG_REQUIRE(!A_in->uperm, "npg_cg_solve: the matrix carries an internal renumbering (npg_csr_block_nodes_dofs): npg_spmv and npg_gmres_solve only");
     const npg_csr *A = A_in;
+    if (int rc = check_record_view(A, false, "npg_cg_solve")) return rc;
     const int64_t nloc = ws->n + ws->n_ghost;     // distributed: vectors the SpMV reads hold [owned | ghosts]
     NPG_REQUIRE(A->m == ws->n && A->n == nloc && y->n == ws->n && x->n == nloc,
                 "npg_cg_solve: workspace is for n=%lld (+%lld ghosts) but A is %lldx%lld, y has %lld, x has %lld",

@@ -217,6 +217,25 @@ int build_tiles(npg_csr *A);
 // tile boundaries (consecutive whole rows, at most tile_slots LDS product slots) for any tile size: tuning harness
 // the form the SpMV kernels read: the record-form companion of a plain matrix if it has one (npg_csr_pack_nodes)
 inline const npg_csr *spmv_form(const npg_csr *A) { return (A && A->packed) ? A->packed : A; }
+// Host-side consistency of what a tile kernel is about to index (O(1), before every launch that takes the matrix): the arrays its
+// record loops read must exist and agree in length.  A kernel instance WITHOUT full-node-record support reading a companion
+// (whose {K, C} array is null) is what the two memory faults of round 3 were - profiles/r04_round3_faults.txt.
+inline int check_record_view(const npg_csr *A, bool n9_capable, const char *who) {
+    if (!A) return NPG_OK;
+    if (A->nnode() > 0) {
+        NPG_REQUIRE(A->prow && A->pcol && (A->pkc != nullptr) != (A->pk9 != nullptr),
+                    "%s: inconsistent record form (row offsets %p, columns %p, {K,C} %p, full records %p)", who, (void *)A->prow,
+                    (void *)A->pcol, (void *)A->pkc, (void *)A->pk9);
+        NPG_REQUIRE(!A->pk9 || n9_capable, "%s: this kernel does not read full node records (npg_csr_pack_nodes)", who);
+        NPG_REQUIRE(!A->pk9 || A->npk9 == A->h_prow[(size_t)A->nnode()], "%s: %lld full node records but offsets for %lld", who,
+                    (long long)A->npk9, (long long)A->h_prow[(size_t)A->nnode()]);
+    } else {
+        NPG_REQUIRE(!A->pk9 && !A->pkc && !A->grow, "%s: record arrays without block nodes", who);
+    }
+    NPG_REQUIRE(!A->grow || (A->gcol && A->gval && A->ngrec == A->h_grow[(size_t)A->nnode()]), "%s: inconsistent column records", who);
+    NPG_REQUIRE(!A->drow || (A->dcol && A->dval && A->ndrec == A->h_drow[(size_t)(A->m - A->block_rows())]), "%s: inconsistent coupling records", who);
+    return NPG_OK;
+}
 // refresh the companion's values from the plain matrix (no-op without one); enqueued on the context's stream
 NPG_SHARED int csr_repack(const npg_csr *A);
 NPG_SHARED int tile_boundaries(const npg_csr *A, int tile_slots, std::vector<int32_t> &tp, int max_rows = kTileRows);

@@ -1504,6 +1504,7 @@ namespace npg {
 // y[0, m) = alpha A x[0, n) + beta y on raw device pointers (x and y may be windows into larger vectors; they must not overlap)
 int spmv_epi(const npg_csr *Ap, const double *x, const SpmvEpi &e) {
     const npg_csr *A = spmv_form(Ap);
+    if (int rc = check_record_view(A, true, "spmv")) return rc;
     switch (A->lanes) {
         case 4: launch_spmv<4>(A, x, e); break;
         case 8: launch_spmv<8>(A, x, e); break;

@@ -1176,6 +1176,7 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A_in, int precond_kind
         return NPG_OK;
     }
     const npg_csr *A = spmv_form(A_in);           // (the record-form companion of a plain matrix, if it has one)
+    if (int rc = check_record_view(A, true, "npg_gmres_solve")) return rc;     // (full node records: the split kernels, forced below)
     const int64_t nloc = ws->n + ws->n_ghost;     // distributed: vectors the SpMV reads hold [owned | ghosts]
     NPG_REQUIRE(A->m == ws->n && A->n == nloc && y->n == ws->n && x->n == nloc,
                 "npg_gmres_solve: workspace is for n=%lld (+%lld ghosts) but A is %lldx%lld, y has %lld, x has %lld",

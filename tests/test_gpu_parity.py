@@ -791,6 +791,16 @@ def test_full_node_records(arch):
     for tag in ("packed", "packed+gather"):
         assert abs(out[tag][0] - out["plain"][0]) <= 0.06 * out["plain"][0], (tag, out[tag][0], out["plain"][0])
         assert rel(out[tag][1], out["plain"][1]) < 2e-4
+    # Kernel instances that do not read full node records must never see such a matrix (its {K, C} array is null: the round-3
+    # memory faults, profiles/r04_round3_faults.txt).  The CG kernels refuse it on the host; a GMRES workspace told to use the
+    # fused organisation - whose kernel has no full-record instance - is moved to the split one and solves as before.
+    cgw = npg.CgWorkspace(arch.ctx, ref2.shape[0])
+    with pytest.raises(L.DeviceError):
+        cgw.solve(A, dy, cgw.x, None)
+    ws = npg.GmresWorkspace(arch.ctx, ref2.shape[0], memory=20)
+    ws.set_split(0)
+    st = ws.solve(A, dy, ws.x, P)
+    assert st["solved"] == 1 and rel(ws.x.to_host(), out["plain"][1]) < 2e-4
 
 
 def test_extrapolated_initial_guess(arch):
