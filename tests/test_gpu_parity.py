@@ -1153,6 +1153,41 @@ def test_full_size_properties(arch):
     assert abs(np.linalg.norm(r) / h ** 3 - st["rnorm"]) <= 1e-6 * st["rnorm0"] + 1e-6 * st["rnorm"]
 
 
+@pytest.mark.skipif(os.environ.get("NPG_TEST_9M", "1") == "0", reason="NPG_TEST_9M=0")
+def test_nine_million_unknowns_properties(arch):
+    """bowl3D h = 0.0125 (8 973 419 unknowns, 537.8 M non-zeros: the largest configuration quoted, three refinements of the
+    reference's h = 0.1 mesh) - trimmed version of test_full_size_properties: device assembly, record storage against plain CSR
+    (1e-13), the windowed tile set against the plain-CSR product of the fp32-rounded vector (1e-13), and ONE restart cycle of
+    GMRES(20) whose reported residual is the true scaled residual recomputed with the other storage format."""
+    from nupgcm_amd import workloads
+    fed = workloads.example_fe_data(workloads.bowl_mesh_model("bowl3D_h0.0125"))
+    prm, frc = workloads.example_parameters()
+    d, ctx = fed.dofs, arch.ctx
+    N = d.nu + d.np
+    assert N == 8973419
+    A_csr = npg.build_A_inversion(arch, fed, prm, frc.nu)
+    A_blk = npg.build_A_inversion(arch, fed, prm, frc.nu)
+    assert A_blk.block_nodes(d.n_full, d.n_surf) and A_csr.nnz == A_blk.nnz
+    nodes, rec, ent = A_blk.storage()
+    info = A_blk.window_info()
+    assert nodes == d.n_full + d.n_surf and ent == 0 and info["block_tiles"] > 20000 and info["distinct"] < 0.35 * (rec + A_blk.coupling_records() / 2)
+    rng = np.random.default_rng(1)
+    xh = rng.standard_normal(N)
+    x = npg.DeviceVector.from_host(ctx, xh)
+    ax = A_csr.mul(x).to_host()
+    assert rel(A_blk.mul(x).to_host(), ax) < 1e-13
+    x32 = npg.DeviceVector.from_host(ctx, xh.astype(np.float32).astype(np.float64))
+    assert rel(A_blk.mul_gather32(x, windowed=True).to_host(), A_csr.mul(x32).to_host()) < 1e-13
+    # one restart cycle from a cold start on a smooth right-hand side: the Givens recurrence's residual = the true one
+    h = fed.mesh.median_edge_length()
+    yh = ax * 1e-3
+    ws = npg.GmresWorkspace(ctx, N, memory=20)
+    st = ws.solve(A_blk, npg.DeviceVector.from_host(ctx, yh), ws.x, npg.Diagonal(scalar=1 / h ** 3), itmax=20)
+    assert st["niter"] == 20 and st["status"] == 2 and st["rnorm"] < st["rnorm0"]
+    r = yh - A_csr.mul(ws.x).to_host()
+    assert abs(np.linalg.norm(r) / h ** 3 - st["rnorm"]) <= 1e-6 * st["rnorm0"]
+
+
 def test_run_saves_checkpoints_every_n_save(arch, tmp_path):
     """run!(model; n_save) - src/model.jl:194-197: state_%016d.jld2 and .vtu under <out_dir>/data every n_save steps
     (set_out_dir!, src/nuPGCM.jl:36-54); the last checkpoint holds the state the run ended with."""
