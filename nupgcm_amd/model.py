@@ -155,6 +155,12 @@ def run(model: Model, n_info=10, n_save=float("inf"), n_plot=float("inf"), advec
         pv["b_curr"].copy_from(b)
         evolve(model, pv["x_prev"], pv["b_prev"])                                               # src/model.jl:144
         order = int(getattr(model, "extrapolate_guess", 0) or 0)
+        if order >= 2 and not getattr(model, "_warned_quadratic_guess", False):
+            import warnings
+            model._warned_quadratic_guess = True
+            warnings.warn("extrapolate_guess=2 (quadratic initial guess) is kept for experiments only: on bowl3D h = 0.02 restarted "
+                          "GMRES(20) stagnated on what it leaves of the residual (up to 240 997 iterations in one step, "
+                          "profiles/r03_bench_quadratic_guess_bowl3D_h0.02.json); use extrapolate_guess=1", RuntimeWarning)
         if order >= 2 and i > 2 and "x_prev2" in pv:
             # ... or the quadratic one, 3 x_{n-1} - 3 x_{n-2} + x_{n-3}
             inv_x.axpby(-3.0, pv["x_prev"], 3.0)
