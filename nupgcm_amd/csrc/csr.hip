@@ -148,8 +148,9 @@ static void free_window_tiles(npg_csr *A) {
 // nodes (16 B each) and of distinct other columns (4 B each) - followed by the ordinary tiles of the rows behind the block
 // rows.  pcol / gcol: host copies of the record columns (every node's list already padded to an even count).
 // Leaves the matrix without a windowed set (no error) when some node's rows would not fit a tile.
-static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, const std::vector<int32_t> &gcol,
-                              const std::vector<int32_t> &dcol, const std::vector<double> &pkc, const std::vector<double> &dxy) {
+static int build_window_tiles_scaled(npg_csr *A, const std::vector<int32_t> &pcol, const std::vector<int32_t> &gcol,
+                                     const std::vector<int32_t> &dcol, const std::vector<double> &pkc, const std::vector<double> &dxy,
+                                     double scale) {
     free_window_tiles(A);
     const int64_t nnode = A->nnode(), nfull = A->nfull, nbr = A->block_rows();
     if (nnode == 0 || !A->grow || A->pk9) return NPG_OK;
@@ -157,7 +158,8 @@ static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, cons
     constexpr int NT = 512;
     int64_t hard = 8 * (int64_t)kTileNnz;
     if (getenv("NPG_WIN_BYTES")) hard = std::min<int64_t>(hard, std::max<int64_t>(8192, atoll(getenv("NPG_WIN_BYTES"))));    // tuning: smaller tiles
-    const double scale = getenv("NPG_WIN_SCALE") ? std::min(1.0, std::max(0.25, atof(getenv("NPG_WIN_SCALE")))) : 1.0;       // tuning: all caps scaled
+    scale = std::min(1.0, std::max(0.25, scale));       // all caps of a tile scaled (build_window_tiles; NPG_WIN_SCALE)
+    hard = (int64_t)(scale * (double)hard);
     const int64_t cap_p = (int64_t)(scale * kWinPairs * NT), cap_c = (int64_t)(scale * kWinCols * NT);
     // small matrices: about one tile per CU (as tile_boundaries does)
     const int64_t total = 8 * (3 * (prow[nfull] / 2 + grow[nfull]) + 2 * ((prow[nnode] - prow[nfull]) / 2 + grow[nnode] - grow[nfull]));
@@ -402,6 +404,16 @@ static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, cons
     if (getenv("NPG_SPMV_WLANES")) A->wlanes = atoi(getenv("NPG_SPMV_WLANES")) == 8 ? 8 : 4;
     A->gen++;
     return NPG_OK;
+}
+
+// The windowed tile set at full tile size (NPG_WIN_SCALE: all caps of a tile scaled, tuning).  A rule that shrinks the tiles of
+// small matrices until their number fills a whole number of rounds of the 3 x num_cu persistent workgroups was measured and
+// dropped: bowl3D h = 0.04 (2.2 -> 2.9 rounds) 27.5 -> 29.0 us per Arnoldi launch, h = 0.05 (1.1 -> 1.9 rounds) 18.8 -> 20.6 us -
+// the workgroups do not move in rounds, and smaller tiles cost more than a partly filled last round (profiles/r04_windowed_tiles.txt).
+static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, const std::vector<int32_t> &gcol,
+                              const std::vector<int32_t> &dcol, const std::vector<double> &pkc, const std::vector<double> &dxy) {
+    const double s_env = getenv("NPG_WIN_SCALE") ? atof(getenv("NPG_WIN_SCALE")) : -1.0;
+    return build_window_tiles_scaled(A, pcol, gcol, dcol, pkc, dxy, s_env > 0 ? s_env : 1.0);
 }
 
 constexpr int kSpmvThreads = 512;
