@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where a CSR-stream tile spends its time: cycle stamps inside the product SpMV tile loop (csrc/spmv_variants.hip,
+"""Where a CSR-stream tile spends its time: cycle stamps inside the product SpMV tile loop (tools/tune/spmv_variants.hip,
 npg_spmv_phase_cycles), averaged per tile, for 1..3 workgroups per CU, with and without the x gathers.
 Usage: python tools/spmv_phases.py [workload] [--plain]"""
 import ctypes as C

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times the stand-alone CSR-stream SpMV variants of csrc/spmv_variants.hip on the assembled A_inversion of a bowl mesh.
+"""Times the stand-alone CSR-stream SpMV variants of tools/tune/spmv_variants.hip on the assembled A_inversion of a bowl mesh.
 Usage: python tools/spmv_tune.py [workload] [reps]"""
 import ctypes as C
 import os

@@ -27,7 +27,7 @@
 //   F  s_waitcnt lgkmcnt(0) ; s_barrier ; epilogue (reads sw)
 // C and F are raw s_barrier: a __syncthreads() would drain the DMA (vmcnt(0)).
 #pragma once
-#include "spmv_device.h"
+#include "../../nupgcm_amd/csrc/spmv_device.h"
 
 namespace npg {
 

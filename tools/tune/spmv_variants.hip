@@ -4,8 +4,8 @@
 #include <algorithm>
 #include <map>
 
-#include "common.h"
-#include "spmv_device.h"
+#include "../../nupgcm_amd/csrc/common.h"
+#include "../../nupgcm_amd/csrc/spmv_device.h"
 #include "spmv_pack.h"
 
 namespace npg {
