@@ -929,8 +929,10 @@ NPG_API int npg_csr_pack_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, int *pa
     P->ngrec = ng;
     P->ndrec = nd;
     std::vector<int64_t> map9((size_t)9 * n9), mapg((size_t)3 * ng), mapd((size_t)3 * nd);
-    for (int64_t e = 0; e < n9; ++e)
-        for (int s9 = 0; s9 < 9; ++s9) map9[(size_t)s9 * n9 + e] = m9[(size_t)9 * e + s9];
+    for (int64_t e = 0; e < n9; ++e) {           // (a_2k, a_2k+1) pairs as four 16-byte streams, a_8 as one 8-byte stream (spmv_device.h)
+        for (int s9 = 0; s9 < 8; ++s9) map9[(size_t)(s9 & ~1) * n9 + 2 * e + (s9 & 1)] = m9[(size_t)9 * e + s9];
+        map9[(size_t)8 * n9 + e] = m9[(size_t)9 * e + 8];
+    }
     for (int64_t e = 0; e < ng; ++e) {               // [2 ng] (a_x, a_y) pairs, then [ng] a_z
         mapg[2 * e] = mg3[3 * e];
         mapg[2 * e + 1] = mg3[3 * e + 1];

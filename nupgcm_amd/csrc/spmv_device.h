@@ -75,7 +75,8 @@ struct CsrDev {
     const float2 *gxy32;      // fp32 copies
     const float *gz32;
     // full node records (function-valued viscosity: all nine component pairs of a node pair; npg_csr_pack_nodes): record e of
-    // the prow / pcol index holds a_rs = A[row component r of q, column component s of c] at pk9[(3 r + s) npk9 + e]
+    // the prow / pcol index holds a_i = A[row component i / 3 of q, column component i % 3 of c]; a_0 .. a_7 are stored in PAIRS -
+    // (a_2k, a_2k+1) at pk9[2 k npk9 + 2 e + {0, 1}], four 16-byte-per-record streams - and a_8 at pk9[8 npk9 + e]
     const double *pk9;
     const float *pk9_32;
     int64_t npk9;
@@ -264,17 +265,19 @@ __device__ __forceinline__ void spmv_tile(const CsrDev &A, const XF x, const Til
                         const int e = e0 + u * NT;
                         const bool in = e < npe;
                         c[u] = in ? __builtin_nontemporal_load(A.pcol + pbase + e) : 0;
+                        // values in PAIRS: (a_0, a_1) .. (a_6, a_7) as four 16-byte streams, a_8 as an 8-byte one (pk9 layout below) -
+                        // five loads per record instead of nine: the tile is bound by the vector-memory instructions it issues
+                        const double *__restrict__ b9 = A.pk9 + 2 * (pbase + e);
 #pragma unroll
-                        for (int s9 = 0; s9 < 9; ++s9) {
-                            if (!full && s9 >= 6) {       // (x, y)-only row nodes have no z row (but their rows do reach z_c)
-                                a[u][s9] = 0.0;
-                            } else if (in) {
-                                a[u][s9] = F32 ? (double)__builtin_nontemporal_load(A.pk9_32 + (int64_t)s9 * A.npk9 + pbase + e)
-                                               : __builtin_nontemporal_load(A.pk9 + (int64_t)s9 * A.npk9 + pbase + e);
+                        for (int k = 0; k < 4; ++k) {
+                            if ((!full && k == 3) || !in) {       // (x, y)-only row nodes have no z row (but their rows do reach z_c)
+                                a[u][2 * k] = a[u][2 * k + 1] = 0.0;
                             } else {
-                                a[u][s9] = 0.0;
+                                a[u][2 * k] = __builtin_nontemporal_load(b9 + (int64_t)(2 * k) * A.npk9);
+                                a[u][2 * k + 1] = __builtin_nontemporal_load(b9 + (int64_t)(2 * k) * A.npk9 + 1);
                             }
                         }
+                        a[u][8] = (full && in) ? __builtin_nontemporal_load(A.pk9 + 8 * A.npk9 + pbase + e) : 0.0;
                     }
 #pragma unroll
                     for (int u = 0; u < U9; ++u) {
