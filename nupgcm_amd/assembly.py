@@ -42,6 +42,7 @@ class DeviceFE:
         L.check(L.lib().npg_fe_create(ctx.h, C.byref(d), C.byref(h)))
         self.h = h
         self._patterns = {}
+        self._f_probe = None
 
     def __del__(self):
         try:
@@ -67,12 +68,24 @@ class DeviceFE:
         # the eddy closure does, src/inversion.jl:149-170) would re-evaluate it at every quadrature point on the host for
         # nothing - 0.4 s of the 0.6 s a re-assembly took at 3.9 M unknowns.  (nu / kappa tables are also rewritten on the
         # device by the closures, so they are always re-set.)
-        if name == "f" and callable(v) and getattr(self, "_f_src", None) is v:
-            return
+        # The skip is keyed on VALUES, not on the object: the function is sampled at a few fixed cells and the samples must equal
+        # the ones taken when the table was built - a callable whose captured state changed (params.beta mutated, a lambda
+        # closing over a params object) re-evaluates.  force=True (keyword of set_coeff_force) always re-evaluates.
+        if name == "f" and callable(v) and getattr(self, "_f_src", None) is v and self._f_probe is not None:
+            if np.array_equal(self._probe(v), self._f_probe):
+                return
         tab = L.as_f64(eval_at_quad_points(self.fe_data.mesh, v))
         L.check(L.lib().npg_fe_set_coeff(self.h, name.encode(), L.ptr(tab)))
         if name == "f":
             self._f_src = v if callable(v) else None
+            self._f_probe = self._probe(v) if callable(v) else None
+
+    def _probe(self, fn):
+        """the function at the quadrature points of up to 64 cells spread over the mesh (the table's own values there)"""
+        if getattr(self, "_probe_x", None) is None:          # (the points are taken once: evaluating them all is what the skip saves)
+            xq = self.fe_data.mesh.quad_points()
+            self._probe_x = xq[np.linspace(0, len(xq) - 1, num=min(64, len(xq)), dtype=np.int64)].copy()
+        return np.asarray(fn(self._probe_x), dtype=np.float64).copy()
 
     def new_matrix(self, kind, structural=False):
         """zero-valued DeviceCSR with the pattern of 'A', 'B' or 'b' (buoyancy-buoyancy)"""

@@ -307,6 +307,8 @@ def partitioned_model(arch, fe_data, params, forcings, ts, dist, atol=1e-6, rtol
     src/inversion.jl:20-94 and src/evolution.jl:62-126 on the rank's cells and rows; the reference's GPU preconditioner
     Diagonal(1/h^dim) uses the GLOBAL median edge length (src/inversion.jl:42-54)."""
     from .architectures import comm_unique_id
+    if getattr(fe_data.mesh, "dim", 3) != 3:
+        raise NotImplementedError("partitioned_model: tetrahedral meshes only (the embedded 2-D meshes run on one GPU)")
     ctx = arch.ctx
     rank, world = dist.get_rank(), dist.get_world_size()
     if ctx.nranks != world:
@@ -316,6 +318,13 @@ def partitioned_model(arch, fe_data, params, forcings, ts, dist, atol=1e-6, rtol
     d = fe_data.dofs
     part = (NodePartition(fe_data, world) if partition == "node" else
             RowPartition(d.nu, d.np, d.nb, world, d.n_full, d.n_surf))
+    # every rank must own rows of both systems: a rank left empty (tiny mesh, many ranks) would fail alone in npg_gmres_create
+    # while the others wait in a collective - all ranks see the same partition, so all of them raise together here
+    counts_i = np.bincount(part.inv_owner(), minlength=world)
+    counts_b = np.bincount(part.b_owner(), minlength=world)
+    if counts_i.min() == 0 or counts_b.min() == 0:
+        raise ValueError(f"partitioned_model: {world} ranks leave a rank without rows (inversion rows per rank {counts_i.tolist()}, "
+                         f"buoyancy rows {counts_b.tolist()}): use fewer ranks for this mesh")
     lay = RankLayout(fe_data, part, rank)
     lfd = LocalFEData(fe_data, lay)
     fe = DeviceFE(ctx, lfd)
