@@ -579,6 +579,7 @@ WinDev win_view(const npg_csr *A) {
     WinDev w;
     w.widx = A->widx;
     w.gidx = A->gidx;
+    w.ngrec = A->ngrec;
     w.wlist = A->wlist;
     w.vlist = A->vlist;
     w.pkc2 = reinterpret_cast<const double2 *>(A->pkc2);
@@ -1079,6 +1080,24 @@ NPG_API int npg_csr_block_nodes_dofs(npg_csr *A, const int64_t *node_of_dof, con
     // A' = A[perm, perm] on the host, rows sorted
     NPG_HIP(hipSetDevice(A->ctx->device));
     NPG_HIP(hipStreamSynchronize(A->ctx->stream));
+    // (what the handle will carry is allocated first: a failure here leaves the caller's matrix as it was)
+    int32_t *d_perm = nullptr;
+    double *d_vec[3] = {nullptr, nullptr, nullptr};
+    auto release = [&]() {
+        if (d_perm) hipFree(d_perm);
+        for (double *q : d_vec)
+            if (q) hipFree(q);
+    };
+    {
+        hipError_t e0 = hipMalloc((void **)&d_perm, (size_t)N * sizeof(int32_t));
+        for (int k = 0; k < 3 && e0 == hipSuccess; ++k) e0 = hipMalloc((void **)&d_vec[k], (size_t)N * sizeof(double));
+        if (e0 == hipSuccess) e0 = hipMemcpy(d_perm, perm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e0 != hipSuccess) {
+            release();
+            set_error("npg_csr_block_nodes_dofs: out of device memory");
+            return NPG_ENOMEM;
+        }
+    }
     std::vector<int32_t> col((size_t)A->nnz), ncol((size_t)A->nnz);
     std::vector<double> val((size_t)A->nnz), nval((size_t)A->nnz);
     NPG_HIP(hipMemcpy(col.data(), A->col, col.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1114,11 +1133,11 @@ NPG_API int npg_csr_block_nodes_dofs(npg_csr *A, const int64_t *node_of_dof, con
             const int rc2 = put(orp, col, val);
             if (rc == NPG_OK) rc = rc2;
         }
+        release();
         return rc;
     }
-    NPG_HIP(hipMalloc((void **)&A->uperm, (size_t)N * sizeof(int32_t)));
-    NPG_HIP(hipMemcpy(A->uperm, perm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
-    for (int k = 0; k < 3; ++k) NPG_HIP(hipMalloc((void **)&A->uvec[k], (size_t)N * sizeof(double)));
+    A->uperm = d_perm;
+    for (int k = 0; k < 3; ++k) A->uvec[k] = d_vec[k];
     return NPG_OK;
 }
 

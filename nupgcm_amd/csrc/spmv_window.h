@@ -35,6 +35,7 @@ namespace npg {
 // device view of a matrix's windowed tile set (npg_csr, build_window_tiles); passed beside CsrDev to the kernels that use it
 struct WinDev {
     const uint16_t *widx, *gidx;   // 16-bit window indices of the node records / column records (indexed like pcol / gcol)
+    int64_t ngrec;                 // column records in all (a tile WITHOUT any clamps its idle loads to the last one)
     const int32_t *wlist, *vlist;  // per-tile lists of distinct column nodes / other columns (WTileDesc::woff, voff index them)
     const double2 *pkc2;           // {K, C} split by position in the record pair: [npairs] first records, [npairs] second records
     int64_t npairs;
@@ -152,7 +153,6 @@ __device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const WinDev &W, 
     uint32_t gi[kWinCols];
     double ax[kWinCols], ay[kWinCols], az[kWinCols];
     {
-        const double *__restrict__ gp = reinterpret_cast<const double *>(A.gxy + base);
 #pragma unroll
         for (int u = 0; u < kWinCols; ++u) {
             const int e = min(tid + u * NT, max(n - 1, 0));
@@ -161,10 +161,13 @@ __device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const WinDev &W, 
                 ax[u] = ay[u] = az[u] = (double)e;
                 continue;
             }
-            gi[u] = __builtin_nontemporal_load(W.gidx + base + e);
-            ax[u] = __builtin_nontemporal_load(gp + 2 * e);
-            ay[u] = __builtin_nontemporal_load(gp + 2 * e + 1);
-            az[u] = __builtin_nontemporal_load(A.gz + base + e);
+            // (a tile without column records - n = 0 - still issues these loads: keep them inside the arrays)
+            const int64_t ge = min(base + e, W.ngrec - 1);
+            const double *__restrict__ gq = reinterpret_cast<const double *>(A.gxy + ge);
+            gi[u] = __builtin_nontemporal_load(W.gidx + ge);
+            ax[u] = __builtin_nontemporal_load(gq);
+            ay[u] = __builtin_nontemporal_load(gq + 1);
+            az[u] = __builtin_nontemporal_load(A.gz + ge);
         }
     }
     prof.stamp(9);
