@@ -304,6 +304,12 @@ int npg_fgmres_set_halo(npg_fgmres *ws, npg_halo *h);
 int npg_precond_mg_set_level_dist(npg_precond *pc, int level, const npg_csr *A, int64_t nu_owned, const npg_csr *G,
                                   const npg_csr *D, const npg_csr *Dinv, const npg_csr *S, const npg_csr *P, const npg_csr *R,
                                   npg_halo *hx, npg_halo *hu, npg_halo *hp);
+/* Two distributed levels: the level below a distributed level may be distributed as well (the finest one or two levels of a
+ * hierarchy).  Set the coarser one first - npg_precond_mg_set_level_dist with its transfers to the replicated level below it -,
+ * then the finer one with P = R = NULL, then the transfers between the two: P = this rank's rows of the prolongation over the
+ * coarser level's [owned | ghosts of hP] columns, R = the coarser level's owned rows of the restriction over the finer level's
+ * [owned | ghosts of hR] columns; hP / hR are halo plans on the coarser iterate / the finer residual. */
+int npg_precond_mg_set_transfer_dist(npg_precond *pc, int level, const npg_csr *P, const npg_csr *R, npg_halo *hP, npg_halo *hR);
 int npg_fgmres_solve(npg_fgmres *ws, const npg_csr *A, npg_precond *pc, const npg_vec *y, npg_vec *x, double scale,
                      double atol, double rtol, int64_t itmax, npg_solve_stats *stats);
 int64_t npg_fgmres_history(npg_fgmres *ws, double *buf, int64_t cap);

@@ -104,6 +104,7 @@ def _declare(L):
         "npg_precond_apply": [P, P, P], "npg_precond_counters": [P, C.POINTER(I64), C.POINTER(I64)],
         "npg_fgmres_create": [P, I64, C.c_int, PP], "npg_fgmres_destroy": [P], "npg_fgmres_set_halo": [P, P],
         "npg_precond_mg_set_level_dist": [P, C.c_int, P, I64, P, P, P, P, P, P, P, P, P],
+        "npg_precond_mg_set_transfer_dist": [P, C.c_int, P, P, P, P],
         "npg_fgmres_solve": [P, P, P, P, P, D, D, D, I64, C.POINTER(SolveStats)],
         "npg_fe_set_precision": [P, C.c_int], "npg_fe_get_precision": [P],
         "npg_fe_create": [P, C.POINTER(FeDesc), PP], "npg_fe_destroy": [P], "npg_fe_set_coeff": [P, C.c_char_p, VP],

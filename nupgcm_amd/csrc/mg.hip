@@ -242,6 +242,11 @@ struct MgLevel {
     // ones, filled by these plans before each product - hx: whole vectors (A), hu: velocity parts (D), hp: pressure parts (G, S)
     npg_halo *hx = nullptr, *hu = nullptr, *hp = nullptr;
     bool dist = false;
+    // transfers between TWO distributed levels (npg_precond_mg_set_transfer_dist; this level being the finer one): P holds this
+    // rank's rows over the coarser level's [owned | ghosts of hP] columns, R the coarser level's owned rows over this level's
+    // [owned | ghosts of hR] columns; the vectors that feed them are copied into xP / rR, whose ghost segments the plans fill
+    npg_halo *hP = nullptr, *hR = nullptr;
+    double *xP = nullptr, *rR = nullptr;
 };
 
 struct BlockPc {
@@ -495,8 +500,10 @@ NPG_API int npg_precond_mg_set_level_dist(npg_precond *pc, int level, const npg_
                                           const npg_csr *D, const npg_csr *Dinv, const npg_csr *S, const npg_csr *P,
                                           const npg_csr *R, npg_halo *hx, npg_halo *hu, npg_halo *hp) {
     NPG_REQUIRE(pc && pc->kind == NPG_PC_MG, "npg_precond_mg_set_level_dist: not a multigrid preconditioner");
-    NPG_REQUIRE(level >= 1 && level == (int)pc->L.size() - 1, "npg_precond_mg_set_level_dist: only the finest level can be distributed");
-    NPG_REQUIRE(A && G && D && Dinv && S && P && R && hx && hu && hp, "npg_precond_mg_set_level_dist: NULL argument");
+    NPG_REQUIRE(level >= 1 && level < (int)pc->L.size(), "npg_precond_mg_set_level_dist: level %d cannot be distributed", level);
+    NPG_REQUIRE(A && G && D && Dinv && S && hx && hu && hp, "npg_precond_mg_set_level_dist: NULL argument");
+    NPG_REQUIRE(level == (int)pc->L.size() - 1 || level == (int)pc->L.size() - 2,
+                "npg_precond_mg_set_level_dist: the distributed levels are the finest one or two");
     const int64_t n = A->m, np = n - nu;
     NPG_REQUIRE(nu > 0 && np > 0 && hx->n_owned == n && A->n == n + hx->n_ghost && hu->n_owned == nu && D->m == np &&
                     D->n == nu + hu->n_ghost && hp->n_owned == np && G->m == nu && G->n == np + hp->n_ghost && S->m == np &&
@@ -505,9 +512,15 @@ NPG_API int npg_precond_mg_set_level_dist(npg_precond *pc, int level, const npg_
                 (long long)nu);
     MgLevel &l = pc->L[level];
     NPG_REQUIRE(l.A == nullptr && pc->L[level - 1].A, "npg_precond_mg_set_level_dist: set the coarser levels first, this one once");
-    const int64_t nc = pc->L[level - 1].n;
-    NPG_REQUIRE(P->m == n && P->n == nc && R->m == nc && R->n == n, "npg_precond_mg_set_level_dist: P must be %lld x %lld and R its transpose",
-                (long long)n, (long long)nc);
+    if (pc->L[level - 1].dist) {
+        // the level below is distributed too: its transfers come with npg_precond_mg_set_transfer_dist
+        NPG_REQUIRE(!P && !R, "npg_precond_mg_set_level_dist: above a distributed level P and R are set by npg_precond_mg_set_transfer_dist");
+    } else {
+        NPG_REQUIRE(P && R, "npg_precond_mg_set_level_dist: NULL transfer operators");
+        const int64_t nc = pc->L[level - 1].n;
+        NPG_REQUIRE(P->m == n && P->n == nc && R->m == nc && R->n == n, "npg_precond_mg_set_level_dist: P must be %lld x %lld and R its transpose",
+                    (long long)n, (long long)nc);
+    }
     l.A = A; l.G = G; l.D = D; l.Dinv = Dinv; l.S = S; l.P = P; l.R = R;
     l.n = n; l.nu = nu; l.np = np;
     l.hx = hx; l.hu = hu; l.hp = hp;
@@ -521,10 +534,28 @@ NPG_API int npg_precond_mg_set_level_dist(npg_precond *pc, int level, const npg_
         (rc = mg_alloc(pc, &l.dp, G->n)) || (rc = mg_alloc(pc, &l.dp2, G->n)) || (rc = mg_alloc(pc, &l.res, np)) ||
         (rc = mg_alloc(pc, &l.x, A->n)))
         return rc;
-    // the coarse level below receives its right-hand side and iterate buffers from its own setter (it is not the top level)
+    // (a distributed level that is not the finest receives a right-hand side from the level above; its iterate is l.x)
+    if (level + 1 < (int)pc->L.size() && (rc = mg_alloc(pc, &l.b, n))) return rc;
     pc->n = n;
     pc->use_graphs = false;      // host barriers (rehearsal transports) and library collectives sit inside the cycle
     if (pc->mixed && (rc = mg_refresh_fp32(l))) return rc;
+    return NPG_OK;
+}
+
+// Transfers between two DISTRIBUTED levels (`level` and the one below it, both set): P = this rank's rows of the prolongation over
+// the coarser level's [owned | ghosts] columns (hP: the plan on the coarser iterate that fills those ghosts), R = the coarser
+// level's owned rows of the restriction over this level's [owned | ghosts] columns (hR: the plan on this level's residual).
+NPG_API int npg_precond_mg_set_transfer_dist(npg_precond *pc, int level, const npg_csr *P, const npg_csr *R, npg_halo *hP, npg_halo *hR) {
+    NPG_REQUIRE(pc && pc->kind == NPG_PC_MG && level >= 1 && level < (int)pc->L.size(), "npg_precond_mg_set_transfer_dist: bad level");
+    NPG_REQUIRE(P && R && hP && hR, "npg_precond_mg_set_transfer_dist: NULL argument");
+    MgLevel &l = pc->L[level], &lc = pc->L[level - 1];
+    NPG_REQUIRE(l.A && lc.A && l.dist && lc.dist && !l.P, "npg_precond_mg_set_transfer_dist: both levels must be distributed, the transfers set once");
+    NPG_REQUIRE(hP->n_owned == lc.n && P->m == l.n && P->n == lc.n + hP->n_ghost && hR->n_owned == l.n && R->m == lc.n &&
+                    R->n == l.n + hR->n_ghost,
+                "npg_precond_mg_set_transfer_dist: operator shapes do not match the halo plans");
+    l.P = P; l.R = R; l.hP = hP; l.hR = hR;
+    int rc;
+    if ((rc = mg_alloc(pc, &l.xP, P->n)) || (rc = mg_alloc(pc, &l.rR, R->n))) return rc;
     return NPG_OK;
 }
 
@@ -651,22 +682,34 @@ static int mg_cycle(npg_precond *pc, int lev, double *x, const double *b, bool x
     MgLevel &l = pc->L[lev], &lc = pc->L[lev - 1];
     if (pc->nu1 > 0 && (rc = mg_smooth(pc, lev, x, b, pc->nu1, x_is_zero))) return rc;
     const bool still_zero = x_is_zero && pc->nu1 == 0;
-    if (still_zero) {
-        if ((rc = spmv_raw(l.R, b, lc.b, 1.0, 0.0, pc->mixed))) return rc;
-    } else {
+    const double *rfine = b;                    // what is restricted: b itself while x = 0, else the residual
+    if (!still_zero) {
         if (l.hx && (rc = halo_exchange_raw(l.hx, x))) return rc;
         SpmvEpi e{};
         e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l.r; e.f32 = pc->mixed;
         if ((rc = spmv_epi(l.A, x, e))) return rc;
-        if ((rc = spmv_raw(l.R, l.r, lc.b, 1.0, 0.0, pc->mixed))) return rc;
+        rfine = l.r;
     }
+    if (l.hR) {
+        // both levels distributed: the coarser level's OWNED rows of R reach this level's residual at a few rows of other ranks
+        NPG_HIP(hipMemcpyAsync(l.rR, rfine, (size_t)l.n * sizeof(double), hipMemcpyDeviceToDevice, pc->ctx->stream));
+        if ((rc = halo_exchange_raw(l.hR, l.rR))) return rc;
+        rfine = l.rR;
+    }
+    if ((rc = spmv_raw(l.R, rfine, lc.b, 1.0, 0.0, pc->mixed))) return rc;
     // a distributed level above replicated ones: R holds this rank's columns of the restriction, the coarse right-hand side is
     // the sum of the ranks' parts - after it every rank runs the coarse levels redundantly on identical data - and the
     // prolongation back needs no communication (P holds this rank's rows)
     if (l.dist && !lc.dist && (rc = allreduce_big_device(pc->ctx, lc.b, lc.n))) return rc;
     for (int g = 0; g < pc->gamma; ++g)
         if ((rc = mg_cycle(pc, lev - 1, lc.x, lc.b, g == 0))) return rc;
-    if ((rc = spmv_raw(l.P, lc.x, x, 1.0, still_zero ? 0.0 : 1.0, pc->mixed))) return rc;
+    const double *xc = lc.x;
+    if (l.hP) {             // both levels distributed: this rank's rows of P reach coarse entries of other ranks
+        NPG_HIP(hipMemcpyAsync(l.xP, lc.x, (size_t)lc.n * sizeof(double), hipMemcpyDeviceToDevice, pc->ctx->stream));
+        if ((rc = halo_exchange_raw(l.hP, l.xP))) return rc;
+        xc = l.xP;
+    }
+    if ((rc = spmv_raw(l.P, xc, x, 1.0, still_zero ? 0.0 : 1.0, pc->mixed))) return rc;
     return mg_smooth(pc, lev, x, b, pc->nu2, false);
 }
 

@@ -49,23 +49,30 @@ class NodePartition:
     one layer of cells across those surfaces (`distributed.RowPartition` cuts each field's own RCM sequence separately,
     which leaves e.g. all surface nodes with the last rank).  Same interface as RowPartition where partition.py uses it."""
 
-    def __init__(self, fe_data, nranks):
+    def __init__(self, fe_data, nranks, node_owner=None):
+        """node_owner: an ownership given from outside (a coarser multigrid level inherits the owner of the fine node each of
+        its nodes coincides with) instead of the work-balanced cut of this mesh's own RCM sweep"""
         from scipy.sparse.csgraph import reverse_cuthill_mckee
         m, t, d = fe_data.mesh, fe_data.tables, fe_data.dofs
         self.nu, self.np, self.nb, self.nranks = d.nu, d.np, d.nb, int(nranks)
         self.n_full, self.n_surf = d.n_full, d.n_surf
-        order = np.asarray(reverse_cuthill_mckee(sp.csr_matrix(d.adj2), symmetric_mode=True), dtype=np.int64)
-        rowlen = np.diff(fe_data.pattern_A()[0]).astype(np.float64)
-        w = np.zeros(m.nn)
-        for a in range(3):
-            on = t.u_pos[:, a] >= 0
-            w[on] += rowlen[t.u_pos[on, a]]
-        on = t.p_pos >= 0
-        w[:m.nv][on] += rowlen[t.p_pos[on]]
-        cum = np.cumsum(w[order])
-        cuts = np.searchsorted(cum, cum[-1] * np.arange(1, nranks) / nranks, side="left")
-        node_owner = np.empty(m.nn, dtype=np.int32)
-        node_owner[order] = np.searchsorted(cuts, np.arange(m.nn), side="right").astype(np.int32)
+        if node_owner is None:
+            order = np.asarray(reverse_cuthill_mckee(sp.csr_matrix(d.adj2), symmetric_mode=True), dtype=np.int64)
+            rowlen = np.diff(fe_data.pattern_A()[0]).astype(np.float64)
+            w = np.zeros(m.nn)
+            for a in range(3):
+                on = t.u_pos[:, a] >= 0
+                w[on] += rowlen[t.u_pos[on, a]]
+            on = t.p_pos >= 0
+            w[:m.nv][on] += rowlen[t.p_pos[on]]
+            cum = np.cumsum(w[order])
+            cuts = np.searchsorted(cum, cum[-1] * np.arange(1, nranks) / nranks, side="left")
+            node_owner = np.empty(m.nn, dtype=np.int32)
+            node_owner[order] = np.searchsorted(cuts, np.arange(m.nn), side="right").astype(np.int32)
+        else:
+            node_owner = np.ascontiguousarray(node_owner, dtype=np.int32)
+            if node_owner.shape != (m.nn,):
+                raise ValueError("NodePartition: one owner per P2 node")
         self.node_owner = node_owner
         self._inv_owner = np.empty(d.nu + d.np, dtype=np.int32)
         for a in range(3):
@@ -491,7 +498,9 @@ def example_model(arch, mesh_model, dist, dt=1e-3, t_stop=1e9, preconditioner="d
     ts = BDF2(t_start=0.0, t_stop=t_stop, dt=dt)
     if preconditioner == "multigrid":
         hier = [workloads.example_fe_data(m) for m in workloads.bowl_hierarchy_models(mesh_model)]
-        return use_multigrid(partitioned_model(arch, hier[-1], prm, frc, ts, dist, **kw), hier)
+        # two partitioned levels where the hierarchy has a third one to keep replicated (NPG_MG_DIST_LEVELS=1: only the finest)
+        nlev = int(os.environ.get("NPG_MG_DIST_LEVELS", 2 if len(hier) >= 3 else 1))
+        return use_multigrid(partitioned_model(arch, hier[-1], prm, frc, ts, dist, **kw), hier, distributed_levels=nlev)
     fed = workloads.example_fe_data(workloads.bowl_mesh_model(mesh_model) if isinstance(mesh_model, str) else mesh_model)
     return partitioned_model(arch, fed, prm, frc, ts, dist, **kw)
 
@@ -526,12 +535,23 @@ class DistributedMultigridPreconditioner:
     re-assembled on the device with the injected buoyancy's viscosity, as on one GPU)."""
 
     def __init__(self, arch, params, forcings, hierarchy, model, omega=2.5, jacobi_weight=0.7, schur_sweeps=3, nu1=2, nu2=2,
-                 coarse_sweeps=20, cycle="V", coarse_dense=None):
+                 coarse_sweeps=20, cycle="V", coarse_dense=None, distributed_levels=1):
+        """distributed_levels: 1 = the finest level row-partitioned, every coarser level replicated; 2 = the level below it
+        partitioned as well (a coarse node belongs to the rank that owns the fine node it coincides with; its rows are assembled
+        on that rank's cells of the coarse mesh; P / R between the two levels are row blocks with halo plans of their own) -
+        hierarchies of >= 3 levels, static viscosity."""
         import ctypes as C
         from . import multigrid as mgm
         from .inversion import build_A_inversion
         if len(hierarchy) < 2:
             raise ValueError("DistributedMultigridPreconditioner: needs a refinement hierarchy (>= 2 levels)")
+        if distributed_levels not in (1, 2):
+            raise ValueError("distributed_levels: 1 or 2")
+        if distributed_levels == 2 and len(hierarchy) < 3:
+            raise ValueError("two distributed levels need a hierarchy of >= 3 levels (the coarsest stays replicated)")
+        if distributed_levels == 2 and forcings.eddy_param.is_on:
+            raise NotImplementedError("two distributed multigrid levels: the eddy closure's refresh of the second one is not implemented")
+        self.distributed_levels = distributed_levels
         ctx = arch.ctx
         self.ctx, self.arch = ctx, arch
         self.prm, self.frc, self.hierarchy = params, forcings, hierarchy
@@ -543,7 +563,7 @@ class DistributedMultigridPreconditioner:
         # ---- replicated coarse levels: exactly MultigridPreconditioner's set-up --------------------------------------
         prev = None
         self.cA, self.cops = [], []
-        for lev, fed in enumerate(hierarchy[:-1]):
+        for lev, fed in enumerate(hierarchy[:len(hierarchy) - distributed_levels]):
             d = fed.dofs
             A = build_A_inversion(arch, fed, params, forcings.nu, structural=full)
             ops = mgm._LevelOperators(ctx, fed, fed.pattern_A(structural=full)).update(A)
@@ -560,17 +580,87 @@ class DistributedMultigridPreconditioner:
                                                      None if Pd is None else Pd.h, None if Rd is None else Rd.h))
             self.levels.append(d.nu + d.np)
             prev = fed
-        # ---- the distributed finest level ------------------------------------------------------------------------------
+        # ---- the distributed level(s) ----------------------------------------------------------------------------------
         fed, lay = hierarchy[-1], model.layout
         f = lay.inv
-        Gl, Dh, Dinv, Sl = self._fine_operators(model, first=True)
-        Pg = mgm.prolongation(hierarchy[-2], fed)
-        Pl = sp.csr_matrix(Pg[f.owned])
-        ops = [DeviceCSR.from_scipy(ctx, M) for M in (Gl, Dh, sp.csr_matrix(Dinv), Sl, Pl, sp.csr_matrix(Pl.T))]
-        self._fine_ops = ops
+        dist, rank, world = model.dist, model.dist.get_rank(), model.dist.get_world_size()
+        top = len(hierarchy) - 1
+        lv0 = SimpleNamespace(fed=fed, lay=lay, part=model.partition, fe=model.fe, dist=dist, hx=model.inversion.solver.halo, st={})
+        self._lv = [lv0]
+        lv1 = None
+        if distributed_levels == 2:
+            # the level below: ownership inherited through the injection (a coarse node IS a fine node), rows assembled by an
+            # engine over this rank's cells of the coarse mesh - what partitioned_model does for the finest level
+            fed_c = hierarchy[-2]
+            inj = mgm.injection(fed_c.mesh, fed.mesh, False)
+            part_c = NodePartition(fed_c, world, node_owner=model.partition.node_owner[inj])
+            counts = np.bincount(part_c.inv_owner(), minlength=world)
+            if counts.min() == 0:
+                raise ValueError(f"two distributed multigrid levels: a rank owns no row of the second level ({counts.tolist()})")
+            lay_c = RankLayout(fed_c, part_c, rank)
+            fe_c = DeviceFE(ctx, LocalFEData(fed_c, lay_c))
+            fe_c.set_precision(model.fe.precision)
+            fe_c.set_coeff("nu", forcings.nu)
+            fe_c.set_coeff("f", params.f)
+            rp, ci, shp = lay_c.local_pattern(fed_c.pattern_A(structural=full), lay_c.inv, lay_c.inv)
+            A_c = DeviceCSR.from_pattern(ctx, shp[0], shp[1], rp, ci)
+            fe_c.assemble(L.NPG_MAT_A, A_c, scale=params.alpha ** 2 * params.eps ** 2, full_stress=full)
+            hx_c, _ = _make_halos(ctx, dist, rank, lay_c.inv, lay_c.owner_inv)
+            lv1 = SimpleNamespace(fed=fed_c, lay=lay_c, part=part_c, fe=fe_c, dist=dist, hx=hx_c, st={}, A=A_c)
+            self._lv.append(lv1)
+            G1, D1, Dinv1, S1 = self._level_operators(lv1, first=True)
+            fc = lay_c.inv
+            Pg1 = mgm.prolongation(hierarchy[-3], fed_c)
+            Pl1 = sp.csr_matrix(Pg1[fc.owned])
+            ops1 = [DeviceCSR.from_scipy(ctx, M) for M in (G1, D1, sp.csr_matrix(Dinv1), S1, Pl1, sp.csr_matrix(Pl1.T))]
+            lv1.ops = ops1
+            L.check(L.lib().npg_precond_mg_set_level_dist(self.h, top - 1, A_c.h, int(lay_c.n_own_u), ops1[0].h, ops1[1].h, ops1[2].h,
+                                                          ops1[3].h, ops1[4].h, ops1[5].h, hx_c.h, lv1.st["hu"].h, lv1.st["hp"].h))
+            self.levels.append(fed_c.dofs.nu + fed_c.dofs.np)
+        Gl, Dh, Dinv, Sl = self._level_operators(lv0, first=True)
+        self.hx, self.hu, self.hp = lv0.hx, lv0.st["hu"], lv0.st["hp"]
+        self._want, self._gp = lv0.st["want"], lv0.st["gp"]
         A_sol = model.inversion.solver.A
-        L.check(L.lib().npg_precond_mg_set_level_dist(self.h, len(hierarchy) - 1, A_sol.h, int(lay.n_own_u), ops[0].h, ops[1].h,
-                                                      ops[2].h, ops[3].h, ops[4].h, ops[5].h, self.hx.h, self.hu.h, self.hp.h))
+        if lv1 is None:
+            Pg = mgm.prolongation(hierarchy[-2], fed)
+            Pl = sp.csr_matrix(Pg[f.owned])
+            ops = [DeviceCSR.from_scipy(ctx, M) for M in (Gl, Dh, sp.csr_matrix(Dinv), Sl, Pl, sp.csr_matrix(Pl.T))]
+            self._fine_ops = ops
+            L.check(L.lib().npg_precond_mg_set_level_dist(self.h, top, A_sol.h, int(lay.n_own_u), ops[0].h, ops[1].h,
+                                                          ops[2].h, ops[3].h, ops[4].h, ops[5].h, self.hx.h, self.hu.h, self.hp.h))
+        else:
+            ops = [DeviceCSR.from_scipy(ctx, M) for M in (Gl, Dh, sp.csr_matrix(Dinv), Sl)]
+            self._fine_ops = ops
+            L.check(L.lib().npg_precond_mg_set_level_dist(self.h, top, A_sol.h, int(lay.n_own_u), ops[0].h, ops[1].h,
+                                                          ops[2].h, ops[3].h, None, None, self.hx.h, self.hu.h, self.hp.h))
+            # transfers between the two partitioned levels: row blocks with [owned | ghosts] column spaces and plans of their own
+            fc, owner_c, owner_f = lv1.lay.inv, lv1.lay.owner_inv, lay.owner_inv
+            Pg = sp.csr_matrix(mgm.prolongation(lv1.fed, fed))                   # n_fine x n_coarse, both in their device orders
+            Rg = sp.csr_matrix(Pg.T)
+
+            def row_block(M, rows, own_cols, owner_cols):
+                """rows `rows` of M with the columns renumbered [own_cols | ghosts sorted by owner]; (block, ghost list)"""
+                B = sp.csr_matrix(M[rows])
+                used = np.unique(B.indices)
+                gh = _by_owner(used[owner_cols[used] != rank], owner_cols) if len(used) else np.zeros(0, np.int64)
+                lut = np.full(M.shape[1], -1, dtype=np.int64)
+                lut[own_cols] = np.arange(len(own_cols))
+                lut[gh] = len(own_cols) + np.arange(len(gh))
+                lc = lut[B.indices]
+                assert (lc >= 0).all()
+                Q = sp.csr_matrix((B.data, lc, B.indptr), shape=(len(rows), len(own_cols) + len(gh)))
+                Q.sort_indices()
+                return Q, gh
+            P_loc, gP = row_block(Pg, f.owned, fc.owned, owner_c)
+            R_loc, gR = row_block(Rg, fc.owned, f.owned, owner_f)
+            allg = [None] * world
+            dist.all_gather_object(allg, (gP, gR))
+            hP = Halo(ctx, fc.n_own, len(gP), halo_plan(rank, fc.owned, owner_c, [a[0] for a in allg]))
+            hR = Halo(ctx, f.n_own, len(gR), halo_plan(rank, f.owned, owner_f, [a[1] for a in allg]))
+            tr = [DeviceCSR.from_scipy(ctx, P_loc), DeviceCSR.from_scipy(ctx, R_loc)]
+            self._keep += tr + [hP, hR]
+            L.check(L.lib().npg_precond_mg_set_transfer_dist(self.h, top, tr[0].h, tr[1].h, hP.h, hR.h))
+            self.layout_mg2 = dict(rows=int(fc.n_own), ghost_x=int(len(fc.g_sol)), ghost_P=int(len(gP)), ghost_R=int(len(gR)))
         self.levels.append(fed.dofs.nu + fed.dofs.np)
         L.check(L.lib().npg_precond_mg_set_params(self.h, float(omega), float(jacobi_weight), int(schur_sweeps), int(nu1),
                                                   int(nu2), int(coarse_sweeps)))
@@ -586,14 +676,15 @@ class DistributedMultigridPreconditioner:
         self.layout_mg = dict(ghost_u=int(len(self._want)), ghost_p=int(len(self._gp)), S_nnz=int(Sl.nnz))
         self._inj = None
 
-    def _fine_operators(self, model, first):
-        """(G, D, Dinv, S) of the distributed level as host matrices in the level's local layouts, from the rank's rows of the
-        CURRENT inversion matrix (assembled afresh into a plain-CSR copy with whatever viscosity table the engine holds).
-        Collective: the rows of T = Dinv G that belong to a neighbour's ghost velocity DoFs travel between the ranks.  The first
-        call also fixes the layouts - ghost velocity / pressure lists, halo plans - which later calls reuse."""
+    def _level_operators(self, lv, first):
+        """(G, D, Dinv, S) of a distributed level as host matrices in the level's local layouts, from the rank's rows of the
+        level's CURRENT matrix (assembled afresh into a plain-CSR copy with whatever viscosity table the level's engine holds).
+        lv: the level's (fed, lay, part, fe, dist, st).  Collective: the rows of T = Dinv G that belong to a neighbour's ghost
+        velocity DoFs travel between the ranks.  The first call also fixes the layouts - ghost velocity / pressure lists, halo
+        plans (lv.st) - which later calls reuse."""
         from . import multigrid as mgm
-        ctx, params, hierarchy = self.ctx, self.prm, self.hierarchy
-        fed, lay, part, dist = hierarchy[-1], model.layout, model.partition, model.dist
+        ctx, params = self.ctx, self.prm
+        fed, lay, part, dist = lv.fed, lv.lay, lv.part, lv.dist
         rank, world = dist.get_rank(), dist.get_world_size()
         full = self._full
         f = lay.inv
@@ -602,7 +693,7 @@ class DistributedMultigridPreconditioner:
         a2e2 = params.alpha ** 2 * params.eps ** 2
         rp, ci, shp = lay.local_pattern(fed.pattern_A(structural=full), f, f)
         Ap = DeviceCSR.from_pattern(ctx, shp[0], shp[1], rp, ci)             # a plain-CSR copy of the rank's rows for the host
-        model.fe.assemble(L.NPG_MAT_A, Ap, scale=a2e2, full_stress=full)
+        lv.fe.assemble(L.NPG_MAT_A, Ap, scale=a2e2, full_stress=full)
         Ah = Ap.to_scipy_csr()
         del Ap
         g = f.globals()[:n_sol]                                              # global id of every local column
@@ -664,23 +755,22 @@ class DistributedMultigridPreconditioner:
             lut_p = np.full(fed.dofs.nu + fed.dofs.np, -1, dtype=np.int64)
             lut_p[own_p] = np.arange(len(own_p))
             lut_p[gp] = len(own_p) + np.arange(len(gp))
-            self._lut_p, self._npl, self._want, self._gp = lut_p, len(own_p) + len(gp), want, gp
+            lv.st.update(lut_p=lut_p, npl=len(own_p) + len(gp), want=want, gp=gp)
             # halo plans of the velocity-part and pressure-part vectors
             allg = [None] * world
             dist.all_gather_object(allg, (want, gp))
             own_u = f.owned[:nu_o]
             plan_u = halo_plan(rank, own_u, lay.owner_inv, [a[0] for a in allg])
             plan_p = halo_plan(rank, own_p, lay.owner_inv, [a[1] for a in allg])
-            self.hu = Halo(ctx, nu_o, len(want), plan_u)
-            self.hp = Halo(ctx, len(own_p), len(gp), plan_p)
-            self.hx = model.inversion.solver.halo
+            lv.st["hu"] = Halo(ctx, nu_o, len(want), plan_u)
+            lv.st["hp"] = Halo(ctx, len(own_p), len(gp), plan_p)
 
         def to_p_layout(M_global_cols, pattern=None):
             M = sp.csr_matrix(M_global_cols)
-            lc = self._lut_p[M.indices]
+            lc = lv.st["lut_p"][M.indices]
             if not (lc >= 0).all():
                 raise RuntimeError("distributed multigrid: a re-assembled operator reaches a pressure column outside the level's layout")
-            Q = sp.csr_matrix((M.data, lc, M.indptr), shape=(M.shape[0], self._npl))
+            Q = sp.csr_matrix((M.data, lc, M.indptr), shape=(M.shape[0], lv.st["npl"]))
             Q.sort_indices()
             return Q
         return to_p_layout(G0g), Dh, Dinv, to_p_layout(Sg)
@@ -694,7 +784,7 @@ class DistributedMultigridPreconditioner:
         if model is None:
             raise ValueError("DistributedMultigridPreconditioner.refresh needs the model (its engine holds the viscosity table)")
         top = len(self.hierarchy) - 1
-        Gl, Dh, Dinv, Sl = self._fine_operators(model, first=False)
+        Gl, Dh, Dinv, Sl = self._level_operators(self._lv[0], first=False)
         new = [DeviceCSR.from_scipy(self.ctx, M) for M in (Gl, Dh, sp.csr_matrix(Dinv), Sl)]
         L.check(L.lib().npg_precond_mg_update_level(self.h, top, A.h, new[0].h, new[1].h, new[2].h, new[3].h))
         self._fine_ops[:4] = new

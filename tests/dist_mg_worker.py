@@ -27,10 +27,11 @@ def main():
         partition.use_multigrid(m, hier, omega=2.0)
         assert m.verify_transport()
     else:
+        nlev = int(sys.argv[4]) if len(sys.argv) > 4 else 1              # distributed multigrid levels (1 or 2)
         hier = [workloads.example_fe_data(m) for m in workloads.bowl_hierarchy_models(label)]
         prm, frc = workloads.example_parameters()
         m = partition.partitioned_model(arch, hier[-1], prm, frc, npg.BDF2(t_start=0.0, t_stop=1e9, dt=1e-3), dist)
-        partition.use_multigrid(m, hier)
+        partition.use_multigrid(m, hier, distributed_levels=nlev)
         assert m.verify_transport()
     npg.invert(m)
     npg.run(m, n_steps=nsteps)
@@ -39,6 +40,7 @@ def main():
     np.savez(f"{out}.rank{rank}.npz", u=u, p=p, b=b, its=[s[1]["niter"] for s in m.stats],
              solved=[bool(s[1]["solved"]) and bool(s[0]["solved"]) for s in m.stats], rn=[s[1]["rnorm"] for s in m.stats],
              mg=np.array([m.inversion.solver.P.layout_mg[k] for k in ("ghost_u", "ghost_p", "S_nnz")]),
+             mg2=np.array([getattr(m.inversion.solver.P, "layout_mg2", {}).get(k, 0) for k in ("rows", "ghost_x", "ghost_P", "ghost_R")]),
              precond=repr(m.inversion.solver.P))
     dist.barrier()
     dist.destroy_process_group()

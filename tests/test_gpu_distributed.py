@@ -164,6 +164,38 @@ def test_distributed_multigrid_rehearsal(world, tmp_path):
     assert rel(z["b"], ref.state.b) < 1e-6 and rel(z["u"], ref.state.u) < 2e-3 and rel(z["p"], ref.state.p) < 2e-3
 
 
+def test_two_distributed_multigrid_levels(tmp_path):
+    """Three-level hierarchy (bowl3D h = 0.1 -> 0.05 -> 0.025, 1.02 M unknowns) on 3 ranks with the TWO finest levels
+    row-partitioned (partition.DistributedMultigridPreconditioner(distributed_levels=2): the second level's ownership inherited
+    through the injection, its rows assembled on the rank's coarse cells, prolongation and restriction between the two levels as
+    row blocks with halo plans of their own) and only the coarsest one replicated: the same outer iteration counts, step by step,
+    as the one-GPU multigrid model of the same hierarchy, the same trajectory to the solver tolerance."""
+    arch = npg.GPU()
+    label, nsteps, world = "bowl3D_h0.025", 3, 3
+    ref = workloads.example_model(arch, label, preconditioner="multigrid")
+    npg.invert(ref)
+    npg.run(ref, n_steps=nsteps)
+    ref_its = [s[1]["niter"] for s in ref.stats]
+    out = str(tmp_path / "dmg2")
+    env = dict(os.environ, NPG_COMM_TRANSPORT="peer", NPG_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
+               NPG_PEER_TIMEOUT_S="90")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_mg_worker.py"), out, str(nsteps), label, "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ranks = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
+    for z in ranks[1:]:
+        assert np.array_equal(z["u"], ranks[0]["u"]) and np.array_equal(z["its"], ranks[0]["its"])
+    z = ranks[0]
+    assert z["solved"].all()
+    # every rank holds a share of the SECOND level too (rows, ghosts of its iterate, of P's and R's inputs)
+    for zz in ranks:
+        assert zz["mg2"][0] > 0.2 * 134866 / world and zz["mg2"][2] > 0 and zz["mg2"][3] > 0
+    assert sum(int(zz["mg2"][0]) for zz in ranks) == 134866
+    assert list(z["its"]) == ref_its, (list(z["its"]), ref_its)
+    assert rel(z["b"], ref.state.b) < 1e-6 and rel(z["u"], ref.state.u) < 2e-3 and rel(z["p"], ref.state.p) < 2e-3
+
+
 def test_distributed_multigrid_follows_the_eddy_closure(tmp_path):
     """BASELINE configs[4] with converged inversions on 3 ranks: the distributed multigrid (finest level partitioned, coarse
     level replicated) behind flexible GMRES, both closures on.  At step 10 the eddy closure re-assembles A in the full-stress
