@@ -156,6 +156,9 @@ int npg_csr_spmv_bytes(const npg_csr *A, int64_t *matrix_bytes);
  * block rows), *matrix_bytes = what one product streams from HBM in that form (records with 2-byte indices, window lists,
  * offsets, descriptors, and the coupling records / CSR entries of the rows behind the block rows). */
 int npg_csr_window_info(const npg_csr *A, int64_t *tiles, int64_t *block_tiles, int64_t *distinct, int64_t *matrix_bytes);
+/* lanes per row in the tiled SpMV's segmented sums (4, 8, 16 or 32; 0 returns to the rule of thumb from the mean row length that
+ * every matrix starts with).  A tuning knob: results change only in the order of a row's partial sums. */
+int npg_csr_set_lanes(npg_csr *A, int lanes);
 /* y = A fl32(x): the product of the Krylov kernels' gather-layout instance as a call of its own - x is copied, rounded to fp32,
  * into the gather layout (a node's components padded to 16 bytes) and multiplied in fp64 (synchronous).  windowed != 0: on the
  * windowed tile set (an error without one), 0: on the ordinary tiles.  reps > 1 repeats the product (timing).  Only for matrices
@@ -173,6 +176,8 @@ int npg_csr_gather_values(npg_csr *dst, const npg_csr *src, const npg_index *map
  * are an error).  With npg_csr_gather_values for G = A[u, p] and D = A[p, u] a re-assembled A (eddy closure) refreshes a
  * level's smoother without leaving the device. */
 int npg_csr_node_block_inverse(npg_csr *Dinv, const npg_csr *A, int64_t n_full, int64_t n_surf);
+/* C = A B on C's FIXED pattern (plain CSR; an error if a product falls outside it) */
+int npg_csr_product(npg_csr *C, const npg_csr *A, const npg_csr *B);
 int npg_csr_triple_product(npg_csr *S, const npg_csr *D, const npg_csr *Dinv, const npg_csr *G);
 /* d[i] = 1 / A[i,i]   -- `Diagonal(1 ./ diag(A))` (src/evolution.jl:149,167; src/model.jl:256) */
 int npg_csr_inv_diag(const npg_csr *A, npg_vec *d);
@@ -262,6 +267,10 @@ int npg_precond_mg_set_level(npg_precond *pc, int level, const npg_csr *A, int64
                              const npg_csr *Dinv, const npg_csr *S, const npg_csr *P, const npg_csr *R);
 /* replace the operators of a level by re-assembled ones of the same shapes (the eddy closure's refresh of A,
  * src/model.jl:160-170); the previous handles are no longer referenced afterwards */
+/* Gh = Dinv G (same shape as G; borrowed, values kept current by the caller: npg_csr_product after every change of Dinv / G).
+ * With it a smoothing step applies Dinv once instead of twice: x_u += Dinv (r_u - G dp) / w is formed as t / w (in the kernel that
+ * forms t = Dinv r_u) minus (Dinv G) dp / w.  NULL returns to the two-product form. */
+int npg_precond_mg_set_scaled_gradient(npg_precond *pc, int level, const npg_csr *Gh);
 int npg_precond_mg_update_level(npg_precond *pc, int level, const npg_csr *A, const npg_csr *G, const npg_csr *D,
                                 const npg_csr *Dinv, const npg_csr *S);
 /* omega: scaling of the node-block diagonal in the Braess-Sarazin smoother (> largest eigenvalue of Dinv F; default 2.5),
@@ -285,7 +294,8 @@ int npg_precond_dense_set(npg_precond *pc, const npg_csr *A, int fp32_storage);
 /* fp32_storage != 0 keeps the inverse rounded to fp32 (half the bytes per application; products still accumulate in fp64):
  * one application then carries ~1e-7 relative error and flexible GMRES takes 2-3 iterations at tight tolerances.
  * multigrid: solve the coarsest level with its dense inverse instead of smoothing steps; on = 1: fp64 storage, on = 2: fp32
- * (a coarse-grid correction inside a preconditioner does not need more), on = 0: back to smoothing steps */
+ * (a coarse-grid correction inside a preconditioner does not need more), on = 3: fp16 storage, every column divided by its
+ * largest magnitude (a quarter of the bytes; products and chunk sums in fp32), on = 0: back to smoothing steps */
 int npg_precond_mg_set_coarse_dense(npg_precond *pc, int on);
 /* z = M^-1 r (one application: one V-cycle / one round of inner CG solves) */
 int npg_precond_apply(npg_precond *pc, const npg_vec *r, npg_vec *z);

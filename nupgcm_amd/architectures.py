@@ -366,6 +366,11 @@ class DeviceCSR:
         m, n = self.shape
         return mb.value + 8 * n + 8 * m
 
+    def set_lanes(self, lanes):
+        """lanes per row in the tiled SpMV's segmented sums: 4, 8, 16, 32 (0: the default rule) - npg_csr_set_lanes"""
+        L.check(L.lib().npg_csr_set_lanes(self.h, int(lanes)))
+        return self
+
     def window_info(self):
         """the windowed tile set of a node-blocked matrix (csrc/spmv_window.h): dict(tiles, block_tiles, distinct, bytes) -
         bytes = what one product of the Krylov kernels' gather-layout instance streams from HBM (matrix + x + y); tiles = 0

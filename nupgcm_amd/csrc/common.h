@@ -99,7 +99,9 @@ struct npg_csr {
     int32_t ntiles = 0;
     int32_t ntiles_interior = 0; // row block of a distributed matrix (n > m: columns [owned | ghosts]): the first
                                  // ntiles_interior descriptors are tiles without ghost columns (= ntiles otherwise)
-    int32_t lanes = 16;          // lanes per row chosen from the mean row length
+    int32_t lanes = 16;          // lanes per row chosen from the mean row length (lanes_default) or set by npg_csr_set_lanes
+    int32_t lanes_default = 16;
+    bool lanes_set = false;
     std::vector<int64_t> h_rowptr;
     // node-block part (npg_csr_block_nodes, spmv_device.h): the rows of the first nfull (x, y, z) nodes and of the nsurf
     // (x, y) nodes after them keep only their non-block entries in rowptr/col/val; `nnz` stays the LOGICAL entry count of
@@ -244,7 +246,7 @@ NPG_SHARED CsrDev csr_view(const npg_csr *A);
 struct WinDev;
 WinDev win_view(const npg_csr *A);
 // epilogue of the tiled SpMV kernel: y = alpha (A x) + beta c   [c may be y itself; not read when beta == 0]
-//                           and, if z:  z = zc zin + w dg .* y  [zin may be null]
+//                           and, if z:  z = zc zin + w dg .* y  [zin may be null; dg null: ones]
 struct SpmvEpi {
     double alpha = 1.0, beta = 0.0;
     const double *c = nullptr;

@@ -71,8 +71,9 @@ int build_tiles(npg_csr *A) {
     // measured on bowl3D h = 0.02 (42 slots per row with node blocks) 8 lanes beat 16 by 2-3 % and 4 by 1 %
     const int64_t nrec = A->nnode() ? A->h_prow[A->nnode()] : 0;
     const double mean = m > 0 ? (double)(A->rnnz + 3 * nrec + A->ndrec + 3 * A->ngrec) / (double)m : 0.0;
-    A->lanes = mean <= 12 ? 4 : mean <= 64 ? 8 : mean <= 256 ? 16 : 32;
-    if (getenv("NPG_SPMV_LANES")) A->lanes = atoi(getenv("NPG_SPMV_LANES"));      // tuning override: 4, 8, 16 or 32
+    A->lanes_default = mean <= 12 ? 4 : mean <= 64 ? 8 : mean <= 256 ? 16 : 32;
+    if (getenv("NPG_SPMV_LANES")) A->lanes_default = atoi(getenv("NPG_SPMV_LANES"));      // tuning override: 4, 8, 16 or 32
+    if (!A->lanes_set) A->lanes = A->lanes_default;
     const int64_t *rp = A->h_rowptr.data();
     const int64_t nf3 = 3 * (int64_t)A->nfull, nbr = A->block_rows();
     auto node = [&](int64_t r) { return r < nf3 ? r / 3 : A->nfull + (r - nf3) / 2; };
@@ -437,7 +438,7 @@ __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv(CsrDev A, const TileDe
             if (e.beta != 0.0) v += e.beta * e.c[row];
             e.y[row] = v;
             if (e.z) {                                   // second output: z = zc zin + w dg .* y  (smoother relaxations, mg.hip)
-                double t = e.w * e.dg[row] * v;
+                double t = e.w * (e.dg ? e.dg[row] : 1.0) * v;
                 if (e.zin) t += e.zc * e.zin[row];
                 e.z[row] = t;
             }
@@ -1445,6 +1446,33 @@ __global__ void k_triple_product(const int64_t *__restrict__ drp, const int32_t 
     }
 }
 
+// C = A B into C's fixed pattern (one thread per row; products outside the pattern are counted in *missing)
+__global__ void k_fixed_product(const int64_t *__restrict__ arp, const int32_t *__restrict__ acol, const double *__restrict__ aval,
+                                const int64_t *__restrict__ brp, const int32_t *__restrict__ bcol, const double *__restrict__ bval,
+                                int64_t m, const int64_t *__restrict__ crp, const int32_t *__restrict__ ccol,
+                                double *__restrict__ cval, int *missing) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s0 = crp[i], s1 = crp[i + 1];
+        for (int64_t k = s0; k < s1; ++k) cval[k] = 0.0;
+        for (int64_t ka = arp[i]; ka < arp[i + 1]; ++ka) {
+            const int32_t a = acol[ka];
+            const double w = aval[ka];
+            for (int64_t kb = brp[a]; kb < brp[a + 1]; ++kb) {
+                const int32_t j = bcol[kb];
+                int64_t lo = s0, hi = s1 - 1, slot = -1;
+                while (lo <= hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    const int32_t v = ccol[mid];
+                    if (v == j) { slot = mid; break; }
+                    if (v < j) lo = mid + 1; else hi = mid - 1;
+                }
+                if (slot >= 0) cval[slot] += w * bval[kb];
+                else atomicAdd(missing, 1);
+            }
+        }
+    }
+}
+
 struct npg_index {
     npg_ctx *ctx = nullptr;
     int64_t n = 0, bound = 0;
@@ -1522,6 +1550,24 @@ NPG_API int npg_csr_triple_product(npg_csr *S, const npg_csr *D, const npg_csr *
     NPG_HIP(hipStreamSynchronize(ctx->stream));
     NPG_REQUIRE(miss == 0, "npg_csr_triple_product: %d products fall outside S's pattern", miss);
     return NPG_OK;
+}
+
+NPG_API int npg_csr_product(npg_csr *Cm, const npg_csr *A, const npg_csr *B) {
+    NPG_REQUIRE(Cm && A && B, "npg_csr_product: NULL argument");
+    NPG_REQUIRE(Cm->nnode() == 0 && A->nnode() == 0 && B->nnode() == 0, "npg_csr_product: node-blocked matrices are not supported");
+    NPG_REQUIRE(A->n == B->m && Cm->m == A->m && Cm->n == B->n, "npg_csr_product: shapes do not chain");
+    npg_ctx *ctx = Cm->ctx;
+    int *missing = reinterpret_cast<int *>(ctx->d_scratch);
+    NPG_HIP(hipMemsetAsync(missing, 0, sizeof(int), ctx->stream));
+    const int grid = (int)std::min<int64_t>(4096, (Cm->m + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_fixed_product, dim3(std::max(grid, 1)), dim3(kBlock), 0, ctx->stream, A->rowptr, A->col, A->val, B->rowptr,
+                       B->col, B->val, Cm->m, Cm->rowptr, Cm->col, Cm->val, missing);
+    NPG_HIP(hipGetLastError());
+    int miss = 0;
+    NPG_HIP(hipMemcpyAsync(&miss, missing, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    NPG_HIP(hipStreamSynchronize(ctx->stream));
+    NPG_REQUIRE(miss == 0, "npg_csr_product: %d products fall outside the result's pattern", miss);
+    return csr_repack(Cm);
 }
 
 NPG_API int npg_csr_inv_diag(const npg_csr *A, npg_vec *d) {
@@ -1760,6 +1806,17 @@ NPG_API int npg_spmv_gather32(const npg_csr *A, const npg_vec *x, npg_vec *y, in
     hipFree(buf);
     NPG_HIP(e);
     NPG_HIP(e2);
+    return NPG_OK;
+}
+
+NPG_API int npg_csr_set_lanes(npg_csr *A, int lanes) {
+    NPG_REQUIRE(A, "npg_csr_set_lanes: NULL handle");
+    NPG_REQUIRE(lanes == 0 || lanes == 4 || lanes == 8 || lanes == 16 || lanes == 32, "npg_csr_set_lanes: %d lanes (4, 8, 16, 32 or 0)", lanes);
+    npg_csr *S = const_cast<npg_csr *>(spmv_form(A));
+    NPG_HIP(hipStreamSynchronize(A->ctx->stream));
+    S->lanes_set = lanes != 0;
+    S->lanes = lanes ? lanes : S->lanes_default;
+    S->gen++;                    // captured graphs that launch this matrix's products bake the instance in
     return NPG_OK;
 }
 

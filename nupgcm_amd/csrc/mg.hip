@@ -191,6 +191,87 @@ __global__ void __launch_bounds__(kBlock) k_dense_gemv_part4(const float *__rest
     if (i + 3 < n) out[3] = a3;
 }
 
+// fp16 inverse, every column scaled by its largest magnitude (cs[j]; the scale is folded into x when the chunk of x is staged):
+// thread = EIGHT adjacent rows (one 16-byte load per column), the same four-columns-per-trip pipeline; products and the sums
+// over a chunk's 512 columns in fp32 (the stored numbers carry 11 bits), the sum over the chunks in fp64 (k_dense_gemv_sum)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f16x8 nt_load8h(const _Float16 *p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    return __builtin_bit_cast(f16x8, v);
+}
+__global__ void __launch_bounds__(kBlock) k_dense_gemv_part8h(const _Float16 *__restrict__ M, int64_t n, int64_t ld,
+                                                              const double *__restrict__ cs, const double *__restrict__ x,
+                                                              double *__restrict__ part) {
+    __shared__ float xs[kGemvChunkCols];
+    const int64_t j0 = (int64_t)blockIdx.y * kGemvChunkCols;
+    const int nj = (int)min((int64_t)kGemvChunkCols, n - j0);
+    for (int j = threadIdx.x; j < nj; j += kBlock) xs[j] = (float)(x[j0 + j] * cs[j0 + j]);
+    __syncthreads();
+    const int64_t i = 8 * (blockIdx.x * (int64_t)kBlock + threadIdx.x);
+    if (i >= n) return;
+    const _Float16 *__restrict__ Mi = M + i + j0 * ld;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    f16x8 v[U], vn[U];
+    const int ntrip = nj / U;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (ntrip > 0) v[u] = nt_load8h(Mi + (int64_t)u * ld);
+    for (int tr = 0; tr < ntrip; ++tr) {
+        const int j = tr * U;
+        if (tr + 1 < ntrip) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) vn[u] = nt_load8h(Mi + (int64_t)(j + U + u) * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float xv = xs[j + u];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = __builtin_fmaf((float)v[u][k], xv, a[k]);
+        }
+        if (tr + 1 < ntrip) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = vn[u];
+        }
+    }
+    for (int j = ntrip * U; j < nj; ++j) {
+        const f16x8 f = *reinterpret_cast<const f16x8 *>(Mi + (int64_t)j * ld);
+        const float xv = xs[j];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = __builtin_fmaf((float)f[k], xv, a[k]);
+    }
+    double *out = part + (int64_t)blockIdx.y * n + i;          // (rows past n are padding of M: computed, not stored)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (i + k < n) out[k] = (double)a[k];
+}
+
+// cs[j] = max_i |M[i, j]| of a column-major fp64 n x n array (1 for an all-zero column): one workgroup per column
+__global__ void __launch_bounds__(kBlock) k_col_absmax(const double *__restrict__ M, int64_t n, double *__restrict__ cs) {
+    __shared__ double sh[kBlock];
+    for (int64_t j = blockIdx.x; j < n; j += gridDim.x) {
+        double m = 0.0;
+        for (int64_t i = threadIdx.x; i < n; i += kBlock) m = fmax(m, fabs(M[j * n + i]));
+        sh[threadIdx.x] = m;
+        __syncthreads();
+        for (int s = kBlock / 2; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) cs[j] = sh[0] > 0.0 ? sh[0] : 1.0;
+        __syncthreads();
+    }
+}
+
+// fp64 column-major n x n -> fp16 with leading dimension ld >= n, column j divided by cs[j] (pad rows zeroed)
+__global__ void k_to_half_ld(const double *__restrict__ src, const double *__restrict__ cs, _Float16 *__restrict__ dst, int64_t n,
+                             int64_t ld) {
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < ld * n; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = k / ld, i = k - j * ld;
+        dst[k] = i < n ? (_Float16)(float)(src[j * n + i] / cs[j]) : (_Float16)0.f;
+    }
+}
+
 // fp64 column-major n x n -> fp32 with leading dimension ld >= n (pad rows zeroed)
 __global__ void k_to_float_ld(const double *__restrict__ src, float *__restrict__ dst, int64_t n, int64_t ld) {
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < ld * n; k += (int64_t)gridDim.x * blockDim.x) {
@@ -233,6 +314,7 @@ using namespace npg;
 
 struct MgLevel {
     const npg_csr *A = nullptr, *G = nullptr, *D = nullptr, *Dinv = nullptr, *S = nullptr, *P = nullptr, *R = nullptr;
+    const npg_csr *Gh = nullptr;                     // Dinv G (npg_precond_mg_set_scaled_gradient): one Dinv product less per step
     int64_t n = 0, nu = 0, np = 0;
     double *sdinv = nullptr;                         // 1 / diag(S)
     double *r = nullptr, *t = nullptr, *rhs = nullptr, *dp = nullptr, *dp2 = nullptr, *res = nullptr, *x = nullptr,
@@ -264,6 +346,8 @@ struct DenseInv {
     double *M = nullptr;       // A^-1, column-major (fp64 storage) ...
     float *Mf = nullptr;       // ... or rounded to fp32 (half the bytes per application; a preconditioner may be inexact),
     int64_t ldf = 0;           //     leading dimension ldf = n rounded up to 4 (16-byte aligned columns)
+    _Float16 *Mh = nullptr;    // ... or to fp16, column j divided by cs[j] = its largest magnitude (a quarter of the bytes),
+    double *cs = nullptr;      //     leading dimension ldf = n rounded up to 8
     double *part = nullptr;    // [nsplit][n] partial products
     int nsplit = 0;
 };
@@ -271,6 +355,8 @@ struct DenseInv {
 static void dense_free(DenseInv &d) {
     if (d.M) hipFree(d.M);
     if (d.Mf) hipFree(d.Mf);
+    if (d.Mh) hipFree(d.Mh);
+    if (d.cs) hipFree(d.cs);
     if (d.part) hipFree(d.part);
     d = DenseInv{};
 }
@@ -352,7 +438,10 @@ static int dense_apply(npg_precond *pc, const double *r, double *z, double a, do
     const DenseInv &d = pc->dense;
     hipStream_t st = pc->ctx->stream;
     const int gx = (int)((d.n + kBlock - 1) / kBlock);
-    if (d.Mf)
+    if (d.Mh)
+        hipLaunchKernelGGL(k_dense_gemv_part8h, dim3((unsigned)((d.n + 8 * kBlock - 1) / (8 * kBlock)), d.nsplit), dim3(kBlock), 0, st,
+                           (const _Float16 *)d.Mh, d.n, d.ldf, (const double *)d.cs, r, d.part);
+    else if (d.Mf)
         hipLaunchKernelGGL(k_dense_gemv_part4, dim3((unsigned)((d.n + 4 * kBlock - 1) / (4 * kBlock)), d.nsplit), dim3(kBlock), 0, st,
                            (const float *)d.Mf, d.n, d.ldf, r, d.part);
     else
@@ -364,7 +453,7 @@ static int dense_apply(npg_precond *pc, const double *r, double *z, double a, do
 
 // A^-1 of a plain-CSR matrix as a dense fp64 array in HBM: densify, LU with partial pivoting and inversion by rocSOLVER
 // (set-up; n^2 doubles - 2 GB at 16 k unknowns, 8 GB at 31 k), applied per solve by the hand-written GEMV above
-static int dense_build(npg_precond *pc, const npg_csr *A, bool fp32) {
+static int dense_build(npg_precond *pc, const npg_csr *A, bool fp32, bool fp16 = false) {
     NPG_REQUIRE(A && A->m == A->n && A->nnode() == 0, "dense inverse: a square plain-CSR matrix is required");
     const int64_t n = A->m;
     NPG_REQUIRE(n > 0 && n <= 65536, "dense inverse: %lld unknowns (limit 65 536: n^2 doubles must fit in HBM with room to spare)",
@@ -407,7 +496,17 @@ static int dense_build(npg_precond *pc, const npg_csr *A, bool fp32) {
     NPG_REQUIRE(s1 == rocblas_status_success && i1 == 0 && s2 == rocblas_status_success && i2 == 0,
                 "dense inverse: rocSOLVER getrf/getri failed (status %d/%d, info %d/%d: the matrix is singular to working "
                 "precision, or out of memory)", (int)s1, (int)s2, (int)i1, (int)i2);
-    if (fp32) {
+    if (fp16) {
+        d.ldf = (n + 7) / 8 * 8;
+        NPG_HIP(hipMalloc((void **)&d.cs, (size_t)n * sizeof(double)));
+        NPG_HIP(hipMalloc((void **)&d.Mh, (size_t)d.ldf * n * sizeof(_Float16)));
+        hipLaunchKernelGGL(k_col_absmax, dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(kBlock), 0, st, d.M, n, d.cs);
+        hipLaunchKernelGGL(k_to_half_ld, dim3(4096), dim3(kBlock), 0, st, d.M, d.cs, d.Mh, n, d.ldf);
+        NPG_HIP(hipGetLastError());
+        NPG_HIP(hipStreamSynchronize(st));
+        NPG_HIP(hipFree(d.M));
+        d.M = nullptr;
+    } else if (fp32) {
         d.ldf = (n + 3) / 4 * 4;
         NPG_HIP(hipMalloc((void **)&d.Mf, (size_t)d.ldf * n * sizeof(float)));
         hipLaunchKernelGGL(k_to_float_ld, dim3(4096), dim3(kBlock), 0, st, d.M, d.Mf, n, d.ldf);
@@ -437,13 +536,14 @@ NPG_API int npg_precond_mg_set_coarse_dense(npg_precond *pc, int on) {
         dense_free(pc->dense);
         return NPG_OK;
     }
-    return dense_build(pc, pc->L[0].A, on == 2);
+    NPG_REQUIRE(on >= 1 && on <= 3, "npg_precond_mg_set_coarse_dense: mode %d (0 off, 1 fp64, 2 fp32, 3 scaled fp16 storage)", on);
+    return dense_build(pc, pc->L[0].A, on == 2, on == 3);
 }
 
 // fp32 copies of one level's operators (mixed mode)
 static int mg_refresh_fp32(const MgLevel &l) {
     int rc;
-    for (const npg_csr *M : {l.A, l.G, l.D, l.Dinv, l.S, l.P, l.R})
+    for (const npg_csr *M : {l.A, l.G, l.D, l.Dinv, l.S, l.P, l.R, l.Gh})
         if (M && (rc = csr_refresh_fp32(M))) return rc;
     return NPG_OK;
 }
@@ -560,6 +660,19 @@ NPG_API int npg_precond_mg_set_transfer_dist(npg_precond *pc, int level, const n
 }
 
 // Swap in re-assembled operators of one level (same shapes): what the eddy closure's A refresh needs (src/model.jl:160-170)
+NPG_API int npg_precond_mg_set_scaled_gradient(npg_precond *pc, int level, const npg_csr *Gh) {
+    NPG_REQUIRE(pc && pc->kind == NPG_PC_MG && level >= 0 && level < (int)pc->L.size() && pc->L[level].A,
+                "npg_precond_mg_set_scaled_gradient: the level is not set");
+    MgLevel &l = pc->L[level];
+    NPG_REQUIRE(!Gh || (Gh->m == l.G->m && Gh->n == l.G->n), "npg_precond_mg_set_scaled_gradient: Dinv G must have the shape of G (%lld x %lld)",
+                (long long)l.G->m, (long long)l.G->n);
+    NPG_HIP(hipStreamSynchronize(pc->ctx->stream));
+    drop_graphs(pc);
+    l.Gh = Gh;
+    if (Gh && pc->mixed) return csr_refresh_fp32(Gh);
+    return NPG_OK;
+}
+
 NPG_API int npg_precond_mg_update_level(npg_precond *pc, int level, const npg_csr *A, const npg_csr *G, const npg_csr *D,
                                         const npg_csr *Dinv, const npg_csr *S) {
     NPG_REQUIRE(pc && pc->kind == NPG_PC_MG, "npg_precond_mg_update_level: not a multigrid preconditioner");
@@ -619,7 +732,7 @@ NPG_API int npg_precond_mg_set_cycle(npg_precond *pc, int gamma) {
     return NPG_OK;
 }
 
-// nsteps Braess-Sarazin steps on level l for A x = b.  Eight launches per step: the vector updates ride in the epilogues of
+// nsteps Braess-Sarazin steps on level l for A x = b.  Eight launches per step (seven with the scaled gradient): the vector updates ride in the epilogues of
 // the SpMV kernels (SpmvEpi) - on the coarse levels, where every kernel is latency-bound, the launch count is the cost.
 static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int nsteps, bool x_is_zero) {
     MgLevel &l = pc->L[lev];
@@ -637,7 +750,13 @@ static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int n
             e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l.r; e.f32 = pc->mixed;
             if ((rc = spmv_epi(l.A, x, e))) return rc;
         }
-        if ((rc = spmv_raw(l.Dinv, r, l.t, 1.0, 0.0, pc->mixed))) return rc;         // t = Dh^-1 r_u
+        if (l.Gh) {
+            // x_u += Dh^-1 (r_u - G dp) / w  =  t / w - (Dh^-1 G) dp / w: the first part rides in the kernel that forms t
+            SpmvEpi e{};                                                             // t = Dh^-1 r_u ; x_u (+)= t / w
+            e.alpha = 1.0; e.beta = 0.0; e.y = l.t; e.f32 = pc->mixed;
+            e.w = 1.0 / pc->omega; e.zin = zero ? nullptr : x; e.zc = 1.0; e.z = x;
+            if ((rc = spmv_epi(l.Dinv, r, e))) return rc;
+        } else if ((rc = spmv_raw(l.Dinv, r, l.t, 1.0, 0.0, pc->mixed))) return rc;  // t = Dh^-1 r_u
         double *dp = l.dp, *dq = l.dp2;
         if (l.hu && (rc = halo_exchange_raw(l.hu, l.t))) return rc;
         {
@@ -655,12 +774,14 @@ static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int n
             std::swap(dp, dq);
         }
         if (l.hp && (rc = halo_exchange_raw(l.hp, dp))) return rc;
-        {
+        if (l.Gh) {
+            if ((rc = spmv_raw(l.Gh, dp, x, -1.0 / pc->omega, 1.0, pc->mixed))) return rc;   // x_u -= (Dh^-1 G) dp / w
+        } else {
             SpmvEpi e{};                                                             // t = r_u - G dp   (t is free again)
             e.alpha = -1.0; e.beta = 1.0; e.c = r; e.y = l.t; e.f32 = pc->mixed;
             if ((rc = spmv_epi(l.G, dp, e))) return rc;
+            if ((rc = spmv_raw(l.Dinv, l.t, x, 1.0 / pc->omega, zero ? 0.0 : 1.0, pc->mixed))) return rc;   // x_u += Dh^-1 t / w
         }
-        if ((rc = spmv_raw(l.Dinv, l.t, x, 1.0 / pc->omega, zero ? 0.0 : 1.0, pc->mixed))) return rc;   // x_u += Dh^-1 t / w
         axpby(c, x + nu, 1.0, dp, zero ? 0.0 : 1.0, np);                             // x_p += dp
     }
     return NPG_OK;
@@ -670,7 +791,7 @@ static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int n
 // every level is visited gamma times, the second visit continuing from the first one's result).
 static int mg_cycle(npg_precond *pc, int lev, double *x, const double *b, bool x_is_zero) {
     int rc;
-    if (lev == 0 && (pc->dense.M || pc->dense.Mf)) {                 // direct coarsest-level solve
+    if (lev == 0 && (pc->dense.M || pc->dense.Mf || pc->dense.Mh)) {                 // direct coarsest-level solve
         if (x_is_zero) return dense_apply(pc, b, x, 1.0, 0.0);
         MgLevel &l0 = pc->L[0];
         SpmvEpi e{};
@@ -755,7 +876,7 @@ static int precond_apply_raw(npg_precond *pc, const double *r, double *z) {
         // preconditioner or be replaced through the setters, which drop the graphs.)
         uint64_t gsum = 0;
         for (const MgLevel &lv : pc->L)
-            for (const npg_csr *M : {lv.A, lv.G, lv.D, lv.Dinv, lv.S, lv.P, lv.R})
+            for (const npg_csr *M : {lv.A, lv.G, lv.D, lv.Dinv, lv.S, lv.P, lv.R, lv.Gh})
                 if (M) gsum += spmv_form(M)->gen;
         if (gsum != pc->graphs_gen) {
             drop_graphs(pc);

@@ -18,6 +18,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -238,12 +240,18 @@ class _LevelOperators:
         Sp = sp.csr_matrix(one(Dt) @ Ip @ one(Gt))
         Sp.sort_indices()
         self.S = DeviceCSR.from_pattern(ctx, n - nu, n - nu, Sp.indptr, Sp.indices)
+        # Dinv G (the smoother's velocity update with ONE application of Dinv per step: npg_precond_mg_set_scaled_gradient);
+        # the components of a node couple to the same pressure nodes, so this is G's pattern wherever the node blocks are full
+        Hp = sp.csr_matrix(Ip @ one(Gt))
+        Hp.sort_indices()
+        self.Gh = DeviceCSR.from_pattern(ctx, nu, n - nu, Hp.indptr, Hp.indices)
 
     def update(self, A: DeviceCSR):
         self.G.gather_values(A, self.mapG)
         self.D.gather_values(A, self.mapD)
         L.check(L.lib().npg_csr_node_block_inverse(self.Dinv.h, A.h, int(self.n_full), int(self.n_surf)))
         L.check(L.lib().npg_csr_triple_product(self.S.h, self.D.h, self.Dinv.h, self.G.h))
+        L.check(L.lib().npg_csr_product(self.Gh.h, self.Dinv.h, self.G.h))
         return self
 
 
@@ -276,8 +284,10 @@ class MultigridPreconditioner(GeneralPreconditioner):
 
     def __init__(self, arch, params, forcings, hierarchy, A_fine: DeviceCSR = None, omega=2.5, jacobi_weight=0.7,
                  schur_sweeps=3, nu1=2, nu2=2, coarse_sweeps=20, block_nodes=None, cycle="V", coarse_dense=None,
-                 mixed=False):
-        """mixed: the cycle's SpMVs read fp32 copies of the level operators' values (npg_precond_mg_set_mixed); vectors,
+                 mixed=False, scaled_gradient=None):
+        """scaled_gradient: hand the smoother Dinv G, so that a step applies Dinv once instead of twice (None: on unless
+        NPG_MG_SCALED_GRADIENT=0).
+        mixed: the cycle's SpMVs read fp32 copies of the level operators' values (npg_precond_mg_set_mixed); vectors,
         sums and the outer flexible GMRES stay fp64.
         coarse_dense: solve the coarsest level exactly with its dense inverse (DenseInversePreconditioner's machinery)
         instead of `coarse_sweeps` smoothing steps; None = whenever a hierarchy's coarsest level has <= 40 000 unknowns
@@ -293,6 +303,9 @@ class MultigridPreconditioner(GeneralPreconditioner):
         self._top = hierarchy[-1]
         full = callable(forcings.nu) or forcings.eddy_param.is_on
         prev = None
+        if scaled_gradient is None:
+            scaled_gradient = os.environ.get("NPG_MG_SCALED_GRADIENT", "1") != "0"
+        self.scaled_gradient = bool(scaled_gradient)
         for lev, fed in enumerate(hierarchy):
             d = fed.dofs
             top = lev == len(hierarchy) - 1
@@ -312,14 +325,21 @@ class MultigridPreconditioner(GeneralPreconditioner):
             self.A.append(A)
             L.check(L.lib().npg_precond_mg_set_level(self.h, lev, A.h, int(nu), ops.G.h, ops.D.h, ops.Dinv.h, ops.S.h,
                                                      None if Pd is None else Pd.h, None if Rd is None else Rd.h))
+            if scaled_gradient:
+                L.check(L.lib().npg_precond_mg_set_scaled_gradient(self.h, lev, ops.Gh.h))
             self.levels.append(dict(n=d.nu + d.np, nu=nu, S_nnz=ops.S.nnz))
             prev = fed
         self.set_params(omega, jacobi_weight, schur_sweeps, nu1, nu2, coarse_sweeps, cycle)
         if coarse_dense is None:
-            coarse_dense = len(hierarchy) > 1 and self.levels[0]["n"] <= 40000
+            coarse_dense = "fp16" if len(hierarchy) > 1 and self.levels[0]["n"] <= 40000 else False
         # True / "fp32": inverse stored in fp32 (half the bytes per V-cycle; a coarse-grid correction inside a preconditioner
-        # needs no more: same 19 iterations, 4.0 instead of 4.7 ms each at 2.15 M unknowns); "fp64": full precision
-        self._dense_mode = 0 if not coarse_dense else (1 if coarse_dense == "fp64" else 2)
+        # needs no more: same 19 iterations, 4.0 instead of 4.7 ms each at 2.15 M unknowns); "fp64": full precision;
+        # "fp16" (what None picks): every column scaled by its largest magnitude and stored in fp16 - a quarter of the bytes,
+        # the same iteration counts step by step at 2.15 M unknowns, 3.14 instead of 3.50 ms per outer iteration
+        # (profiles/r04_multigrid_cycle.txt)
+        if coarse_dense and os.environ.get("NPG_MG_COARSE_DENSE"):
+            coarse_dense = os.environ["NPG_MG_COARSE_DENSE"]
+        self._dense_mode = 0 if not coarse_dense else {"fp64": 1, "fp16": 3}.get(coarse_dense, 2)
         if self._dense_mode:
             L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, self._dense_mode))
         self.coarse_dense = bool(coarse_dense)
@@ -371,7 +391,7 @@ class MultigridPreconditioner(GeneralPreconditioner):
 
     def __repr__(self):
         return (f"MultigridPreconditioner({[lv['n'] for lv in self.levels]}, {self.params}, "
-                f"coarsest level: {'dense inverse' if self.coarse_dense else 'smoothing steps'}"
+                f"coarsest level: {('dense inverse (' + {1: 'fp64', 2: 'fp32', 3: 'scaled fp16'}[self._dense_mode] + ' storage)') if self.coarse_dense else 'smoothing steps'}"
                 f"{', fp32 operator values inside the cycle' if self.mixed else ''})")
 
 

@@ -578,6 +578,8 @@ class DistributedMultigridPreconditioner:
             self.cops.append(ops)
             L.check(L.lib().npg_precond_mg_set_level(self.h, lev, A.h, int(d.nu), ops.G.h, ops.D.h, ops.Dinv.h, ops.S.h,
                                                      None if Pd is None else Pd.h, None if Rd is None else Rd.h))
+            if os.environ.get("NPG_MG_SCALED_GRADIENT", "1") != "0":
+                L.check(L.lib().npg_precond_mg_set_scaled_gradient(self.h, lev, ops.Gh.h))
             self.levels.append(d.nu + d.np)
             prev = fed
         # ---- the distributed level(s) ----------------------------------------------------------------------------------
@@ -665,9 +667,11 @@ class DistributedMultigridPreconditioner:
         L.check(L.lib().npg_precond_mg_set_params(self.h, float(omega), float(jacobi_weight), int(schur_sweeps), int(nu1),
                                                   int(nu2), int(coarse_sweeps)))
         L.check(L.lib().npg_precond_mg_set_cycle(self.h, {"V": 1, "W": 2}[cycle]))
-        if coarse_dense is None:
-            coarse_dense = self.levels[0] <= 40000
-        self._dense_mode = 0 if not coarse_dense else (1 if coarse_dense == "fp64" else 2)
+        if coarse_dense is None:                 # as MultigridPreconditioner: scaled fp16 storage of the coarsest level's inverse
+            coarse_dense = "fp16" if self.levels[0] <= 40000 else False
+        if coarse_dense and os.environ.get("NPG_MG_COARSE_DENSE"):
+            coarse_dense = os.environ["NPG_MG_COARSE_DENSE"]
+        self._dense_mode = 0 if not coarse_dense else {"fp64": 1, "fp16": 3}.get(coarse_dense, 2)
         if self._dense_mode:
             L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, self._dense_mode))
         self.coarse_dense = bool(coarse_dense)

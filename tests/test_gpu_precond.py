@@ -252,12 +252,15 @@ def test_multigrid_with_exact_coarse_solve(arch, two_level):
     x = mo.smooth(l, np.zeros(n), r, 2, 2.5, 0.7, 3)
     x = x + l.P @ lu0.solve(l.P.T @ (r - l.A @ x))
     zr = mo.smooth(l, x, r, 2, 2.5, 0.7, 3)
-    for mode, bar in (("fp64", 1e-8), ("fp32", 1e-5)):          # the inverse stored in full precision / rounded to fp32
+    # the inverse stored in full precision / rounded to fp32 / columns scaled and rounded to fp16 (11 bits: what None picks)
+    for mode, bar in (("fp64", 1e-8), ("fp32", 1e-5), ("fp16", 2e-2)):
         P2 = mgm.MultigridPreconditioner(arch, prm, frc, hier, A_fine=A, block_nodes=False, coarse_dense=mode)
         z = P2.apply(npg.DeviceVector.from_host(arch.ctx, r), npg.DeviceVector(arch.ctx, n)).to_host()
         assert rel(z, zr) < bar, (mode, rel(z, zr))
         if mode == "fp32":
             assert rel(z, zr) > 1e-10                            # the fp32 copy is really what ran
+        if mode == "fp16":
+            assert rel(z, zr) > 1e-7 and "fp16" in repr(P2)
 
 
 def test_multigrid_with_fp32_operator_values(arch, two_level):
