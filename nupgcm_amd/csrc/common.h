@@ -258,6 +258,10 @@ struct SpmvEpi {
 };
 int spmv_epi(const npg_csr *A, const double *x, const SpmvEpi &e);
 int spmv_raw(const npg_csr *A, const double *x, double *y, double alpha, double beta, int f32 = 0);
+// the same product of a node-blocked matrix with a windowed tile set (spmv_window.h), its input rounded to fp32 into the gather
+// layout first: xg = scratch of gather32_floats(A) floats (0: A cannot take this path)
+int spmv_epi_gather32(const npg_csr *A, const double *x, float *xg, const SpmvEpi &e);
+int64_t gather32_floats(const npg_csr *A);
 // vectors of a matrix with an internal renumbering (npg_csr::uperm): dst[i] = src[uperm[i]] / dst[uperm[i]] = src[i]
 void perm_gather(const npg_csr *A, double *dst, const double *src);
 void perm_scatter(const npg_csr *A, double *dst, const double *src);

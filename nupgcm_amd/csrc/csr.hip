@@ -1726,6 +1726,84 @@ __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32(CsrDev A, WinDev W
     }
 }
 
+// the same product with the tiled SpMV's epilogue (SpmvEpi: y = alpha A x + beta c, second output z) on the windowed tile set:
+// the residuals of the multigrid cycle's finest level (mg.hip), whose input is the fp32 gather-layout copy of the iterate
+template <int L, int WL>
+__global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32e(CsrDev A, WinDev W, const WTileDesc *__restrict__ tiles, int ntiles, GatherMap g,
+                                                             SpmvEpi e) {
+    __shared__ TileLds tl;
+    __shared__ double sw[kTileRows];
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    WTileDesc td = tiles[t];
+    WinPre pre;
+    bool have = false;           // `pre` holds td's window
+    while (true) {
+        const int tn = t + gridDim.x;
+        WTileDesc nd = td;
+        if (tn < ntiles) nd = tiles[tn];
+        if (td.nw) {
+            if (!have) win_first<kSpmvThreads>(W, PaddedX{g}, td, pre);
+            have = tn < ntiles && nd.nw != 0;
+            if (td.r0 < block_rows(A))
+                spmv_tile_win<kSpmvThreads, WL, PaddedX, kTileNnz, NoProf, 0>(A, W, PaddedX{g}, td, nd, have, pre, tl, sw);
+            else
+                spmv_tile_winrows<kSpmvThreads, L>(A, W, PaddedX{g}, td, nd, have, pre, tl, sw);
+        } else {
+            have = false;
+            spmv_tile<kSpmvThreads, L, PaddedX, kTileNnz, 2, NoProf, false, true, false>(A, PaddedX{g}, ordinary(td), tl, sw);
+            pre = WinPre{};
+        }
+        for (int r = threadIdx.x; r < td.nrows; r += kSpmvThreads) {
+            const int row = td.r0 + r;
+            double v = e.alpha * sw[r];
+            if (e.beta != 0.0) v += e.beta * e.c[row];
+            e.y[row] = v;
+            if (e.z) {
+                double q = e.w * (e.dg ? e.dg[row] : 1.0) * v;
+                if (e.zin) q += e.zc * e.zin[row];
+                e.z[row] = q;
+            }
+        }
+        if (tn >= ntiles) break;
+        t = tn;
+        td = nd;
+    }
+}
+
+int64_t gather32_floats(const npg_csr *Ap);
+// x (n entries, fp64) -> its fp32 gather-layout copy; then y = alpha A fl32(x) + beta c ... on A's windowed tiles
+int spmv_epi_gather32(const npg_csr *Ap, const double *x, float *xg, const SpmvEpi &e) {
+    const npg_csr *A = spmv_form(Ap);
+    NPG_REQUIRE(gather32_floats(A) > 0 && xg, "spmv_epi_gather32: the matrix has no windowed tile set");
+    if (int rc = check_record_view(A, false, "spmv_epi_gather32")) return rc;
+    const int64_t nbr = A->block_rows();
+    const GatherMap g{xg, 3 * A->nfull, A->nfull, (int)nbr, (int)(4 * A->nnode() - nbr)};
+    hipLaunchKernelGGL(k_fill_gather32, dim3((unsigned)std::min<int64_t>(2048, (A->n + 255) / 256)), dim3(256), 0, A->ctx->stream, x, g, A->n);
+    const dim3 grid(std::max(1, std::min<int>(A->nwtiles, 3 * A->ctx->num_cu))), blk(kSpmvThreads);
+    const WinDev W = win_view(A);
+#define NPG_G32E(LL)                                                                                                              \
+    if (A->wlanes == 8)                                                                                                           \
+        hipLaunchKernelGGL((k_spmv_g32e<LL, 8>), grid, blk, 0, A->ctx->stream, csr_view(A), W, A->wtile_ptr, A->nwtiles, g, e);   \
+    else                                                                                                                          \
+        hipLaunchKernelGGL((k_spmv_g32e<LL, 4>), grid, blk, 0, A->ctx->stream, csr_view(A), W, A->wtile_ptr, A->nwtiles, g, e)
+    switch (A->lanes) {
+        case 4: NPG_G32E(4); break;
+        case 8: NPG_G32E(8); break;
+        case 16: NPG_G32E(16); break;
+        default: NPG_G32E(32); break;
+    }
+#undef NPG_G32E
+    NPG_HIP(hipGetLastError());
+    return NPG_OK;
+}
+// floats the gather-layout copy of one of A's input vectors takes (0: A has no windowed tile set to multiply it with)
+int64_t gather32_floats(const npg_csr *Ap) {
+    const npg_csr *A = spmv_form(Ap);
+    if (!(A->nnode() > 0 && !A->pk9 && !A->uperm && A->wtile_ptr && A->n == A->m)) return 0;
+    return 4 * A->nnode() + (A->n - A->block_rows()) + 8;
+}
+
 template <int L>
 static void launch_spmv_g32(const npg_csr *A, const GatherMap &g, double *y, bool win) {
     const void *tiles = win ? (const void *)A->wtile_ptr : (const void *)A->tile_ptr;

@@ -329,6 +329,10 @@ struct MgLevel {
     // [owned | ghosts of hR] columns; the vectors that feed them are copied into xP / rR, whose ghost segments the plans fill
     npg_halo *hP = nullptr, *hR = nullptr;
     double *xP = nullptr, *rR = nullptr;
+    // fp32 gather-layout copy of the iterate for the residuals r = b - A x of a large level whose A carries windowed tiles
+    // (csr.hip: spmv_epi_gather32; mg_prepare)
+    float *xg = nullptr;
+    int64_t xg_n = 0;
 };
 
 struct BlockPc {
@@ -424,6 +428,8 @@ NPG_API int npg_precond_destroy(npg_precond *pc) {
     drop_graphs(pc);
     dense_free(pc->dense);
     for (void *p : pc->allocs) hipFree(p);
+    for (MgLevel &l : pc->L)
+        if (l.xg) hipFree(l.xg);
     for (BlockPc &b : pc->blocks) {
         if (b.cg) npg_cg_destroy(b.cg);
         if (b.xk) npg_vec_destroy(b.xk);
@@ -732,6 +738,34 @@ NPG_API int npg_precond_mg_set_cycle(npg_precond *pc, int gamma) {
     return NPG_OK;
 }
 
+// Levels of a million rows and more whose matrix carries a windowed tile set form their residuals from the fp32 gather-layout
+// copy of the iterate (one fill kernel + the windowed product: 150 + 8 instead of 190 us at 2.15 M unknowns) - the rounding of x,
+// 6e-8 |A| |x|, is far below what a smoothing step or the coarse-grid correction leaves; the outer flexible GMRES forms its own
+// product from the fp64 vector.  Called before a cycle is enqueued or captured: buffers follow the matrices' current layouts.
+constexpr int64_t kMgGatherMinRows = 1000000;
+static int mg_prepare(npg_precond *pc) {
+    static const bool on = !getenv("NPG_MG_GATHER32") || atoi(getenv("NPG_MG_GATHER32")) != 0;
+    for (MgLevel &l : pc->L) {
+        const int64_t need = (on && l.A && !l.dist && !pc->mixed && l.n >= kMgGatherMinRows) ? gather32_floats(l.A) : 0;
+        if (need == l.xg_n) continue;
+        NPG_HIP(hipStreamSynchronize(pc->ctx->stream));
+        drop_graphs(pc);
+        if (l.xg) hipFree(l.xg);
+        l.xg = nullptr;
+        l.xg_n = 0;
+        if (need) {
+            NPG_HIP(hipMalloc((void **)&l.xg, (size_t)need * sizeof(float)));
+            NPG_HIP(hipMemsetAsync(l.xg, 0, (size_t)need * sizeof(float), pc->ctx->stream));    // (the pad slots stay zero)
+            l.xg_n = need;
+        }
+    }
+    return NPG_OK;
+}
+// y = alpha A x + beta c (+ second output) on level l: the level's matrix in whichever form serves it fastest
+static int mg_product(npg_precond *pc, MgLevel &l, const double *x, const SpmvEpi &e) {
+    return l.xg ? spmv_epi_gather32(l.A, x, l.xg, e) : spmv_epi(l.A, x, e);
+}
+
 // nsteps Braess-Sarazin steps on level l for A x = b.  Eight launches per step (seven with the scaled gradient): the vector updates ride in the epilogues of
 // the SpMV kernels (SpmvEpi) - on the coarse levels, where every kernel is latency-bound, the launch count is the cost.
 static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int nsteps, bool x_is_zero) {
@@ -748,7 +782,7 @@ static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int n
             if (l.hx && (rc = halo_exchange_raw(l.hx, x))) return rc;
             SpmvEpi e{};                                                             // r = b - A x
             e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l.r; e.f32 = pc->mixed;
-            if ((rc = spmv_epi(l.A, x, e))) return rc;
+            if ((rc = mg_product(pc, l, x, e))) return rc;
         }
         if (l.Gh) {
             // x_u += Dh^-1 (r_u - G dp) / w  =  t / w - (Dh^-1 G) dp / w: the first part rides in the kernel that forms t
@@ -808,7 +842,7 @@ static int mg_cycle(npg_precond *pc, int lev, double *x, const double *b, bool x
         if (l.hx && (rc = halo_exchange_raw(l.hx, x))) return rc;
         SpmvEpi e{};
         e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l.r; e.f32 = pc->mixed;
-        if ((rc = spmv_epi(l.A, x, e))) return rc;
+        if ((rc = mg_product(pc, l, x, e))) return rc;
         rfine = l.r;
     }
     if (l.hR) {
@@ -860,6 +894,7 @@ static int precond_apply_raw(npg_precond *pc, const double *r, double *z) {
     }
     if (pc->kind == NPG_PC_MG) {
         NPG_REQUIRE(pc->L.back().A, "npg_precond_apply: multigrid levels are not all set");
+        if (int rcp = mg_prepare(pc)) return rcp;
         const int top = (int)pc->L.size() - 1;
         if (pc->L[top].dist) {
             // the iterate is an SpMV input: it lives in the level's own buffer, which has room for the ghost entries
