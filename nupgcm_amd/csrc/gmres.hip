@@ -35,6 +35,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 #include "spmv_device.h"
 #include "spmv_window.h"
@@ -929,29 +931,38 @@ static void launch_rows_kernel(const GDev &d, int j, hipStream_t st, bool orth) 
 
 // the Arnoldi kernel instance for this matrix / input form: tiles [t0, t1) on `grid` workgroups
 template <int L>
-static void launch_arnoldi_split(const GDev &d, int grid, int j, int t0, int t1, hipStream_t st) {
+static void launch_arnoldi_split(const GDev &d, int grid, int j, int t0, int t1, hipStream_t st, hipEvent_t e0 = nullptr,
+                                 hipEvent_t e1 = nullptr) {
     const dim3 g(std::max(1, grid)), b(kKB);
+    // profile mode: e0 / e1 are the LAUNCH'S OWN start and stop events (hipExtLaunchKernelGGL: the dispatch packet's timestamps, what
+    // rocprofv3's kernel trace reports) - events recorded before and after the launch also time the two marker packets, 4-6 us
+#define NPG_ARNOLDI(...)                                                                          \
+    do {                                                                                          \
+        if (e0) hipExtLaunchKernelGGL((__VA_ARGS__), g, b, 0, st, e0, e1, 0, d, j, t0, t1);       \
+        else hipLaunchKernelGGL((__VA_ARGS__), g, b, 0, st, d, j, t0, t1);                        \
+    } while (0)
     if (d.A.pk9) {
         if (d.xg.p)
-            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1, true>), g, b, 0, st, d, j, t0, t1);
+            NPG_ARNOLDI(k_gmres_arnoldi<L, false, 1, true>);
         else
-            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 0, true>), g, b, 0, st, d, j, t0, t1);
+            NPG_ARNOLDI(k_gmres_arnoldi<L, false, 0, true>);
     } else if (d.xg.p && d.xg.nbr == 0) {
-        hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 2>), g, b, 0, st, d, j, t0, t1);
+        NPG_ARNOLDI(k_gmres_arnoldi<L, false, 2>);
     } else if (d.xg.p && d.wt_ptr) {
         if (d.wl == 8 && !d.word)
-            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1, false, 8, false>), g, b, 0, st, d, j, t0, t1);
+            NPG_ARNOLDI(k_gmres_arnoldi<L, false, 1, false, 8, false>);
         else if (d.wl == 8)
-            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1, false, 8, true>), g, b, 0, st, d, j, t0, t1);
+            NPG_ARNOLDI(k_gmres_arnoldi<L, false, 1, false, 8, true>);
         else if (!d.word)
-            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1, false, 4, false>), g, b, 0, st, d, j, t0, t1);
+            NPG_ARNOLDI(k_gmres_arnoldi<L, false, 1, false, 4, false>);
         else
-            hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1, false, 4, true>), g, b, 0, st, d, j, t0, t1);
+            NPG_ARNOLDI(k_gmres_arnoldi<L, false, 1, false, 4, true>);
     } else if (d.xg.p) {
-        hipLaunchKernelGGL((k_gmres_arnoldi<L, false, 1>), g, b, 0, st, d, j, t0, t1);
+        NPG_ARNOLDI(k_gmres_arnoldi<L, false, 1>);
     } else {
-        hipLaunchKernelGGL((k_gmres_arnoldi<L, false>), g, b, 0, st, d, j, t0, t1);
+        NPG_ARNOLDI(k_gmres_arnoldi<L, false>);
     }
+#undef NPG_ARNOLDI
 }
 template <int L>
 static void launch_residual_L(const GDev &d, hipStream_t st) {
@@ -1014,12 +1025,12 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
             launch_rows_kernel(d, j, st, false);
         } else {
         if (dist && (rc = halo_exchange_raw(ws->halo, d.wt, g32))) return rc;
-        if (pev) hipEventRecord(pev[2 * j], st);
         if (d.split) {
-            launch_arnoldi_split<L>(d, std::min(d.G1, std::max(1, a_nt)), j, 0, a_nt, st);
-            if (pev) hipEventRecord(pev[2 * j + 1], st);
+            launch_arnoldi_split<L>(d, std::min(d.G1, std::max(1, a_nt)), j, 0, a_nt, st, pev ? pev[2 * j] : nullptr,
+                                    pev ? pev[2 * j + 1] : nullptr);
             launch_rows_kernel(d, j, st, false);
         } else {
+            if (pev) hipEventRecord(pev[2 * j], st);
             hipLaunchKernelGGL((k_gmres_arnoldi<L, true>), dim3(d.G1), dim3(kKB), 0, st, d, j, 0, d.ntiles);
             if (pev) hipEventRecord(pev[2 * j + 1], st);
         }

@@ -746,7 +746,7 @@ constexpr int64_t kMgGatherMinRows = 1000000;
 static int mg_prepare(npg_precond *pc) {
     static const bool on = !getenv("NPG_MG_GATHER32") || atoi(getenv("NPG_MG_GATHER32")) != 0;
     for (MgLevel &l : pc->L) {
-        const int64_t need = (on && l.A && !l.dist && !pc->mixed && l.n >= kMgGatherMinRows) ? gather32_floats(l.A) : 0;
+        const int64_t need = (on && l.A && !l.dist && l.n >= kMgGatherMinRows) ? gather32_floats(l.A) : 0;
         if (need == l.xg_n) continue;
         NPG_HIP(hipStreamSynchronize(pc->ctx->stream));
         drop_graphs(pc);

@@ -343,7 +343,7 @@ class MultigridPreconditioner(GeneralPreconditioner):
         if self._dense_mode:
             L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, self._dense_mode))
         self.coarse_dense = bool(coarse_dense)
-        self.mixed = bool(mixed)
+        self.mixed = bool(mixed) or os.environ.get("NPG_MG_MIXED", "0") == "1"
         if self.mixed:
             L.check(L.lib().npg_precond_mg_set_mixed(self.h, 1))
         self._inj = None
