@@ -37,6 +37,7 @@ typedef struct npg_cg npg_cg;
 typedef struct npg_fe npg_fe;
 typedef struct npg_halo npg_halo;
 typedef struct npg_precond npg_precond;
+typedef struct npg_ilu0 npg_ilu0;
 typedef struct npg_index npg_index;
 typedef struct npg_fgmres npg_fgmres;
 
@@ -259,6 +260,22 @@ int npg_precond_destroy(npg_precond *pc);
  * matrices and vectors are borrowed and must outlive the preconditioner. */
 int npg_precond_blockdiag_set(npg_precond *pc, int k, int64_t offset, const npg_csr *A_k, const npg_vec *jacobi,
                               int64_t itmax, double atol, double rtol);
+/* ILU(0) of a plain-CSR square matrix with a full diagonal and ascending columns - KrylovPreconditioners.kp_ilu0(P) of the
+ * reference's GPU P-block (src/preconditioners.jl:101-107; csrilu02 + two csrsv2 there): level-scheduled IKJ factorisation in
+ * A's pattern and level-scheduled triangular solves, csrc/ilu.hip.  The handle keeps its own copy of the pattern. */
+int npg_ilu0_create(npg_ctx *ctx, const npg_csr *A, npg_ilu0 **out);
+int npg_ilu0_destroy(npg_ilu0 *M);
+int npg_ilu0_refactor(npg_ilu0 *M, const npg_csr *A);                 /* A's values changed, same pattern */
+int npg_ilu0_apply(npg_ilu0 *M, const npg_vec *r, npg_vec *z);        /* z = U^-1 L^-1 r  (ldiv!) */
+int npg_ilu0_info(const npg_ilu0 *M, int64_t *levels_lower, int64_t *levels_upper, int64_t *nnz);
+int npg_ilu0_factors(const npg_ilu0 *M, double *host_values);         /* L (strictly lower, unit diagonal implied) and U, A's pattern */
+/* CG on A x = b with M = the factors, ldiv = true, warm start x: what the reference's CgPreconditioner runs for the P-block
+ * (src/preconditioners.jl:24-37; Krylov.jl cg: gamma = r'z, stop at sqrt(gamma) <= atol + rtol sqrt(gamma_0); itmax 0 = 2 n) */
+int npg_cg_ilu0_solve(npg_ilu0 *M, const npg_csr *A, const npg_vec *b, npg_vec *x, double atol, double rtol, int64_t itmax,
+                      npg_solve_stats *stats);
+/* block k of a block-diagonal preconditioner (already set with npg_precond_blockdiag_set) runs its CG with M = these factors
+ * instead of the Jacobi vector (NULL: back to Jacobi).  Borrowed. */
+int npg_precond_blockdiag_set_ilu0(npg_precond *pc, int k, npg_ilu0 *M);
 /* Multigrid level `level` (0 = coarsest; set them coarse to fine).  A = the level's saddle-point matrix ordered [u; p]
  * with nu velocity unknowns, G = A[0:nu, nu:], D = A[nu:, 0:nu], Dinv = inverse of the node-block diagonal of A[0:nu, 0:nu]
  * (a node's components are adjacent; <= 3 entries per row), S = D Dinv G.  P (n_level x n_{level-1}) interpolates from the

@@ -1,7 +1,7 @@
 """nupgcm_amd - MI355X-native hot path of nuPGCM (assembly -> Krylov inversion -> buoyancy evolution) behind the
 reference's Architecture / InversionToolkit / EvolutionToolkit / invert! / evolve! surface.  GPU() only: the device layer
 is libnupgcm_hip.so (hand-written HIP for gfx950) and there is no CPU fallback."""
-from .architectures import (CPU, GPU, AbstractArchitecture, DeviceCSR, DeviceVector, architecture, on_architecture,
+from .architectures import (CPU, GPU, AbstractArchitecture, DeviceCSR, DeviceILU0, DeviceVector, architecture, on_architecture,
                             print_memory_status, vector_type)
 from .evolution import EvolutionToolkit, collect_evolution_LHS, evolution_parameter
 from .fe import DoFHandler, FEData, Mesh, Spaces, get_n_dofs

@@ -95,7 +95,10 @@ def _declare(L):
         "npg_cg_create": [P, I64, PP], "npg_cg_destroy": [P],
         "npg_cg_solve": [P, P, C.c_int, D, P, P, P, D, D, I64, C.POINTER(SolveStats)],
         "npg_precond_create": [P, C.c_int, C.c_int, PP], "npg_precond_destroy": [P],
-        "npg_precond_blockdiag_set": [P, C.c_int, I64, P, P, I64, D, D],
+        "npg_precond_blockdiag_set": [P, C.c_int, I64, P, P, I64, D, D], "npg_precond_blockdiag_set_ilu0": [P, C.c_int, P],
+        "npg_ilu0_create": [P, P, C.POINTER(P)], "npg_ilu0_destroy": [P], "npg_ilu0_refactor": [P, P], "npg_ilu0_apply": [P, P, P],
+        "npg_ilu0_info": [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)], "npg_ilu0_factors": [P, P],
+        "npg_cg_ilu0_solve": [P, P, P, P, D, D, I64, C.POINTER(SolveStats)],
         "npg_precond_mg_set_level": [P, C.c_int, P, I64, P, P, P, P, P, P],
         "npg_precond_mg_update_level": [P, C.c_int, P, P, P, P, P],
         "npg_precond_mg_set_params": [P, D, D, C.c_int, C.c_int, C.c_int, C.c_int],

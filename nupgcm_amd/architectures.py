@@ -252,6 +252,54 @@ class DeviceIndex:
             pass
 
 
+class DeviceILU0:
+    """ILU(0) factors of a plain-CSR DeviceCSR in HBM - KrylovPreconditioners.kp_ilu0(P) of the reference's GPU P-block
+    (src/preconditioners.jl:101-107): level-scheduled factorisation and triangular solves (csrc/ilu.hip)."""
+
+    def __init__(self, A: "DeviceCSR"):
+        h = C.c_void_p()
+        L.check(L.lib().npg_ilu0_create(A.ctx.h, A.h, C.byref(h)))
+        self.h, self.ctx, self.A = h, A.ctx, A
+        lo, up, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(L.lib().npg_ilu0_info(self.h, C.byref(lo), C.byref(up), C.byref(nnz)))
+        self.levels, self.nnz, self.stats = (lo.value, up.value), nnz.value, None
+
+    def refactor(self, A: "DeviceCSR" = None):
+        """A's values changed (same pattern): factorise again"""
+        L.check(L.lib().npg_ilu0_refactor(self.h, (A or self.A).h))
+        return self
+
+    def ldiv(self, r: DeviceVector, z: DeviceVector = None):
+        """z = U^-1 L^-1 r  (ldiv!(z, P_prec, r))"""
+        z = z or DeviceVector(self.ctx, r.n)
+        L.check(L.lib().npg_ilu0_apply(self.h, r.h, z.h))
+        return z
+
+    def factors(self):
+        """the factors' values in A's pattern as a scipy CSR (strictly lower: L without its unit diagonal, rest: U)"""
+        import scipy.sparse as sp
+        M = self.A.to_scipy_csr()
+        M.sort_indices()
+        v = np.empty(self.nnz)
+        L.check(L.lib().npg_ilu0_factors(self.h, L.ptr(v)))
+        return sp.csr_matrix((v, M.indices, M.indptr), shape=M.shape)
+
+    def cg(self, A: "DeviceCSR", b: DeviceVector, x: DeviceVector, atol=1e-6, rtol=1e-6, itmax=0):
+        """cg(A, b, x; M = self, ldiv = true), x in/out (warm start) - npg_cg_ilu0_solve"""
+        st = L.SolveStats()
+        L.check(L.lib().npg_cg_ilu0_solve(self.h, A.h, b.h, x.h, float(atol), float(rtol), int(itmax), C.byref(st)))
+        self.stats = st.as_dict()
+        return self.stats
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.lib().npg_ilu0_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 class DeviceCSR:
     """fp64 CSR matrix with int32 column indices in HBM (the reference's CuSparseMatrixCSR{Float64,Int32})."""
 

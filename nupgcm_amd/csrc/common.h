@@ -262,6 +262,12 @@ int spmv_raw(const npg_csr *A, const double *x, double *y, double alpha, double 
 // layout first: xg = scratch of gather32_floats(A) floats (0: A cannot take this path)
 int spmv_epi_gather32(const npg_csr *A, const double *x, float *xg, const SpmvEpi &e);
 int64_t gather32_floats(const npg_csr *A);
+}  // namespace npg
+struct npg_ilu0;
+namespace npg {
+// CG with the ILU(0) factors as M on raw device pointers (ilu.hip)
+int ilu_pcg_raw(npg_ilu0 *m, const npg_csr *A, const double *b, double *x, double atol, double rtol, int64_t itmax,
+                npg_solve_stats *stats);
 // vectors of a matrix with an internal renumbering (npg_csr::uperm): dst[i] = src[uperm[i]] / dst[uperm[i]] = src[i]
 void perm_gather(const npg_csr *A, double *dst, const double *src);
 void perm_scatter(const npg_csr *A, double *dst, const double *src);

@@ -340,6 +340,7 @@ struct BlockPc {
     const npg_csr *A = nullptr;
     const npg_vec *jac = nullptr;
     npg_cg *cg = nullptr;
+    npg_ilu0 *ilu = nullptr;                         // M of the block's CG: these factors instead of the Jacobi vector
     npg_vec *xk = nullptr, *rk = nullptr;            // the block's warm-started solution / right-hand side
     int64_t itmax = 0;
     double atol = 0.0, rtol = 0.0;
@@ -886,6 +887,20 @@ NPG_API int npg_precond_blockdiag_set(npg_precond *pc, int k, int64_t offset, co
     return NPG_OK;
 }
 
+NPG_API int npg_precond_blockdiag_set_ilu0(npg_precond *pc, int k, npg_ilu0 *M) {
+    NPG_REQUIRE(pc && pc->kind == NPG_PC_BLOCKDIAG, "npg_precond_blockdiag_set_ilu0: not a block-diagonal preconditioner");
+    NPG_REQUIRE(k >= 0 && k < (int)pc->blocks.size() && pc->blocks[k].A, "npg_precond_blockdiag_set_ilu0: block %d is not set", k);
+    int64_t nnz = 0;
+    if (M) {
+        int rc = npg_ilu0_info(M, nullptr, nullptr, &nnz);
+        if (rc) return rc;
+        NPG_REQUIRE(nnz == pc->blocks[k].A->nnz, "npg_precond_blockdiag_set_ilu0: the factors are not of this block's matrix");
+    }
+    NPG_HIP(hipStreamSynchronize(pc->ctx->stream));
+    pc->blocks[k].ilu = M;
+    return NPG_OK;
+}
+
 static int precond_apply_raw(npg_precond *pc, const double *r, double *z) {
     ++pc->applications;
     if (pc->kind == NPG_PC_DENSE) {
@@ -944,7 +959,8 @@ static int precond_apply_raw(npg_precond *pc, const double *r, double *z) {
         // mul!(yb, block.P^-1, xb): CG on the block, warm-started from its previous output (src/preconditioners.jl:24-37,118-125)
         NPG_HIP(hipMemcpyAsync(b.rk->d, r + b.off, (size_t)b.n * sizeof(double), hipMemcpyDeviceToDevice, pc->ctx->stream));
         npg_solve_stats st{};
-        int rc = npg_cg_solve(b.cg, b.A, NPG_PRECOND_DIAG, 0.0, b.jac, b.rk, b.xk, b.atol, b.rtol, b.itmax, &st);
+        int rc = b.ilu ? ilu_pcg_raw(b.ilu, b.A, b.rk->d, b.xk->d, b.atol, b.rtol, b.itmax, &st)
+                       : npg_cg_solve(b.cg, b.A, NPG_PRECOND_DIAG, 0.0, b.jac, b.rk, b.xk, b.atol, b.rtol, b.itmax, &st);
         if (rc) return rc;
         pc->inner_iterations += st.niter;
         NPG_HIP(hipMemcpyAsync(z + b.off, b.xk->d, (size_t)b.n * sizeof(double), hipMemcpyDeviceToDevice, pc->ctx->stream));

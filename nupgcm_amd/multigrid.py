@@ -73,11 +73,13 @@ def pressure_mass_matrix(fe_data: FEData):
 
 class BlockDiagonalPreconditioner(GeneralPreconditioner):
     """BlockDiagonalPreconditioner(arch, params, fe_data, A_inversion) - src/preconditioners.jl:53-93: velocity block = CG on
-    the friction-only A[1:nu, 1:nu] assembled with nu = 1 (:74-80; the reference preconditions that CG with ILU(0) on the
-    GPU, itmax = 100 - here Jacobi, the variant its log lists as `BlockDiagonal(I/h^3)`), pressure block = CG on the
-    pressure mass matrix / (alpha^2 eps^2) with its diagonal (:83-88, itmax = 0)."""
+    the friction-only A[1:nu, 1:nu] assembled with nu = 1 (:74-80), pressure block = CG on the pressure mass matrix /
+    (alpha^2 eps^2) with its diagonal (:83-88, itmax = 0).  u_precond: what preconditions the velocity block's CG - "ilu0", the
+    reference's GPU recipe (P_block_setup(::GPU): kp_ilu0, ldiv = true, itmax = 100, :101-107; DeviceILU0), or "jacobi", the
+    variant its log lists as `BlockDiagonal(I/h^3)` / the commented-out Diagonal(1 ./ diag(A)) (:109-115) - the default here,
+    because a level-scheduled triangular solve costs one dependent launch per level (thousands on a P2 friction block)."""
 
-    def __init__(self, arch, params, fe_data, A_inversion=None, u_itmax=100, p_itmax=0, atol=1e-6, rtol=1e-6):
+    def __init__(self, arch, params, fe_data, A_inversion=None, u_itmax=100, p_itmax=0, atol=1e-6, rtol=1e-6, u_precond="jacobi"):
         super().__init__(arch.ctx, L.NPG_PC_BLOCKDIAG, 2)
         d, ctx = fe_data.dofs, arch.ctx
         # a PRIVATE assembly engine: the friction-only matrix needs nu = 1, f = 0, and the engine cached per FEData is
@@ -97,6 +99,14 @@ class BlockDiagonalPreconditioner(GeneralPreconditioner):
             self._keep += [Ad, jac]
             L.check(L.lib().npg_precond_blockdiag_set(self.h, k, int(off), Ad.h, jac.h, int(u_itmax if k == 0 else p_itmax),
                                                       float(atol), float(rtol)))
+            if k == 0 and u_precond == "ilu0":
+                from .architectures import DeviceILU0
+                self.ilu = DeviceILU0(Ad)
+                self._keep.append(self.ilu)
+                L.check(L.lib().npg_precond_blockdiag_set_ilu0(self.h, 0, self.ilu.h))
+            elif k == 0 and u_precond != "jacobi":
+                raise ValueError(f"BlockDiagonalPreconditioner: u_precond = {u_precond!r} (\"jacobi\" or \"ilu0\")")
+        self.u_precond = u_precond
 
 
 class DenseInversePreconditioner(GeneralPreconditioner):
