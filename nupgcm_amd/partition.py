@@ -539,7 +539,7 @@ class DistributedMultigridPreconditioner:
         """distributed_levels: 1 = the finest level row-partitioned, every coarser level replicated; 2 = the level below it
         partitioned as well (a coarse node belongs to the rank that owns the fine node it coincides with; its rows are assembled
         on that rank's cells of the coarse mesh; P / R between the two levels are row blocks with halo plans of their own) -
-        hierarchies of >= 3 levels, static viscosity."""
+        hierarchies of >= 3 levels.  `refresh` follows the eddy closure on both."""
         import ctypes as C
         from . import multigrid as mgm
         from .inversion import build_A_inversion
@@ -549,8 +549,6 @@ class DistributedMultigridPreconditioner:
             raise ValueError("distributed_levels: 1 or 2")
         if distributed_levels == 2 and len(hierarchy) < 3:
             raise ValueError("two distributed levels need a hierarchy of >= 3 levels (the coarsest stays replicated)")
-        if distributed_levels == 2 and forcings.eddy_param.is_on:
-            raise NotImplementedError("two distributed multigrid levels: the eddy closure's refresh of the second one is not implemented")
         self.distributed_levels = distributed_levels
         ctx = arch.ctx
         self.ctx, self.arch = ctx, arch
@@ -801,7 +799,23 @@ class DistributedMultigridPreconditioner:
             s_f = fine.spaces
             b_glob = model.state.b                                            # collective gather of the owned slices, native order
             nodal = np.where(s_f.b_dof >= 0, b_glob[np.maximum(s_f.b_dof, 0)], s_f.b_diri_val)
-            for lev in range(top - 1, -1, -1):
+            lo = top - 1
+            if self.distributed_levels == 2:
+                # the second partitioned level: the injected buoyancy on this rank's coarse cells -> its engine's viscosity table ->
+                # its rows of A and its smoother, as on the finest level
+                lv1 = self._lv[1]
+                fed_c = lv1.fed
+                nodal = nodal[self._inj[top - 1]]
+                s = fed_c.spaces
+                bl = DeviceVector.from_host(self.ctx, nodal[s.b_dof >= 0], fed_c.dofs.p_b[lv1.lay.b.globals()])
+                lv1.fe.update_nu_eddy(ep.N2min, self.prm.alpha, self.prm.N2, bl)
+                lv1.fe.assemble(L.NPG_MAT_A, lv1.A, scale=self.prm.alpha ** 2 * self.prm.eps ** 2, full_stress=self._full)
+                G1, D1, Dinv1, S1 = self._level_operators(lv1, first=False)
+                new1 = [DeviceCSR.from_scipy(self.ctx, M) for M in (G1, D1, sp.csr_matrix(Dinv1), S1)]
+                L.check(L.lib().npg_precond_mg_update_level(self.h, top - 1, lv1.A.h, new1[0].h, new1[1].h, new1[2].h, new1[3].h))
+                lv1.ops[:4] = new1
+                lo = top - 2
+            for lev in range(lo, -1, -1):
                 fed = self.hierarchy[lev]
                 nodal = nodal[self._inj[lev]]
                 s = fed.spaces

@@ -21,10 +21,13 @@ def main():
         # BASELINE configs[4] with converged inversions: x-periodic channel basin, both closures (the eddy closure re-assembles A
         # in the full-stress form at step 10 and the preconditioner follows), two-level hierarchy, finest level partitioned
         hh = float(label.split("_h")[1])
-        models = workloads.channel_basin_hierarchy_models(hh, 1)
+        nlev = int(sys.argv[4]) if len(sys.argv) > 4 else 1              # distributed multigrid levels = refinements of the hierarchy
+        models = workloads.channel_basin_hierarchy_models(hh, nlev)
         hier = [workloads.channel_basin_fe_data(mm) for mm in models]
-        m = partition.channel_basin_model(arch, models[-1], dist, element_precision="fp64", itmax=0, fe_data=hier[-1], invert_now=False)
-        partition.use_multigrid(m, hier, omega=2.0)
+        # (itmax: a preconditioner gone wrong fails the test's `solved` check instead of iterating to 2 N)
+        m = partition.channel_basin_model(arch, models[-1], dist, element_precision="fp64", itmax=0 if nlev == 1 else 2000, fe_data=hier[-1],
+                                          invert_now=False)
+        partition.use_multigrid(m, hier, omega=2.0, distributed_levels=nlev)
         assert m.verify_transport()
     else:
         nlev = int(sys.argv[4]) if len(sys.argv) > 4 else 1              # distributed multigrid levels (1 or 2)

@@ -226,6 +226,34 @@ def test_distributed_multigrid_follows_the_eddy_closure(tmp_path):
     assert rel(z["b"], ref.state.b) < 1e-4 and rel(z["u"], ref.state.u) < 5e-3 and rel(z["p"], ref.state.p) < 5e-3
 
 
+def test_two_distributed_levels_follow_the_eddy_closure(tmp_path):
+    """the same one refinement finer, with a three-level hierarchy (2 431 / 20 807 / 172 591 unknowns; three levels under
+    h = 0.0625 start from a mesh too coarse to precondition this system at all) whose TWO finest levels are partitioned over 3 ranks:
+    at step 10 the second level's engine takes the injected buoyancy's viscosity on the rank's coarse cells, its rows and its
+    smoother are rebuilt like the finest level's, and the counts stay the one-GPU model's through the refresh"""
+    world, nsteps, label = 3, 12, "channel_basin_h0.03125"
+    arch = npg.GPU()
+    ref = workloads.channel_basin_model(arch, h=0.03125, levels=2, element_precision="fp64", itmax=2000)
+    npg.run(ref, n_steps=nsteps)
+    ref_its = [s[1]["niter"] for s in ref.stats]
+    assert all(s[1]["solved"] == 1 for s in ref.stats)
+    out = str(tmp_path / "dmge2")
+    env = dict(os.environ, NPG_COMM_TRANSPORT="peer", NPG_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
+               NPG_PEER_TIMEOUT_S="90")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_mg_worker.py"), out, str(nsteps), label, "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ranks = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
+    z = ranks[0]
+    for zz in ranks[1:]:
+        assert np.array_equal(zz["its"], z["its"])
+    assert z["solved"].all() and all(int(zz["mg2"][0]) > 0 for zz in ranks)           # every rank holds rows of the second level
+    assert max(abs(int(a) - int(b)) for a, b in zip(z["its"], ref_its)) <= 2, (list(z["its"]), ref_its)
+    assert abs(int(np.sum(z["its"])) - sum(ref_its)) <= 0.05 * sum(ref_its)
+    assert rel(z["b"], ref.state.b) < 1e-4 and rel(z["u"], ref.state.u) < 5e-3 and rel(z["p"], ref.state.p) < 5e-3
+
+
 @pytest.mark.parametrize("records", [False, True])
 def test_channel_basin_mesh_partitioned(tmp_path, records, monkeypatch):
     """BASELINE configs[4] on 3 ranks with the mesh partitioned: closures re-evaluated and K_v / the full-stress A
