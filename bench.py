@@ -178,7 +178,7 @@ def main():
         elif a.preconditioner == "multigrid":
             # converged inversions instead of run.jl's 1000-iteration cap: V-cycle over a 3-level refinement hierarchy whose
             # finest mesh has the requested spacing
-            model = workloads.channel_basin_model(arch, h=hh, levels=2, surface=surf, itmax=0)
+            model = workloads.channel_basin_model(arch, h=hh, levels=int(os.environ.get("NPG_CB_LEVELS", 2)), surface=surf, itmax=0)
         else:
             model = workloads.channel_basin_model(arch, mesh_model=mesh_model, surface=surf)
     elif (world > 1 or force_dist) and not replicated:

@@ -177,6 +177,10 @@ int npg_csr_gather_values(npg_csr *dst, const npg_csr *src, const npg_index *map
  * are an error).  With npg_csr_gather_values for G = A[u, p] and D = A[p, u] a re-assembled A (eddy closure) refreshes a
  * level's smoother without leaving the device. */
 int npg_csr_node_block_inverse(npg_csr *Dinv, const npg_csr *A, int64_t n_full, int64_t n_surf);
+/* Dinv = inverse of a block diagonal of A[0:nu, 0:nu] with arbitrary blocks: block b = block_dofs[block_ptr[b] .. block_ptr[b+1])
+ * (ascending; the blocks partition [0, nu); at most 136 unknowns each), Dinv's pattern = exactly the blocks.  The z-line smoother
+ * of the multigrid cycle: a block = the velocity unknowns of the nodes above one another (new work, csrc/mg.hip). */
+int npg_csr_line_block_inverse(npg_csr *Dinv, const npg_csr *A, const npg_index *block_ptr, const npg_index *block_dofs);
 /* C = A B on C's FIXED pattern (plain CSR; an error if a product falls outside it) */
 int npg_csr_product(npg_csr *C, const npg_csr *A, const npg_csr *B);
 int npg_csr_triple_product(npg_csr *S, const npg_csr *D, const npg_csr *Dinv, const npg_csr *G);

@@ -1413,6 +1413,71 @@ __global__ void k_node_block_inverse(const int64_t *__restrict__ arp, const int3
     }
 }
 
+// Dinv = inverse of a block diagonal of A[0:nu, 0:nu] whose blocks are arbitrary index sets (the velocity unknowns of a vertical
+// line of nodes: the z-line smoother of mg.hip): block b = dofs[bp[b] .. bp[b+1]), ascending; Dinv's pattern holds exactly the blocks
+// (row i: all unknowns of its block, ascending), so entry (dofs[bp[b] + i], dofs[bp[b] + j]) sits at drp[row] + j.  One workgroup
+// per block: the block is collected from A's rows into LDS, inverted in place by Gauss-Jordan elimination WITHOUT pivoting (the
+// velocity block's symmetric part is positive definite - friction - and the Coriolis part skew: every leading minor is regular),
+// and written out.  *bad counts blocks that met a zero or non-finite pivot.
+__global__ void __launch_bounds__(256) k_line_block_inverse(const int64_t *__restrict__ arp, const int32_t *__restrict__ acol,
+                                                            const double *__restrict__ aval, const int64_t *__restrict__ bp,
+                                                            const int64_t *__restrict__ dofs, int64_t nblocks,
+                                                            const int64_t *__restrict__ drp, double *__restrict__ dval, int *bad) {
+    extern __shared__ double lds[];
+    __shared__ int flag;
+    for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const int64_t b0 = bp[b];
+        const int n = (int)(bp[b + 1] - b0);
+        double *M = lds;                                         // n x n, row-major
+        int32_t *ids = reinterpret_cast<int32_t *>(lds + (size_t)n * n);
+        __syncthreads();
+        for (int e = threadIdx.x; e < n * n; e += blockDim.x) M[e] = 0.0;
+        for (int e = threadIdx.x; e < n; e += blockDim.x) ids[e] = (int32_t)dofs[b0 + e];
+        if (threadIdx.x == 0) flag = 0;
+        __syncthreads();
+        // row i of the block <- the entries of A's row ids[i] whose column is in the block (16 lanes per row)
+        for (int i = threadIdx.x / 16; i < n; i += blockDim.x / 16) {
+            const int64_t r = ids[i];
+            for (int64_t k = arp[r] + (threadIdx.x & 15); k < arp[r + 1]; k += 16) {
+                const int32_t c = acol[k];
+                int lo = 0, hi = n - 1;
+                while (lo <= hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const int32_t v = ids[mid];
+                    if (v == c) { M[i * n + mid] = aval[k]; break; }
+                    if (v < c) lo = mid + 1; else hi = mid - 1;
+                }
+            }
+        }
+        __syncthreads();
+        for (int k = 0; k < n; ++k) {
+            const double piv = M[k * n + k];
+            if (threadIdx.x == 0 && !(fabs(piv) > 0.0 && fabs(piv) < 1e300)) flag = 1;
+            __syncthreads();
+            const double ip = 1.0 / piv;
+            // row k <- row k / pivot with the pivot's own column replaced by the identity's (in-place Gauss-Jordan)
+            for (int j = threadIdx.x; j < n; j += blockDim.x) M[k * n + j] = (j == k) ? ip : M[k * n + j] * ip;
+            __syncthreads();
+            for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+                const int i = e / n, j = e - i * n;
+                if (i == k) continue;
+                const double f = M[i * n + k];               // (column k of the other rows is read before any of it is rewritten:
+                if (j == k) continue;                        //  those entries are finished in the pass below)
+                M[e] -= f * M[k * n + j];
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += blockDim.x)
+                if (i != k) M[i * n + k] = -M[i * n + k] * ip;
+            __syncthreads();
+        }
+        for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+            const int i = e / n, j = e - i * n;
+            dval[drp[ids[i]] + j] = M[e];
+        }
+        if (threadIdx.x == 0 && flag) atomicAdd(bad, 1);
+    }
+}
+
 // S = D Dinv G into S's fixed pattern: one thread per row, the row's slots found by binary search; products outside the
 // pattern are counted in *missing
 __global__ void k_triple_product(const int64_t *__restrict__ drp, const int32_t *__restrict__ dcol, const double *__restrict__ dval,
@@ -1531,6 +1596,54 @@ NPG_API int npg_csr_node_block_inverse(npg_csr *Dinv, const npg_csr *A, int64_t 
                        n_full, n_surf, nu, Dinv->rowptr, Dinv->val);
     NPG_HIP(hipGetLastError());
     return NPG_OK;
+}
+
+constexpr int kMaxLineBlock = 136;          // unknowns in one block: 136^2 doubles + ids = 148.5 KB of the CU's 160 KB of LDS
+NPG_API int npg_csr_line_block_inverse(npg_csr *Dinv, const npg_csr *A, const npg_index *block_ptr, const npg_index *block_dofs) {
+    NPG_REQUIRE(Dinv && A && block_ptr && block_dofs, "npg_csr_line_block_inverse: NULL argument");
+    NPG_REQUIRE(A->nnode() == 0 && Dinv->nnode() == 0, "npg_csr_line_block_inverse: node-blocked matrices are not supported");
+    const int64_t nu = Dinv->m, nb = block_ptr->n - 1;
+    NPG_REQUIRE(Dinv->n == nu && A->m >= nu && A->n >= nu && nb >= 1 && block_dofs->n == nu && block_dofs->bound == nu &&
+                    block_ptr->bound == nu + 1,
+                "npg_csr_line_block_inverse: Dinv must be nu x nu, the blocks a partition of [0, nu) (block_dofs: nu entries below nu; "
+                "block_ptr: offsets up to nu)");
+    // the blocks against Dinv's pattern (host: index arrays only)
+    std::vector<int64_t> bp((size_t)nb + 1), dofs((size_t)nu);
+    NPG_HIP(hipSetDevice(A->ctx->device));
+    NPG_HIP(hipStreamSynchronize(A->ctx->stream));
+    NPG_HIP(hipMemcpy(bp.data(), block_ptr->d, bp.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    NPG_HIP(hipMemcpy(dofs.data(), block_dofs->d, dofs.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    NPG_REQUIRE(bp[0] == 0 && bp[(size_t)nb] == nu, "npg_csr_line_block_inverse: block_ptr must run from 0 to nu");
+    int64_t nmax = 0, total = 0;
+    const int64_t *drp = Dinv->h_rowptr.data();
+    for (int64_t b = 0; b < nb; ++b) {
+        const int64_t n = bp[(size_t)b + 1] - bp[(size_t)b];
+        NPG_REQUIRE(n >= 1 && n <= kMaxLineBlock, "npg_csr_line_block_inverse: block %lld has %lld unknowns (1..%d)", (long long)b,
+                    (long long)n, kMaxLineBlock);
+        for (int64_t e = bp[(size_t)b]; e < bp[(size_t)b + 1]; ++e) {
+            NPG_REQUIRE(e == bp[(size_t)b] || dofs[(size_t)e] > dofs[(size_t)e - 1], "npg_csr_line_block_inverse: block %lld is not ascending", (long long)b);
+            NPG_REQUIRE(drp[dofs[(size_t)e] + 1] - drp[dofs[(size_t)e]] == n, "npg_csr_line_block_inverse: row %lld of Dinv does not hold its block (%lld entries, block of %lld)",
+                        (long long)dofs[(size_t)e], (long long)(drp[dofs[(size_t)e] + 1] - drp[dofs[(size_t)e]]), (long long)n);
+        }
+        nmax = std::max(nmax, n);
+        total += n * n;
+    }
+    NPG_REQUIRE(total == Dinv->nnz, "npg_csr_line_block_inverse: Dinv's pattern must hold exactly the blocks (%lld entries expected, %lld found)",
+                (long long)total, (long long)Dinv->nnz);
+    const size_t lds = (size_t)nmax * nmax * sizeof(double) + (size_t)nmax * sizeof(int32_t) + 8;
+    NPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_line_block_inverse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    npg_ctx *ctx = A->ctx;
+    int *bad = reinterpret_cast<int *>(ctx->d_scratch);
+    NPG_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+    const int grid = (int)std::min<int64_t>(nb, 8 * ctx->num_cu);
+    hipLaunchKernelGGL(k_line_block_inverse, dim3(grid), dim3(256), lds, ctx->stream, A->rowptr, A->col, A->val, block_ptr->d, block_dofs->d,
+                       nb, Dinv->rowptr, Dinv->val, bad);
+    NPG_HIP(hipGetLastError());
+    int nbad = 0;
+    NPG_HIP(hipMemcpyAsync(&nbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    NPG_HIP(hipStreamSynchronize(ctx->stream));
+    NPG_REQUIRE(nbad == 0, "npg_csr_line_block_inverse: %d blocks are singular to working precision (zero or non-finite pivot)", nbad);
+    return csr_repack(Dinv);
 }
 
 NPG_API int npg_csr_triple_product(npg_csr *S, const npg_csr *D, const npg_csr *Dinv, const npg_csr *G) {

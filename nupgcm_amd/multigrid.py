@@ -213,6 +213,59 @@ def node_block_inverse(F, n_full, n_surf):
     return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nu, nu))
 
 
+def line_blocks(fed: FEData, decimals=7):
+    """(block_ptr, block_dofs, line_of_dof): the velocity unknowns (positions in the device order) grouped by the (x, y) of their
+    nodes - the unknowns of the nodes above one another form one block (a structured-to-tet mesh such as the channel basin's
+    stacks its nodes in vertical lines; on an unstructured mesh the blocks fall back to the single nodes).  Blocks are numbered
+    by their first unknown; each block's unknowns ascend."""
+    s, d = fed.spaces, fed.dofs
+    nu = d.nu
+    node_of = np.full(nu, -1, dtype=np.int64)
+    for a in range(3):
+        nodes = np.nonzero(s.u_dof[:, a] >= 0)[0]
+        node_of[d.inv_p_u[s.u_dof[nodes, a]]] = nodes
+    xy = np.round(fed.mesh.node_coords[node_of][:, :2], decimals)
+    _, grp = np.unique(xy, axis=0, return_inverse=True)
+    grp = np.asarray(grp).ravel()
+    first = np.full(grp.max() + 1, nu, dtype=np.int64)
+    np.minimum.at(first, grp, np.arange(nu))
+    line_of = np.argsort(np.argsort(first))[grp]                  # blocks renumbered by their first unknown
+    order = np.lexsort((np.arange(nu), line_of))
+    sizes = np.bincount(line_of)
+    bp = np.zeros(len(sizes) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=bp[1:])
+    return bp, order.astype(np.int64), line_of.astype(np.int64)
+
+
+def line_block_inverse(F, block_ptr, block_dofs):
+    """host counterpart of npg_csr_line_block_inverse (tests, distributed set-up): inverse of the block diagonal of F with the
+    blocks of line_blocks(); blocks of equal size are inverted together"""
+    F = sp.csr_matrix(F)
+    nu = F.shape[0]
+    sizes = np.diff(block_ptr)
+    rows, cols, vals = [], [], []
+    for n in np.unique(sizes):
+        bs = np.nonzero(sizes == n)[0]
+        idx = block_dofs[block_ptr[bs][:, None] + np.arange(n)[None, :]]            # (nblk, n)
+        blk = np.empty((len(bs), n, n))
+        for i in range(n):
+            for j in range(n):
+                blk[:, i, j] = np.asarray(F[idx[:, i], idx[:, j]]).ravel()
+        inv = np.linalg.inv(blk)
+        rows.append(np.repeat(idx, n, axis=1).ravel()); cols.append(np.tile(idx, (1, n)).ravel()); vals.append(inv.ravel())
+    return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nu, nu))
+
+
+def _line_block_pattern(nu, block_ptr, block_dofs, line_of):
+    """CSR pattern of the line-block diagonal: row i holds every unknown of its block, ascending"""
+    sizes = np.diff(block_ptr)
+    size = sizes[line_of]
+    rp = np.zeros(nu + 1, dtype=np.int64)
+    np.cumsum(size, out=rp[1:])
+    col = block_dofs[np.repeat(block_ptr[line_of], size) + (np.arange(rp[-1]) - np.repeat(rp[:-1], size))]
+    return rp, col.astype(np.int32)
+
+
 def _node_block_pattern(nu, n_full, n_surf):
     """CSR pattern (rowptr, col) of the node-block diagonal: 3 x 3 / 2 x 2 / 1 x 1 blocks in the node-block DoF order"""
     r3, r2 = 3 * n_full, 3 * n_full + 2 * n_surf
@@ -229,7 +282,9 @@ class _LevelOperators:
     G = A[u, p] and D = A[p, u] by entry gathers, Dinv by the node-block inverse kernel, S = D Dinv G by the fixed-pattern
     triple product.  The host only ever touches index arrays (the global sparsity pattern), at set-up."""
 
-    def __init__(self, ctx, fed, pattern):
+    def __init__(self, ctx, fed, pattern, smoother="node"):
+        """smoother: "node" - Dinv inverts the node-block diagonal of the velocity block; "zline" - the blocks are the unknowns of
+        the nodes above one another (line_blocks; npg_csr_line_block_inverse): the anisotropic meshes' smoother"""
         from .architectures import DeviceIndex
         d = fed.dofs
         nu, n = d.nu, d.nu + d.np
@@ -243,25 +298,63 @@ class _LevelOperators:
         self.D = DeviceCSR.from_pattern(ctx, n - nu, nu, Dt.indptr, Dt.indices)
         self.mapG = DeviceIndex(ctx, np.rint(Gt.data).astype(np.int64) - 1, nnz)
         self.mapD = DeviceIndex(ctx, np.rint(Dt.data).astype(np.int64) - 1, nnz)
-        irp, icol = _node_block_pattern(nu, d.n_full, d.n_surf)
-        self.Dinv = DeviceCSR.from_pattern(ctx, nu, nu, irp, icol)
         one = lambda M: sp.csr_matrix((np.ones(M.nnz, dtype=np.float32), M.indices, M.indptr), shape=M.shape)
-        Ip = sp.csr_matrix((np.ones(len(icol), dtype=np.float32), icol, irp), shape=(nu, nu))
-        Sp = sp.csr_matrix(one(Dt) @ Ip @ one(Gt))
+        self.smoother = smoother
+        if smoother == "zline":
+            bp, bd, line_of = line_blocks(fed)
+            self.blocks = (DeviceIndex(ctx, bp, nu + 1), DeviceIndex(ctx, bd, nu))
+            self.block_sizes = np.diff(bp)
+            irp, icol = _line_block_pattern(nu, bp, bd, line_of)
+            self.Dinv = DeviceCSR.from_pattern(ctx, nu, nu, irp, icol)
+            # pattern of S = D Dinv G through the lines: pressure node p reaches p' when both touch one line
+            nl = len(bp) - 1
+            Dl = sp.csr_matrix((np.ones(Dt.nnz, dtype=np.float32), line_of[Dt.indices], Dt.indptr), shape=(n - nu, nl))
+            Gc = sp.coo_matrix(Gt)
+            Gl = sp.csr_matrix((np.ones(Gc.nnz, dtype=np.float32), (line_of[Gc.row], Gc.col)), shape=(nl, n - nu))
+            Sp = sp.csr_matrix(Dl @ Gl)
+            self.Gh = None                     # Dinv G would hold a whole line's pressure neighbours per row: not formed
+        elif smoother == "node":
+            irp, icol = _node_block_pattern(nu, d.n_full, d.n_surf)
+            self.Dinv = DeviceCSR.from_pattern(ctx, nu, nu, irp, icol)
+            Ip = sp.csr_matrix((np.ones(len(icol), dtype=np.float32), icol, irp), shape=(nu, nu))
+            Sp = sp.csr_matrix(one(Dt) @ Ip @ one(Gt))
+            # Dinv G (the smoother's velocity update with ONE application of Dinv per step: npg_precond_mg_set_scaled_gradient);
+            # the components of a node couple to the same pressure nodes, so this is G's pattern wherever the node blocks are full
+            Hp = sp.csr_matrix(Ip @ one(Gt))
+            Hp.sort_indices()
+            self.Gh = DeviceCSR.from_pattern(ctx, nu, n - nu, Hp.indptr, Hp.indices)
+        else:
+            raise ValueError(f"smoother = {smoother!r} (\"node\" or \"zline\")")
         Sp.sort_indices()
         self.S = DeviceCSR.from_pattern(ctx, n - nu, n - nu, Sp.indptr, Sp.indices)
-        # Dinv G (the smoother's velocity update with ONE application of Dinv per step: npg_precond_mg_set_scaled_gradient);
-        # the components of a node couple to the same pressure nodes, so this is G's pattern wherever the node blocks are full
-        Hp = sp.csr_matrix(Ip @ one(Gt))
-        Hp.sort_indices()
-        self.Gh = DeviceCSR.from_pattern(ctx, nu, n - nu, Hp.indptr, Hp.indices)
 
     def update(self, A: DeviceCSR):
+        if os.environ.get("NPG_MG_TIMING") == "1":
+            import time
+            ctx, t = A.ctx, [time.time()]
+            def lap(what):
+                ctx.sync()
+                t.append(time.time())
+                print(f"[npg mg] level of {A.shape[0]} unknowns: {what} {1e3 * (t[-1] - t[-2]):.1f} ms", flush=True)
+            self.G.gather_values(A, self.mapG); self.D.gather_values(A, self.mapD); lap("G, D gathered")
+            if self.smoother == "zline":
+                L.check(L.lib().npg_csr_line_block_inverse(self.Dinv.h, A.h, self.blocks[0].h, self.blocks[1].h))
+            else:
+                L.check(L.lib().npg_csr_node_block_inverse(self.Dinv.h, A.h, int(self.n_full), int(self.n_surf)))
+            lap("Dinv")
+            L.check(L.lib().npg_csr_triple_product(self.S.h, self.D.h, self.Dinv.h, self.G.h)); lap("S = D Dinv G")
+            if self.Gh is not None:
+                L.check(L.lib().npg_csr_product(self.Gh.h, self.Dinv.h, self.G.h)); lap("Dinv G")
+            return self
         self.G.gather_values(A, self.mapG)
         self.D.gather_values(A, self.mapD)
-        L.check(L.lib().npg_csr_node_block_inverse(self.Dinv.h, A.h, int(self.n_full), int(self.n_surf)))
+        if self.smoother == "zline":
+            L.check(L.lib().npg_csr_line_block_inverse(self.Dinv.h, A.h, self.blocks[0].h, self.blocks[1].h))
+        else:
+            L.check(L.lib().npg_csr_node_block_inverse(self.Dinv.h, A.h, int(self.n_full), int(self.n_surf)))
         L.check(L.lib().npg_csr_triple_product(self.S.h, self.D.h, self.Dinv.h, self.G.h))
-        L.check(L.lib().npg_csr_product(self.Gh.h, self.Dinv.h, self.G.h))
+        if self.Gh is not None:
+            L.check(L.lib().npg_csr_product(self.Gh.h, self.Dinv.h, self.G.h))
         return self
 
 
@@ -294,8 +387,11 @@ class MultigridPreconditioner(GeneralPreconditioner):
 
     def __init__(self, arch, params, forcings, hierarchy, A_fine: DeviceCSR = None, omega=2.5, jacobi_weight=0.7,
                  schur_sweeps=3, nu1=2, nu2=2, coarse_sweeps=20, block_nodes=None, cycle="V", coarse_dense=None,
-                 mixed=False, scaled_gradient=None):
-        """scaled_gradient: hand the smoother Dinv G, so that a step applies Dinv once instead of twice (None: on unless
+                 mixed=False, scaled_gradient=None, smoother=None):
+        """smoother: "node" (Braess-Sarazin on the node blocks of the velocity block) or "zline" (its blocks are the unknowns of
+        the nodes above one another - the anisotropic, structured-in-z meshes: on the channel basin's three-level hierarchy a
+        third of the outer iterations; None: NPG_MG_SMOOTHER, else "node").
+        scaled_gradient: hand the smoother Dinv G, so that a step applies Dinv once instead of twice (None: on unless
         NPG_MG_SCALED_GRADIENT=0).
         mixed: the cycle's SpMVs read fp32 copies of the level operators' values (npg_precond_mg_set_mixed); vectors,
         sums and the outer flexible GMRES stay fp64.
@@ -315,12 +411,15 @@ class MultigridPreconditioner(GeneralPreconditioner):
         prev = None
         if scaled_gradient is None:
             scaled_gradient = os.environ.get("NPG_MG_SCALED_GRADIENT", "1") != "0"
-        self.scaled_gradient = bool(scaled_gradient)
+        if smoother is None:
+            smoother = os.environ.get("NPG_MG_SMOOTHER", "node")
+        self.smoother = smoother
+        self.scaled_gradient = bool(scaled_gradient) and smoother == "node"
         for lev, fed in enumerate(hierarchy):
             d = fed.dofs
             top = lev == len(hierarchy) - 1
             A = build_A_inversion(arch, fed, params, forcings.nu, structural=full)   # plain CSR, [u; p] device order
-            ops = _LevelOperators(ctx, fed, fed.pattern_A(structural=full)).update(A)
+            ops = _LevelOperators(ctx, fed, fed.pattern_A(structural=full), smoother=smoother).update(A)
             nu = d.nu
             if top and A_fine is not None:
                 A = A_fine
@@ -335,10 +434,15 @@ class MultigridPreconditioner(GeneralPreconditioner):
             self.A.append(A)
             L.check(L.lib().npg_precond_mg_set_level(self.h, lev, A.h, int(nu), ops.G.h, ops.D.h, ops.Dinv.h, ops.S.h,
                                                      None if Pd is None else Pd.h, None if Rd is None else Rd.h))
-            if scaled_gradient:
+            if self.scaled_gradient:
                 L.check(L.lib().npg_precond_mg_set_scaled_gradient(self.h, lev, ops.Gh.h))
             self.levels.append(dict(n=d.nu + d.np, nu=nu, S_nnz=ops.S.nnz))
             prev = fed
+        if os.environ.get("NPG_MG_PARAMS"):          # tuning: "schur_sweeps=6,coarse_sweeps=60,omega=1.8"
+            kv = dict(item.split("=") for item in os.environ["NPG_MG_PARAMS"].split(","))
+            omega, jacobi_weight = float(kv.get("omega", omega)), float(kv.get("jacobi_weight", jacobi_weight))
+            schur_sweeps, nu1, nu2 = int(kv.get("schur_sweeps", schur_sweeps)), int(kv.get("nu1", nu1)), int(kv.get("nu2", nu2))
+            coarse_sweeps, cycle = int(kv.get("coarse_sweeps", coarse_sweeps)), kv.get("cycle", cycle)
         self.set_params(omega, jacobi_weight, schur_sweeps, nu1, nu2, coarse_sweeps, cycle)
         if coarse_dense is None:
             coarse_dense = "fp16" if len(hierarchy) > 1 and self.levels[0]["n"] <= 40000 else False
@@ -400,8 +504,10 @@ class MultigridPreconditioner(GeneralPreconditioner):
                            coarse_sweeps=coarse_sweeps, cycle=cycle)
 
     def __repr__(self):
-        return (f"MultigridPreconditioner({[lv['n'] for lv in self.levels]}, {self.params}, "
-                f"coarsest level: {('dense inverse (' + {1: 'fp64', 2: 'fp32', 3: 'scaled fp16'}[self._dense_mode] + ' storage)') if self.coarse_dense else 'smoothing steps'}"
+        dense = {1: "fp64", 2: "fp32", 3: "scaled fp16"}.get(self._dense_mode, "")
+        coarse = f"dense inverse ({dense} storage)" if self.coarse_dense else "smoothing steps"
+        return (f"MultigridPreconditioner({[lv['n'] for lv in self.levels]}, {self.params}, coarsest level: {coarse}"
+                f"{', z-line smoother' if self.smoother == 'zline' else ''}"
                 f"{', fp32 operator values inside the cycle' if self.mixed else ''})")
 
 

@@ -172,7 +172,7 @@ def channel_basin_model(arch, h=None, dz=None, mesh_model=None, surface="flux", 
         # channel cells 2.0 needs a quarter fewer outer iterations (48-58 against 62-77 at 3.9 M unknowns), 1.8 as many, and
         # 1.5 is past the edge at production size (blow-up) although it is the best at h = 0.02 (tools/mg_sweep_channel.py,
         # tools/mg_channel_omega.py)
-        inv_kw["precond_kw"] = dict(dict(omega=2.0), **(inv_kw.get("precond_kw") or {}))
+        inv_kw["precond_kw"] = dict(dict(omega=float(os.environ.get("NPG_MG_OMEGA", 2.0))), **(inv_kw.get("precond_kw") or {}))
     else:
         mm = mesh_model if mesh_model is not None else channel_basin.channel_basin_model(h, CB_ALPHA, dz)
         fed = channel_basin_fe_data(mm, surface)
