@@ -181,6 +181,15 @@ int npg_csr_node_block_inverse(npg_csr *Dinv, const npg_csr *A, int64_t n_full, 
  * (ascending; the blocks partition [0, nu); at most 136 unknowns each), Dinv's pattern = exactly the blocks.  The z-line smoother
  * of the multigrid cycle: a block = the velocity unknowns of the nodes above one another (new work, csrc/mg.hip). */
 int npg_csr_line_block_inverse(npg_csr *Dinv, const npg_csr *A, const npg_index *block_ptr, const npg_index *block_dofs);
+/* S = D Dinv G for a line-block Dinv (npg_csr_line_block_inverse) without the generic triple product's n_line-fold work: per
+ * line l the dense W_l = B_l G[l, :] over the line's distinct pressure columns wcols[wptr[l] .. wptr[l+1]) (ascending), stored at
+ * woff[l] (n_l x m_l, row-major; woff's bound = total + 1); then row p of S sums D[p, l] W_l over the lines it touches.  dperm:
+ * D's entry positions sorted by (row, line, column); dpos: the position of each such entry's column inside its line; segment s =
+ * entries [seg_start[s], seg_start[s+1]) of that order = one (row, line) pair, line seg_line[s]; row p owns segments
+ * [seg_ptr[p], seg_ptr[p+1]).  All index arrays are the caller's (host logic on patterns: nupgcm_amd/multigrid.py). */
+int npg_csr_line_schur(npg_csr *S, const npg_csr *D, const npg_csr *Dinv, const npg_csr *G, const npg_index *wptr,
+                       const npg_index *wcols, const npg_index *woff, const npg_index *dperm, const npg_index *dpos,
+                       const npg_index *seg_ptr, const npg_index *seg_line, const npg_index *seg_start);
 /* C = A B on C's FIXED pattern (plain CSR; an error if a product falls outside it) */
 int npg_csr_product(npg_csr *C, const npg_csr *A, const npg_csr *B);
 int npg_csr_triple_product(npg_csr *S, const npg_csr *D, const npg_csr *Dinv, const npg_csr *G);

@@ -155,6 +155,14 @@ struct npg_csr {
     uint16_t *dwidx = nullptr;   // device, window index of every coupling record (windowed tiles of the rows behind the block rows)
     int32_t *dbk = nullptr;      // device, per row behind the block rows: tile-local end offset of its coupling record PAIRS
     int32_t nwrow_tiles = 0;     // windowed tiles of the rows behind the block rows (0: those rows keep their ordinary tiles)
+    // block-diagonal matrix with arbitrary index sets as blocks (npg_csr_line_block_inverse): the blocks also packed DENSE,
+    // column-major, one after the other - what products with it stream instead of the CSR arrays (k_line_apply, csr.hip)
+    int64_t lb_nblocks = 0;
+    int64_t *lb_ptr = nullptr;   // device, [nblocks + 1] offsets into lb_dofs
+    int64_t *lb_dofs = nullptr;  // device, the blocks' rows / columns, ascending per block
+    int64_t *lb_off = nullptr;   // device, [nblocks + 1] offsets of the dense blocks (sum of n^2)
+    double *lb_val = nullptr;    // device, the dense blocks
+    float *lb_val32 = nullptr;   //         and rounded to fp32 (products that ask for fp32 operator values)
     int64_t ndrec_real = 0;      // coupling records without the zero records that pad a row's list to an even count
     int64_t nwlist = 0, nvlist = 0;
     int64_t nrec_real = 0;       // node records without the zero records that pad a node's list to an even count

@@ -1222,6 +1222,8 @@ NPG_API int npg_csr_destroy(npg_csr *A) {
     if (A->dval) hipFree(A->dval);
     if (A->dval32) hipFree(A->dval32);
     free_window_tiles(A);
+    for (void *q : {(void *)A->lb_ptr, (void *)A->lb_dofs, (void *)A->lb_off, (void *)A->lb_val, (void *)A->lb_val32})
+        if (q) hipFree(q);
     if (A->uperm) hipFree(A->uperm);
     for (double *p : A->uvec)
         if (p) hipFree(p);
@@ -1422,7 +1424,9 @@ __global__ void k_node_block_inverse(const int64_t *__restrict__ arp, const int3
 __global__ void __launch_bounds__(256) k_line_block_inverse(const int64_t *__restrict__ arp, const int32_t *__restrict__ acol,
                                                             const double *__restrict__ aval, const int64_t *__restrict__ bp,
                                                             const int64_t *__restrict__ dofs, int64_t nblocks,
-                                                            const int64_t *__restrict__ drp, double *__restrict__ dval, int *bad) {
+                                                            const int64_t *__restrict__ drp, double *__restrict__ dval,
+                                                            const int64_t *__restrict__ boff, double *__restrict__ dense,
+                                                            float *__restrict__ dense32, int *bad) {
     extern __shared__ double lds[];
     __shared__ int flag;
     for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
@@ -1470,9 +1474,13 @@ __global__ void __launch_bounds__(256) k_line_block_inverse(const int64_t *__res
                 if (i != k) M[i * n + k] = -M[i * n + k] * ip;
             __syncthreads();
         }
+        const int64_t o = boff[b];
         for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
             const int i = e / n, j = e - i * n;
             dval[drp[ids[i]] + j] = M[e];
+            const double t = M[j * n + i];                    // dense pack: column-major, entry (j, i) at o + i n + j
+            dense[o + e] = t;
+            dense32[o + e] = (float)t;
         }
         if (threadIdx.x == 0 && flag) atomicAdd(bad, 1);
     }
@@ -1598,6 +1606,91 @@ NPG_API int npg_csr_node_block_inverse(npg_csr *Dinv, const npg_csr *A, int64_t 
     return NPG_OK;
 }
 
+// S = D Dinv G for a LINE-block Dinv (npg_csr_line_block_inverse) in two passes that never touch a product twice:
+//   W_l = B_l G[l, :]   per line l: its dense inverse block times its rows of G, as a dense n_l x m_l array over the line's distinct
+//                        pressure columns wcols[wptr[l] ..) (one workgroup per line, W_l accumulated in LDS);
+//   S[p, :] = sum over the lines l that row p of D touches of D[p, l] W_l   (one wavefront per row: lanes over W_l's columns, the
+//                        row's entries of D pre-sorted by line on the host; sums accumulated in LDS in a fixed order).
+// The generic triple product (k_triple_product) costs n_l times more on such a Dinv: 1.7 s against milliseconds at 3.9 M unknowns.
+__global__ void __launch_bounds__(256) k_line_schur_w(const int64_t *__restrict__ bp, const int64_t *__restrict__ dofs,
+                                                      const int64_t *__restrict__ boff, const double *__restrict__ B, int64_t nlines,
+                                                      const int64_t *__restrict__ grp, const int32_t *__restrict__ gcol,
+                                                      const double *__restrict__ gval, const int64_t *__restrict__ wptr,
+                                                      const int64_t *__restrict__ wcols, const int64_t *__restrict__ woff,
+                                                      double *__restrict__ W, int *missing) {
+    extern __shared__ double lds[];
+    for (int64_t l = blockIdx.x; l < nlines; l += gridDim.x) {
+        const int64_t b0 = bp[l];
+        const int n = (int)(bp[l + 1] - b0), m = (int)(wptr[l + 1] - wptr[l]);
+        const double *__restrict__ Bb = B + boff[l];
+        const int64_t *__restrict__ wc = wcols + wptr[l];
+        __syncthreads();
+        for (int e = threadIdx.x; e < n * m; e += blockDim.x) lds[e] = 0.0;
+        __syncthreads();
+        for (int k = 0; k < n; ++k) {
+            const int64_t r = dofs[b0 + k], g0 = grp[r];
+            const int ng = (int)(grp[r + 1] - g0);
+            // (i, e) pairs: row i of the block, entry e of G's row r - distinct entries, distinct columns of W: no two threads meet
+            for (int q = threadIdx.x; q < n * ng; q += blockDim.x) {
+                const int e = q / n, i = q - e * n;
+                const int64_t c = gcol[g0 + e];
+                int lo = 0, hi = m - 1, pos = -1;
+                while (lo <= hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const int64_t v = wc[mid];
+                    if (v == c) { pos = mid; break; }
+                    if (v < c) lo = mid + 1; else hi = mid - 1;
+                }
+                if (pos >= 0) lds[i * m + pos] += Bb[(size_t)k * n + i] * gval[g0 + e];
+                else if (i == 0) atomicAdd(missing, 1);
+            }
+            __syncthreads();
+        }
+        double *__restrict__ Wl = W + woff[l];
+        for (int e = threadIdx.x; e < n * m; e += blockDim.x) Wl[e] = lds[e];
+    }
+}
+
+constexpr int kMaxSchurRow = 1024;          // entries in one row of S that k_line_schur_s accumulates in LDS
+__global__ void __launch_bounds__(256) k_line_schur_s(int64_t np, const double *__restrict__ dval, const int64_t *__restrict__ dperm,
+                                                      const int64_t *__restrict__ dpos, const int64_t *__restrict__ seg_ptr,
+                                                      const int64_t *__restrict__ seg_line, const int64_t *__restrict__ seg_start,
+                                                      const int64_t *__restrict__ wptr, const int64_t *__restrict__ wcols,
+                                                      const int64_t *__restrict__ woff, const double *__restrict__ W,
+                                                      const int64_t *__restrict__ srp, const int32_t *__restrict__ scol,
+                                                      double *__restrict__ sval, int *missing) {
+    __shared__ double acc[4][kMaxSchurRow];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t p = (int64_t)blockIdx.x * 4 + w; p < np; p += (int64_t)gridDim.x * 4) {
+        const int64_t s0 = srp[p];
+        const int len = (int)(srp[p + 1] - s0);
+        for (int e = lane; e < len; e += 64) acc[w][e] = 0.0;
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t sg = seg_ptr[p]; sg < seg_ptr[p + 1]; ++sg) {
+            const int64_t l = seg_line[sg], e0 = seg_start[sg], e1 = seg_start[sg + 1];
+            const int m = (int)(wptr[l + 1] - wptr[l]);
+            const double *__restrict__ Wl = W + woff[l];
+            for (int c = lane; c < m; c += 64) {
+                double a = 0.0;
+                for (int64_t e = e0; e < e1; ++e) a += dval[dperm[e]] * Wl[dpos[e] * m + c];
+                const int32_t col = (int32_t)wcols[wptr[l] + c];
+                int lo = 0, hi = len - 1, pos = -1;
+                while (lo <= hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const int32_t v = scol[s0 + mid];
+                    if (v == col) { pos = mid; break; }
+                    if (v < col) lo = mid + 1; else hi = mid - 1;
+                }
+                if (pos >= 0) acc[w][pos] += a;          // (the columns of one line are distinct: no two lanes meet)
+                else atomicAdd(missing, 1);
+            }
+            __builtin_amdgcn_wave_barrier();             // (a wave's LDS operations complete in order: the next line sees these sums)
+        }
+        for (int e = lane; e < len; e += 64) sval[s0 + e] = acc[w][e];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 constexpr int kMaxLineBlock = 136;          // unknowns in one block: 136^2 doubles + ids = 148.5 KB of the CU's 160 KB of LDS
 NPG_API int npg_csr_line_block_inverse(npg_csr *Dinv, const npg_csr *A, const npg_index *block_ptr, const npg_index *block_dofs) {
     NPG_REQUIRE(Dinv && A && block_ptr && block_dofs, "npg_csr_line_block_inverse: NULL argument");
@@ -1633,17 +1726,97 @@ NPG_API int npg_csr_line_block_inverse(npg_csr *Dinv, const npg_csr *A, const np
     const size_t lds = (size_t)nmax * nmax * sizeof(double) + (size_t)nmax * sizeof(int32_t) + 8;
     NPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_line_block_inverse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     npg_ctx *ctx = A->ctx;
+    if (Dinv->lb_nblocks != nb || !Dinv->lb_val) {         // first call: the dense pack and the handle's own copy of the blocks
+        for (void *q : {(void *)Dinv->lb_ptr, (void *)Dinv->lb_dofs, (void *)Dinv->lb_off, (void *)Dinv->lb_val, (void *)Dinv->lb_val32})
+            if (q) hipFree(q);
+        Dinv->lb_ptr = Dinv->lb_dofs = Dinv->lb_off = nullptr;
+        Dinv->lb_val = nullptr;
+        Dinv->lb_val32 = nullptr;
+        Dinv->lb_nblocks = 0;
+        std::vector<int64_t> off((size_t)nb + 1, 0);
+        for (int64_t b = 0; b < nb; ++b) {
+            const int64_t n = bp[(size_t)b + 1] - bp[(size_t)b];
+            off[(size_t)b + 1] = off[(size_t)b] + n * n;
+        }
+        NPG_HIP(hipMalloc((void **)&Dinv->lb_ptr, bp.size() * sizeof(int64_t)));
+        NPG_HIP(hipMalloc((void **)&Dinv->lb_dofs, dofs.size() * sizeof(int64_t)));
+        NPG_HIP(hipMalloc((void **)&Dinv->lb_off, off.size() * sizeof(int64_t)));
+        NPG_HIP(hipMalloc((void **)&Dinv->lb_val, (size_t)total * sizeof(double)));
+        NPG_HIP(hipMalloc((void **)&Dinv->lb_val32, (size_t)total * sizeof(float)));
+        NPG_HIP(hipMemcpy(Dinv->lb_ptr, bp.data(), bp.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        NPG_HIP(hipMemcpy(Dinv->lb_dofs, dofs.data(), dofs.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        NPG_HIP(hipMemcpy(Dinv->lb_off, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        Dinv->lb_nblocks = nb;
+        Dinv->gen++;
+    }
     int *bad = reinterpret_cast<int *>(ctx->d_scratch);
     NPG_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
     const int grid = (int)std::min<int64_t>(nb, 8 * ctx->num_cu);
     hipLaunchKernelGGL(k_line_block_inverse, dim3(grid), dim3(256), lds, ctx->stream, A->rowptr, A->col, A->val, block_ptr->d, block_dofs->d,
-                       nb, Dinv->rowptr, Dinv->val, bad);
+                       nb, Dinv->rowptr, Dinv->val, (const int64_t *)Dinv->lb_off, Dinv->lb_val, Dinv->lb_val32, bad);
     NPG_HIP(hipGetLastError());
     int nbad = 0;
     NPG_HIP(hipMemcpyAsync(&nbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     NPG_HIP(hipStreamSynchronize(ctx->stream));
     NPG_REQUIRE(nbad == 0, "npg_csr_line_block_inverse: %d blocks are singular to working precision (zero or non-finite pivot)", nbad);
     return csr_repack(Dinv);
+}
+
+NPG_API int npg_csr_line_schur(npg_csr *S, const npg_csr *D, const npg_csr *Dinv, const npg_csr *G, const npg_index *wptr,
+                               const npg_index *wcols, const npg_index *woff, const npg_index *dperm, const npg_index *dpos,
+                               const npg_index *seg_ptr, const npg_index *seg_line, const npg_index *seg_start) {
+    NPG_REQUIRE(S && D && Dinv && G && wptr && wcols && woff && dperm && dpos && seg_ptr && seg_line && seg_start,
+                "npg_csr_line_schur: NULL argument");
+    NPG_REQUIRE(S->nnode() == 0 && D->nnode() == 0 && G->nnode() == 0, "npg_csr_line_schur: node-blocked matrices are not supported");
+    NPG_REQUIRE(Dinv->lb_nblocks > 0 && Dinv->lb_val, "npg_csr_line_schur: Dinv is not a line-block inverse (npg_csr_line_block_inverse)");
+    const int64_t nl = Dinv->lb_nblocks, np = S->m, nu = Dinv->m;
+    NPG_REQUIRE(D->n == nu && G->m == nu && D->m == np && S->n == G->n, "npg_csr_line_schur: shapes do not chain");
+    NPG_REQUIRE(wptr->n == nl + 1 && woff->n == nl + 1 && wcols->bound == G->n && dperm->n == D->nnz && dperm->bound == D->nnz &&
+                    dpos->n == D->nnz && seg_ptr->n == np + 1 && seg_start->n == seg_line->n + 1 && seg_line->bound == nl &&
+                    seg_start->bound == D->nnz + 1 && seg_ptr->bound == seg_line->n + 1,
+                "npg_csr_line_schur: the index arrays do not match the matrices (lines %lld, rows %lld, entries of D %lld)", (long long)nl,
+                (long long)np, (long long)D->nnz);
+    npg_ctx *ctx = S->ctx;
+    NPG_HIP(hipSetDevice(ctx->device));
+    std::vector<int64_t> h_woff((size_t)nl + 1);
+    NPG_HIP(hipStreamSynchronize(ctx->stream));
+    NPG_HIP(hipMemcpy(h_woff.data(), woff->d, h_woff.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    const int64_t wtotal = h_woff[(size_t)nl];
+    NPG_REQUIRE(h_woff[0] == 0 && wtotal == woff->bound - 1, "npg_csr_line_schur: woff must run from 0 to its bound - 1 = the size of the W arrays");
+    int64_t wmax = 0;
+    for (int64_t l = 0; l < nl; ++l) {
+        NPG_REQUIRE(h_woff[(size_t)l + 1] >= h_woff[(size_t)l], "npg_csr_line_schur: woff must ascend");
+        wmax = std::max(wmax, h_woff[(size_t)l + 1] - h_woff[(size_t)l]);
+    }
+    constexpr int64_t kMaxW = 150 * 1024 / 8;          // doubles of one W_l that fit the CU's LDS beside nothing else
+    NPG_REQUIRE(wmax <= kMaxW, "npg_csr_line_schur: a line's W block has %lld entries (limit %lld)", (long long)wmax, (long long)kMaxW);
+    int64_t max_row = 0;
+    for (int64_t r = 0; r < np; ++r) max_row = std::max(max_row, S->h_rowptr[(size_t)r + 1] - S->h_rowptr[(size_t)r]);
+    NPG_REQUIRE(max_row <= kMaxSchurRow, "npg_csr_line_schur: a row of S has %lld entries (limit %d)", (long long)max_row, kMaxSchurRow);
+    double *W = nullptr;
+    NPG_HIP(hipMalloc((void **)&W, std::max<size_t>(1, (size_t)wtotal) * sizeof(double)));
+    int *missing = reinterpret_cast<int *>(ctx->d_scratch);
+    NPG_HIP(hipMemsetAsync(missing, 0, sizeof(int), ctx->stream));
+    const size_t lds = std::max<size_t>(1024, (size_t)wmax * sizeof(double));          // LDS of the W pass: the largest n_l m_l
+    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(k_line_schur_w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) { hipFree(W); NPG_HIP(ea); }
+    hipLaunchKernelGGL(k_line_schur_w, dim3((unsigned)std::min<int64_t>(nl, 4 * ctx->num_cu)), dim3(256), lds, ctx->stream,
+                       (const int64_t *)Dinv->lb_ptr, (const int64_t *)Dinv->lb_dofs, (const int64_t *)Dinv->lb_off, (const double *)Dinv->lb_val, nl,
+                       G->rowptr, G->col, G->val, (const int64_t *)wptr->d, (const int64_t *)wcols->d, (const int64_t *)woff->d, W, missing);
+    hipLaunchKernelGGL(k_line_schur_s, dim3((unsigned)std::min<int64_t>((np + 3) / 4, 16 * ctx->num_cu)), dim3(256), 0, ctx->stream, np,
+                       (const double *)D->val, (const int64_t *)dperm->d, (const int64_t *)dpos->d, (const int64_t *)seg_ptr->d,
+                       (const int64_t *)seg_line->d, (const int64_t *)seg_start->d, (const int64_t *)wptr->d, (const int64_t *)wcols->d,
+                       (const int64_t *)woff->d, (const double *)W, S->rowptr, S->col, S->val, missing);
+    hipError_t el = hipGetLastError();
+    int miss = 0;
+    hipError_t ec = hipMemcpyAsync(&miss, missing, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t es = hipStreamSynchronize(ctx->stream);
+    hipFree(W);
+    NPG_HIP(el);
+    NPG_HIP(ec);
+    NPG_HIP(es);
+    NPG_REQUIRE(miss == 0, "npg_csr_line_schur: %d products fall outside the patterns handed in", miss);
+    return NPG_OK;
 }
 
 NPG_API int npg_csr_triple_product(npg_csr *S, const npg_csr *D, const npg_csr *Dinv, const npg_csr *G) {
@@ -1693,9 +1866,77 @@ NPG_API int npg_csr_inv_diag(const npg_csr *A, npg_vec *d) {
 }
 
 namespace npg {
+// y = alpha B x + beta c for a block-diagonal B held as dense column-major blocks (npg_csr_line_block_inverse): one wavefront per
+// block, lane = row (two rows per lane from 65 unknowns on), the block's x staged in LDS; a column is one contiguous read
+template <typename T>
+__global__ void __launch_bounds__(256) k_line_apply(const int64_t *__restrict__ bp, const int64_t *__restrict__ dofs,
+                                                    const int64_t *__restrict__ boff, const T *__restrict__ B, int64_t nblocks,
+                                                    const double *__restrict__ x, double alpha, double beta, const double *c,
+                                                    double *y) {
+    constexpr int kMaxN = 136;
+    __shared__ double xs[4][kMaxN];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + w; b < nblocks; b += (int64_t)gridDim.x * 4) {
+        const int64_t b0 = bp[b];
+        const int n = (int)(bp[b + 1] - b0);
+        const T *__restrict__ Bb = B + boff[b];
+        int64_t r0 = -1, r1 = -1, r2 = -1;
+        if (lane < n) r0 = dofs[b0 + lane];
+        if (lane + 64 < n) r1 = dofs[b0 + lane + 64];
+        if (lane + 128 < n) r2 = dofs[b0 + lane + 128];
+        if (r0 >= 0) xs[w][lane] = x[r0];
+        if (r1 >= 0) xs[w][lane + 64] = x[r1];
+        if (r2 >= 0) xs[w][lane + 128] = x[r2];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the wave's LDS stores have landed (a wave is in lock-step)
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        if (n <= 64) {
+            int j = 0;
+            for (; j + 4 <= n; j += 4) {
+                T v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                if (lane < n) {
+                    v0 = Bb[(size_t)j * n + lane]; v1 = Bb[(size_t)(j + 1) * n + lane];
+                    v2 = Bb[(size_t)(j + 2) * n + lane]; v3 = Bb[(size_t)(j + 3) * n + lane];
+                }
+                a0 += (double)v0 * xs[w][j] + (double)v1 * xs[w][j + 1] + (double)v2 * xs[w][j + 2] + (double)v3 * xs[w][j + 3];
+            }
+            for (; j < n; ++j)
+                if (lane < n) a0 += (double)Bb[(size_t)j * n + lane] * xs[w][j];
+        } else {
+            for (int j = 0; j < n; ++j) {
+                const double xv = xs[w][j];
+                const T *__restrict__ col = Bb + (size_t)j * n;
+                a0 += (double)col[lane] * xv;                                   // (n > 64: lane < n)
+                if (lane + 64 < n) a1 += (double)col[lane + 64] * xv;
+                if (lane + 128 < n) a2 += (double)col[lane + 128] * xv;
+            }
+        }
+        if (r0 >= 0) y[r0] = alpha * a0 + (beta != 0.0 ? beta * c[r0] : 0.0);
+        if (r1 >= 0) y[r1] = alpha * a1 + (beta != 0.0 ? beta * c[r1] : 0.0);
+        if (r2 >= 0) y[r2] = alpha * a2 + (beta != 0.0 ? beta * c[r2] : 0.0);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+static int line_apply(const npg_csr *A, const double *x, const SpmvEpi &e) {
+    const int grid = (int)std::min<int64_t>((A->lb_nblocks + 3) / 4, 16 * (int64_t)A->ctx->num_cu);
+    if (e.f32)
+        hipLaunchKernelGGL(k_line_apply<float>, dim3(std::max(grid, 1)), dim3(256), 0, A->ctx->stream, (const int64_t *)A->lb_ptr,
+                           (const int64_t *)A->lb_dofs, (const int64_t *)A->lb_off, (const float *)A->lb_val32, A->lb_nblocks, x, e.alpha, e.beta, e.c,
+                           e.y);
+    else
+        hipLaunchKernelGGL(k_line_apply<double>, dim3(std::max(grid, 1)), dim3(256), 0, A->ctx->stream, (const int64_t *)A->lb_ptr,
+                           (const int64_t *)A->lb_dofs, (const int64_t *)A->lb_off, (const double *)A->lb_val, A->lb_nblocks, x, e.alpha, e.beta, e.c,
+                           e.y);
+    NPG_HIP(hipGetLastError());
+    return NPG_OK;
+}
+
 // y[0, m) = alpha A x[0, n) + beta y on raw device pointers (x and y may be windows into larger vectors; they must not overlap)
 int spmv_epi(const npg_csr *Ap, const double *x, const SpmvEpi &e) {
     const npg_csr *A = spmv_form(Ap);
+    static const bool dense_blocks = !getenv("NPG_LINE_DENSE") || atoi(getenv("NPG_LINE_DENSE")) != 0;
+    if (A->lb_nblocks && !e.z && dense_blocks) return line_apply(A, x, e);
     if (int rc = check_record_view(A, true, "spmv")) return rc;
     switch (A->lanes) {
         case 4: launch_spmv<4>(A, x, e); break;

@@ -313,6 +313,25 @@ class _LevelOperators:
             Gl = sp.csr_matrix((np.ones(Gc.nnz, dtype=np.float32), (line_of[Gc.row], Gc.col)), shape=(nl, n - nu))
             Sp = sp.csr_matrix(Dl @ Gl)
             self.Gh = None                     # Dinv G would hold a whole line's pressure neighbours per row: not formed
+            # index arrays of npg_csr_line_schur (S = D Dinv G line by line): the lines' distinct pressure columns and dense W
+            # blocks, and D's entries sorted by (row, line) with their positions inside the lines
+            Gl.sort_indices()
+            sizes = np.diff(bp)
+            woff = np.zeros(nl + 1, dtype=np.int64)
+            np.cumsum(sizes * np.diff(Gl.indptr), out=woff[1:])
+            pos_in_line = np.empty(nu, dtype=np.int64)
+            pos_in_line[bd] = np.arange(nu) - bp[line_of[bd]]
+            rows = np.repeat(np.arange(n - nu, dtype=np.int64), np.diff(Dt.indptr))
+            lines = line_of[Dt.indices]
+            order = np.lexsort((Dt.indices, lines, rows)).astype(np.int64)
+            key = rows[order] * nl + lines[order]
+            cut = np.concatenate([[0], np.flatnonzero(np.diff(key)) + 1, [len(order)]]).astype(np.int64) if len(order) else np.zeros(1, np.int64)
+            seg_line = lines[order][cut[:-1]]
+            seg_ptr = np.searchsorted(rows[order][cut[:-1]], np.arange(n - nu + 1)).astype(np.int64)
+            self.schur = [DeviceIndex(ctx, Gl.indptr.astype(np.int64), Gl.nnz + 1), DeviceIndex(ctx, Gl.indices.astype(np.int64), n - nu),
+                          DeviceIndex(ctx, woff, int(woff[-1]) + 1), DeviceIndex(ctx, order, max(Dt.nnz, 1)),
+                          DeviceIndex(ctx, pos_in_line[Dt.indices[order]], int(sizes.max())), DeviceIndex(ctx, seg_ptr, len(seg_line) + 1),
+                          DeviceIndex(ctx, seg_line, nl), DeviceIndex(ctx, cut, Dt.nnz + 1)]
         elif smoother == "node":
             irp, icol = _node_block_pattern(nu, d.n_full, d.n_surf)
             self.Dinv = DeviceCSR.from_pattern(ctx, nu, nu, irp, icol)
@@ -342,7 +361,7 @@ class _LevelOperators:
             else:
                 L.check(L.lib().npg_csr_node_block_inverse(self.Dinv.h, A.h, int(self.n_full), int(self.n_surf)))
             lap("Dinv")
-            L.check(L.lib().npg_csr_triple_product(self.S.h, self.D.h, self.Dinv.h, self.G.h)); lap("S = D Dinv G")
+            self._schur(); lap("S = D Dinv G")
             if self.Gh is not None:
                 L.check(L.lib().npg_csr_product(self.Gh.h, self.Dinv.h, self.G.h)); lap("Dinv G")
             return self
@@ -352,10 +371,17 @@ class _LevelOperators:
             L.check(L.lib().npg_csr_line_block_inverse(self.Dinv.h, A.h, self.blocks[0].h, self.blocks[1].h))
         else:
             L.check(L.lib().npg_csr_node_block_inverse(self.Dinv.h, A.h, int(self.n_full), int(self.n_surf)))
-        L.check(L.lib().npg_csr_triple_product(self.S.h, self.D.h, self.Dinv.h, self.G.h))
+        self._schur()
         if self.Gh is not None:
             L.check(L.lib().npg_csr_product(self.Gh.h, self.Dinv.h, self.G.h))
         return self
+
+    def _schur(self):
+        """S = D Dinv G on S's fixed pattern: line by line for the z-line blocks, the generic triple product for node blocks"""
+        if self.smoother == "zline" and os.environ.get("NPG_MG_LINE_SCHUR", "1") != "0":
+            L.check(L.lib().npg_csr_line_schur(self.S.h, self.D.h, self.Dinv.h, self.G.h, *[ix.h for ix in self.schur]))
+        else:
+            L.check(L.lib().npg_csr_triple_product(self.S.h, self.D.h, self.Dinv.h, self.G.h))
 
 
 def injection(mesh_c: Mesh, mesh_f: Mesh, p1):
