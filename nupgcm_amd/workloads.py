@@ -168,11 +168,17 @@ def channel_basin_model(arch, h=None, dz=None, mesh_model=None, surface="flux", 
         hier = [channel_basin_fe_data(m, surface) for m in channel_basin_hierarchy_models(h, levels, dz)]
         fed = hier[-1]
         inv_kw = dict(inv_kw, hierarchy=hier, preconditioner="multigrid")
-        # Braess-Sarazin scaling: the bowl's optimum (omega = 2.5, tools/mg_sweep.py) is not this mesh's - on the anisotropic
-        # channel cells 2.0 needs a quarter fewer outer iterations (48-58 against 62-77 at 3.9 M unknowns), 1.8 as many, and
-        # 1.5 is past the edge at production size (blow-up) although it is the best at h = 0.02 (tools/mg_sweep_channel.py,
-        # tools/mg_channel_omega.py)
-        inv_kw["precond_kw"] = dict(dict(omega=float(os.environ.get("NPG_MG_OMEGA", 2.0))), **(inv_kw.get("precond_kw") or {}))
+        # The cycle for these anisotropic cells (alpha = 1/8, a dozen cells deep at production size): the z-LINE smoother (the
+        # velocity blocks of Braess-Sarazin = the unknowns of the nodes above one another), fp32 operator values inside the cycle,
+        # 60 smoothing steps on the coarsest level (58 k unknowns: too large for the dense inverse to follow the eddy closure's
+        # re-assembly) and omega = 1.7 - 297 ms per timestep at 3.9 M unknowns against 479 with the node-block smoother at its
+        # own optimum (omega = 2.0, 20 coarse steps; 1.5 blows up there), outer iterations 16 / 24-31 after a re-assembly against
+        # 55-77 (profiles/r04_zline_smoother.txt; NPG_MG_SMOOTHER=node, NPG_MG_OMEGA, NPG_MG_PARAMS override)
+        if os.environ.get("NPG_MG_SMOOTHER", "zline") == "zline":
+            dflt = dict(smoother="zline", mixed=True, coarse_sweeps=60, omega=float(os.environ.get("NPG_MG_OMEGA", 1.7)))
+        else:
+            dflt = dict(smoother="node", omega=float(os.environ.get("NPG_MG_OMEGA", 2.0)))
+        inv_kw["precond_kw"] = dict(dflt, **(inv_kw.get("precond_kw") or {}))
     else:
         mm = mesh_model if mesh_model is not None else channel_basin.channel_basin_model(h, CB_ALPHA, dz)
         fed = channel_basin_fe_data(mm, surface)
