@@ -120,11 +120,12 @@ def test_velocity_block_of_the_reference_with_ilu0(arch):
     assert 2 * inner_i < inner_j, (inner_i, inner_j)            # (both counts include the pressure block's Jacobi-CG iterations)
     with pytest.raises(ValueError):
         npg.BlockDiagonalPreconditioner(arch, prm, fed, u_precond="ssor")
-    inv = npg.InversionToolkit(arch, fed, prm, frc, preconditioner="block_diagonal", atol=1e-8, rtol=1e-8,
+    # (every inner iteration is two triangular solves of hundreds of level launches: a loose outer tolerance keeps the test short)
+    inv = npg.InversionToolkit(arch, fed, prm, frc, preconditioner="block_diagonal", atol=1e-5, rtol=1e-5,
                                precond_kw=dict(u_itmax=100, p_itmax=0, u_precond="ilu0"))
     bfree = S.orc.interpolate_b(lambda x: 0.1 * np.exp(-(x[..., 2] + 0.5 * (1 - x[..., 0] ** 2 - x[..., 1] ** 2)) / 0.05))
     npg.inversion.invert(inv, npg.DeviceVector.from_host(ctx, bfree, d.p_b))
     st = inv.solver.workspace.stats
     x = inv.solver.x.to_host(d.inv_p_inversion)
     xd = spla.splu(sp.csc_matrix(S.A)).solve(S.B @ bfree + S.b0)
-    assert st["solved"] == 1 and rel(x[:d.nu], xd[:d.nu]) < 1e-5
+    assert st["solved"] == 1 and rel(x[:d.nu], xd[:d.nu]) < 1e-3
