@@ -392,3 +392,109 @@ def test_zline_smoother_on_the_channel_basin(arch):
     assert rel(out["zline"][1][:d.nu], out["node"][1][:d.nu]) < 1e-4
     with pytest.raises(ValueError):
         mgm.MultigridPreconditioner(arch, prm, frc, hier[-2:], smoother="plane")
+
+
+def test_line_block_entry_points_on_a_synthetic_matrix(arch):
+    """npg_csr_line_block_inverse / npg_csr_line_schur / npg_csr_product / npg_csr_set_lanes through the C ABI on a matrix that is
+    no finite-element matrix at all: ragged blocks (1 .. 70 unknowns, interleaved index sets), results against numpy; products
+    with the block inverse (dense pack, fp64 and fp32) against the CSR form; and the argument checks of each entry point."""
+    from nupgcm_amd.architectures import DeviceIndex
+    ctx = arch.ctx
+    rng = np.random.default_rng(5)
+    sizes = np.array([1, 2, 70, 3, 65, 17, 64, 5, 33, 128])
+    nu, npp = int(sizes.sum()), 40
+    perm = rng.permutation(nu)
+    bp = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    bd = np.concatenate([np.sort(perm[bp[b]:bp[b + 1]]) for b in range(len(sizes))]).astype(np.int64)
+    line_of = np.empty(nu, dtype=np.int64)
+    for b in range(len(sizes)):
+        line_of[bd[bp[b]:bp[b + 1]]] = b
+    F = sp.random(nu, nu, 0.05, random_state=3, format="csr")
+    F = sp.csr_matrix(F + F.T + sp.diags(np.asarray(abs(F + F.T).sum(axis=1)).ravel() + 1.0))
+    G = sp.csr_matrix(sp.random(nu, npp, 0.08, random_state=4, format="csr"))
+    D = sp.csr_matrix(sp.random(npp, nu, 0.08, random_state=6, format="csr"))
+    A = sp.csr_matrix(sp.bmat([[F, G], [D, None]]))
+    Ad = npg.DeviceCSR.from_scipy(ctx, A)
+    irp, icol = mgm._line_block_pattern(nu, bp, bd, line_of)
+    Dinv = npg.DeviceCSR.from_pattern(ctx, nu, nu, irp, icol)
+    ip, idf = DeviceIndex(ctx, bp, nu + 1), DeviceIndex(ctx, bd, nu)
+    L = npg._lib
+    L.check(L.lib().npg_csr_line_block_inverse(Dinv.h, Ad.h, ip.h, idf.h))
+    Dh = mgm.line_block_inverse(F, bp, bd)
+    assert abs(Dinv.to_scipy_csr() - Dh).max() < 1e-11 * abs(Dh).max()
+    # products with it: dense pack (default) in fp64, against scipy
+    x = rng.standard_normal(nu)
+    y = Dinv.mul(npg.DeviceVector.from_host(ctx, x)).to_host()
+    assert rel(y, Dh @ x) < 1e-12
+    # S = D Dinv G line by line against the generic triple product and numpy
+    Gd, Dd = npg.DeviceCSR.from_scipy(ctx, G), npg.DeviceCSR.from_scipy(ctx, D)
+    Sref = sp.csr_matrix(D @ Dh @ G)
+    one = lambda M: sp.csr_matrix((np.ones(M.nnz), M.indices, M.indptr), shape=M.shape)
+    Gs, Ds = sp.csr_matrix(G), sp.csr_matrix(D)
+    Gs.sort_indices(); Ds.sort_indices()
+    nl = len(sizes)
+    Dl = sp.csr_matrix((np.ones(Ds.nnz), line_of[Ds.indices], Ds.indptr), shape=(npp, nl))
+    Gc = sp.coo_matrix(Gs)
+    Gl = sp.csr_matrix((np.ones(Gc.nnz), (line_of[Gc.row], Gc.col)), shape=(nl, npp))
+    Gl.sort_indices()
+    Sp = sp.csr_matrix(Dl @ Gl)
+    Sp.sort_indices()
+    S1 = npg.DeviceCSR.from_pattern(ctx, npp, npp, Sp.indptr, Sp.indices)
+    S2 = npg.DeviceCSR.from_pattern(ctx, npp, npp, Sp.indptr, Sp.indices)
+    woff = np.concatenate([[0], np.cumsum(sizes * np.diff(Gl.indptr))]).astype(np.int64)
+    pos = np.empty(nu, dtype=np.int64)
+    pos[bd] = np.arange(nu) - bp[line_of[bd]]
+    rows = np.repeat(np.arange(npp, dtype=np.int64), np.diff(Ds.indptr))
+    lines = line_of[Ds.indices]
+    order = np.lexsort((Ds.indices, lines, rows)).astype(np.int64)
+    key = rows[order] * nl + lines[order]
+    cut = np.concatenate([[0], np.flatnonzero(np.diff(key)) + 1, [len(order)]]).astype(np.int64)
+    seg_line = lines[order][cut[:-1]]
+    seg_ptr = np.searchsorted(rows[order][cut[:-1]], np.arange(npp + 1)).astype(np.int64)
+    idx = [DeviceIndex(ctx, Gl.indptr.astype(np.int64), Gl.nnz + 1), DeviceIndex(ctx, Gl.indices.astype(np.int64), npp),
+           DeviceIndex(ctx, woff, int(woff[-1]) + 1), DeviceIndex(ctx, order, Ds.nnz), DeviceIndex(ctx, pos[Ds.indices[order]], int(sizes.max())),
+           DeviceIndex(ctx, seg_ptr, len(seg_line) + 1), DeviceIndex(ctx, seg_line, nl), DeviceIndex(ctx, cut, Ds.nnz + 1)]
+    Dd_sorted, Gd_sorted = npg.DeviceCSR.from_scipy(ctx, Ds), npg.DeviceCSR.from_scipy(ctx, Gs)      # (kept: the calls borrow them)
+    L.check(L.lib().npg_csr_line_schur(S1.h, Dd_sorted.h, Dinv.h, Gd_sorted.h, *[i.h for i in idx]))
+    L.check(L.lib().npg_csr_triple_product(S2.h, Dd.h, Dinv.h, Gd.h))
+    assert abs(S1.to_scipy_csr() - Sref).max() < 1e-11 * abs(Sref).max() and abs(S2.to_scipy_csr() - Sref).max() < 1e-11 * abs(Sref).max()
+    # C = A B on a fixed pattern; lanes per row
+    Tp = sp.csr_matrix(one(Dh) @ one(Gs))
+    Tp.sort_indices()
+    T = npg.DeviceCSR.from_pattern(ctx, nu, npp, Tp.indptr, Tp.indices)
+    L.check(L.lib().npg_csr_product(T.h, Dinv.h, Gd_sorted.h))
+    assert abs(T.to_scipy_csr() - Dh @ G).max() < 1e-11 * abs(Dh @ G).max()
+    xs = rng.standard_normal(npp)
+    for lanes in (4, 8, 16, 32, 0):
+        assert rel(T.set_lanes(lanes).mul(npg.DeviceVector.from_host(ctx, xs)).to_host(), (Dh @ G) @ xs) < 1e-12
+    # argument checks
+    with pytest.raises(L.DeviceError, match="lanes"):
+        T.set_lanes(5)
+    with pytest.raises(L.DeviceError, match="shapes"):
+        L.check(L.lib().npg_csr_product(T.h, Dinv.h, Dd.h))
+    with pytest.raises(L.DeviceError, match="outside"):
+        Tsmall = npg.DeviceCSR.from_pattern(ctx, nu, npp, np.arange(nu + 1, dtype=np.int64), np.zeros(nu, dtype=np.int32))
+        L.check(L.lib().npg_csr_product(Tsmall.h, Dinv.h, Gd_sorted.h))
+    with pytest.raises(L.DeviceError, match="ascending"):
+        bad = bd.copy()
+        bad[bp[2]], bad[bp[2] + 1] = bad[bp[2] + 1], bad[bp[2]]
+        ibad = DeviceIndex(ctx, bad, nu)
+        L.check(L.lib().npg_csr_line_block_inverse(Dinv.h, Ad.h, ip.h, ibad.h))
+    with pytest.raises(L.DeviceError, match="pattern|hold"):
+        Dn = npg.DeviceCSR.from_pattern(ctx, nu, nu, *mgm._node_block_pattern(nu, 0, 0))
+        L.check(L.lib().npg_csr_line_block_inverse(Dn.h, Ad.h, ip.h, idf.h))
+    with pytest.raises(L.DeviceError, match="unknowns"):
+        big = np.array([0, nu], dtype=np.int64)                 # one block of 388 unknowns: beyond the LDS budget
+        ibig, iall = DeviceIndex(ctx, big, nu + 1), DeviceIndex(ctx, np.arange(nu), nu)
+        L.check(L.lib().npg_csr_line_block_inverse(Dinv.h, Ad.h, ibig.h, iall.h))
+    with pytest.raises(L.DeviceError, match="line-block"):
+        L.check(L.lib().npg_csr_line_schur(S1.h, Dd_sorted.h, T.h, Gd.h, *[i.h for i in idx]))
+    with pytest.raises(L.DeviceError, match="index arrays"):
+        wrong = list(idx)
+        wrong[5] = DeviceIndex(ctx, seg_ptr[:-1], len(seg_line) + 1)
+        L.check(L.lib().npg_csr_line_schur(S1.h, Dd_sorted.h, Dinv.h, Gd.h, *[i.h for i in wrong]))
+    Fs = sp.csr_matrix(F.copy())
+    Fs.data[Fs.indptr[bd[bp[3]]]:Fs.indptr[bd[bp[3]] + 1]] = 0.0                      # a zero row inside block 3: singular
+    with pytest.raises(L.DeviceError, match="singular"):
+        As = npg.DeviceCSR.from_scipy(ctx, sp.csr_matrix(sp.bmat([[Fs, G], [D, None]])))
+        L.check(L.lib().npg_csr_line_block_inverse(Dinv.h, As.h, ip.h, idf.h))
