@@ -421,4 +421,41 @@ function nuPGCM.update_Δt!(ts::nuPGCM.BDF1, u, dΩ, h_cells::Vector{Float64}; u
     return ts
 end
 
+# ---- P_block_setup(::GPU, A): src/preconditioners.jl:101-107 with the library's ILU(0) instead of KrylovPreconditioners.kp_ilu0 ----
+# The reference builds `P_prec = kp_ilu0(P)` for a CuSparseMatrixCSR and hands it to its CgPreconditioner with ldiv = true; for a
+# HIPSparseMatrixCSR the factors are npg_ilu0_create's (level-scheduled csrilu02 / csrsv2 counterparts, csrc/ilu.hip), and the
+# block's whole CG - `mul!(y, cgp, x)`, :24-37 - is one call (npg_cg_ilu0_solve: Krylov.jl's cg with M = the factors, warm-started
+# from the previous output like `cgp.workspace.x`).
+mutable struct HIPILU0
+    h::Ptr{Cvoid}
+    A::HIPSparseMatrixCSR{Float64}          # kept alive: the CG multiplies with it
+    function HIPILU0(A::HIPSparseMatrixCSR{Float64})
+        out = Ref{Ptr{Cvoid}}()
+        check(@ccall lib.npg_ilu0_create(ctx()::Ptr{Cvoid}, A.h::Ptr{Cvoid}, out::Ptr{Ptr{Cvoid}})::Cint)
+        f = new(out[], A)
+        finalizer(x -> @ccall(lib.npg_ilu0_destroy(x.h::Ptr{Cvoid})::Cint), f)
+    end
+end
+LinearAlgebra.ldiv!(y::HIPVector, F::HIPILU0, x::HIPVector) =
+    (check(@ccall lib.npg_ilu0_apply(F.h::Ptr{Cvoid}, x.h::Ptr{Cvoid}, y.h::Ptr{Cvoid})::Cint); y)
+
+struct HIPCgIlu0Preconditioner <: nuPGCM.Preconditioner
+    F::HIPILU0
+    x::HIPVector{Float64}                   # workspace.x of the reference's CgPreconditioner: the warm start, zero at first
+    itmax::Int
+    label::String
+end
+function nuPGCM.P_block_setup(::GPU, A::HIPSparseMatrixCSR{Float64}; tag = "")
+    F = HIPILU0(A)
+    return HIPCgIlu0Preconditioner(F, fill!(HIPVector{Float64}(size(A, 1)), 0.0), 100, "P$tag-block")
+end
+function LinearAlgebra.mul!(y::HIPVector, cgp::HIPCgIlu0Preconditioner, x::HIPVector)
+    st = Ref{SolveStats}()
+    # (the reference passes no tolerances here: Krylov.jl's defaults, atol = rtol = sqrt(eps))
+    check(@ccall lib.npg_cg_ilu0_solve(cgp.F.h::Ptr{Cvoid}, cgp.F.A.h::Ptr{Cvoid}, x.h::Ptr{Cvoid}, cgp.x.h::Ptr{Cvoid},
+                                       sqrt(eps(Float64))::Float64, sqrt(eps(Float64))::Float64, cgp.itmax::Int64, st::Ptr{SolveStats})::Cint)
+    @debug "$(cgp.label) iterative solve: solved=$(st[].solved != 0), niter=$(st[].niter), time=$(st[].seconds)"
+    return copyto!(y, cgp.x)
+end
+
 end # module
