@@ -535,7 +535,7 @@ class DistributedMultigridPreconditioner:
     re-assembled on the device with the injected buoyancy's viscosity, as on one GPU)."""
 
     def __init__(self, arch, params, forcings, hierarchy, model, omega=2.5, jacobi_weight=0.7, schur_sweeps=3, nu1=2, nu2=2,
-                 coarse_sweeps=20, cycle="V", coarse_dense=None, distributed_levels=1):
+                 coarse_sweeps=20, cycle="V", coarse_dense=None, distributed_levels=1, smoother=None):
         """distributed_levels: 1 = the finest level row-partitioned, every coarser level replicated; 2 = the level below it
         partitioned as well (a coarse node belongs to the rank that owns the fine node it coincides with; its rows are assembled
         on that rank's cells of the coarse mesh; P / R between the two levels are row blocks with halo plans of their own) -
@@ -550,6 +550,11 @@ class DistributedMultigridPreconditioner:
         if distributed_levels == 2 and len(hierarchy) < 3:
             raise ValueError("two distributed levels need a hierarchy of >= 3 levels (the coarsest stays replicated)")
         self.distributed_levels = distributed_levels
+        # "zline": the velocity blocks of the smoother are the unknowns of the nodes above one another (multigrid.line_blocks) -
+        # on a partitioned level the part of each line that this rank owns (a line cut by a rank boundary smooths in pieces)
+        self.smoother = smoother or os.environ.get("NPG_MG_SMOOTHER", "node")
+        if self.smoother not in ("node", "zline"):
+            raise ValueError(f"smoother = {self.smoother!r} (\"node\" or \"zline\")")
         ctx = arch.ctx
         self.ctx, self.arch = ctx, arch
         self.prm, self.frc, self.hierarchy = params, forcings, hierarchy
@@ -564,7 +569,7 @@ class DistributedMultigridPreconditioner:
         for lev, fed in enumerate(hierarchy[:len(hierarchy) - distributed_levels]):
             d = fed.dofs
             A = build_A_inversion(arch, fed, params, forcings.nu, structural=full)
-            ops = mgm._LevelOperators(ctx, fed, fed.pattern_A(structural=full)).update(A)
+            ops = mgm._LevelOperators(ctx, fed, fed.pattern_A(structural=full), smoother=self.smoother).update(A)
             if not full and A.shape[0] >= 100000:
                 A.block_nodes(d.n_full, d.n_surf)
             Pd = Rd = None
@@ -576,7 +581,7 @@ class DistributedMultigridPreconditioner:
             self.cops.append(ops)
             L.check(L.lib().npg_precond_mg_set_level(self.h, lev, A.h, int(d.nu), ops.G.h, ops.D.h, ops.Dinv.h, ops.S.h,
                                                      None if Pd is None else Pd.h, None if Rd is None else Rd.h))
-            if os.environ.get("NPG_MG_SCALED_GRADIENT", "1") != "0":
+            if os.environ.get("NPG_MG_SCALED_GRADIENT", "1") != "0" and ops.Gh is not None:
                 L.check(L.lib().npg_precond_mg_set_scaled_gradient(self.h, lev, ops.Gh.h))
             self.levels.append(d.nu + d.np)
             prev = fed
@@ -706,8 +711,16 @@ class DistributedMultigridPreconditioner:
         Ah = Ah.tocsc()
         G0 = sp.csr_matrix(Ah[:nu_o][:, p_cols_A])                            # own_u x [own_p | ghost p of A]
         Dh = sp.csr_matrix(Ah[nu_o:n_own][:, u_cols])                         # own_p x [own_u | ghost u]
-        nfl, nsl = part.local_nodes(rank)
-        Dinv = mgm.node_block_inverse(sp.csr_matrix(Ah[:nu_o][:, :nu_o]), nfl, nsl)
+        if self.smoother == "zline":
+            if "lines" not in lv.st:                                          # this rank's pieces of the level's lines
+                line_of = mgm.line_blocks(fed)[2][f.owned[:nu_o]]
+                order = np.lexsort((np.arange(nu_o), line_of)).astype(np.int64)
+                cut = np.concatenate([[0], np.flatnonzero(np.diff(line_of[order])) + 1, [nu_o]]).astype(np.int64)
+                lv.st["lines"] = (cut, order)
+            Dinv = mgm.line_block_inverse(sp.csr_matrix(Ah[:nu_o][:, :nu_o]), *lv.st["lines"])
+        else:
+            nfl, nsl = part.local_nodes(rank)
+            Dinv = mgm.node_block_inverse(sp.csr_matrix(Ah[:nu_o][:, :nu_o]), nfl, nsl)
         # T = Dinv G on the owned velocity rows, columns as GLOBAL pressure ids; its ghost rows come from their owners
         T = sp.csr_matrix(Dinv @ G0)
         T = sp.csr_matrix((T.data, g[p_cols_A][T.indices], T.indptr), shape=(nu_o, fed.dofs.nu + fed.dofs.np))
@@ -845,7 +858,8 @@ class DistributedMultigridPreconditioner:
 
     def __repr__(self):
         return (f"DistributedMultigridPreconditioner({self.levels}: finest level row-partitioned, coarser ones replicated; "
-                f"{self.params}, coarsest level: {'dense inverse' if self.coarse_dense else 'smoothing steps'})")
+                f"{self.params}, coarsest level: {'dense inverse' if self.coarse_dense else 'smoothing steps'}"
+                f"{', z-line smoother' if self.smoother == 'zline' else ''})")
 
 
 def use_multigrid(model, hierarchy, memory=20, **mg_kw):

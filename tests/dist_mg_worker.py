@@ -27,7 +27,8 @@ def main():
         # (itmax: a preconditioner gone wrong fails the test's `solved` check instead of iterating to 2 N)
         m = partition.channel_basin_model(arch, models[-1], dist, element_precision="fp64", itmax=0 if nlev == 1 else 2000, fe_data=hier[-1],
                                           invert_now=False)
-        partition.use_multigrid(m, hier, omega=2.0, distributed_levels=nlev)
+        zl = os.environ.get("NPG_TEST_SMOOTHER", "node") == "zline"          # the z-line blocks, cut at the rank boundaries
+        partition.use_multigrid(m, hier, omega=1.7 if zl else 2.0, distributed_levels=nlev, smoother="zline" if zl else "node")
         assert m.verify_transport()
     else:
         nlev = int(sys.argv[4]) if len(sys.argv) > 4 else 1              # distributed multigrid levels (1 or 2)

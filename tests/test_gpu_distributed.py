@@ -229,6 +229,37 @@ def test_distributed_multigrid_follows_the_eddy_closure(tmp_path):
     assert rel(z["b"], ref.state.b) < 1e-4 and rel(z["u"], ref.state.u) < 5e-3 and rel(z["p"], ref.state.p) < 5e-3
 
 
+def test_distributed_multigrid_with_the_zline_smoother(tmp_path):
+    """the z-line smoother on a partitioned level: every rank inverts the pieces of the vertical lines it owns (a line cut by a
+    rank boundary smooths in pieces, so the counts are not the one-GPU cycle's to the digit) - channel basin, 3 ranks, through the
+    eddy closure's re-assembly at step 10: close to the one-GPU z-line counts, far below the node-block smoother's, same trajectory"""
+    world, nsteps, label = 3, 12, "channel_basin_h0.0625"
+    arch = npg.GPU()
+    kw = dict(h=0.0625, levels=1, element_precision="fp64", itmax=0)
+    ref = workloads.channel_basin_model(arch, precond_kw=dict(smoother="zline", mixed=False, omega=1.7, coarse_sweeps=20), **kw)
+    npg.run(ref, n_steps=nsteps)
+    node = workloads.channel_basin_model(arch, precond_kw=dict(smoother="node", omega=2.0), **kw)
+    npg.run(node, n_steps=nsteps)
+    ref_its, node_its = [s[1]["niter"] for s in ref.stats], [s[1]["niter"] for s in node.stats]
+    assert all(s[1]["solved"] == 1 for s in ref.stats)
+    out = str(tmp_path / "dmgz")
+    env = dict(os.environ, NPG_COMM_TRANSPORT="peer", NPG_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
+               NPG_PEER_TIMEOUT_S="90", NPG_TEST_SMOOTHER="zline")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_mg_worker.py"), out, str(nsteps), label]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ranks = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
+    z = ranks[0]
+    for zz in ranks[1:]:
+        assert np.array_equal(zz["its"], z["its"])
+    assert z["solved"].all() and "z-line" in str(z["precond"])
+    print("distributed z-line", list(z["its"]), "one GPU z-line", ref_its, "node blocks", node_its)
+    # (at this size - two levels, lines of five nodes - the node-block smoother is only a fifth behind; the gap opens with depth)
+    assert int(np.sum(z["its"])) <= 1.35 * sum(ref_its) and int(np.sum(z["its"])) < sum(node_its), (list(z["its"]), ref_its, node_its)
+    assert rel(z["b"], ref.state.b) < 1e-4 and rel(z["u"], ref.state.u) < 5e-3 and rel(z["p"], ref.state.p) < 5e-3
+
+
 def test_two_distributed_levels_follow_the_eddy_closure(tmp_path):
     """the same one refinement finer, with a three-level hierarchy (2 431 / 20 807 / 172 591 unknowns; three levels under
     h = 0.0625 start from a mesh too coarse to precondition this system at all) whose TWO finest levels are partitioned over 3 ranks:
