@@ -137,3 +137,43 @@ def test_halo_plans_of_the_partitioned_fields_with_gloo(world):
     for p in procs:
         p.join(60)
     assert all(r[1] == "ok" for r in res), res
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_second_multigrid_level_inherits_ownership_through_the_injection(world):
+    """The distributed multigrid's second partitioned level (DistributedMultigridPreconditioner, distributed_levels = 2): a coarse
+    node belongs to the rank that owns the fine node it coincides with.  bowl3D h = 0.05 over h = 0.1 on CPU: every coarse unknown
+    has one owner, a node's fields sit together, every rank gets rows, the coarse cut follows the fine one, and the rows of the
+    prolongation a rank owns reach only coarse columns it owns or holds as ghosts of ITS coarse cells' neighbours' owners."""
+    from nupgcm_amd import multigrid as mgm
+    models = workloads.bowl_hierarchy_models("bowl3D_h0.05")
+    fed_c, fed_f = (workloads.example_fe_data(m) for m in models)
+    part_f = NodePartition(fed_f, world)
+    inj = mgm.injection(fed_c.mesh, fed_f.mesh, False)
+    # a coarse node IS a fine node (new boundary nodes are projected back on the bowl: the edge nodes there moved a little)
+    dx = np.abs(fed_c.mesh.node_coords - fed_f.mesh.node_coords[inj]).max(axis=1)
+    assert dx.max() < 0.02 and (dx < 1e-12).mean() > 0.7
+    part_c = NodePartition(fed_c, world, node_owner=part_f.node_owner[inj])
+    assert np.array_equal(part_c.node_owner, part_f.node_owner[inj])
+    d = fed_c.dofs
+    io = part_c.inv_owner()
+    own = [part_c.inv_owned(r) for r in range(world)]
+    assert np.array_equal(np.sort(np.concatenate(own)), np.arange(d.nu + d.np)) and all(len(o) > 0 for o in own)
+    t = fed_c.tables
+    for a in range(3):
+        on = t.u_pos[:, a] >= 0
+        assert np.array_equal(io[t.u_pos[on, a]], part_c.node_owner[on])
+    # the rank's rows of P (fine owned x coarse): columns owned here or by the owner of a neighbouring coarse node
+    P = sp.csr_matrix(mgm.prolongation(fed_c, fed_f))
+    io_f = part_f.inv_owner()
+    for r in range(world):
+        lay_c = RankLayout(fed_c, part_c, r)
+        Pr = P[part_f.inv_owned(r)]
+        cols = np.unique(Pr.indices)
+        foreign = cols[io[cols] != r]
+        # ghosts of the transfer are few (the cut is shared) and all of them are unknowns of this rank's coarse cells or their
+        # immediate neighbours - the halo plan of the transfer (npg_precond_mg_set_transfer_dist) moves exactly these
+        assert len(foreign) < 0.25 * len(cols), (r, len(foreign), len(cols))
+        known = np.concatenate([lay_c.inv.owned, lay_c.inv.g_sol, lay_c.inv.g_ext])
+        assert np.isin(foreign, known).mean() > 0.9
+    assert io_f.max() == world - 1
