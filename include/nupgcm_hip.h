@@ -190,6 +190,11 @@ int npg_csr_line_block_inverse(npg_csr *Dinv, const npg_csr *A, const npg_index 
 int npg_csr_line_schur(npg_csr *S, const npg_csr *D, const npg_csr *Dinv, const npg_csr *G, const npg_index *wptr,
                        const npg_index *wcols, const npg_index *woff, const npg_index *dperm, const npg_index *dpos,
                        const npg_index *seg_ptr, const npg_index *seg_line, const npg_index *seg_start);
+/* the stored values of a plain-CSR matrix into the head of a vector, and values[k] = v[map[k]] back: with an ordinary halo plan on
+ * such a vector, matrix VALUES travel between ranks (distributed multigrid: the rows of Dinv G that belong to a neighbour's ghost
+ * unknowns are refreshed without leaving the device) */
+int npg_csr_values_to_vec(const npg_csr *A, npg_vec *v);
+int npg_csr_values_from_vec(npg_csr *A, const npg_vec *v, const npg_index *map);
 /* C = A B on C's FIXED pattern (plain CSR; an error if a product falls outside it) */
 int npg_csr_product(npg_csr *C, const npg_csr *A, const npg_csr *B);
 int npg_csr_triple_product(npg_csr *S, const npg_csr *D, const npg_csr *Dinv, const npg_csr *G);

@@ -1589,6 +1589,29 @@ NPG_API int npg_csr_gather_values(npg_csr *dst, const npg_csr *src, const npg_in
     return csr_repack(dst);
 }
 
+// the stored values of a plain-CSR matrix as a vector and back: what lets an ordinary halo plan move matrix VALUES between ranks
+// (the distributed multigrid's rows of T = Dinv G that belong to a neighbour's ghost unknowns, partition.py)
+__global__ void k_scatter_from_vec(double *__restrict__ dst, const double *__restrict__ v, const int64_t *__restrict__ map, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = v[map[i]];
+}
+NPG_API int npg_csr_values_to_vec(const npg_csr *A, npg_vec *v) {
+    NPG_REQUIRE(A && v, "npg_csr_values_to_vec: NULL argument");
+    NPG_REQUIRE(A->nnode() == 0 && !A->uperm, "npg_csr_values_to_vec: a plain-CSR matrix is required");
+    NPG_REQUIRE(v->n >= A->nnz, "npg_csr_values_to_vec: the vector has %lld entries, the matrix %lld values", (long long)v->n, (long long)A->nnz);
+    NPG_HIP(hipMemcpyAsync(v->d, A->val, (size_t)A->nnz * sizeof(double), hipMemcpyDeviceToDevice, A->ctx->stream));
+    return NPG_OK;
+}
+NPG_API int npg_csr_values_from_vec(npg_csr *A, const npg_vec *v, const npg_index *map) {
+    NPG_REQUIRE(A && v && map, "npg_csr_values_from_vec: NULL argument");
+    NPG_REQUIRE(A->nnode() == 0 && !A->uperm, "npg_csr_values_from_vec: a plain-CSR matrix is required");
+    NPG_REQUIRE(map->n == A->nnz && map->bound <= v->n, "npg_csr_values_from_vec: the map has %lld entries below %lld, the matrix %lld values, the vector %lld entries",
+                (long long)map->n, (long long)map->bound, (long long)A->nnz, (long long)v->n);
+    const int grid = (int)std::min<int64_t>(2048, (A->nnz + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_scatter_from_vec, dim3(std::max(grid, 1)), dim3(kBlock), 0, A->ctx->stream, A->val, (const double *)v->d, (const int64_t *)map->d, A->nnz);
+    NPG_HIP(hipGetLastError());
+    return csr_repack(A);
+}
+
 NPG_API int npg_csr_node_block_inverse(npg_csr *Dinv, const npg_csr *A, int64_t n_full, int64_t n_surf) {
     NPG_REQUIRE(Dinv && A && n_full >= 0 && n_surf >= 0, "npg_csr_node_block_inverse: bad argument");
     NPG_REQUIRE(A->nnode() == 0 && Dinv->nnode() == 0, "npg_csr_node_block_inverse: node-blocked matrices are not supported");

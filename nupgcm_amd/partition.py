@@ -698,16 +698,19 @@ class DistributedMultigridPreconditioner:
         nu_g = fed.dofs.nu
         nu_o, n_own, n_sol = lay.n_own_u, f.n_own, f.n_sol
         a2e2 = params.alpha ** 2 * params.eps ** 2
+        if not first and lv.st.get("dev") is not None:
+            return self._device_operators(lv)                                 # same layouts, new values: nothing leaves the device
         rp, ci, shp = lay.local_pattern(fed.pattern_A(structural=full), f, f)
         Ap = DeviceCSR.from_pattern(ctx, shp[0], shp[1], rp, ci)             # a plain-CSR copy of the rank's rows for the host
         lv.fe.assemble(L.NPG_MAT_A, Ap, scale=a2e2, full_stress=full)
         Ah = Ap.to_scipy_csr()
-        del Ap
+        # (Ap stays: the device plan re-assembles into it)
         g = f.globals()[:n_sol]                                              # global id of every local column
         ghost = np.arange(n_own, n_sol)
         gu_idx, gp_idx = ghost[g[ghost] < nu_g], ghost[g[ghost] >= nu_g]      # (kept in ghost order: sorted by owner, id)
         u_cols = np.concatenate([np.arange(nu_o), gu_idx])
         p_cols_A = np.concatenate([np.arange(nu_o, n_own), gp_idx])
+        Atag = sp.csr_matrix((np.arange(1, len(ci) + 1, dtype=np.float64), ci, rp), shape=shp).tocsc()   # value positions + 1
         Ah = Ah.tocsc()
         G0 = sp.csr_matrix(Ah[:nu_o][:, p_cols_A])                            # own_u x [own_p | ghost p of A]
         Dh = sp.csr_matrix(Ah[nu_o:n_own][:, u_cols])                         # own_p x [own_u | ghost u]
@@ -788,7 +791,107 @@ class DistributedMultigridPreconditioner:
             Q = sp.csr_matrix((M.data, lc, M.indptr), shape=(M.shape[0], lv.st["npl"]))
             Q.sort_indices()
             return Q
-        return to_p_layout(G0g), Dh, Dinv, to_p_layout(Sg)
+        Gl, Sl = to_p_layout(G0g), to_p_layout(Sg)
+        if first and self.smoother == "node" and os.environ.get("NPG_MG_DIST_DEVICE", "1") != "0":
+            # ---- the device plan of later refreshes (npg_csr_gather_values / _node_block_inverse / _product and a halo plan on
+            # the VALUES of T = Dinv G): index work on the patterns, done once ---------------------------------------------------
+            from .architectures import DeviceIndex
+            one = lambda M: sp.csr_matrix((np.ones(M.nnz, dtype=np.float32), M.indices, M.indptr), shape=M.shape)
+            G0t = sp.csr_matrix(Atag[:nu_o][:, p_cols_A])
+            Gt = to_p_layout(sp.csr_matrix((G0t.data, g[p_cols_A][G0t.indices], G0t.indptr), shape=G0g.shape))
+            Dt = sp.csr_matrix(Atag[nu_o:n_own][:, u_cols])
+            assert np.array_equal(Gt.indices, Gl.indices) and np.array_equal(Dt.indices, Dh.indices)
+            nfl, nsl = part.local_nodes(rank)
+            irp, icol = mgm._node_block_pattern(nu_o, nfl, nsl)
+            Ip = sp.csr_matrix((np.ones(len(icol), dtype=np.float32), icol, irp), shape=(nu_o, nu_o))
+            Tp = sp.csr_matrix(Ip @ one(Gl))
+            Tp.sort_indices()
+            p_glob = np.concatenate([own_p, lv.st["gp"]])                     # global id of every column of the pressure layout
+            # what the neighbours want of my rows of T, in their order; the columns travel once as global ids
+            out = {}
+            for q in range(world):
+                if q == rank:
+                    continue
+                mine = wants[q][lay.owner_inv[wants[q]] == rank]
+                if len(mine):
+                    rows = lut_u[mine]
+                    cnt = np.diff(Tp.indptr)[rows]
+                    pos = np.repeat(Tp.indptr[rows], cnt) + (np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+                    out[q] = (mine, cnt, p_glob[Tp.indices[pos]], pos)
+            allout = [None] * world
+            dist.all_gather_object(allout, {q: v[:3] for q, v in out.items()})
+            peers = sorted(set(out) | {q for q in range(world) if q != rank and rank in allout[q]})
+            send_ptr, send_idx, recv_ptr = [0], [], [0]
+            grow = {}                                                         # ghost row gid -> (offset in the received stream, local columns)
+            for q in peers:
+                send_idx.append(out[q][3] if q in out else np.zeros(0, np.int64))
+                send_ptr.append(send_ptr[-1] + len(send_idx[-1]))
+                nrecv = 0
+                if rank in allout[q]:
+                    ids, cnt, cols = allout[q][rank]
+                    off = np.concatenate([[0], np.cumsum(cnt)])
+                    lc = lv.st["lut_p"][cols]
+                    # (lc < 0: a column outside this rank's pressure layout - the row belongs to a ghost velocity unknown that only
+                    #  this rank's VELOCITY rows reach, no row of D does: S never reads it, the entry is left out of T_ext below)
+                    for k, gid in enumerate(ids):
+                        grow[int(gid)] = (recv_ptr[-1] + off[k], lc[off[k]:off[k + 1]])
+                    nrecv = int(off[-1])
+                recv_ptr.append(recv_ptr[-1] + nrecv)
+            nnz_own, nnz_g = int(Tp.nnz), int(recv_ptr[-1])
+            assert sorted(grow) == sorted(int(x) for x in want)
+            # T_ext = [my rows of T | the ghost rows in D's column order], every row ascending; its values come out of the vector
+            # [my values | received values] through mapT
+            rptr, cols_e, mapT = [Tp.indptr.astype(np.int64)], [Tp.indices.astype(np.int64)], [np.arange(nnz_own, dtype=np.int64)]
+            gptr = [nnz_own]
+            for gid in want:
+                o, lc = grow[int(gid)]
+                srt = np.argsort(lc, kind="stable")
+                srt = srt[lc[srt] >= 0]
+                cols_e.append(lc[srt])
+                mapT.append(nnz_own + o + srt)
+                gptr.append(gptr[-1] + len(srt))
+            indptr_e = np.concatenate([rptr[0], np.asarray(gptr[1:], dtype=np.int64)])
+            cols_e, mapT = np.concatenate(cols_e), np.concatenate(mapT)
+            dev = SimpleNamespace(
+                Ap=Ap, nfl=nfl, nsl=nsl,
+                G=DeviceCSR.from_pattern(ctx, Gl.shape[0], Gl.shape[1], Gl.indptr, Gl.indices),
+                D=DeviceCSR.from_pattern(ctx, Dh.shape[0], Dh.shape[1], Dh.indptr, Dh.indices),
+                Dinv=DeviceCSR.from_pattern(ctx, nu_o, nu_o, irp, icol),
+                T=DeviceCSR.from_pattern(ctx, nu_o, Gl.shape[1], Tp.indptr, Tp.indices),
+                Text=DeviceCSR.from_pattern(ctx, nu_o + len(want), Gl.shape[1], indptr_e, cols_e.astype(np.int32)),
+                S=DeviceCSR.from_pattern(ctx, Sl.shape[0], Sl.shape[1], Sl.indptr, Sl.indices),
+                mapG=DeviceIndex(ctx, np.rint(Gt.data).astype(np.int64) - 1, len(ci)),
+                mapD=DeviceIndex(ctx, np.rint(Dt.data).astype(np.int64) - 1, len(ci)),
+                mapT=DeviceIndex(ctx, mapT, nnz_own + nnz_g),
+                tv=DeviceVector(ctx, nnz_own + nnz_g),
+                hT=Halo(ctx, nnz_own, nnz_g, dict(peers=np.asarray(peers, np.int32), send_ptr=np.asarray(send_ptr, np.int64),
+                                                  send_idx=(np.concatenate(send_idx) if send_idx else np.zeros(0)).astype(np.int32),
+                                                  recv_ptr=np.asarray(recv_ptr, np.int64))))
+            lv.st["dev"] = dev
+            Gd, Dd, Did, Sd = self._device_operators(lv, assemble=False)
+            if os.environ.get("NPG_MG_DIST_CHECK") == "1":                    # the device's values against the host's (tests)
+                for name, a, b in (("G", Gd, Gl), ("D", Dd, Dh), ("Dinv", Did, sp.csr_matrix(Dinv)), ("S", Sd, Sl)):
+                    err = abs(a.to_scipy_csr() - b).max() / max(abs(b).max(), 1e-300)
+                    if not err < 1e-10:
+                        raise RuntimeError(f"distributed multigrid: device-side {name} differs from the host's by {err:.2e}")
+        return Gl, Dh, Dinv, Sl
+
+    def _device_operators(self, lv, assemble=True):
+        """refresh (G, D, Dinv, S) of a distributed level on the device from the rank's rows of the level's current matrix: values
+        gathered from the re-assembled rows, node-block inverse, T = Dinv G by the fixed-pattern product, its ghost rows' VALUES
+        through a halo plan, S = D T.  Collective (the halo exchange)."""
+        dev, prm = lv.st["dev"], self.prm
+        if assemble:
+            lv.fe.assemble(L.NPG_MAT_A, dev.Ap, scale=prm.alpha ** 2 * prm.eps ** 2, full_stress=self._full)
+        dev.G.gather_values(dev.Ap, dev.mapG)
+        dev.D.gather_values(dev.Ap, dev.mapD)
+        L.check(L.lib().npg_csr_node_block_inverse(dev.Dinv.h, dev.Ap.h, int(dev.nfl), int(dev.nsl)))
+        L.check(L.lib().npg_csr_product(dev.T.h, dev.Dinv.h, dev.G.h))
+        L.check(L.lib().npg_csr_values_to_vec(dev.T.h, dev.tv.h))
+        dev.hT.exchange(dev.tv)
+        L.check(L.lib().npg_csr_values_from_vec(dev.Text.h, dev.tv.h, dev.mapT.h))
+        L.check(L.lib().npg_csr_product(dev.S.h, dev.D.h, dev.Text.h))
+        return dev.G, dev.D, dev.Dinv, dev.S
 
     def refresh(self, A, model=None):
         """the solver's matrix has been re-assembled on every rank (eddy closure, src/model.jl:160-170): recompute the distributed
@@ -800,7 +903,8 @@ class DistributedMultigridPreconditioner:
             raise ValueError("DistributedMultigridPreconditioner.refresh needs the model (its engine holds the viscosity table)")
         top = len(self.hierarchy) - 1
         Gl, Dh, Dinv, Sl = self._level_operators(self._lv[0], first=False)
-        new = [DeviceCSR.from_scipy(self.ctx, M) for M in (Gl, Dh, sp.csr_matrix(Dinv), Sl)]
+        # (device handles when the level has its device plan - refreshed in place -, host matrices otherwise)
+        new = [Gl, Dh, Dinv, Sl] if isinstance(Gl, DeviceCSR) else [DeviceCSR.from_scipy(self.ctx, M) for M in (Gl, Dh, sp.csr_matrix(Dinv), Sl)]
         L.check(L.lib().npg_precond_mg_update_level(self.h, top, A.h, new[0].h, new[1].h, new[2].h, new[3].h))
         self._fine_ops[:4] = new
         ep = self.frc.eddy_param
@@ -824,7 +928,8 @@ class DistributedMultigridPreconditioner:
                 lv1.fe.update_nu_eddy(ep.N2min, self.prm.alpha, self.prm.N2, bl)
                 lv1.fe.assemble(L.NPG_MAT_A, lv1.A, scale=self.prm.alpha ** 2 * self.prm.eps ** 2, full_stress=self._full)
                 G1, D1, Dinv1, S1 = self._level_operators(lv1, first=False)
-                new1 = [DeviceCSR.from_scipy(self.ctx, M) for M in (G1, D1, sp.csr_matrix(Dinv1), S1)]
+                new1 = ([G1, D1, Dinv1, S1] if isinstance(G1, DeviceCSR) else
+                        [DeviceCSR.from_scipy(self.ctx, M) for M in (G1, D1, sp.csr_matrix(Dinv1), S1)])
                 L.check(L.lib().npg_precond_mg_update_level(self.h, top - 1, lv1.A.h, new1[0].h, new1[1].h, new1[2].h, new1[3].h))
                 lv1.ops[:4] = new1
                 lo = top - 2

@@ -150,7 +150,7 @@ def test_distributed_multigrid_rehearsal(world, tmp_path):
     ref_its = [s[1]["niter"] for s in ref.stats]
     out = str(tmp_path / "dmg")
     env = dict(os.environ, NPG_COMM_TRANSPORT="peer", NPG_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
-               NPG_PEER_TIMEOUT_S="90")
+               NPG_PEER_TIMEOUT_S="90", NPG_MG_DIST_CHECK="1")     # (the check: the device-side operator refresh against the host's)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_mg_worker.py"), out, str(nsteps), label]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -178,7 +178,7 @@ def test_two_distributed_multigrid_levels(tmp_path):
     ref_its = [s[1]["niter"] for s in ref.stats]
     out = str(tmp_path / "dmg2")
     env = dict(os.environ, NPG_COMM_TRANSPORT="peer", NPG_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
-               NPG_PEER_TIMEOUT_S="90")
+               NPG_PEER_TIMEOUT_S="90", NPG_MG_DIST_CHECK="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_mg_worker.py"), out, str(nsteps), label, "2"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -213,7 +213,7 @@ def test_distributed_multigrid_follows_the_eddy_closure(tmp_path):
     assert all(s[1]["solved"] == 1 for s in ref.stats)
     out = str(tmp_path / "dmge")
     env = dict(os.environ, NPG_COMM_TRANSPORT="peer", NPG_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
-               NPG_PEER_TIMEOUT_S="90")
+               NPG_PEER_TIMEOUT_S="90", NPG_MG_DIST_CHECK="1")     # (the check: the device-side operator refresh against the host's)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_mg_worker.py"), out, str(nsteps), label]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -274,7 +274,7 @@ def test_two_distributed_levels_follow_the_eddy_closure(tmp_path):
     assert all(s[1]["solved"] == 1 for s in ref.stats)
     out = str(tmp_path / "dmge2")
     env = dict(os.environ, NPG_COMM_TRANSPORT="peer", NPG_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
-               NPG_PEER_TIMEOUT_S="90")
+               NPG_PEER_TIMEOUT_S="90", NPG_MG_DIST_CHECK="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_mg_worker.py"), out, str(nsteps), label, "2"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
