@@ -264,11 +264,26 @@ struct SpmvEpi {
     double *z = nullptr;
     int f32 = 0;                 // read the matrix's fp32 value copies when it has them
 };
-int spmv_epi(const npg_csr *A, const double *x, const SpmvEpi &e);
+// node-block epilogue of the tiled SpMV kernels (the multigrid smoother's t = Dinv r_u riding in the kernel that forms r = b - A x):
+//   t[row] = sum_k Dinv[row, k] y[k] over the row's node block ; if xu: xu[row] = (zero ? 0 : xu[row]) + w t[row]      for row < rows
+// (xu must not be what the product gathers from: other workgroups may still be reading it)
+// Dinv = the node-block diagonal inverse in CSR (npg_csr_node_block_inverse); A's tiles must not split a node (node-blocked A).
+struct NbEpi {
+    const int64_t *drp;
+    const int32_t *dcol;
+    const double *dval;
+    int32_t rows;
+    double *t, *xu;
+    double w;
+    int zero;
+};
+int spmv_epi(const npg_csr *A, const double *x, const SpmvEpi &e, const NbEpi *nb = nullptr);
 int spmv_raw(const npg_csr *A, const double *x, double *y, double alpha, double beta, int f32 = 0);
 // the same product of a node-blocked matrix with a windowed tile set (spmv_window.h), its input rounded to fp32 into the gather
 // layout first: xg = scratch of gather32_floats(A) floats (0: A cannot take this path)
-int spmv_epi_gather32(const npg_csr *A, const double *x, float *xg, const SpmvEpi &e);
+int spmv_epi_gather32(const npg_csr *A, const double *x, float *xg, const SpmvEpi &e, const NbEpi *nb = nullptr);
+// may the node-block epilogue ride in products with A?  (A stored by node blocks with Dinv's node counts: no tile splits a block)
+bool nb_epilogue_ok(const npg_csr *A, const npg_csr *Dinv, int64_t nu);
 int64_t gather32_floats(const npg_csr *A);
 }  // namespace npg
 struct npg_ilu0;

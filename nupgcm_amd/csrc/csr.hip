@@ -419,9 +419,25 @@ static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, cons
 
 constexpr int kSpmvThreads = 512;
 
-template <int L, bool F32, bool N9 = false>
+// (see NbEpi, common.h) after the tile's y has been written back to LDS
+template <int NT>
+__device__ __forceinline__ void nb_epilogue(const NbEpi &nb, int r0, int nrows, const double *sw) {
+    __syncthreads();
+    for (int r = threadIdx.x; r < nrows; r += NT) {
+        const int row = r0 + r;
+        if (row < nb.rows) {
+            double s = 0.0;
+            for (int64_t k = nb.drp[row]; k < nb.drp[row + 1]; ++k) s += nb.dval[k] * sw[nb.dcol[k] - r0];
+            nb.t[row] = s;
+            if (nb.xu) nb.xu[row] = (nb.zero ? 0.0 : nb.xu[row]) + nb.w * s;
+        }
+    }
+    __syncthreads();               // (the next tile writes sw)
+}
+
+template <int L, bool F32, bool N9 = false, bool NB = false>
 __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv(CsrDev A, const TileDesc *__restrict__ tile_ptr, int ntiles,
-                                                        const double *__restrict__ x, SpmvEpi e) {
+                                                        const double *__restrict__ x, SpmvEpi e, NbEpi nb = NbEpi{}) {
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
     int t = blockIdx.x;
@@ -442,7 +458,9 @@ __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv(CsrDev A, const TileDe
                 if (e.zin) t += e.zc * e.zin[row];
                 e.z[row] = t;
             }
+            if constexpr (NB) sw[r] = v;
         }
+        if constexpr (NB) nb_epilogue<kSpmvThreads>(nb, td.r0, td.nrows, sw);
         if (tn >= ntiles) break;
         t = tn;
         td = nd;
@@ -495,19 +513,24 @@ static int upload_csr(npg_ctx *ctx, int64_t m, int64_t n, std::vector<int64_t> &
 }
 
 template <int L>
-static void launch_spmv(const npg_csr *A, const double *x, const SpmvEpi &e) {
+static void launch_spmv(const npg_csr *A, const double *x, const SpmvEpi &e, const NbEpi *nb = nullptr) {
     const int grid = std::min<int>(A->ntiles, 3 * A->ctx->num_cu);      // 3 x 38 KiB of LDS per CU
+    if (nb) {                   // (node-blocked {K, C} matrices only: nb_epilogue_ok)
+        hipLaunchKernelGGL((k_spmv<L, false, false, true>), dim3(std::max(grid, 1)), dim3(kSpmvThreads), 0, A->ctx->stream, csr_view(A),
+                           A->tile_ptr, A->ntiles, x, e, *nb);
+        return;
+    }
     if (A->pk9) {               // full node records (their fp32 copies are not kept: the values change with the closures)
         hipLaunchKernelGGL((k_spmv<L, false, true>), dim3(std::max(grid, 1)), dim3(kSpmvThreads), 0, A->ctx->stream, csr_view(A),
-                           A->tile_ptr, A->ntiles, x, e);
+                           A->tile_ptr, A->ntiles, x, e, NbEpi{});
         return;
     }
     if (e.f32 && A->val32 && (A->nnode() == 0 || A->pkc32))
         hipLaunchKernelGGL((k_spmv<L, true>), dim3(std::max(grid, 1)), dim3(kSpmvThreads), 0, A->ctx->stream, csr_view(A),
-                           A->tile_ptr, A->ntiles, x, e);
+                           A->tile_ptr, A->ntiles, x, e, NbEpi{});
     else
         hipLaunchKernelGGL((k_spmv<L, false>), dim3(std::max(grid, 1)), dim3(kSpmvThreads), 0, A->ctx->stream, csr_view(A),
-                           A->tile_ptr, A->ntiles, x, e);
+                           A->tile_ptr, A->ntiles, x, e, NbEpi{});
 }
 
 __global__ void k_to_float32(const double *__restrict__ src, float *__restrict__ dst, int64_t n) {
@@ -1956,16 +1979,24 @@ static int line_apply(const npg_csr *A, const double *x, const SpmvEpi &e) {
 }
 
 // y[0, m) = alpha A x[0, n) + beta y on raw device pointers (x and y may be windows into larger vectors; they must not overlap)
-int spmv_epi(const npg_csr *Ap, const double *x, const SpmvEpi &e) {
+bool nb_epilogue_ok(const npg_csr *Ap, const npg_csr *Dinv, int64_t nu) {
+    const npg_csr *A = spmv_form(Ap);
+    if (!A || !Dinv || A->nnode() == 0 || A->pk9 || A->uperm || Dinv->lb_nblocks || Dinv->nnode() || A->n != A->m) return false;
+    const int64_t nf = A->nfull, ns = A->nsurf, rest = nu - 3 * nf - 2 * ns;
+    return rest >= 0 && Dinv->m == nu && Dinv->nnz == 9 * nf + 4 * ns + rest && A->block_rows() <= nu;
+}
+
+int spmv_epi(const npg_csr *Ap, const double *x, const SpmvEpi &e, const NbEpi *nb) {
     const npg_csr *A = spmv_form(Ap);
     static const bool dense_blocks = !getenv("NPG_LINE_DENSE") || atoi(getenv("NPG_LINE_DENSE")) != 0;
     if (A->lb_nblocks && !e.z && dense_blocks) return line_apply(A, x, e);
     if (int rc = check_record_view(A, true, "spmv")) return rc;
+    NPG_REQUIRE(!nb || (A->nnode() > 0 && !A->pk9), "spmv: the node-block epilogue needs a matrix stored by {c, K, C} node blocks");
     switch (A->lanes) {
-        case 4: launch_spmv<4>(A, x, e); break;
-        case 8: launch_spmv<8>(A, x, e); break;
-        case 16: launch_spmv<16>(A, x, e); break;
-        default: launch_spmv<32>(A, x, e); break;
+        case 4: launch_spmv<4>(A, x, e, nb); break;
+        case 8: launch_spmv<8>(A, x, e, nb); break;
+        case 16: launch_spmv<16>(A, x, e, nb); break;
+        default: launch_spmv<32>(A, x, e, nb); break;
     }
     NPG_HIP(hipGetLastError());
     return NPG_OK;
@@ -2105,9 +2136,9 @@ __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32(CsrDev A, WinDev W
 
 // the same product with the tiled SpMV's epilogue (SpmvEpi: y = alpha A x + beta c, second output z) on the windowed tile set:
 // the residuals of the multigrid cycle's finest level (mg.hip), whose input is the fp32 gather-layout copy of the iterate
-template <int L, int WL>
+template <int L, int WL, bool NB = false>
 __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32e(CsrDev A, WinDev W, const WTileDesc *__restrict__ tiles, int ntiles, GatherMap g,
-                                                             SpmvEpi e) {
+                                                             SpmvEpi e, NbEpi nb = NbEpi{}) {
     __shared__ TileLds tl;
     __shared__ double sw[kTileRows];
     int t = blockIdx.x;
@@ -2141,7 +2172,9 @@ __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32e(CsrDev A, WinDev 
                 if (e.zin) q += e.zc * e.zin[row];
                 e.z[row] = q;
             }
+            if constexpr (NB) sw[r] = v;
         }
+        if constexpr (NB) nb_epilogue<kSpmvThreads>(nb, td.r0, td.nrows, sw);
         if (tn >= ntiles) break;
         t = tn;
         td = nd;
@@ -2150,7 +2183,7 @@ __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32e(CsrDev A, WinDev 
 
 int64_t gather32_floats(const npg_csr *Ap);
 // x (n entries, fp64) -> its fp32 gather-layout copy; then y = alpha A fl32(x) + beta c ... on A's windowed tiles
-int spmv_epi_gather32(const npg_csr *Ap, const double *x, float *xg, const SpmvEpi &e) {
+int spmv_epi_gather32(const npg_csr *Ap, const double *x, float *xg, const SpmvEpi &e, const NbEpi *nb) {
     const npg_csr *A = spmv_form(Ap);
     NPG_REQUIRE(gather32_floats(A) > 0 && xg, "spmv_epi_gather32: the matrix has no windowed tile set");
     if (int rc = check_record_view(A, false, "spmv_epi_gather32")) return rc;
@@ -2159,11 +2192,15 @@ int spmv_epi_gather32(const npg_csr *Ap, const double *x, float *xg, const SpmvE
     hipLaunchKernelGGL(k_fill_gather32, dim3((unsigned)std::min<int64_t>(2048, (A->n + 255) / 256)), dim3(256), 0, A->ctx->stream, x, g, A->n);
     const dim3 grid(std::max(1, std::min<int>(A->nwtiles, 3 * A->ctx->num_cu))), blk(kSpmvThreads);
     const WinDev W = win_view(A);
-#define NPG_G32E(LL)                                                                                                              \
-    if (A->wlanes == 8)                                                                                                           \
-        hipLaunchKernelGGL((k_spmv_g32e<LL, 8>), grid, blk, 0, A->ctx->stream, csr_view(A), W, A->wtile_ptr, A->nwtiles, g, e);   \
-    else                                                                                                                          \
-        hipLaunchKernelGGL((k_spmv_g32e<LL, 4>), grid, blk, 0, A->ctx->stream, csr_view(A), W, A->wtile_ptr, A->nwtiles, g, e)
+#define NPG_G32E(LL)                                                                                                                     \
+    if (nb && A->wlanes == 8)                                                                                                            \
+        hipLaunchKernelGGL((k_spmv_g32e<LL, 8, true>), grid, blk, 0, A->ctx->stream, csr_view(A), W, A->wtile_ptr, A->nwtiles, g, e, *nb); \
+    else if (nb)                                                                                                                         \
+        hipLaunchKernelGGL((k_spmv_g32e<LL, 4, true>), grid, blk, 0, A->ctx->stream, csr_view(A), W, A->wtile_ptr, A->nwtiles, g, e, *nb); \
+    else if (A->wlanes == 8)                                                                                                             \
+        hipLaunchKernelGGL((k_spmv_g32e<LL, 8>), grid, blk, 0, A->ctx->stream, csr_view(A), W, A->wtile_ptr, A->nwtiles, g, e, NbEpi{}); \
+    else                                                                                                                                 \
+        hipLaunchKernelGGL((k_spmv_g32e<LL, 4>), grid, blk, 0, A->ctx->stream, csr_view(A), W, A->wtile_ptr, A->nwtiles, g, e, NbEpi{})
     switch (A->lanes) {
         case 4: NPG_G32E(4); break;
         case 8: NPG_G32E(8); break;

@@ -333,6 +333,7 @@ struct MgLevel {
     // (csr.hip: spmv_epi_gather32; mg_prepare)
     float *xg = nullptr;
     int64_t xg_n = 0;
+    bool nb_ok = false;        // t = Dinv r_u may ride in the residual kernel (node-blocked A with Dinv's node counts; mg_prepare)
 };
 
 struct BlockPc {
@@ -746,7 +747,14 @@ NPG_API int npg_precond_mg_set_cycle(npg_precond *pc, int gamma) {
 constexpr int64_t kMgGatherMinRows = 1000000;
 static int mg_prepare(npg_precond *pc) {
     static const bool on = !getenv("NPG_MG_GATHER32") || atoi(getenv("NPG_MG_GATHER32")) != 0;
+    static const bool nb_on = !getenv("NPG_MG_NB_EPILOGUE") || atoi(getenv("NPG_MG_NB_EPILOGUE")) != 0;
     for (MgLevel &l : pc->L) {
+        const bool nb = nb_on && l.A && l.Gh && !l.dist && !pc->mixed && nb_epilogue_ok(l.A, l.Dinv, l.nu);
+        if (nb != l.nb_ok) {
+            NPG_HIP(hipStreamSynchronize(pc->ctx->stream));
+            drop_graphs(pc);
+            l.nb_ok = nb;
+        }
         const int64_t need = (on && l.A && !l.dist && l.n >= kMgGatherMinRows) ? gather32_floats(l.A) : 0;
         if (need == l.xg_n) continue;
         NPG_HIP(hipStreamSynchronize(pc->ctx->stream));
@@ -763,8 +771,8 @@ static int mg_prepare(npg_precond *pc) {
     return NPG_OK;
 }
 // y = alpha A x + beta c (+ second output) on level l: the level's matrix in whichever form serves it fastest
-static int mg_product(npg_precond *pc, MgLevel &l, const double *x, const SpmvEpi &e) {
-    return l.xg ? spmv_epi_gather32(l.A, x, l.xg, e) : spmv_epi(l.A, x, e);
+static int mg_product(npg_precond *pc, MgLevel &l, const double *x, const SpmvEpi &e, const NbEpi *nb = nullptr) {
+    return l.xg ? spmv_epi_gather32(l.A, x, l.xg, e, nb) : spmv_epi(l.A, x, e, nb);
 }
 
 // nsteps Braess-Sarazin steps on level l for A x = b.  Eight launches per step (seven with the scaled gradient): the vector updates ride in the epilogues of
@@ -777,15 +785,25 @@ static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int n
     for (int s = 0; s < nsteps; ++s) {
         const bool zero = x_is_zero && s == 0;
         const double *r = l.r;
+        bool have_t = false;                                                         // t (and x_u += t / w) formed by the residual kernel
         if (zero) {
             r = b;                                                                   // r = b - A 0
         } else {
             if (l.hx && (rc = halo_exchange_raw(l.hx, x))) return rc;
             SpmvEpi e{};                                                             // r = b - A x
             e.alpha = -1.0; e.beta = 1.0; e.c = b; e.y = l.r; e.f32 = pc->mixed;
-            if ((rc = mg_product(pc, l, x, e))) return rc;
+            if (l.nb_ok) {
+                // ... and t = Dh^-1 r_u in the same kernel: the node-block epilogue (NbEpi); x_u takes t / w further down, in the
+                // kernel that subtracts (Dh^-1 G) dp / w (x is this product's input: it must not change under it)
+                const npg_csr *Di = l.Dinv;
+                NbEpi nb{Di->rowptr, Di->col, Di->val, (int32_t)nu, l.t, nullptr, 0.0, 0};
+                if ((rc = mg_product(pc, l, x, e, &nb))) return rc;
+                have_t = true;
+            }
+            if (!have_t && (rc = mg_product(pc, l, x, e))) return rc;
         }
-        if (l.Gh) {
+        if (have_t) {
+        } else if (l.Gh) {
             // x_u += Dh^-1 (r_u - G dp) / w  =  t / w - (Dh^-1 G) dp / w: the first part rides in the kernel that forms t
             SpmvEpi e{};                                                             // t = Dh^-1 r_u ; x_u (+)= t / w
             e.alpha = 1.0; e.beta = 0.0; e.y = l.t; e.f32 = pc->mixed;
@@ -809,7 +827,12 @@ static int mg_smooth(npg_precond *pc, int lev, double *x, const double *b, int n
             std::swap(dp, dq);
         }
         if (l.hp && (rc = halo_exchange_raw(l.hp, dp))) return rc;
-        if (l.Gh) {
+        if (l.Gh && have_t) {
+            SpmvEpi e{};                                 // du = (t - (Dh^-1 G) dp) / w  (into t) ; x_u += du  (second output)
+            e.alpha = -1.0 / pc->omega; e.beta = 1.0 / pc->omega; e.c = l.t; e.y = l.t; e.f32 = pc->mixed;
+            e.w = 1.0; e.zin = x; e.zc = 1.0; e.z = x;
+            if ((rc = spmv_epi(l.Gh, dp, e))) return rc;
+        } else if (l.Gh) {
             if ((rc = spmv_raw(l.Gh, dp, x, -1.0 / pc->omega, 1.0, pc->mixed))) return rc;   // x_u -= (Dh^-1 G) dp / w
         } else {
             SpmvEpi e{};                                                             // t = r_u - G dp   (t is free again)

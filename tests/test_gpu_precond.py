@@ -240,6 +240,25 @@ def test_dense_inverse_preconditioner_on_the_reference_meshes(arch):
         npg.DenseInversePreconditioner(arch, Ab)
 
 
+def test_vcycle_on_node_blocked_levels_matches_host_restatement(arch, two_level):
+    """the same cycle with the level matrices stored by node blocks - the form production sizes get: the residuals run on the
+    record tiles and t = Dinv r_u rides in their node-block epilogue (NbEpi), the velocity update in the (Dinv G) kernel's second
+    output - against the host restatement, and against the plain-CSR cycle"""
+    prm, frc, hier, A, As, P = two_level
+    n = As.shape[0]
+    levels = _host_levels(arch, prm, frc, hier)
+    Ab = npg.build_A_inversion(arch, hier[-1], prm, frc.nu)
+    assert Ab.block_nodes(hier[-1].dofs.n_full, hier[-1].dofs.n_surf)
+    Pb = mgm.MultigridPreconditioner(arch, prm, frc, hier, A_fine=Ab, block_nodes=True, coarse_dense=False)
+    assert all(a.storage()[0] > 0 for a in Pb.A)                       # every level's matrix is in record form
+    r = np.sin(np.arange(n) * 0.37) + 0.1
+    rv = npg.DeviceVector.from_host(arch.ctx, r)
+    z = Pb.apply(rv, npg.DeviceVector(arch.ctx, n)).to_host()
+    zr = mo.vcycle(levels, len(levels) - 1, r, omega=2.5, jw=0.7, sweeps=3, nu1=2, nu2=2, coarse=20)
+    zp = P.apply(rv, npg.DeviceVector(arch.ctx, n)).to_host()
+    assert rel(z, zr) < 1e-10 and rel(z, zp) < 1e-10, (rel(z, zr), rel(z, zp))
+
+
 def test_multigrid_with_exact_coarse_solve(arch, two_level):
     """coarse_dense: the coarsest level solved by its dense inverse; the V-cycle then equals the restatement with an exact
     coarse solve, and the iteration count drops to the two-grid optimum"""
