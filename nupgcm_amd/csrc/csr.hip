@@ -1936,26 +1936,44 @@ __global__ void __launch_bounds__(256) k_line_apply(const int64_t *__restrict__ 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the wave's LDS stores have landed (a wave is in lock-step)
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        // Every load is unconditional, from a row index clamped into the block (a lane without a row re-reads the last one and its
+        // sum is never stored): no control flow between the loads of a trip, so all of them are in flight together - with one
+        // column per trip the kernel ran at the memory LATENCY (2 loads in flight per wave: 3.0 TB/s on 1.1 GB).
+        const int i0 = min(lane, n - 1), i1 = min(lane + 64, n - 1), i2 = min(lane + 128, n - 1);
+        constexpr int U = 8;
+        int j = 0;
         if (n <= 64) {
-            int j = 0;
-            for (; j + 4 <= n; j += 4) {
-                T v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-                if (lane < n) {
-                    v0 = Bb[(size_t)j * n + lane]; v1 = Bb[(size_t)(j + 1) * n + lane];
-                    v2 = Bb[(size_t)(j + 2) * n + lane]; v3 = Bb[(size_t)(j + 3) * n + lane];
+            for (; j + U <= n; j += U) {
+                T v[U];
+#pragma unroll
+                for (int q = 0; q < U; ++q) v[q] = Bb[(size_t)(j + q) * n + i0];
+#pragma unroll
+                for (int q = 0; q < U; ++q) a0 += (double)v[q] * xs[w][j + q];
+            }
+        } else if (n <= 128) {
+            for (; j + U <= n; j += U) {
+                T v[U], u[U];
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const T *__restrict__ col = Bb + (size_t)(j + q) * n;
+                    v[q] = col[i0];
+                    u[q] = col[i1];
                 }
-                a0 += (double)v0 * xs[w][j] + (double)v1 * xs[w][j + 1] + (double)v2 * xs[w][j + 2] + (double)v3 * xs[w][j + 3];
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const double xv = xs[w][j + q];
+                    a0 += (double)v[q] * xv;
+                    a1 += (double)u[q] * xv;
+                }
             }
-            for (; j < n; ++j)
-                if (lane < n) a0 += (double)Bb[(size_t)j * n + lane] * xs[w][j];
-        } else {
-            for (int j = 0; j < n; ++j) {
-                const double xv = xs[w][j];
-                const T *__restrict__ col = Bb + (size_t)j * n;
-                a0 += (double)col[lane] * xv;                                   // (n > 64: lane < n)
-                if (lane + 64 < n) a1 += (double)col[lane + 64] * xv;
-                if (lane + 128 < n) a2 += (double)col[lane + 128] * xv;
-            }
+        }
+        for (; j < n; ++j) {                     // the last columns, and blocks of more than 128 unknowns column by column
+            const double xv = xs[w][j];
+            const T *__restrict__ col = Bb + (size_t)j * n;
+            const T c0 = col[i0], c1 = col[i1], c2 = col[i2];
+            a0 += (double)c0 * xv;
+            a1 += (double)c1 * xv;
+            a2 += (double)c2 * xv;
         }
         if (r0 >= 0) y[r0] = alpha * a0 + (beta != 0.0 ? beta * c[r0] : 0.0);
         if (r1 >= 0) y[r1] = alpha * a1 + (beta != 0.0 ? beta * c[r1] : 0.0);
