@@ -163,6 +163,8 @@ struct npg_csr {
     int64_t *lb_off = nullptr;   // device, [nblocks + 1] offsets of the dense blocks (sum of n^2)
     double *lb_val = nullptr;    // device, the dense blocks
     float *lb_val32 = nullptr;   //         and rounded to fp32 (products that ask for fp32 operator values)
+    _Float16 *lb_val16 = nullptr; //        and to fp16, every column of a block divided by lb_scale[its unknown] = its largest magnitude
+    double *lb_scale = nullptr;  // device, [nu] (what fp32-asking products read with NPG_LINE_FP16=1)
     int64_t ndrec_real = 0;      // coupling records without the zero records that pad a row's list to an even count
     int64_t nwlist = 0, nvlist = 0;
     int64_t nrec_real = 0;       // node records without the zero records that pad a node's list to an even count

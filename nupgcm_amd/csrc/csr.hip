@@ -1245,7 +1245,7 @@ NPG_API int npg_csr_destroy(npg_csr *A) {
     if (A->dval) hipFree(A->dval);
     if (A->dval32) hipFree(A->dval32);
     free_window_tiles(A);
-    for (void *q : {(void *)A->lb_ptr, (void *)A->lb_dofs, (void *)A->lb_off, (void *)A->lb_val, (void *)A->lb_val32})
+    for (void *q : {(void *)A->lb_ptr, (void *)A->lb_dofs, (void *)A->lb_off, (void *)A->lb_val, (void *)A->lb_val32, (void *)A->lb_val16, (void *)A->lb_scale})
         if (q) hipFree(q);
     if (A->uperm) hipFree(A->uperm);
     for (double *p : A->uvec)
@@ -1449,7 +1449,8 @@ __global__ void __launch_bounds__(256) k_line_block_inverse(const int64_t *__res
                                                             const int64_t *__restrict__ dofs, int64_t nblocks,
                                                             const int64_t *__restrict__ drp, double *__restrict__ dval,
                                                             const int64_t *__restrict__ boff, double *__restrict__ dense,
-                                                            float *__restrict__ dense32, int *bad) {
+                                                            float *__restrict__ dense32, _Float16 *__restrict__ dense16,
+                                                            double *__restrict__ scale, int *bad) {
     extern __shared__ double lds[];
     __shared__ int flag;
     for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
@@ -1498,12 +1499,20 @@ __global__ void __launch_bounds__(256) k_line_block_inverse(const int64_t *__res
             __syncthreads();
         }
         const int64_t o = boff[b];
+        // column scales of the fp16 pack: the largest magnitude of every column of the inverse
+        for (int c = threadIdx.x; c < n; c += blockDim.x) {
+            double mx = 0.0;
+            for (int r = 0; r < n; ++r) mx = fmax(mx, fabs(M[r * n + c]));
+            scale[ids[c]] = mx > 0.0 ? mx : 1.0;
+        }
+        __syncthreads();
         for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
             const int i = e / n, j = e - i * n;
             dval[drp[ids[i]] + j] = M[e];
-            const double t = M[j * n + i];                    // dense pack: column-major, entry (j, i) at o + i n + j
+            const double t = M[j * n + i];                    // dense packs: column-major, entry (row j, column i) at o + i n + j
             dense[o + e] = t;
             dense32[o + e] = (float)t;
+            dense16[o + e] = (_Float16)(float)(t / scale[ids[i]]);
         }
         if (threadIdx.x == 0 && flag) atomicAdd(bad, 1);
     }
@@ -1773,11 +1782,14 @@ NPG_API int npg_csr_line_block_inverse(npg_csr *Dinv, const npg_csr *A, const np
     NPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_line_block_inverse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     npg_ctx *ctx = A->ctx;
     if (Dinv->lb_nblocks != nb || !Dinv->lb_val) {         // first call: the dense pack and the handle's own copy of the blocks
-        for (void *q : {(void *)Dinv->lb_ptr, (void *)Dinv->lb_dofs, (void *)Dinv->lb_off, (void *)Dinv->lb_val, (void *)Dinv->lb_val32})
+        for (void *q : {(void *)Dinv->lb_ptr, (void *)Dinv->lb_dofs, (void *)Dinv->lb_off, (void *)Dinv->lb_val, (void *)Dinv->lb_val32,
+                        (void *)Dinv->lb_val16, (void *)Dinv->lb_scale})
             if (q) hipFree(q);
         Dinv->lb_ptr = Dinv->lb_dofs = Dinv->lb_off = nullptr;
         Dinv->lb_val = nullptr;
         Dinv->lb_val32 = nullptr;
+        Dinv->lb_val16 = nullptr;
+        Dinv->lb_scale = nullptr;
         Dinv->lb_nblocks = 0;
         std::vector<int64_t> off((size_t)nb + 1, 0);
         for (int64_t b = 0; b < nb; ++b) {
@@ -1789,6 +1801,8 @@ NPG_API int npg_csr_line_block_inverse(npg_csr *Dinv, const npg_csr *A, const np
         NPG_HIP(hipMalloc((void **)&Dinv->lb_off, off.size() * sizeof(int64_t)));
         NPG_HIP(hipMalloc((void **)&Dinv->lb_val, (size_t)total * sizeof(double)));
         NPG_HIP(hipMalloc((void **)&Dinv->lb_val32, (size_t)total * sizeof(float)));
+        NPG_HIP(hipMalloc((void **)&Dinv->lb_val16, (size_t)total * sizeof(_Float16)));
+        NPG_HIP(hipMalloc((void **)&Dinv->lb_scale, (size_t)nu * sizeof(double)));
         NPG_HIP(hipMemcpy(Dinv->lb_ptr, bp.data(), bp.size() * sizeof(int64_t), hipMemcpyHostToDevice));
         NPG_HIP(hipMemcpy(Dinv->lb_dofs, dofs.data(), dofs.size() * sizeof(int64_t), hipMemcpyHostToDevice));
         NPG_HIP(hipMemcpy(Dinv->lb_off, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -1799,7 +1813,7 @@ NPG_API int npg_csr_line_block_inverse(npg_csr *Dinv, const npg_csr *A, const np
     NPG_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
     const int grid = (int)std::min<int64_t>(nb, 8 * ctx->num_cu);
     hipLaunchKernelGGL(k_line_block_inverse, dim3(grid), dim3(256), lds, ctx->stream, A->rowptr, A->col, A->val, block_ptr->d, block_dofs->d,
-                       nb, Dinv->rowptr, Dinv->val, (const int64_t *)Dinv->lb_off, Dinv->lb_val, Dinv->lb_val32, bad);
+                       nb, Dinv->rowptr, Dinv->val, (const int64_t *)Dinv->lb_off, Dinv->lb_val, Dinv->lb_val32, Dinv->lb_val16, Dinv->lb_scale, bad);
     NPG_HIP(hipGetLastError());
     int nbad = 0;
     NPG_HIP(hipMemcpyAsync(&nbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1918,7 +1932,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_line_apply(const int64_t *__restrict__ bp, const int64_t *__restrict__ dofs,
                                                     const int64_t *__restrict__ boff, const T *__restrict__ B, int64_t nblocks,
                                                     const double *__restrict__ x, double alpha, double beta, const double *c,
-                                                    double *y) {
+                                                    double *y, const double *__restrict__ cs = nullptr) {
     constexpr int kMaxN = 136;
     __shared__ double xs[4][kMaxN];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1930,9 +1944,10 @@ __global__ void __launch_bounds__(256) k_line_apply(const int64_t *__restrict__ 
         if (lane < n) r0 = dofs[b0 + lane];
         if (lane + 64 < n) r1 = dofs[b0 + lane + 64];
         if (lane + 128 < n) r2 = dofs[b0 + lane + 128];
-        if (r0 >= 0) xs[w][lane] = x[r0];
-        if (r1 >= 0) xs[w][lane + 64] = x[r1];
-        if (r2 >= 0) xs[w][lane + 128] = x[r2];
+        // (cs: the column scales of the fp16 pack, folded into x as it is staged)
+        if (r0 >= 0) xs[w][lane] = cs ? x[r0] * cs[r0] : x[r0];
+        if (r1 >= 0) xs[w][lane + 64] = cs ? x[r1] * cs[r1] : x[r1];
+        if (r2 >= 0) xs[w][lane + 128] = cs ? x[r2] * cs[r2] : x[r2];
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the wave's LDS stores have landed (a wave is in lock-step)
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -1984,7 +1999,12 @@ __global__ void __launch_bounds__(256) k_line_apply(const int64_t *__restrict__ 
 
 static int line_apply(const npg_csr *A, const double *x, const SpmvEpi &e) {
     const int grid = (int)std::min<int64_t>((A->lb_nblocks + 3) / 4, 16 * (int64_t)A->ctx->num_cu);
-    if (e.f32)
+    static const bool fp16 = !getenv("NPG_LINE_FP16") || atoi(getenv("NPG_LINE_FP16")) != 0;
+    if (e.f32 && fp16)          // (products that accept rounded operator values: the column-scaled fp16 pack, half of fp32's bytes)
+        hipLaunchKernelGGL(k_line_apply<_Float16>, dim3(std::max(grid, 1)), dim3(256), 0, A->ctx->stream, (const int64_t *)A->lb_ptr,
+                           (const int64_t *)A->lb_dofs, (const int64_t *)A->lb_off, (const _Float16 *)A->lb_val16, A->lb_nblocks, x, e.alpha, e.beta,
+                           e.c, e.y, (const double *)A->lb_scale);
+    else if (e.f32)
         hipLaunchKernelGGL(k_line_apply<float>, dim3(std::max(grid, 1)), dim3(256), 0, A->ctx->stream, (const int64_t *)A->lb_ptr,
                            (const int64_t *)A->lb_dofs, (const int64_t *)A->lb_off, (const float *)A->lb_val32, A->lb_nblocks, x, e.alpha, e.beta, e.c,
                            e.y);

@@ -171,7 +171,7 @@ def channel_basin_model(arch, h=None, dz=None, mesh_model=None, surface="flux", 
         # The cycle for these anisotropic cells (alpha = 1/8, a dozen cells deep at production size): the z-LINE smoother (the
         # velocity blocks of Braess-Sarazin = the unknowns of the nodes above one another), fp32 operator values inside the cycle,
         # 60 smoothing steps on the coarsest level (58 k unknowns: too large for the dense inverse to follow the eddy closure's
-        # re-assembly) and omega = 1.7 - 297 ms per timestep at 3.9 M unknowns against 479 with the node-block smoother at its
+        # re-assembly) and omega = 1.7 - 290 ms per timestep at 3.9 M unknowns against 458 with the node-block smoother at its
         # own optimum (omega = 2.0, 20 coarse steps; 1.5 blows up there), outer iterations 16 / 24-31 after a re-assembly against
         # 55-77 (profiles/r04_zline_smoother.txt; NPG_MG_SMOOTHER=node, NPG_MG_OMEGA, NPG_MG_PARAMS override)
         if os.environ.get("NPG_MG_SMOOTHER", "zline") == "zline":
