@@ -11,8 +11,18 @@ import re
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# NPG_LIB_NAME: another build of the SAME library beside it (A/B timing of two builds on one GPU box; tools only)
-LIB_PATH = os.path.join(_HERE, os.environ.get("NPG_LIB_NAME", "libnupgcm_hip.so"))
+LIB_PATH = os.path.join(_HERE, "libnupgcm_hip.so")
+# NPG_AB_LIB: ANOTHER build of the library for same-box A/B timing (tools only).  It must live outside the product directory (under
+# tools/ or gpurun_out/) and every process that loads it says so on stderr - a run can never pick up a stale binary silently.
+_AB = os.environ.get("NPG_AB_LIB")
+if _AB:
+    _ab = os.path.abspath(_AB)
+    _root = os.path.abspath(os.path.join(_HERE, ".."))
+    if not any(_ab.startswith(os.path.join(_root, d) + os.sep) for d in ("tools", "gpurun_out")):
+        raise ImportError(f"NPG_AB_LIB={_AB}: an A/B build must live under tools/ or gpurun_out/, not beside the product library")
+    import sys as _sys
+    print(f"[npg] NPG_AB_LIB: loading the A/B build {_ab} instead of {LIB_PATH}", file=_sys.stderr)
+    LIB_PATH = _ab
 HEADER_PATH = os.path.join(_HERE, "..", "include", "nupgcm_hip.h")
 
 
@@ -123,7 +133,7 @@ def _declare(L):
         "npg_halo_exchange": [P, P], "npg_gmres_set_halo": [P, P], "npg_gmres_set_dist_options": [P, C.c_int, C.c_int], "npg_cg_set_halo": [P, P],
     }
     for name, args in sig.items():
-        if "NPG_LIB_NAME" in os.environ and not hasattr(L, name):
+        if _AB and not hasattr(L, name):
             continue            # (an older build timed beside the current one: entry points it lacks stay unbound)
         fn = getattr(L, name)
         fn.argtypes = args

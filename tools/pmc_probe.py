@@ -25,6 +25,9 @@ npairs, npe, nnz_rem = A.storage()
 h = fed.mesh.median_edge_length()
 y = npg.DeviceVector.from_host(arch.ctx, np.sin(np.arange(N, dtype=float)) * 1e-3)
 ws = npg.GmresWorkspace(arch.ctx, N, memory=20)
+if os.environ.get("PMC_FP64"):          # the all-fp64 instance (bench.py's `fp64_basis` object): fp64 basis, fp64 gathers
+    ws.set_basis(64)
+    ws.set_gather(0)
 st = ws.solve(A, y, ws.x, npg.Diagonal(scalar=1 / h ** 3), itmax=20 * cycles)
 x = npg.DeviceVector.from_host(arch.ctx, np.cos(np.arange(N, dtype=float)))
 out = npg.DeviceVector(arch.ctx, N)

@@ -26,7 +26,7 @@ N = A.shape[0]
 x = npg.DeviceVector.from_host(arch.ctx, np.sin(np.arange(N, dtype=float)))
 y = npg.DeviceVector(arch.ctx, N)
 L.lib()      # the product library first: the harness links against it
-_tune = C.CDLL(os.path.join(os.path.dirname(L.LIB_PATH), "libnupgcm_tune.so"))   # tuning harness, tools/ only
+_tune = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune", "libnupgcm_tune.so"))   # tuning harness (make -C tools/tune)
 fn = _tune.npg_spmv_phase_cycles
 fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
 fn.restype = C.c_int
