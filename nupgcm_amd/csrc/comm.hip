@@ -151,7 +151,6 @@ constexpr int kMaxRanks = 16;      // ranks of one node
 constexpr int kArSlots = 4;        // ring of all-reduce slots (2 would do: a rank cannot get two collectives ahead of a peer)
 constexpr int kArGran = 2 * kPartStride;   // 8-byte granules per all-reduced row: {epoch, low half}, {epoch, high half}
 constexpr int kMaxPeers = 15;      // neighbours of one halo plan
-constexpr int kHaloChunk = 1024;   // entries per sender workgroup before the cap above stretches the chunks
 
 struct PeerArDev {
     uint64_t *const *win;      // device array [nranks]: every rank's all-reduce window (own included)
@@ -225,7 +224,7 @@ __global__ void __launch_bounds__(1024) k_peer_fold_allreduce(const double *part
 // window (write-through stores), drain, raise its flag.  Then workgroup b < nwait: wait for every neighbour's flags of this
 // epoch, copy its share of the window behind the owned entries; the last one acknowledges and completes the epoch.  Every
 // workgroup pushes BEFORE it waits, and pushes depend only on acknowledgements of epoch e - 2: no cycle of waits between
-// ranks.  (grid = max(npush, nwait) <= 15 * 32 workgroups: all resident.)
+// ranks.  (grid = max(npush, nwait) <= 15 * 64 workgroups of 256 threads: all resident.)
 // A solver that has work which needs no ghost value launches the two halves separately around it (phase 1 = push, phase 2 =
 // wait + unpack), on ONE stream: the neighbours' stores land in this rank's window while that work runs - the overlap needs
 // neither a second stream nor events.
@@ -284,7 +283,16 @@ __global__ void __launch_bounds__(256) k_halo_exchange(double *__restrict__ x, c
     if (phase == 0) halo_launch_done(H, e, gridDim.x);
 }
 
-static int halo_wg_count(int64_t cnt) { return (int)std::min<int64_t>(kHaloWG, (cnt + kHaloChunk - 1) / kHaloChunk); }
+// Sender workgroups of one (sender, receiver) pair; both sides derive the same count from the segment's length.  Round 5: an exchange
+// is a chain of dependent round trips (index -> value -> remote store -> drain -> flag; flag -> uncached window load -> store), so it
+// pays to make every chain ONE trip long: 512 entries per sender workgroup (two per lane) up to 64 workgroups per pair, and the
+// consumers likewise (below).  Rank 4 of 8 of bowl3D h = 0.02 (81 k ghost entries, two neighbours): 12.4 -> see profiles/r05_dist_cycle.txt
+// (NPG_HALO_CHUNK / NPG_HALO_WG / NPG_HALO_WAIT_WG: tuning; every rank must run with the same values.)
+static int halo_wg_count(int64_t cnt) {
+    static const int chunk = getenv("NPG_HALO_CHUNK") ? std::max(64, atoi(getenv("NPG_HALO_CHUNK"))) : 512;
+    static const int wg = getenv("NPG_HALO_WG") ? std::min(kHaloWG, std::max(1, atoi(getenv("NPG_HALO_WG")))) : kHaloWG;
+    return (int)std::min<int64_t>(wg, (cnt + chunk - 1) / chunk);
+}
 
 struct PeerComm {
     ShmComm *boot = nullptr;
@@ -845,7 +853,11 @@ static int halo_peer_setup(npg_halo *h) {
     D.n_ghost = h->n_ghost;
     D.npeers = np;
     w->nwg_push = (int)tab.size();
-    w->nwg_wait = (int)std::max<int64_t>(1, std::min<int64_t>(16, (h->n_ghost + 4095) / 4096));
+    {
+        // consumers: 2 048 window entries per workgroup (eight uncached loads in flight per lane, one trip), at most 64 workgroups
+        static const int wcap = getenv("NPG_HALO_WAIT_WG") ? std::max(1, atoi(getenv("NPG_HALO_WAIT_WG"))) : 64;
+        w->nwg_wait = (int)std::max<int64_t>(1, std::min<int64_t>(wcap, (h->n_ghost + 2047) / 2048));
+    }
     return NPG_OK;
 }
 

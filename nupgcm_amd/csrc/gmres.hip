@@ -997,7 +997,13 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
     }
     // tile range of the Arnoldi launches: the windowed set where the gather-layout instance has one
     const int a_nt = d.wt_ptr ? d.nwt : d.ntiles, a_int = d.wt_ptr ? d.nwt_int : d.nt_int;
-    const bool overlap = dist && d.split && want && a_int > 0 && a_int < a_nt;
+    // By DEFAULT the two-launch form is taken only when at least half of the tiles read no ghost column: splitting costs a second
+    // launch with its prologue and a second partly filled round of workgroups, and with hardly any interior tiles there is nothing to
+    // run beside the exchange (rank 4 of 8 of bowl3D h = 0.02 before the interior-first numbering of partition.py: 106 of 2 606 tiles
+    // interior, 81.8 us per iteration split against 73.5 us exchanged first - profiles/r05_dist_cycle.txt).  An explicit request
+    // (NPG_HALO_OVERLAP=1 / npg_gmres_set_dist_options) splits whenever both parts are non-empty.
+    const bool asked = dist && (ws->halo_overlap >= 0 || overlap_env >= 0);
+    const bool overlap = dist && d.split && want && a_int > 0 && a_int < a_nt && (asked || 2 * a_int >= a_nt);
     const int maxg = ws ? std::min(kMaxG, 3 * ws->ctx->num_cu) : kMaxG;
     static const int reserve_env = getenv("NPG_HALO_RESERVE_CUS") ? atoi(getenv("NPG_HALO_RESERVE_CUS")) : 4;
     const int reserve = std::max(0, std::min(reserve_env, maxg / 6));

@@ -8,7 +8,7 @@
 
 namespace npg {
 
-constexpr int kHaloWG = 32;        // most sender workgroups (= flags) per (sender, receiver) pair
+constexpr int kHaloWG = 64;        // most sender workgroups (= flags) per (sender, receiver) pair: one wave polls a peer's flags at once
 
 // system-scope (cross-device) accesses: write-through stores / cache-bypassing loads (sc0 sc1 on gfx950)
 // (global address space spelled out: global_load / global_store, never flat_)

@@ -159,9 +159,40 @@ class RankLayout:
             ext = np.setdiff1d(ext, sol, assume_unique=True)
             return FieldLayout(n, owned, _by_owner(sol, owner), _by_owner(ext, owner))
 
-        self.inv = layout(inv_ids, c_inv, part.inv_owned(rank), own_inv, d.nu + d.np)
+        self.inv = layout(inv_ids, c_inv, self._interior_first(fe_data, part, rank, part.inv_owned(rank), own_inv), own_inv, d.nu + d.np)
         self.b = layout(b_ids, c_b, part.b_owned(rank), own_b, d.nb)
         self.n_own_u = part.n_own_u(rank) if hasattr(part, "n_own_u") else int(part.u_bounds[rank + 1] - part.u_bounds[rank])
+
+    @staticmethod
+    def _interior_first(fe_data, part, rank, owned, owner):
+        """Local order of the owned inversion rows: within each class of the node-block numbering - (x, y, z) triples of full nodes,
+        (x, y) pairs of surface nodes, the other velocity rows, the pressure rows - the NODES none of whose rows reads an off-rank
+        column come first, the nodes on the rank's boundary last, each group in ascending global order.  The SpMV tiles are runs of
+        consecutive local rows, and a tile with one ghost column has to wait for the halo exchange: in ascending global order the
+        boundary nodes are spread over the whole range whenever the sweep that numbers the DoFs and the sweep that cuts the ranks
+        are not the same (they are separate RCM runs: velocity mass graph, pressure mass graph, node graph) - rank 4 of 8 of bowl3D
+        h = 0.02 had 106 of 2 606 tiles without a ghost column; with the boundary nodes last the interior tiles are what runs beside
+        the exchange.  MEASURED (profiles/r05_dist_cycle.txt, same box): 1 010 of 2 612 tiles interior instead of 106 - but the
+        Arnoldi kernel gets SLOWER (35.2 -> 38.5 us: the boundary nodes collected at the end of each class gather from all over the
+        range) and the two-launch form costs 9.5 us more than exchanging first (83.6 against 74.1 us per iteration): OFF by
+        default, NPG_PART_INTERIOR_FIRST=1 turns it on (for a wire slow enough that hiding it pays for the split)."""
+        if os.environ.get("NPG_PART_INTERIOR_FIRST", "0") != "1" or len(owned) == 0 or not isinstance(part, NodePartition):
+            return owned
+        d = fe_data.dofs
+        rp, ci, _ = fe_data.pattern_A()
+        rp = np.asarray(rp, dtype=np.int64)
+        off = (owner[np.asarray(ci)] != rank).astype(np.int64)
+        cs = np.concatenate([[0], np.cumsum(off)])
+        row_bnd = (cs[rp[owned + 1]] - cs[rp[owned]]) > 0                      # owned row reads an off-rank column
+        nf3, nbr = 3 * int(getattr(d, "n_full", 0)), 3 * int(getattr(d, "n_full", 0)) + 2 * int(getattr(d, "n_surf", 0))
+        # node key of every owned row: rows of one node share it (ownership is by node, so a node's rows are all here or none)
+        key = np.where(owned < nf3, owned // 3, np.where(owned < nbr, nf3 + (owned - nf3) // 2, nbr + owned))
+        cls = np.where(owned < nf3, 0, np.where(owned < nbr, 1, np.where(owned < d.nu, 2, 3)))
+        uk, inv = np.unique(key, return_inverse=True)
+        node_bnd = np.zeros(len(uk), dtype=bool)
+        np.logical_or.at(node_bnd, inv, row_bnd)
+        order = np.lexsort((owned, node_bnd[inv], cls))                       # class, then interior before boundary, then global id
+        return owned[order]
 
     def local_tables(self, fe_data) -> DeviceTables:
         t = fe_data.tables
