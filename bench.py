@@ -50,20 +50,27 @@ def parse():
     return ap.parse_args()
 
 
-PMC_FILE = "profiles/r04_pmc.json"
+PMC_FILE = "profiles/r05_pmc.json"
 
 
-def pmc_traffic(workload, kernel="k_gmres_arnoldi"):
+def pmc_traffic(workload, kernel="k_gmres_arnoldi", stored=None):
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (a builder run, not this run:
-    profiles/r04_pmc.json, made by `tools/prof.sh pmc` = tools/pmc_probe.py + tools/pmc_summary.py on this workload with THIS
-    round's kernel; FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied as described in profiles/README.md) -
-    the line says so in `traffic_source`.  None when no counters were collected for the workload (the roofline is then priced
-    in the bytes the layout says must move, `stored_bytes_per_launch`)."""
+    profiles/r05_pmc.json, made by `tools/prof.sh pmc` = tools/pmc_probe.py + tools/pmc_summary.py on this workload; FETCH_SIZE /
+    WRITE_SIZE in separate passes, gfx950 correction applied as described in profiles/README.md) - the line says so in
+    `traffic_source`.  The figure belongs to ONE layout of the matrix: when the record carries `stored_bytes_per_launch` and the
+    layout that is running lays out a different number of bytes (> 0.5 %), the figure is refused (returns None with the reason)
+    and the roofline is priced in `stored_bytes_per_launch` instead.  Returns (bytes or None, reason or None)."""
     p = os.path.join(ROOT, PMC_FILE)
     if not os.path.exists(p):
-        return None
+        return None, f"{PMC_FILE} is missing"
     rec = json.load(open(p)).get(workload, {}).get(kernel)
-    return None if rec is None else rec["traffic_bytes_per_launch"]
+    if rec is None:
+        return None, f"no counters on file for {kernel} on {workload}"
+    on_file = rec.get("stored_bytes_per_launch")
+    if stored is not None and on_file is not None and abs(on_file - stored) > 0.005 * stored:
+        return None, (f"{PMC_FILE} was measured on a layout of {on_file} stored bytes per launch, the layout running now has "
+                      f"{int(stored)}: the committed traffic figure does not describe this kernel")
+    return rec["traffic_bytes_per_launch"], None
 
 
 def cpu_baseline(workload, mesh_model, dt, gm_its, cg_its, budget, A_host=None, h=None, ncell=None):
@@ -93,7 +100,8 @@ def cpu_baseline(workload, mesh_model, dt, gm_its, cg_its, budget, A_host=None, 
         per = max(timer["loop_seconds"], 1e-3)
         n = int(max(2, min(50, budget / per)))
         rc.run(S, n, timer=timer)
-        return dict(value=n / timer["loop_seconds"], unit="timesteps/s", cores=1, host_cores=cores, cores_visible=visible, kind="port",
+        return dict(value=n / timer["loop_seconds"], unit="timesteps/s", cores=1, host_cores=cores, cores_visible=visible, kind="port", threads=1,
+                    timesteps_sampled=int(n), seconds_per_timestep=timer["loop_seconds"] / n, extrapolated=False,
                     sample=f"{n} timesteps of the oracle's direct-solve path (reference CPU() recipe: advection "
                            f"assembly + 2 sparse-LU solves per step, factorisation excluded; numpy + SuperLU, one core) "
                            f"on {workload}")
@@ -122,7 +130,10 @@ def cpu_baseline(workload, mesh_model, dt, gm_its, cg_its, budget, A_host=None, 
     per_cell = (time.perf_counter() - t2) / len(S.orc.topo.cells)
     nb_big = int(round(Ab.shape[0] * ncell / len(S.orc.topo.cells)))
     step = per_gm * np.mean(gm_its) + per_cg_row * nb_big * np.mean(cg_its) + per_cell * ncell
-    return dict(value=1.0 / step, unit="timesteps/s", cores=cores, cores_visible=visible, kind="port",
+    return dict(value=1.0 / step, unit="timesteps/s", cores=cores, cores_visible=visible, kind="port", threads=cores,
+                gmres_ms_per_iteration=per_gm * 1e3, gmres_iterations_sampled=int(its), gmres_iterations_per_timestep=float(np.mean(gm_its)),
+                cg_ms_per_iteration=per_cg_row * nb_big * 1e3, advection_seconds_per_timestep=per_cell * ncell, seconds_per_timestep=float(step),
+                extrapolated=True,
                 sample=f"host Krylov branch of the reference (src/iterative_solvers.jl:58) restated in C + OpenMP on {cores} "
                        f"cores: {its} GMRES(20) iterations on the {workload} inversion matrix = {per_gm * 1e3:.1f} ms/iteration "
                        f"x {np.mean(gm_its):.0f} iterations per timestep (the GPU run's count: same algorithm and stopping "
@@ -166,30 +177,23 @@ def main():
         mesh_model = channel_basin.channel_basin_model(hh, workloads.CB_ALPHA)
     else:
         mesh_model = workloads.bowl_mesh_model(a.workload)
-    replicated = bool(os.environ.get("NPG_BENCH_REPLICATED"))      # round-2 multi-GPU layout: rows partitioned, mesh / state replicated
     if channel:
         surf = "dirichlet" if a.workload.endswith("dirichlet") else "flux"
-        if (world > 1 or force_dist) and not replicated:
+        if world > 1 or force_dist:
             from nupgcm_amd import partition                        # mesh, matrices and state partitioned over the ranks
             model = partition.channel_basin_model(arch, mesh_model, dist, surface=surf)
-        elif world > 1 or force_dist:
-            from nupgcm_amd import distributed
-            model = distributed.channel_basin_model(arch, mesh_model, dist, surface=surf)
         elif a.preconditioner == "multigrid":
             # converged inversions instead of run.jl's 1000-iteration cap: V-cycle over a 3-level refinement hierarchy whose
             # finest mesh has the requested spacing
             model = workloads.channel_basin_model(arch, h=hh, levels=int(os.environ.get("NPG_CB_LEVELS", 2)), surface=surf, itmax=0)
         else:
             model = workloads.channel_basin_model(arch, mesh_model=mesh_model, surface=surf)
-    elif (world > 1 or force_dist) and not replicated:
+    elif world > 1 or force_dist:
         from nupgcm_amd import partition
         if a.preconditioner == "multigrid":     # finest level row-partitioned, coarser levels replicated
             model = partition.example_model(arch, a.workload, dist, dt=a.dt, preconditioner="multigrid")
         else:
             model = partition.example_model(arch, mesh_model, dist, dt=a.dt)
-    elif world > 1 or force_dist:
-        from nupgcm_amd import distributed
-        model = distributed.example_model(arch, mesh_model, dist, dt=a.dt)
     else:
         kw = {} if a.reorth_eta is None else {"reorth_eta": a.reorth_eta}
         if a.preconditioner in ("multigrid", "dense_inverse"):
@@ -275,7 +279,9 @@ def main():
         winfo = A.window_info() if hasattr(A, "window_info") and getattr(A, "paired", False) else {"tiles": 0}
         windowed = bool(winfo["tiles"]) and os.environ.get("NPG_GMRES_WINDOW", "1") != "0"
         stored = (winfo["bytes"] if windowed else A.stored_spmv_bytes()) + 2 * 8 * N
-        measured = pmc_traffic(a.workload) if world == 1 else None
+        measured, refused = pmc_traffic(a.workload, stored=stored if windowed else None) if world == 1 else (None, "one GPU only")
+        if not windowed and measured is not None:
+            measured, refused = None, "the committed counters are for the windowed-tile instance; this run's Arnoldi kernel uses another"
         real = measured or stored
         real_gbps = real / (avg_ms * 1e-3) / 1e9
         csr_gbps = alg_bytes / (avg_ms * 1e-3) / 1e9
@@ -288,7 +294,7 @@ def main():
                         traffic=measured,
                         traffic_source=(f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a builder run of this "
                                         "round's kernel on this workload, not measured in this run)" if measured is not None else None),
-                        bytes_priced="traffic (PMC)" if measured is not None else "stored_bytes_per_launch (no PMC measurement on file)",
+                        bytes_priced="traffic (PMC)" if measured is not None else f"stored_bytes_per_launch ({refused})",
                         kernel="k_gmres_arnoldi (Givens prologue + record-stream SpMV"
                         + (", windowed tiles" if windowed else "") + (")" if N >= 8192 else " + fused Gram-Schmidt dots)"),
                         avg_launch_us=avg_ms * 1e3, launches=launches, stored_bytes_per_launch=int(stored),
@@ -356,10 +362,17 @@ def main():
                                          int(getattr(model, "extrapolate_guess", 0) or 0)],
                    "all_solved": all(s[1]["solved"] == 1 for s in stats), "preconditioner": repr(model.inversion.solver.P),
                    "setup_seconds": round(t_setup, 1),
-                   "parallelism": ("1 GPU" if world == 1 else f"rows partitioned x{world}, mesh and state replicated" if replicated
-                                   else f"mesh, matrices and state partitioned x{world} (node-aligned, one ghost-cell layer)")},
+                   "parallelism": ("1 GPU" if world == 1 else
+                                   f"mesh, matrices and state partitioned x{world} (node-aligned, one ghost-cell layer)")},
         "roofline": roofline,
-        "spmv_standalone": {"avg_launch_us": spmv_ms * 1e3, "GBps": alg_bytes / (spmv_ms * 1e-3) / 1e9},
+        # stand-alone k_spmv (ordinary tiles, fp64 gathers): priced in the bytes its layout moves; the CSR-equivalent rate (the
+        # algorithmic bytes of SURVEY 8(d) over the same time) is labelled as such and may exceed the HBM peak
+        "spmv_standalone": {"avg_launch_us": spmv_ms * 1e3, "stored_bytes_per_launch": int(A.stored_spmv_bytes() + 8 * A.shape[1] + 8 * N),
+                            "GBps": (A.stored_spmv_bytes() + 8 * A.shape[1] + 8 * N) / (spmv_ms * 1e-3) / 1e9,
+                            "frac_of_8TBps": (A.stored_spmv_bytes() + 8 * A.shape[1] + 8 * N) / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "csr_equivalent_GBps": alg_bytes / (spmv_ms * 1e-3) / 1e9,
+                            "note": "GBps = bytes of the stored layout (records) per launch time; csr_equivalent_GBps = what a plain-CSR "
+                                    "SpMV of the same matrix would have had to stream in that time (not a physical rate)"},
         "spmv_plain_csr": spmv_plain,
     }
     # ---- the same loop with the multigrid-preconditioned inversion (new work; the headline above stays the reference's
@@ -387,6 +400,31 @@ def main():
             "fgmres_iterations_per_step": [x[1]["niter"] for x in st], "all_solved": all(x[1]["solved"] == 1 for x in st),
             "inversion_ms_per_step": [round(1e3 * x[1]["seconds"], 2) for x in st],
             "preconditioner": repr(mg.inversion.solver.P), "setup_seconds": round(t_mg, 1)}
+        # roofline of the path itself: ONE application of the V-cycle (what every outer iteration pays), timed live on the library's
+        # stream over 20 back-to-back applications, against the bytes its operators lay out (npg_precond_cycle_bytes: every product of
+        # the cycle with the matrix in the form its kernel reads + its vectors; counted by the library when the cycle was captured)
+        Pmg = mg.inversion.solver.P
+        if hasattr(Pmg, "cycle_bytes") and Pmg.cycle_bytes() > 0:
+            rr = npg.DeviceVector.from_host(ctx, np.sin(np.arange(N_glob, dtype=float)) * 1e-3)
+            zz = npg.DeviceVector(ctx, N_glob)
+            for _ in range(3):
+                Pmg.apply(rr, zz)
+            ctx.timer_start()
+            for _ in range(20):
+                Pmg.apply(rr, zz)
+            cyc_ms = ctx.timer_stop() / 20
+            cb = Pmg.cycle_bytes()
+            its_mg = [x[1]["niter"] for x in st]
+            out["multigrid"]["roofline"] = {
+                "bound": "hbm on the finest level, launch latency on the coarse levels", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "achieved": cb / (cyc_ms * 1e-3) / 1e9, "frac": cb / (cyc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "cycle_ms": cyc_ms, "stored_bytes_per_cycle": int(cb), "traffic": None,
+                "kernel": "one V(2,2) cycle = every launch of csrc/mg.hip's mg_cycle; dominant kernels: the finest level's products with A "
+                          "(k_spmv_g32e on the windowed tiles for residuals, k_spmv in the smoother) and the coarsest level's dense fp16 "
+                          "inverse (k_dense_gemv_part8h) - positions and times: profiles/r04_multigrid_cycle.txt",
+                "ms_per_outer_iteration": 1e3 * sum(x[1]["seconds"] for x in st) / max(1, sum(its_mg)),
+                "note": "bytes as laid out (not PMC-measured); an outer FGMRES iteration = this cycle + one product with A + two "
+                        "Gram-Schmidt passes"}
         del mg
     # ---- the reference's solver configuration with ONE change outside the solver: each inversion starts from the extrapolation
     # 2 x_{n-1} - x_{n-2} of the last two solutions instead of x_{n-1} (model.extrapolate_guess; the answer moves within the
@@ -445,6 +483,19 @@ def main():
             "value": k / el, "unit": "timesteps/s", "steps": k, "warmup": a.warmup, "ms_per_step": 1e3 * el / k,
             "gmres_iterations_per_step": [x[1]["niter"] for x in st], "all_solved": all(x[1]["solved"] == 1 for x in st),
             "arnoldi_avg_launch_us": (1e3 * ms64 / l64) if l64 else None, "setup_seconds": round(t_x, 1)}
+        if l64:
+            # the all-fp64 instance runs on the ORDINARY tiles with fp64 gathers: its own PMC passes (profiles/r05_pmc.json)
+            A64 = f64.inversion.solver.A
+            st64 = A64.stored_spmv_bytes() + 8 * A64.shape[1] + 3 * 8 * N        # matrix + wt gathered once + wt row, w, fp64 basis column
+            tr64, why64 = pmc_traffic(a.workload, "k_gmres_arnoldi_fp64")
+            b64 = tr64 or st64
+            out["fp64_basis"]["roofline"] = {
+                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": b64 / (ms64 / l64 * 1e-3) / 1e9,
+                "frac": b64 / (ms64 / l64 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr64, "stored_bytes_per_launch": int(st64),
+                "bytes_priced": "traffic (PMC)" if tr64 is not None else f"stored_bytes_per_launch ({why64})",
+                "avg_launch_us": 1e3 * ms64 / l64, "launches": l64,
+                "kernel": "k_gmres_arnoldi<8, false, 0, false, 0, true> (fp64 basis, fp64 gathers, ordinary record tiles)",
+                "csr_equivalent_GBps": alg_bytes / (ms64 / l64 * 1e-3) / 1e9}
         del f64
     # ---- small meshes (the reference's own): the explicit inverse in HBM instead of latency-bound Krylov iterations
     if rank == 0 and world == 1 and not channel and a.preconditioner == "diagonal" and not a.no_multigrid and N <= 40000:

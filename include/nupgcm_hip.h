@@ -335,6 +335,11 @@ int npg_precond_mg_set_coarse_dense(npg_precond *pc, int on);
 /* z = M^-1 r (one application: one V-cycle / one round of inner CG solves) */
 int npg_precond_apply(npg_precond *pc, const npg_vec *r, npg_vec *z);
 int npg_precond_counters(npg_precond *pc, int64_t *applications, int64_t *inner_iterations);
+/* Bytes ONE application of the preconditioner streams as its operators are laid out in HBM (multigrid: every product of the
+ * V-cycle with the matrix in the form its kernel reads - records, windowed tiles, fp32 / fp16 value copies - plus its vectors;
+ * dense inverse: n^2 values in their storage type).  Counted on the host when the cycle is first enqueued (0 before that); the
+ * numerator of the multigrid roofline in bench.py.  Distributed levels are not counted (0). */
+int npg_precond_cycle_bytes(npg_precond *pc, int64_t *bytes);
 
 /* Right-preconditioned flexible GMRES(memory), restarted.  x in/out (warm start, as npg_gmres_solve).  pc may be NULL.
  * Stopping rule of the reference with its Diagonal(scale) preconditioner made explicit: scale ||y - A x|| <= atol + rtol

@@ -1,6 +1,8 @@
 """nupgcm_amd - MI355X-native hot path of nuPGCM (assembly -> Krylov inversion -> buoyancy evolution) behind the
-reference's Architecture / InversionToolkit / EvolutionToolkit / invert! / evolve! surface.  GPU() only: the device layer
-is libnupgcm_hip.so (hand-written HIP for gfx950) and there is no CPU fallback."""
+reference's Architecture / InversionToolkit / EvolutionToolkit / invert! / evolve! surface.  GPU(): the device layer is
+libnupgcm_hip.so (hand-written HIP for gfx950) - no fallback: without the library or a gfx950 device it raises.  CPU() (round 5;
+BASELINE configs[0]): the same C ABI built for the host (libnupgcm_host.so, plain C++ / OpenMP) with the reference's CPU() solver
+branches (sparse LU / backslash / host Krylov) - an architecture chosen explicitly, one per process, never a stand-in for GPU()."""
 from .architectures import (CPU, GPU, AbstractArchitecture, DeviceCSR, DeviceILU0, DeviceVector, architecture, on_architecture,
                             print_memory_status, vector_type)
 from .evolution import EvolutionToolkit, collect_evolution_LHS, evolution_parameter

@@ -1,7 +1,8 @@
 """ctypes binding of libnupgcm_hip.so (include/nupgcm_hip.h) - the same symbols ext/nuPGCMHIPExt.jl `ccall`s.
 
-There is no CPU fallback: if the shared library is missing this module raises, and creating a context without a gfx950
-device raises `DeviceError` (NPG_ENODEV)."""
+There is no CPU fallback for GPU(): if the shared library is missing this module raises, and creating a context without a
+gfx950 device raises `DeviceError` (NPG_ENODEV).  The reference's CPU() architecture is a different library behind the same names
+(libnupgcm_host.so, csrc_host/), selected explicitly by creating a CPU() context - see select()."""
 from __future__ import annotations
 
 import ctypes as C
@@ -58,20 +59,42 @@ def declared_symbols(header=HEADER_PATH):
 
 
 _lib = None
+# One process runs on ONE architecture.  "hip" (default): libnupgcm_hip.so, the GPU() architecture.  "host": libnupgcm_host.so, the
+# same C ABI (the subset Model(CPU(), ...) drives) in plain C++ / OpenMP for the reference's CPU() architecture - chosen explicitly
+# by creating a CPU() context (architectures.CPU.ctx -> select("host")), never a fallback: GPU() without the HIP library or without a
+# gfx950 device still raises.
+HOST_LIB_PATH = os.path.join(_HERE, "libnupgcm_host.so")
+_kind = "hip"
+
+
+def select(kind):
+    """choose the library behind lib(): "hip" or "host".  Switching drops the loaded library object, so the caller
+    (architectures.py) refuses it while handles of the other architecture are alive."""
+    global _lib, _kind
+    if kind not in ("hip", "host"):
+        raise ValueError(kind)
+    if kind != _kind:
+        _lib, _kind = None, kind
+
+
+def kind():
+    return _kind
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                              "(make -C nupgcm_amd/csrc). nupgcm_amd has no CPU fallback.")
-        _lib = C.CDLL(LIB_PATH)
-        _declare(_lib)
+        path = LIB_PATH if _kind == "hip" else HOST_LIB_PATH
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              f"(make -C nupgcm_amd/{'csrc' if _kind == 'hip' else 'csrc_host'}). "
+                              + ("nupgcm_amd has no CPU fallback for GPU()." if _kind == "hip" else ""))
+        _lib = C.CDLL(path)
+        _declare(_lib, partial=_kind == "host")
     return _lib
 
 
-def _declare(L):
+def _declare(L, partial=False):
     P, I64, I32, D, VP = C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p
     PP = C.POINTER(C.c_void_p)
     sig = {
@@ -115,6 +138,7 @@ def _declare(L):
         "npg_precond_mg_set_cycle": [P, C.c_int], "npg_precond_mg_set_mixed": [P, C.c_int], "npg_precond_dense_set": [P, P, C.c_int],
         "npg_precond_mg_set_coarse_dense": [P, C.c_int],
         "npg_precond_apply": [P, P, P], "npg_precond_counters": [P, C.POINTER(I64), C.POINTER(I64)],
+        "npg_precond_cycle_bytes": [P, C.POINTER(I64)],
         "npg_fgmres_create": [P, I64, C.c_int, PP], "npg_fgmres_destroy": [P], "npg_fgmres_set_halo": [P, P],
         "npg_precond_mg_set_level_dist": [P, C.c_int, P, I64, P, P, P, P, P, P, P, P, P],
         "npg_precond_mg_set_transfer_dist": [P, C.c_int, P, P, P, P],
@@ -133,7 +157,7 @@ def _declare(L):
         "npg_halo_exchange": [P, P], "npg_gmres_set_halo": [P, P], "npg_gmres_set_dist_options": [P, C.c_int, C.c_int], "npg_cg_set_halo": [P, P],
     }
     for name, args in sig.items():
-        if _AB and not hasattr(L, name):
+        if (_AB or partial) and not hasattr(L, name):
             continue            # (an older build timed beside the current one: entry points it lacks stay unbound)
         fn = getattr(L, name)
         fn.argtypes = args
@@ -148,8 +172,9 @@ def _declare(L):
     L.npg_gmres_history.argtypes = [P, VP, I64]
     L.npg_cg_history.restype = I64
     L.npg_cg_history.argtypes = [P, VP, I64]
-    L.npg_fgmres_history.restype = I64
-    L.npg_fgmres_history.argtypes = [P, VP, I64]
+    if hasattr(L, "npg_fgmres_history"):           # (the host library has no flexible GMRES: general preconditioners are device work)
+        L.npg_fgmres_history.restype = I64
+        L.npg_fgmres_history.argtypes = [P, VP, I64]
 
 
 def check(rc):

@@ -32,7 +32,21 @@ class AbstractArchitecture:
 
 
 class CPU(AbstractArchitecture):
-    pass
+    """The reference's CPU() architecture (src/architectures.jl:5).  As a marker it keeps its round-1 meaning -
+    on_architecture(CPU(), device_object) brings data to the host.  As the architecture of a MODEL (BASELINE configs[0]: the
+    reference's test configuration on CPU(), "runs without a GPU") its context lives in libnupgcm_host.so, the host build of the
+    same C ABI (csrc_host/): Model(CPU(), ...) assembles with the host element kernels, multiplies with the host SpMV and solves
+    as the reference's CPU() path does - sparse LU wherever it factorises (src/inversion.jl:55-58, src/evolution.jl:150-153,
+    src/iterative_solvers.jl:42-55), host Krylov otherwise (:58).  One process runs on one architecture: asking for a CPU() context
+    while GPU() handles are alive (or the other way round) is refused."""
+    device = -1
+
+    @property
+    def ctx(self):
+        if any(d >= 0 for d in _contexts):
+            raise RuntimeError("CPU(): this process already holds GPU() contexts; one process runs on one architecture")
+        L.select("host")
+        return context(-1)
 
 
 class GPU(AbstractArchitecture):
@@ -44,6 +58,9 @@ class GPU(AbstractArchitecture):
 
     @property
     def ctx(self):
+        if -1 in _contexts:
+            raise RuntimeError("GPU(): this process already holds a CPU() context; one process runs on one architecture")
+        L.select("hip")
         return context(self.device)
 
 
@@ -483,7 +500,9 @@ def on_architecture(arch, a, **kw):
 
 
 def architecture(a):
-    return GPU(a.ctx.device) if isinstance(a, (DeviceVector, DeviceCSR)) else CPU()
+    if isinstance(a, (DeviceVector, DeviceCSR)):
+        return GPU(a.ctx.device) if a.ctx.device >= 0 else CPU()
+    return CPU()
 
 
 def vector_type(arch, T=np.float64):

@@ -279,6 +279,12 @@ struct NbEpi {
     double w;
     int zero;
 };
+// Byte accounting of an operator application (round 5: the multigrid bench line's roofline).  While `byte_sink` points somewhere,
+// every product launched through spmv_epi / spmv_epi_gather32 adds the bytes its layout says it streams: the matrix in the form the
+// kernel reads it (records, fp32 / fp16 value copies where the product takes them, the windowed set for the gather-layout product)
+// + 8 B per input, output and epilogue-operand entry.  Host-side, free when null; a captured cycle is counted once, at capture.
+extern thread_local int64_t *byte_sink;
+int64_t spmv_stream_bytes(const npg_csr *A, const SpmvEpi &e, bool windowed);
 int spmv_epi(const npg_csr *A, const double *x, const SpmvEpi &e, const NbEpi *nb = nullptr);
 int spmv_raw(const npg_csr *A, const double *x, double *y, double alpha, double beta, int f32 = 0);
 // the same product of a node-blocked matrix with a windowed tile set (spmv_window.h), its input rounded to fp32 into the gather

@@ -2045,9 +2045,34 @@ bool nb_epilogue_ok(const npg_csr *Ap, const npg_csr *Dinv, int64_t nu) {
     return rest >= 0 && Dinv->m == nu && Dinv->nnz == 9 * nf + 4 * ns + rest && A->block_rows() <= nu;
 }
 
+thread_local int64_t *byte_sink = nullptr;
+
+int64_t spmv_stream_bytes(const npg_csr *Ap, const SpmvEpi &e, bool windowed) {
+    const npg_csr *A = spmv_form(Ap);
+    static const bool dense_blocks = !getenv("NPG_LINE_DENSE") || atoi(getenv("NPG_LINE_DENSE")) != 0;
+    static const bool fp16 = !getenv("NPG_LINE_FP16") || atoi(getenv("NPG_LINE_FP16")) != 0;
+    int64_t b = 0;
+    if (A->lb_nblocks && !e.z && dense_blocks) {
+        // dense column-major block pack (k_line_apply): sum of n_b^2 values = the CSR form's nnz, + block offsets and DoF lists
+        b = A->nnz * (e.f32 ? (fp16 ? 2 : 4) : 8) + 16 * A->lb_nblocks + 8 * A->m + (e.f32 && fp16 ? 8 * A->m : 0);
+    } else if (windowed) {
+        int64_t wb = 0;
+        npg_csr_window_info(A, nullptr, nullptr, nullptr, &wb);
+        b = wb;
+    } else {
+        npg_csr_spmv_bytes(A, &b);
+        if (e.f32 && A->val32) b -= 4 * A->rnnz + (A->pkc32 && A->nnode() ? 8 * A->h_prow[A->nnode()] : 0);      // fp32 value copies
+    }
+    // vectors: input once (gathers beyond that are cache hits by design), outputs and epilogue operands per row
+    b += (windowed ? 4 : 8) * A->n + 8 * A->m * (1 + (e.beta != 0.0 && e.c != e.y ? 1 : 0) + (e.beta != 0.0 && e.c == e.y ? 1 : 0) +
+                                                 (e.z ? 1 + (e.zin ? 1 : 0) + (e.dg ? 1 : 0) : 0));
+    return b;
+}
+
 int spmv_epi(const npg_csr *Ap, const double *x, const SpmvEpi &e, const NbEpi *nb) {
     const npg_csr *A = spmv_form(Ap);
     static const bool dense_blocks = !getenv("NPG_LINE_DENSE") || atoi(getenv("NPG_LINE_DENSE")) != 0;
+    if (byte_sink) *byte_sink += spmv_stream_bytes(A, e, false) + (nb ? 8 * (int64_t)nb->rows * 4 : 0);
     if (A->lb_nblocks && !e.z && dense_blocks) return line_apply(A, x, e);
     if (int rc = check_record_view(A, true, "spmv")) return rc;
     NPG_REQUIRE(!nb || (A->nnode() > 0 && !A->pk9), "spmv: the node-block epilogue needs a matrix stored by {c, K, C} node blocks");
@@ -2245,6 +2270,7 @@ int64_t gather32_floats(const npg_csr *Ap);
 int spmv_epi_gather32(const npg_csr *Ap, const double *x, float *xg, const SpmvEpi &e, const NbEpi *nb) {
     const npg_csr *A = spmv_form(Ap);
     NPG_REQUIRE(gather32_floats(A) > 0 && xg, "spmv_epi_gather32: the matrix has no windowed tile set");
+    if (byte_sink) *byte_sink += spmv_stream_bytes(A, e, true) + 12 * A->n + (nb ? 8 * (int64_t)nb->rows * 4 : 0);    // (+ the fill kernel: 8 B in, 4 B out)
     if (int rc = check_record_view(A, false, "spmv_epi_gather32")) return rc;
     const int64_t nbr = A->block_rows();
     const GatherMap g{xg, 3 * A->nfull, A->nfull, (int)nbr, (int)(4 * A->nnode() - nbr)};

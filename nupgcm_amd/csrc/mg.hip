@@ -387,6 +387,7 @@ struct npg_precond {
     // block diagonal
     std::vector<BlockPc> blocks;
     int64_t inner_iterations = 0, applications = 0;
+    int64_t cycle_bytes = 0;   // bytes one application streams as its operators are laid out (counted once: byte_sink, common.h)
 };
 
 static void drop_graphs(npg_precond *pc) {
@@ -395,6 +396,7 @@ static void drop_graphs(npg_precond *pc) {
 }
 
 static inline void axpby(npg_ctx *c, double *y, double a, const double *x, double b, int64_t n) {
+    if (byte_sink) *byte_sink += (b != 0.0 ? 24 : 16) * n;
     hipLaunchKernelGGL(k_mg_axpby, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, y, a, x, b, n);
 }
 static inline void daxpby(npg_ctx *c, double *y, double w, const double *d, const double *x, double b, int64_t n) {
@@ -445,6 +447,8 @@ NPG_API int npg_precond_destroy(npg_precond *pc) {
 static int dense_apply(npg_precond *pc, const double *r, double *z, double a, double b) {
     const DenseInv &d = pc->dense;
     hipStream_t st = pc->ctx->stream;
+    if (byte_sink)          // the inverse in the storage that is read, + the split-column partial sums written and re-read, + r, z
+        *byte_sink += (d.Mh ? 2 * d.n * d.ldf : d.Mf ? 4 * d.n * d.ldf : 8 * d.n * d.n) + 16 * (int64_t)d.nsplit * d.n + 24 * d.n;
     const int gx = (int)((d.n + kBlock - 1) / kBlock);
     if (d.Mh)
         hipLaunchKernelGGL(k_dense_gemv_part8h, dim3((unsigned)((d.n + 8 * kBlock - 1) / (8 * kBlock)), d.nsplit), dim3(kBlock), 0, st,
@@ -942,7 +946,14 @@ static int precond_apply_raw(npg_precond *pc, const double *r, double *z) {
             NPG_HIP(hipMemcpyAsync(z, lt.x, (size_t)lt.n * sizeof(double), hipMemcpyDeviceToDevice, pc->ctx->stream));
             return NPG_OK;
         }
-        if (!pc->use_graphs) return mg_vcycle(pc, top, z, r);
+        if (!pc->use_graphs) {
+            int64_t count = 0;
+            if (pc->cycle_bytes == 0) byte_sink = &count;
+            const int rcv = mg_vcycle(pc, top, z, r);
+            byte_sink = nullptr;
+            if (count) pc->cycle_bytes = count;
+            return rcv;
+        }
         hipStream_t st = pc->ctx->stream;
         // the captured cycles bake in the borrowed matrices' tile tables and value arrays: a matrix whose layout was
         // rebuilt since (build_tiles, block_nodes, first fp32 copy) invalidates them.  (A borrowed matrix must outlive the
@@ -961,7 +972,11 @@ static int precond_apply_raw(npg_precond *pc, const double *r, double *z) {
             if (pc->graphs.size() >= 64) drop_graphs(pc);                  // a caller that keeps changing buffers
             hipGraph_t g = nullptr;
             NPG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            int64_t count = 0;
+            byte_sink = &count;
             const int rcv = mg_vcycle(pc, top, z, r);
+            byte_sink = nullptr;
+            if (!rcv) pc->cycle_bytes = count;
             const hipError_t ec = hipStreamEndCapture(st, &g);
             if (rcv || ec != hipSuccess) {
                 if (g) hipGraphDestroy(g);
@@ -998,6 +1013,12 @@ NPG_API int npg_precond_apply(npg_precond *pc, const npg_vec *r, npg_vec *z) {
     NPG_REQUIRE(r->n == pc->n && z->n == pc->n && r->d != z->d, "npg_precond_apply: vectors must have %lld entries and not alias",
                 (long long)pc->n);
     return precond_apply_raw(pc, r->d, z->d);
+}
+
+NPG_API int npg_precond_cycle_bytes(npg_precond *pc, int64_t *bytes) {
+    NPG_REQUIRE(pc && bytes, "npg_precond_cycle_bytes: NULL argument");
+    *bytes = pc->cycle_bytes;
+    return NPG_OK;
 }
 
 NPG_API int npg_precond_counters(npg_precond *pc, int64_t *applications, int64_t *inner_iterations) {

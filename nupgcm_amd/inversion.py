@@ -12,9 +12,9 @@ import os
 import numpy as np
 
 from . import _lib as L
-from .architectures import GPU, DeviceVector, print_memory_status
+from .architectures import CPU, GPU, DeviceVector, print_memory_status
 from .assembly import DeviceFE
-from .iterative_solvers import Diagonal, GmresWorkspace, IterativeSolverToolkit, iterative_solve
+from .iterative_solvers import LU, Diagonal, GmresWorkspace, IterativeSolverToolkit, iterative_solve
 
 
 def device_fe(arch, fe_data) -> DeviceFE:
@@ -78,8 +78,11 @@ class InversionToolkit:
         "multigrid" = MultigridPreconditioner over `hierarchy` (FEData coarse ... fine, the last one being fe_data);
         "dense_inverse" = the explicit inverse in HBM (small meshes).  These
         are general operators: the workspace is then a flexible GMRES(memory) with the same stopping rule."""
-        if not isinstance(arch, GPU):
-            raise TypeError("nupgcm_amd implements the GPU() architecture only (no CPU fallback)")
+        if not isinstance(arch, (GPU, CPU)):
+            raise TypeError("InversionToolkit: arch must be GPU() or CPU()")
+        on_gpu = isinstance(arch, GPU)
+        if not on_gpu and preconditioner != "diagonal":
+            raise NotImplementedError("CPU(): the general preconditioners (multigrid, dense inverse, block diagonal) are device work")
         if not restart:
             raise NotImplementedError("restart=false (growing Krylov basis) is not supported; the reference uses restart=true")
         if len(args) == 3:                          # InversionToolkit(arch, fe_data, params, forcings; kwargs...)
@@ -90,6 +93,8 @@ class InversionToolkit:
             A = build_A_inversion(arch, fe_data, params, forcings.nu, structural=forcings.eddy_param.is_on)
             if block_nodes is None and os.environ.get("NPG_BLOCK_NODES"):
                 block_nodes = os.environ["NPG_BLOCK_NODES"] != "0"          # tuning override
+            if not on_gpu:
+                block_nodes = False                     # the record layouts are HBM layouts
             if block_nodes is None:
                 # bandwidth-bound sizes only: below ~1e5 rows the solve is latency-bound and the extra stream costs time
                 block_nodes = A.shape[0] >= 100000
@@ -106,6 +111,8 @@ class InversionToolkit:
             # GPU preconditioner: Diagonal(1/h^dim) with the median edge length (src/inversion.jl:42-54)
             h = fe_data.mesh.median_edge_length()
             P = Diagonal(scalar=1.0 / h ** getattr(fe_data.mesh, "dim", 3), n=A.shape[0])      # 1/h^dim: dim = 2 on the embedded 2-D meshes
+            if not on_gpu and not forcings.eddy_param.is_on:
+                P = LU(A)                               # "on CPU and fixed nu -> can just LU factor" (src/inversion.jl:55-58)
             if preconditioner != "diagonal":
                 from . import multigrid as mgm
                 self.scale = P.scalar                   # the residual keeps the reference's 1/h^dim scaling
@@ -129,7 +136,7 @@ class InversionToolkit:
         y = DeviceVector(arch.ctx, N)
         kwargs = dict(atol=atol, rtol=rtol, itmax=itmax, history=history, verbose=int(verbose), restart=restart,
                       reorth_eta=reorth_eta)
-        if isinstance(P, Diagonal) or P is None:
+        if isinstance(P, (Diagonal, LU)) or P is None:
             ws = GmresWorkspace(arch.ctx, N, memory=memory)
         else:
             from .multigrid import FgmresWorkspace

@@ -30,6 +30,23 @@ class Diagonal:
         return f"Diagonal(scalar={self.scalar})" if self.scalar is not None else f"Diagonal({self.diag!r})"
 
 
+class LU:
+    """`P = lu(A)` of the reference's CPU() path (src/inversion.jl:55-58, src/evolution.jl:150-153: UMFPACK through
+    SparseArrays) - here SuperLU through scipy, the sparse direct solver this image has.  iterative_solve! then takes the
+    `P <: Factorization` branch: x = P \\ y (src/iterative_solvers.jl:42-47)."""
+
+    def __init__(self, A: DeviceCSR):
+        import scipy.sparse.linalg as spla
+        self.n = A.shape[0]
+        self.factor = spla.splu(A.to_scipy_csc())
+
+    def solve(self, y):
+        return self.factor.solve(y)
+
+    def __repr__(self):
+        return f"LU({self.n}x{self.n}, SuperLU)"
+
+
 class _Workspace:
     def __init__(self):
         self.stats = None
@@ -144,12 +161,30 @@ class IterativeSolverToolkit:
 
 
 def iterative_solve(solver: IterativeSolverToolkit):
-    """iterative_solve!(solver) - src/iterative_solvers.jl:31-68.  The reference's CPU() branches (`ldiv!` with an LU,
-    `A\\y`) belong to its CPU architecture and are not reproduced: this package is the GPU() architecture."""
+    """iterative_solve!(solver) - src/iterative_solvers.jl:31-68, all three branches: a factorisation as P -> x = P \\ y (:42-47,
+    CPU() with fixed coefficients); CPU() and fewer than 300 000 rows -> x = A \\ y (:49-55); otherwise the Krylov solve (:58) -
+    on GPU() the device-resident solvers of libnupgcm_hip.so, on CPU() Krylov.jl's methods restated in libnupgcm_host.so."""
     if hasattr(solver, "solve"):            # distributed.DistributedSolverToolkit: row-block solve + all-gather
         solver.solve()
         return solver
     if not isinstance(solver.A, DeviceCSR):
-        raise TypeError("iterative_solve: nupgcm_amd only implements the GPU() architecture; A must be a DeviceCSR")
+        raise TypeError("iterative_solve: A must be a DeviceCSR (GPU(): in HBM; CPU(): a handle of the host library)")
+    on_host = solver.A.ctx.device < 0
+    if isinstance(solver.P, LU):
+        import time
+        t0 = time.perf_counter()
+        solver.x.upload(solver.P.solve(solver.y.to_host()))
+        solver.workspace.stats = dict(solved=1, niter=0, npass=0, status=1, nreorth=0, nflagged=0, rnorm0=0.0, rnorm=0.0,
+                                      seconds=time.perf_counter() - t0, direct=True)
+        return solver
+    if on_host and solver.A.shape[0] < 300_000:
+        import time
+
+        import scipy.sparse.linalg as spla
+        t0 = time.perf_counter()
+        solver.x.upload(spla.spsolve(solver.A.to_scipy_csc(), solver.y.to_host()))
+        solver.workspace.stats = dict(solved=1, niter=0, npass=0, status=1, nreorth=0, nflagged=0, rnorm0=0.0, rnorm=0.0,
+                                      seconds=time.perf_counter() - t0, direct=True)
+        return solver
     solver.workspace.solve(solver.A, solver.y, solver.x, solver.P, **solver.kwargs)
     return solver

@@ -11,7 +11,7 @@ import time
 import numpy as np
 
 from . import _lib as L
-from .architectures import GPU, DeviceVector
+from .architectures import CPU, GPU, DeviceVector
 from .evolution import EvolutionToolkit, collect_evolution_LHS, collect_evolution_LHS_into, evolution_parameter
 from .inversion import InversionToolkit, build_A_inversion, invert as invert_toolkit
 from .iterative_solvers import iterative_solve
@@ -53,8 +53,8 @@ class Model:
 
     def __init__(self, arch, params, forcings, fe_data, inversion: InversionToolkit, evolution: EvolutionToolkit = None,
                  timestepper=None):
-        if not isinstance(arch, GPU):
-            raise TypeError("nupgcm_amd implements the GPU() architecture only (no CPU fallback)")
+        if not isinstance(arch, (GPU, CPU)):
+            raise TypeError("Model: arch must be GPU() or CPU()")
         self.arch, self.params, self.forcings, self.fe_data = arch, params, forcings, fe_data
         self.inversion, self.evolution, self.timestepper = inversion, evolution, timestepper
         ctx = arch.ctx

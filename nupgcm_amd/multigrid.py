@@ -56,6 +56,12 @@ class GeneralPreconditioner:
         L.check(L.lib().npg_precond_counters(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def cycle_bytes(self):
+        """bytes one application streams as its operators are laid out (npg_precond_cycle_bytes; 0 before the first application)"""
+        a = C.c_int64()
+        L.check(L.lib().npg_precond_cycle_bytes(self.h, C.byref(a)))
+        return a.value
+
 
 # ---- reference's block-diagonal preconditioner -----------------------------------------------------------------------------
 def pressure_mass_matrix(fe_data: FEData):
