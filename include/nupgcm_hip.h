@@ -113,6 +113,12 @@ int npg_csr_combine(npg_csr *out, double a, const npg_csr *X, double b, const np
  * matrix is untouched if it does not hold (e.g. function-valued nu).  A node-blocked matrix can be multiplied and solved
  * with, but not downloaded, cloned or re-assembled. */
 int npg_csr_block_nodes(npg_csr *A, int64_t n_full, int64_t n_surf, double rtol, int *blocked);
+/* (round 5; multi-GPU) Ghost NODES of a rank's row block - the matrix's columns [m, n) are the rank's ghosts: node g's (x, y[, z])
+ * components are the ghost columns [first_col[g], first_col[g] + ncomp[g]), ncomp = 3 or 2.  Call before npg_csr_block_nodes:
+ * the windowed tile set then stores the coupling of an owned node to a ghost node as ONE {c, K, C} node record instead of three
+ * column records (a rank's boundary tiles keep their size), the gather-layout copy of the Krylov vector gives
+ * ghost nodes 4-float slots behind the owned nodes' and the halo unpack fills them. */
+int npg_csr_set_ghost_nodes(npg_csr *A, int64_t n_nodes, const int32_t *first_col, const int32_t *ncomp);
 /* The same for a matrix in ANY DoF order - the reference's own RCM of the velocity mass-matrix graph comes out component by
  * component (src/dofs.jl:27-41,70-100), not node by node.  node_of_dof[i] >= 0: DoF i is component comp_of_dof[i] (0, 1, 2) of
  * the velocity node with that label (any non-negative labels: Gridap's node ids); < 0: not a velocity DoF.  The library

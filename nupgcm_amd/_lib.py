@@ -115,7 +115,7 @@ def _declare(L, partial=False):
         "npg_csr_zero_values": [P], "npg_csr_pair_xy": [P, I64, D, C.POINTER(C.c_int)],
         "npg_csr_block_nodes": [P, I64, I64, D, C.POINTER(C.c_int)],
         "npg_csr_storage": [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
-        "npg_csr_coupling_records": [P, C.POINTER(C.c_int64)], "npg_csr_pack_nodes": [P, I64, I64, C.POINTER(C.c_int)], "npg_csr_spmv_bytes": [P, C.POINTER(C.c_int64)],
+        "npg_csr_coupling_records": [P, C.POINTER(C.c_int64)], "npg_csr_pack_nodes": [P, I64, I64, C.POINTER(C.c_int)], "npg_csr_set_ghost_nodes": [P, I64, VP, VP], "npg_csr_spmv_bytes": [P, C.POINTER(C.c_int64)],
         "npg_spmv_gather32": [P, P, P, C.c_int, C.c_int],
         "npg_csr_block_nodes_dofs": [P, C.c_void_p, C.c_void_p, D, C.POINTER(C.c_int)],
         "npg_csr_window_info": [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)], "npg_csr_set_lanes": [P, C.c_int], "npg_csr_product": [P, P, P], "npg_csr_values_to_vec": [P, P], "npg_csr_values_from_vec": [P, P, P], "npg_csr_line_block_inverse": [P, P, P, P], "npg_csr_line_schur": [P] * 12, "npg_precond_mg_set_scaled_gradient": [P, C.c_int, P], "npg_csr_combine": [P, D, P, D, P, P], "npg_csr_inv_diag": [P, P],

@@ -385,6 +385,14 @@ class DeviceCSR:
         self.paired = bool(flag.value)
         return self.paired
 
+    def set_ghost_nodes(self, first_col, ncomp):
+        """a rank's row block: ghost columns [first_col[g], first_col[g] + ncomp[g]) are the components of ONE velocity node
+        (npg_csr_set_ghost_nodes; before block_nodes) - owned-ghost node couplings then become node records in the windowed tiles"""
+        fc = np.ascontiguousarray(first_col, dtype=np.int32)
+        nc = np.ascontiguousarray(ncomp, dtype=np.int32)
+        L.check(L.lib().npg_csr_set_ghost_nodes(self.h, len(fc), fc.ctypes.data_as(C.c_void_p), nc.ctypes.data_as(C.c_void_p)))
+        return self
+
     def pack_nodes(self, n_full, n_surf):
         """attach a record-form companion with FULL node records (function-valued viscosity; npg_csr_pack_nodes): the matrix
         stays plain for assembly / download, products and solves read the companion, which follows every re-assembly"""

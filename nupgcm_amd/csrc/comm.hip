@@ -229,7 +229,8 @@ __global__ void __launch_bounds__(1024) k_peer_fold_allreduce(const double *part
 // wait + unpack), on ONE stream: the neighbours' stores land in this rank's window while that work runs - the overlap needs
 // neither a second stream nor events.
 __global__ void __launch_bounds__(256) k_halo_exchange(double *__restrict__ x, const int32_t *__restrict__ send_idx, int64_t n_owned,
-                                                       int npush, int nwait, int phase, HaloPeerDev H, float *__restrict__ g32) {
+                                                       int npush, int nwait, int phase, HaloPeerDev H, float *__restrict__ g32,
+                                                       const int32_t *__restrict__ gslot = nullptr, float *__restrict__ xgb = nullptr) {
     const uint64_t e = *H.epoch + 1;
     if (phase != 2 && (int)blockIdx.x < npush) {
         const int4 t = H.tab[blockIdx.x];
@@ -270,13 +271,17 @@ __global__ void __launch_bounds__(256) k_halo_exchange(double *__restrict__ x, c
     const int64_t stride = nwait * 256LL;
     for (int64_t i0 = blockIdx.x * 256LL + threadIdx.x; i0 < H.n_ghost; i0 += 8 * stride) {
         double v[8];
+        int32_t sl[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = i0 + u * stride < H.n_ghost ? __builtin_nontemporal_load(src + i0 + u * stride) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sl[u] = (gslot && i0 + u * stride < H.n_ghost) ? gslot[i0 + u * stride] : -1;      // (in flight with the window loads)
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (i0 + u * stride < H.n_ghost) {
                 xg[i0 + u * stride] = v[u];
                 if (g32) g32[i0 + u * stride] = (float)v[u];
+                if (sl[u] >= 0) xgb[sl[u]] = (float)v[u];
             }
     }
     halo_consumed(H, e, (unsigned)nwait, phase == 2);
@@ -924,19 +929,27 @@ NPG_API int npg_halo_destroy(npg_halo *h) {
     return NPG_OK;
 }
 
-static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st, float *g32);
+static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st, float *g32, const int32_t *gslot, float *xgb);
 
-__global__ void k_ghosts_to_f32(const double *__restrict__ src, float *__restrict__ dst, int64_t n) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
+__global__ void k_ghosts_to_f32(const double *__restrict__ src, float *__restrict__ dst, int64_t n, const int32_t *__restrict__ gslot,
+                                float *__restrict__ xgb) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        dst[i] = (float)src[i];
+        if (gslot && gslot[i] >= 0) xgb[gslot[i]] = (float)src[i];
+    }
 }
 
-int npg::halo_exchange_raw(npg_halo *h, double *x, float *g32) { return halo_exchange_on(h, x, h->ctx->stream, g32); }
+int npg::halo_exchange_raw(npg_halo *h, double *x, float *g32, const int32_t *gslot, float *xgb) {
+    return halo_exchange_on(h, x, h->ctx->stream, g32, gslot, xgb);
+}
 
-int npg::halo_exchange_async(npg_halo *h, double *x, float *g32) {
+int npg::halo_exchange_async(npg_halo *h, double *x, float *g32, const int32_t *gslot, float *xgb) {
     npg_ctx *ctx = h->ctx;
     if (h->npeers == 0 && !ctx->shm) return NPG_OK;
     h->pending_x = x;
     h->pending_g32 = g32;
+    h->pending_gslot = gslot;
+    h->pending_xgb = xgb;
     if (ctx->shm) return NPG_OK;          // host-driven loop-back transport: the exchange happens in halo_exchange_wait()
     // NPG_HALO_TWO_STREAM=1 (diagnostic; profiles/r04_overlap_rerun.txt): the peer exchange as ONE kernel on the plan's own stream,
     // ordered against the context's stream by two events - round 2's arrangement, which is what RCCL's overlap still uses
@@ -949,7 +962,7 @@ int npg::halo_exchange_async(npg_halo *h, double *x, float *g32) {
         if (rc) return rc;
         if (w->nwg_push > 0)
             hipLaunchKernelGGL(k_halo_exchange, dim3(w->nwg_push), dim3(256), 0, ctx->stream, x, (const int32_t *)h->send_idx,
-                               h->n_owned, w->nwg_push, w->nwg_wait, 1, w->dev, (float *)nullptr);
+                               h->n_owned, w->nwg_push, w->nwg_wait, 1, w->dev, (float *)nullptr, (const int32_t *)nullptr, (float *)nullptr);
         NPG_HIP(hipGetLastError());
         return NPG_OK;
     }
@@ -961,7 +974,7 @@ int npg::halo_exchange_async(npg_halo *h, double *x, float *g32) {
     }
     NPG_HIP(hipEventRecord(h->ev_ready, ctx->stream));
     NPG_HIP(hipStreamWaitEvent(h->cstream, h->ev_ready, 0));
-    int rc = halo_exchange_on(h, x, h->cstream, g32);
+    int rc = halo_exchange_on(h, x, h->cstream, g32, gslot, xgb);
     if (rc != NPG_OK) return rc;
     NPG_HIP(hipEventRecord(h->ev_done, h->cstream));
     return NPG_OK;
@@ -970,12 +983,12 @@ int npg::halo_exchange_async(npg_halo *h, double *x, float *g32) {
 int npg::halo_exchange_wait(npg_halo *h) {
     npg_ctx *ctx = h->ctx;
     if (h->npeers == 0 && !ctx->shm) return NPG_OK;
-    if (ctx->shm) return halo_exchange_on(h, h->pending_x, ctx->stream, h->pending_g32);
+    if (ctx->shm) return halo_exchange_on(h, h->pending_x, ctx->stream, h->pending_g32, h->pending_gslot, h->pending_xgb);
     static const int two_stream = getenv("NPG_HALO_TWO_STREAM") ? atoi(getenv("NPG_HALO_TWO_STREAM")) : 0;
     if (h->pw && !two_stream) {
         HaloPeer *w = (HaloPeer *)h->pw;
         hipLaunchKernelGGL(k_halo_exchange, dim3(w->nwg_wait), dim3(256), 0, ctx->stream, h->pending_x, (const int32_t *)h->send_idx,
-                           h->n_owned, w->nwg_push, w->nwg_wait, 2, w->dev, h->pending_g32);
+                           h->n_owned, w->nwg_push, w->nwg_wait, 2, w->dev, h->pending_g32, h->pending_gslot, h->pending_xgb);
         NPG_HIP(hipGetLastError());
         return NPG_OK;
     }
@@ -983,7 +996,7 @@ int npg::halo_exchange_wait(npg_halo *h) {
     return NPG_OK;
 }
 
-static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st, float *g32) {
+static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st, float *g32, const int32_t *gslot, float *xgb) {
     npg_ctx *ctx = h->ctx;
     if (h->npeers == 0 && !ctx->shm) return NPG_OK;
     if (h->pw) {
@@ -993,7 +1006,7 @@ static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st, float *g32) 
         int rc = peer_status(ctx);
         if (rc) return rc;
         hipLaunchKernelGGL(k_halo_exchange, dim3(std::max(w->nwg_push, w->nwg_wait)), dim3(256), 0, st, x,
-                           (const int32_t *)h->send_idx, h->n_owned, w->nwg_push, w->nwg_wait, 0, w->dev, g32);
+                           (const int32_t *)h->send_idx, h->n_owned, w->nwg_push, w->nwg_wait, 0, w->dev, g32, gslot, xgb);
         NPG_HIP(hipGetLastError());
         return NPG_OK;
     }
@@ -1045,7 +1058,7 @@ static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st, float *g32) 
         NPG_SHM_BARRIER(c);
         if (g32 && h->n_ghost > 0 && !bad)
             hipLaunchKernelGGL(k_ghosts_to_f32, dim3((unsigned)std::min<int64_t>(256, (h->n_ghost + 255) / 256)), dim3(256), 0, st,
-                               (const double *)(x + h->n_owned), g32, h->n_ghost);
+                               (const double *)(x + h->n_owned), g32, h->n_ghost, gslot, xgb);
         return bad ? NPG_ECOMM : NPG_OK;
     }
     ncclComm_t comm = (ncclComm_t)ctx->comm;
@@ -1060,7 +1073,7 @@ static int halo_exchange_on(npg_halo *h, double *x, hipStream_t st, float *g32) 
     NPG_NCCL(ncclGroupEnd());
     if (g32 && h->n_ghost > 0)
         hipLaunchKernelGGL(k_ghosts_to_f32, dim3((unsigned)std::min<int64_t>(256, (h->n_ghost + 255) / 256)), dim3(256), 0, st,
-                           (const double *)(x + h->n_owned), g32, h->n_ghost);
+                           (const double *)(x + h->n_owned), g32, h->n_ghost, gslot, xgb);
     return NPG_OK;
 }
 

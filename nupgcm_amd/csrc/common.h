@@ -147,6 +147,18 @@ struct npg_csr {
     uint16_t *gidx = nullptr;    // device, window index of every column record (same indexing as gcol)
     int32_t *wlist = nullptr;    // device, concatenated per-tile lists of distinct column nodes (ascending per tile)
     int32_t *vlist = nullptr;    // device, concatenated per-tile lists of distinct columns of the column records
+    // GHOST NODES of a rank's row block (npg_csr_set_ghost_nodes, round 5): ghost columns [gn_col[g], gn_col[g] + gn_ncomp[g]) are the
+    // (x, y[, z]) components of ONE velocity node owned by a neighbour.  The windowed tile set then stores a row node's coupling to
+    // such a node as ONE {c, K, C} node record with c = nnode() + g (its window entry is the node's 4-float slot behind the owned
+    // nodes' slots in the gather-layout copy) instead of three column records - which is what kept a rank's boundary tiles at a
+    // fifth of their size.  The ordinary tiles and the fp64 kernels keep the column records.
+    std::vector<int32_t> gn_col, gn_ncomp;
+    int32_t *gslot = nullptr;    // device, per ghost column (n - m entries): float position of its slot in the gather-layout copy, -1: none
+    double *wgval = nullptr;     // device, the WINDOWED set's own column-record values when it differs from gval: [2 nw_grec] (a_x, a_y), [nw_grec] a_z
+    int64_t nw_grec = 0, nw_rec = 0;   // column records / padded node records of the windowed set (= ngrec / h_prow[nnode] without ghost nodes)
+    double *wdz = nullptr;       // device, d_z of the windowed set's own coupling records (rows behind the block rows, ghost nodes included)
+    int64_t nw_drec = 0;         // its padded coupling records
+    int64_t ngn() const { return (int64_t)gn_col.size(); }
     double *pkc2 = nullptr;      // device, the {K, C} values split by position in the record pair: [npairs] firsts, [npairs] seconds
     int64_t npairs = 0;
     double *dxy2 = nullptr;      // device, the (d_x, d_y) of the coupling records split the same way: [ndpairs] firsts, [ndpairs] seconds
@@ -199,6 +211,8 @@ struct npg_halo {
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
     double *pending_x = nullptr;   // vector of the exchange begun by halo_exchange_async()
     float *pending_g32 = nullptr;  // ... and where its ghosts are ALSO stored as floats (null: nowhere)
+    const int32_t *pending_gslot = nullptr;   // ... and their node slots in the gather-layout copy (halo_exchange_raw)
+    float *pending_xgb = nullptr;
     void *pw = nullptr;            // peer-transport part of the plan (comm.hip, HaloPeer); null for RCCL / shm
 };
 
@@ -206,12 +220,14 @@ namespace npg {
 // enqueue the exchange of x's ghost segment / an in-place sum over ranks of n doubles on the context's stream
 // g32 (optional): the received ghost values are also stored, rounded to fp32, in g32[0 .. n_ghost) - the Krylov kernels'
 // gather-layout copy of their SpMV input (gmres.hip)
-int halo_exchange_raw(npg_halo *h, double *x, float *g32 = nullptr);
+// gslot / xgb (optional, with g32): ghost entry i is ALSO stored, rounded, at xgb[gslot[i]] where gslot[i] >= 0 - its node's 4-float
+// slot in the gather-layout copy (ghost nodes as record columns of the windowed tiles, npg_csr_set_ghost_nodes)
+int halo_exchange_raw(npg_halo *h, double *x, float *g32 = nullptr, const int32_t *gslot = nullptr, float *xgb = nullptr);
 // The same exchange in two halves, for a caller with work that needs no ghost value: kernels enqueued between the two calls
 // run while the exchange is in flight and must not touch x's ghost segment.  Peer transport: the push half and the wait +
 // unpack half are kernels on the context's own stream (the neighbours' stores arrive meanwhile).  RCCL: the exchange runs on
 // the plan's own stream, ordered against the context's stream by two events.
-int halo_exchange_async(npg_halo *h, double *x, float *g32 = nullptr);
+int halo_exchange_async(npg_halo *h, double *x, float *g32 = nullptr, const int32_t *gslot = nullptr, float *xgb = nullptr);
 int halo_exchange_wait(npg_halo *h);
 int allreduce_sum_device(npg_ctx *ctx, double *buf, int n);
 // in-place sum over the ranks of a long device vector (not a per-iteration collective: comm.hip)
@@ -293,6 +309,8 @@ int spmv_epi_gather32(const npg_csr *A, const double *x, float *xg, const SpmvEp
 // may the node-block epilogue ride in products with A?  (A stored by node blocks with Dinv's node counts: no tile splits a block)
 bool nb_epilogue_ok(const npg_csr *A, const npg_csr *Dinv, int64_t nu);
 int64_t gather32_floats(const npg_csr *A);
+// 4-float node slots at the head of that copy: owned block nodes + the ghost nodes the windowed set uses as record columns
+int64_t gather32_nodes(const npg_csr *A);
 }  // namespace npg
 struct npg_ilu0;
 namespace npg {

@@ -131,8 +131,13 @@ int build_tiles(npg_csr *A) {
 }
 
 static void free_window_tiles(npg_csr *A) {
-    for (void *p : {(void *)A->wtile_ptr, (void *)A->widx, (void *)A->gidx, (void *)A->wlist, (void *)A->vlist, (void *)A->wbk, (void *)A->dwidx, (void *)A->dbk, (void *)A->pkc2, (void *)A->dxy2})
+    for (void *p : {(void *)A->wtile_ptr, (void *)A->widx, (void *)A->gidx, (void *)A->wlist, (void *)A->vlist, (void *)A->wbk, (void *)A->dwidx, (void *)A->dbk, (void *)A->pkc2, (void *)A->dxy2,
+                    (void *)A->gslot, (void *)A->wgval, (void *)A->wdz})
         if (p) hipFree(p);
+    A->gslot = nullptr;
+    A->wgval = nullptr;
+    A->wdz = nullptr;
+    A->nw_grec = A->nw_rec = A->nw_drec = 0;
     A->wtile_ptr = nullptr;
     A->widx = A->gidx = nullptr;
     A->wlist = A->vlist = nullptr;
@@ -149,13 +154,98 @@ static void free_window_tiles(npg_csr *A) {
 // nodes (16 B each) and of distinct other columns (4 B each) - followed by the ordinary tiles of the rows behind the block
 // rows.  pcol / gcol: host copies of the record columns (every node's list already padded to an even count).
 // Leaves the matrix without a windowed set (no error) when some node's rows would not fit a tile.
-static int build_window_tiles_scaled(npg_csr *A, const std::vector<int32_t> &pcol, const std::vector<int32_t> &gcol,
-                                     const std::vector<int32_t> &dcol, const std::vector<double> &pkc, const std::vector<double> &dxy,
-                                     double scale) {
+static int build_window_tiles_scaled(npg_csr *A, const std::vector<int32_t> &pcol_in, const std::vector<int32_t> &gcol_in,
+                                     const std::vector<int32_t> &dcol_in, const std::vector<double> &pkc_in, const std::vector<double> &dxy_in,
+                                     const std::vector<double> &gxy_in, const std::vector<double> &gz_in, const std::vector<double> &dz_in,
+                                     const std::vector<int32_t> &rcol, const std::vector<double> &rval, double scale) {
     free_window_tiles(A);
     const int64_t nnode = A->nnode(), nfull = A->nfull, nbr = A->block_rows();
     if (nnode == 0 || !A->grow || A->pk9) return NPG_OK;
-    const std::vector<int64_t> &prow = A->h_prow, &grow = A->h_grow;
+    // ---- ghost nodes (npg_csr_set_ghost_nodes): the column records of a row node that reference the components of ONE ghost node
+    // and carry the {K, C} structure (A[x_q,x_c] = A[y_q,y_c] = A[z_q,z_c] = K, A[x_q,y_c] = -A[y_q,x_c] = C, nothing else) become a
+    // node record with column node nnode + g in THIS tile set's own record arrays; everything else is carried over unchanged
+    const int64_t ngn = A->ngn();
+    std::vector<int64_t> wprow, wgrow;
+    std::vector<int32_t> wpcol, wgcol;
+    std::vector<double> wpkc, wgxy, wgz;
+    int64_t converted = 0;
+    std::vector<int32_t> gnode((size_t)std::max<int64_t>(A->n - A->m, 0), -1), gcomp(gnode.size(), 0);
+    if (ngn > 0) {
+        for (int64_t g = 0; g < ngn; ++g)
+            for (int a = 0; a < A->gn_ncomp[(size_t)g]; ++a) {
+                gnode[(size_t)(A->gn_col[(size_t)g] - A->m + a)] = (int32_t)g;
+                gcomp[(size_t)(A->gn_col[(size_t)g] - A->m + a)] = a;
+            }
+        const std::vector<int64_t> &prow0 = A->h_prow, &grow0 = A->h_grow;
+        wprow.assign((size_t)nnode + 1, 0);
+        wgrow.assign((size_t)nnode + 1, 0);
+        std::vector<int64_t> slot;           // per ghost node touched by the current row node: index of its records by component
+        for (int64_t q = 0; q < nnode; ++q) {
+            const bool qfull = q < nfull;
+            // the node's own records, without the zero record that padded them (it is re-made below)
+            int64_t pe = prow0[q + 1];
+            if (pe - prow0[q] >= 2 && pkc_in[2 * (pe - 1)] == 0.0 && pkc_in[2 * (pe - 1) + 1] == 0.0 && pcol_in[pe - 1] == pcol_in[pe - 2]) --pe;
+            for (int64_t e = prow0[q]; e < pe; ++e) {
+                wpcol.push_back(pcol_in[e]);
+                wpkc.push_back(pkc_in[2 * e]);
+                wpkc.push_back(pkc_in[2 * e + 1]);
+            }
+            double scale_q = 0.0;
+            for (int64_t e = prow0[q]; e < pe; ++e) scale_q = std::max(scale_q, std::fabs(pkc_in[2 * e]));
+            const double tol = 1e-12 * scale_q;
+            // column records, ascending columns: the components of a ghost node are adjacent
+            for (int64_t e = grow0[q]; e < grow0[q + 1];) {
+                const int64_t m0 = gcol_in[e];
+                const int32_t g = m0 >= A->m ? gnode[(size_t)(m0 - A->m)] : -1;
+                if (g < 0 || gcomp[(size_t)(m0 - A->m)] != 0) {
+                    wgcol.push_back(gcol_in[e]);
+                    wgxy.push_back(gxy_in[2 * e]);
+                    wgxy.push_back(gxy_in[2 * e + 1]);
+                    wgz.push_back(gz_in[e]);
+                    ++e;
+                    continue;
+                }
+                // records of this ghost node: columns m0 (x), m0 + 1 (y)[, m0 + 2 (z)], any of them possibly absent
+                const int nc = A->gn_ncomp[(size_t)g];
+                int64_t rec[3] = {-1, -1, -1}, e1 = e;
+                while (e1 < grow0[q + 1] && gcol_in[e1] < m0 + nc) {
+                    rec[gcol_in[e1] - m0] = e1;
+                    ++e1;
+                }
+                auto val = [&](int c, int a) { return rec[c] < 0 ? 0.0 : (a == 2 ? gz_in[rec[c]] : gxy_in[2 * rec[c] + a]); };
+                const double K = val(0, 0), Cc = val(1, 0);
+                bool ok = std::fabs(val(1, 1) - K) <= tol && std::fabs(val(0, 1) + Cc) <= tol && std::fabs(val(0, 2)) <= tol &&
+                          std::fabs(val(1, 2)) <= tol;
+                if (nc == 3) ok = ok && std::fabs(val(2, 0)) <= tol && std::fabs(val(2, 1)) <= tol && (!qfull || std::fabs(val(2, 2) - K) <= tol);
+                if (ok) {
+                    wpcol.push_back((int32_t)(nnode + g));
+                    wpkc.push_back(K);
+                    wpkc.push_back(Cc);
+                    ++converted;
+                } else {
+                    for (int64_t k = e; k < e1; ++k) {
+                        wgcol.push_back(gcol_in[k]);
+                        wgxy.push_back(gxy_in[2 * k]);
+                        wgxy.push_back(gxy_in[2 * k + 1]);
+                        wgz.push_back(gz_in[k]);
+                    }
+                }
+                e = e1;
+            }
+            if (((int64_t)wpcol.size() - wprow[q]) & 1) {            // zero record on the node's last column node
+                wpcol.push_back(wpcol.back());
+                wpkc.push_back(0.0);
+                wpkc.push_back(0.0);
+            }
+            wprow[q + 1] = (int64_t)wpcol.size();
+            wgrow[q + 1] = (int64_t)wgcol.size();
+        }
+    }
+    const bool own = ngn > 0 && converted > 0;
+    const std::vector<int64_t> &prow = own ? wprow : A->h_prow, &grow = own ? wgrow : A->h_grow;
+    const std::vector<int32_t> &pcol = own ? wpcol : pcol_in, &gcol = own ? wgcol : gcol_in;
+    const std::vector<double> &pkc = own ? wpkc : pkc_in;
+    const int64_t nwin_nodes = nnode + (own ? ngn : 0);
     constexpr int NT = 512;
     int64_t hard = 8 * (int64_t)kTileNnz;
     if (getenv("NPG_WIN_BYTES")) hard = std::min<int64_t>(hard, std::max<int64_t>(8192, atoll(getenv("NPG_WIN_BYTES"))));    // tuning: smaller tiles
@@ -165,7 +255,7 @@ static int build_window_tiles_scaled(npg_csr *A, const std::vector<int32_t> &pco
     // small matrices: about one tile per CU (as tile_boundaries does)
     const int64_t total = 8 * (3 * (prow[nfull] / 2 + grow[nfull]) + 2 * ((prow[nnode] - prow[nfull]) / 2 + grow[nnode] - grow[nfull]));
     const int64_t soft = std::min<int64_t>(hard, std::max<int64_t>(8 * 1024, total / std::max(1, A->ctx->num_cu)));
-    std::vector<int32_t> stampW((size_t)nnode, -1), stampV((size_t)A->n, -1), posW((size_t)nnode, 0), posV((size_t)A->n, 0);
+    std::vector<int32_t> stampW((size_t)nwin_nodes, -1), stampV((size_t)A->n, -1), posW((size_t)nwin_nodes, 0), posV((size_t)A->n, 0);
     std::vector<uint16_t> widx(pcol.size()), gidx(gcol.size());
     std::vector<int32_t> wlist, vlist, tw, tv, nwl, nvl, wbk((size_t)2 * nnode);
     std::vector<WTileDesc> blk;
@@ -237,7 +327,7 @@ static int build_window_tiles_scaled(npg_csr *A, const std::vector<int32_t> &pco
             wlist.insert(wlist.end(), tw.begin(), tw.end());
             vlist.insert(vlist.end(), tv.begin(), tv.end());
             blk.push_back(d);
-            ghost.push_back(!tv.empty() && tv.back() >= A->m);          // (record columns are owned nodes by construction)
+            ghost.push_back((!tv.empty() && tv.back() >= A->m) || tw.back() >= nnode);   // (ghost columns; ghost nodes as record columns)
             q = qe;
         }
     }
@@ -246,12 +336,66 @@ static int build_window_tiles_scaled(npg_csr *A, const std::vector<int32_t> &pco
     // kWinNodes distinct column nodes per lane - small tiles, one dependent chain each (the ordinary tile function walks such
     // a row block in four trips of two round trips).  NPG_WIN_ROWS=0: ordinary tiles for these rows.
     std::vector<WTileDesc> rowt;
+    std::vector<char> rghost;
     std::vector<uint16_t> dwidx;
     std::vector<int32_t> dbk;
     const int64_t nbehind = A->m - nbr;
     const bool rows_env = !(getenv("NPG_WIN_ROWS") && atoi(getenv("NPG_WIN_ROWS")) == 0);
-    if (rows_env && A->drow && nbehind > 0 && A->h_rowptr[A->m] - A->h_rowptr[nbr] == 0 && A->n == A->m) {
-        const std::vector<int64_t> &drow = A->h_drow;
+    // A rank's row block with ghost nodes: what the rows behind the block rows (the divergence rows) hold on ghost columns is CSR
+    // remainder for the ordinary tiles; for THIS tile set the entries on a ghost node's components become one coupling record
+    // {nnode + g, d_x, d_y, d_z} behind the row's owned-node records - if that accounts for every remaining entry of those rows,
+    // they are windowed like a one-GPU matrix's (and the Arnoldi kernel runs its instance without ordinary tile code)
+    std::vector<int64_t> wdrow;
+    std::vector<int32_t> wdcol;
+    std::vector<double> wdxy, wdz;
+    bool rows_own = false;
+    if (own && rows_env && A->drow && nbehind > 0 && A->n > A->m) {
+        rows_own = true;
+        wdrow.assign((size_t)nbehind + 1, 0);
+        const std::vector<int64_t> &d0 = A->h_drow, &rp0 = A->h_rowptr;
+        for (int64_t r = 0; r < nbehind && rows_own; ++r) {
+            int64_t e1 = d0[r + 1];
+            if (e1 - d0[r] >= 2 && dxy_in[2 * (e1 - 1)] == 0.0 && dxy_in[2 * (e1 - 1) + 1] == 0.0 && dz_in[e1 - 1] == 0.0 &&
+                dcol_in[e1 - 1] == dcol_in[e1 - 2])
+                --e1;                                                    // (the zero record that padded the list: re-made below)
+            for (int64_t e = d0[r]; e < e1; ++e) {
+                wdcol.push_back(dcol_in[e]);
+                wdxy.push_back(dxy_in[2 * e]);
+                wdxy.push_back(dxy_in[2 * e + 1]);
+                wdz.push_back(dz_in[e]);
+            }
+            int32_t cur = -1;
+            for (int64_t k = rp0[nbr + r]; k < rp0[nbr + r + 1]; ++k) {
+                const int64_t m0 = rcol[k];
+                const int32_t g = m0 >= A->m ? gnode[(size_t)(m0 - A->m)] : -1;
+                if (g < 0) {
+                    rows_own = false;                                    // an entry that is no node component: ordinary tiles for these rows
+                    break;
+                }
+                if (g != cur) {
+                    wdcol.push_back((int32_t)(nnode + g));
+                    wdxy.push_back(0.0);
+                    wdxy.push_back(0.0);
+                    wdz.push_back(0.0);
+                    cur = g;
+                }
+                const int a = gcomp[(size_t)(m0 - A->m)];
+                if (a == 2) wdz.back() = rval[k];
+                else wdxy[wdxy.size() - 2 + a] = rval[k];
+            }
+            if (((int64_t)wdcol.size() - wdrow[r]) & 1) {
+                wdcol.push_back(wdcol.back());
+                wdxy.push_back(0.0);
+                wdxy.push_back(0.0);
+                wdz.push_back(0.0);
+            }
+            wdrow[r + 1] = (int64_t)wdcol.size();
+        }
+    }
+    const std::vector<int32_t> &dcol = rows_own ? wdcol : dcol_in;
+    const std::vector<double> &dxy = rows_own ? wdxy : dxy_in;
+    if (rows_env && A->drow && nbehind > 0 && ((A->h_rowptr[A->m] - A->h_rowptr[nbr] == 0 && A->n == A->m) || rows_own)) {
+        const std::vector<int64_t> &drow = rows_own ? wdrow : A->h_drow;
         dwidx.assign(dcol.size(), 0);
         dbk.assign((size_t)nbehind, 0);
         int64_t cap_pairs = cap_p;
@@ -309,6 +453,7 @@ static int build_window_tiles_scaled(npg_csr *A, const std::vector<int32_t> &pco
             }
             wlist.insert(wlist.end(), tw.begin(), tw.end());
             rowt.push_back(d);
+            rghost.push_back(tw.back() >= nnode);
             r = re;
         }
         if (!ok) rowt.clear();
@@ -328,7 +473,8 @@ static int build_window_tiles_scaled(npg_csr *A, const std::vector<int32_t> &pco
         for (size_t t = 0; t < blk.size(); ++t)
             if ((ghost[t] != 0) == (pass == 1)) a.push_back(blk[t]);
         if (!rowt.empty()) {
-            if (pass == 0) b = rowt;         // (only matrices without ghost columns get here)
+            for (size_t t = 0; t < rowt.size(); ++t)
+                if ((rghost[t] != 0) == (pass == 1)) b.push_back(rowt[t]);
         } else {
             for (int32_t t = 0; t < A->ntiles; ++t)
                 if (A->h_tiles[t].r0 >= nbr && (t >= A->ntiles_interior) == (pass == 1)) b.push_back(widen(A->h_tiles[t]));
@@ -388,7 +534,22 @@ static int build_window_tiles_scaled(npg_csr *A, const std::vector<int32_t> &pco
         }
         chk(up((void **)&A->dxy2, d2.data(), d2.size() * sizeof(double)));
         A->ndpairs = (int64_t)P;
+        if (rows_own) chk(up((void **)&A->wdz, wdz.data(), wdz.size() * sizeof(double)));
+        A->nw_drec = (int64_t)dcol.size();
     }
+    if (own) {
+        std::vector<double> gv(3 * wgz.size());
+        std::copy(wgxy.begin(), wgxy.end(), gv.begin());
+        std::copy(wgz.begin(), wgz.end(), gv.begin() + (ptrdiff_t)wgxy.size());
+        chk(up((void **)&A->wgval, gv.data(), gv.size() * sizeof(double)));
+        // where the halo unpack stores a ghost column's float beside its place behind the owned entries: its node's 4-float slot
+        std::vector<int32_t> gs((size_t)(A->n - A->m), -1);
+        for (int64_t g = 0; g < ngn; ++g)
+            for (int a = 0; a < A->gn_ncomp[(size_t)g]; ++a) gs[(size_t)(A->gn_col[(size_t)g] - A->m + a)] = (int32_t)(4 * (nnode + g) + a);
+        chk(up((void **)&A->gslot, gs.data(), gs.size() * sizeof(int32_t)));
+    }
+    A->nw_grec = (int64_t)gcol.size();
+    A->nw_rec = prow[nnode];
     A->nwrow_tiles = (int32_t)rowt.size();
     if (rc != NPG_OK) {
         free_window_tiles(A);
@@ -412,9 +573,11 @@ static int build_window_tiles_scaled(npg_csr *A, const std::vector<int32_t> &pco
 // dropped: bowl3D h = 0.04 (2.2 -> 2.9 rounds) 27.5 -> 29.0 us per Arnoldi launch, h = 0.05 (1.1 -> 1.9 rounds) 18.8 -> 20.6 us -
 // the workgroups do not move in rounds, and smaller tiles cost more than a partly filled last round (profiles/r04_windowed_tiles.txt).
 static int build_window_tiles(npg_csr *A, const std::vector<int32_t> &pcol, const std::vector<int32_t> &gcol,
-                              const std::vector<int32_t> &dcol, const std::vector<double> &pkc, const std::vector<double> &dxy) {
+                              const std::vector<int32_t> &dcol, const std::vector<double> &pkc, const std::vector<double> &dxy,
+                              const std::vector<double> &gxy, const std::vector<double> &gz, const std::vector<double> &dz,
+                              const std::vector<int32_t> &rcol, const std::vector<double> &rval) {
     const double s_env = getenv("NPG_WIN_SCALE") ? atof(getenv("NPG_WIN_SCALE")) : -1.0;
-    return build_window_tiles_scaled(A, pcol, gcol, dcol, pkc, dxy, s_env > 0 ? s_env : 1.0);
+    return build_window_tiles_scaled(A, pcol, gcol, dcol, pkc, dxy, gxy, gz, dz, rcol, rval, s_env > 0 ? s_env : 1.0);
 }
 
 constexpr int kSpmvThreads = 512;
@@ -603,7 +766,10 @@ WinDev win_view(const npg_csr *A) {
     WinDev w;
     w.widx = A->widx;
     w.gidx = A->gidx;
-    w.ngrec = A->ngrec;
+    w.ngrec = A->wgval ? A->nw_grec : A->ngrec;
+    w.gxy = reinterpret_cast<const double2 *>(A->wgval ? A->wgval : A->gval);
+    w.gz = A->wgval ? A->wgval + 2 * A->nw_grec : (A->gval ? A->gval + 2 * A->ngrec : nullptr);
+    w.dz = A->wdz ? A->wdz : (A->dval ? A->dval + 2 * A->ndrec : nullptr);
     w.wlist = A->wlist;
     w.vlist = A->vlist;
     w.pkc2 = reinterpret_cast<const double2 *>(A->pkc2);
@@ -827,7 +993,7 @@ NPG_API int npg_csr_block_nodes(npg_csr *A, int64_t nfull, int64_t nsurf, double
     A->nrec_real = nrec_real;
     int rc = build_tiles(A);
     if (rc) return rc;
-    if (want_win && colrec && (rc = build_window_tiles(A, pcol, gcolv, dcol, pkc, dxy))) return rc;
+    if (want_win && colrec && (rc = build_window_tiles(A, pcol, gcolv, dcol, pkc, dxy, gxy, gzv, dz, ncol, nval))) return rc;
     *blocked = 1;
     return NPG_OK;
 }
@@ -1174,6 +1340,28 @@ NPG_API int npg_csr_block_nodes_dofs(npg_csr *A, const int64_t *node_of_dof, con
     return NPG_OK;
 }
 
+// Ghost nodes of a rank's row block (columns [m, n) are the ghosts): node g's components are the ghost columns
+// [first_col[g], first_col[g] + ncomp[g]), ncomp 3 or 2.  Call BEFORE npg_csr_block_nodes: its windowed tile set then stores
+// owned-ghost node couplings as node records (common.h, npg_csr::gn_col).  The caller orders a rank's ghosts so that a node's
+// components are adjacent (ascending global ids within an owner do that in the node-block numbering).
+NPG_API int npg_csr_set_ghost_nodes(npg_csr *A, int64_t n_nodes, const int32_t *first_col, const int32_t *ncomp) {
+    NPG_REQUIRE(A && n_nodes >= 0 && (n_nodes == 0 || (first_col && ncomp)), "npg_csr_set_ghost_nodes: bad argument");
+    NPG_REQUIRE(A->nnode() == 0 && !A->packed, "npg_csr_set_ghost_nodes: call before npg_csr_block_nodes");
+    std::vector<char> seen((size_t)std::max<int64_t>(A->n - A->m, 0), 0);
+    for (int64_t g = 0; g < n_nodes; ++g) {
+        NPG_REQUIRE(ncomp[g] == 2 || ncomp[g] == 3, "npg_csr_set_ghost_nodes: node %lld has %d components", (long long)g, (int)ncomp[g]);
+        NPG_REQUIRE(first_col[g] >= A->m && (int64_t)first_col[g] + ncomp[g] <= A->n, "npg_csr_set_ghost_nodes: node %lld is not in the ghost columns",
+                    (long long)g);
+        for (int a = 0; a < ncomp[g]; ++a) {
+            NPG_REQUIRE(!seen[(size_t)(first_col[g] - A->m + a)], "npg_csr_set_ghost_nodes: ghost column %d named twice", first_col[g] + a);
+            seen[(size_t)(first_col[g] - A->m + a)] = 1;
+        }
+    }
+    A->gn_col.assign(first_col, first_col + n_nodes);
+    A->gn_ncomp.assign(ncomp, ncomp + n_nodes);
+    return NPG_OK;
+}
+
 // the (x, y)-only special case kept for callers that interleave two components: rows 2q, 2q+1 for q < npairs
 NPG_API int npg_csr_pair_xy(npg_csr *A, int64_t npairs, double rtol, int *paired) {
     return npg_csr_block_nodes(A, 0, npairs, rtol, paired);
@@ -1309,10 +1497,10 @@ NPG_API int npg_csr_window_info(const npg_csr *Ap, int64_t *tiles, int64_t *bloc
     if (matrix_bytes) {
         int64_t b = 0;
         if (A->wtile_ptr) {
-            const int64_t nnode = A->nnode(), nrec = A->h_prow[nnode];
-            b = 48 * (int64_t)A->nwtiles + 18 * nrec + 26 * A->ngrec + 4 * (A->nwlist + A->nvlist) + 8 * nnode +
+            const int64_t nnode = A->nnode(), nrec = A->nw_rec ? A->nw_rec : A->h_prow[nnode], ngr = A->nw_rec ? A->nw_grec : A->ngrec;
+            b = 48 * (int64_t)A->nwtiles + 18 * nrec + 26 * ngr + 4 * (A->nwlist + A->nvlist) + 8 * nnode +
                 12 * A->rnnz + 8 * (A->m - A->block_rows() + 1);
-            if (A->drow) b += A->nwrow_tiles ? 4 * (A->m - A->block_rows()) + 26 * A->ndrec : 8 * (A->m - A->block_rows() + 1) + 28 * A->ndrec;
+            if (A->drow) b += A->nwrow_tiles ? 4 * (A->m - A->block_rows()) + 26 * (A->nw_drec ? A->nw_drec : A->ndrec) : 8 * (A->m - A->block_rows() + 1) + 28 * A->ndrec;
         }
         *matrix_bytes = b;
     }
@@ -2266,6 +2454,12 @@ __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32e(CsrDev A, WinDev 
 }
 
 int64_t gather32_floats(const npg_csr *Ap);
+// node slots (4 floats each) at the head of a gather-layout copy of one of A's input vectors: the owned block nodes and, behind
+// them, the ghost nodes the windowed tile set addresses as record columns
+int64_t gather32_nodes(const npg_csr *Ap) {
+    const npg_csr *A = spmv_form(Ap);
+    return A->nnode() + (A->gslot ? A->ngn() : 0);
+}
 // x (n entries, fp64) -> its fp32 gather-layout copy; then y = alpha A fl32(x) + beta c ... on A's windowed tiles
 int spmv_epi_gather32(const npg_csr *Ap, const double *x, float *xg, const SpmvEpi &e, const NbEpi *nb) {
     const npg_csr *A = spmv_form(Ap);
@@ -2273,7 +2467,7 @@ int spmv_epi_gather32(const npg_csr *Ap, const double *x, float *xg, const SpmvE
     if (byte_sink) *byte_sink += spmv_stream_bytes(A, e, true) + 12 * A->n + (nb ? 8 * (int64_t)nb->rows * 4 : 0);    // (+ the fill kernel: 8 B in, 4 B out)
     if (int rc = check_record_view(A, false, "spmv_epi_gather32")) return rc;
     const int64_t nbr = A->block_rows();
-    const GatherMap g{xg, 3 * A->nfull, A->nfull, (int)nbr, (int)(4 * A->nnode() - nbr)};
+    const GatherMap g{xg, 3 * A->nfull, A->nfull, (int)nbr, (int)(gather32_nodes(A) * 4 - nbr)};
     hipLaunchKernelGGL(k_fill_gather32, dim3((unsigned)std::min<int64_t>(2048, (A->n + 255) / 256)), dim3(256), 0, A->ctx->stream, x, g, A->n);
     const dim3 grid(std::max(1, std::min<int>(A->nwtiles, 3 * A->ctx->num_cu))), blk(kSpmvThreads);
     const WinDev W = win_view(A);
@@ -2300,7 +2494,7 @@ int spmv_epi_gather32(const npg_csr *Ap, const double *x, float *xg, const SpmvE
 int64_t gather32_floats(const npg_csr *Ap) {
     const npg_csr *A = spmv_form(Ap);
     if (!(A->nnode() > 0 && !A->pk9 && !A->uperm && A->wtile_ptr && A->n == A->m)) return 0;
-    return 4 * A->nnode() + (A->n - A->block_rows()) + 8;
+    return 4 * gather32_nodes(A) + (A->n - A->block_rows()) + 8;
 }
 
 template <int L>
@@ -2365,11 +2559,11 @@ NPG_API int npg_spmv_gather32(const npg_csr *A, const npg_vec *x, npg_vec *y, in
     NPG_REQUIRE(!A->uperm, "npg_spmv_gather32: the matrix carries an internal renumbering (npg_csr_block_nodes_dofs)");
     NPG_REQUIRE(!windowed || A->wtile_ptr, "npg_spmv_gather32: the matrix has no windowed tile set");
     NPG_HIP(hipSetDevice(A->ctx->device));
-    const int64_t nbr = A->block_rows(), need = 4 * A->nnode() + (A->n - nbr) + 8;
+    const int64_t nbr = A->block_rows(), need = 4 * gather32_nodes(A) + (A->n - nbr) + 8;
     float *buf = nullptr;
     NPG_HIP(hipMalloc((void **)&buf, (size_t)need * sizeof(float)));
     NPG_HIP(hipMemsetAsync(buf, 0, (size_t)need * sizeof(float), A->ctx->stream));
-    const GatherMap g{buf, 3 * A->nfull, A->nfull, (int)nbr, (int)(4 * A->nnode() - nbr)};
+    const GatherMap g{buf, 3 * A->nfull, A->nfull, (int)nbr, (int)(4 * gather32_nodes(A) - nbr)};
     hipLaunchKernelGGL(k_fill_gather32, dim3((unsigned)std::min<int64_t>(4096, (A->n + 255) / 256)), dim3(256), 0, A->ctx->stream, x->d, g,
                        A->n);
     for (int r = 0; r < std::max(1, reps); ++r) switch (A->lanes) {

@@ -90,6 +90,7 @@ struct GDev {
                           // what one sweep read last is what the next reads first (Infinity Cache reuse of the basis)
     GatherMap xg;         // fp32-stored basis, fast mode, node-blocked A: wt ALSO in fp32 gather layout (spmv_device.h),
                           // written by the kernels that write wt, gathered by the Arnoldi kernel (p = null: off)
+    const int32_t *gslot; // distributed, ghost nodes as record columns: float position of every ghost column's node slot in xg (-1: none)
     int fast;             // one GPU, split mode: the orthogonalisation kernel does not form the second-pass sums at all; a
                           // column that would have needed them is counted (pad1) and later solves run the full kernels
     // what the CONSUMER prologues reduce: the producers' partial rows on one GPU, or the single all-reduced row when
@@ -1018,7 +1019,7 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
     float *g32 = (dist && d.xg.p) ? d.xg.p + d.xg.pos(d.n) : nullptr;
     for (int j = 0; j < d.mem; ++j) {
         if (overlap) {
-            if ((rc = halo_exchange_async(ws->halo, d.wt, g32))) return rc;
+            if ((rc = halo_exchange_async(ws->halo, d.wt, g32, d.gslot, d.xg.p))) return rc;
             if (pev) hipEventRecord(pev[2 * j], st);
             // RCCL: the interior launch leaves a few CUs free - its workgroups are persistent (they hold their CU until the last
             // tile) and RCCL's send/recv kernels on the other stream could otherwise not start before they are all done.  Peer
@@ -1030,7 +1031,7 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
             if (pev) hipEventRecord(pev[2 * j + 1], st);
             launch_rows_kernel(d, j, st, false);
         } else {
-        if (dist && (rc = halo_exchange_raw(ws->halo, d.wt, g32))) return rc;
+        if (dist && (rc = halo_exchange_raw(ws->halo, d.wt, g32, d.gslot, d.xg.p))) return rc;
         if (d.split) {
             launch_arnoldi_split<L>(d, std::min(d.G1, std::max(1, a_nt)), j, 0, a_nt, st, pev ? pev[2 * j] : nullptr,
                                     pev ? pev[2 * j + 1] : nullptr);
@@ -1282,7 +1283,11 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A_in, int precond_kind
     static const int xg_csr_env = getenv("NPG_GMRES_XG_CSR") ? atoi(getenv("NPG_GMRES_XG_CSR")) : -1;
     const bool xg_csr = xg_csr_env >= 0 ? xg_csr_env != 0 : ws->n >= 100000;
     if ((ws->gather32 >= 0 ? ws->gather32 : xg_env) && basis32 && d.fast && (A->nnode() > 0 || xg_csr) && (dist ? A->n == A->m + ws->n_ghost : A->n == A->m)) {
-        const int64_t nbr = A->block_rows(), need = 4 * A->nnode() + (A->n - nbr) + 8;
+        // node slots: the owned block nodes and, behind them, the ghost nodes the windowed tiles use as record columns
+        // (NOT gather32_floats(A): that is the stand-alone product's question and answers 0 for a rank's row block - round 5's first
+        //  version sized the copy without the ghost slots through it and the unpack wrote 4 ngn floats past the end)
+        const int64_t nslots = A->wtile_ptr ? gather32_nodes(A) : A->nnode();
+        const int64_t nbr = A->block_rows(), need = 4 * nslots + (A->n - nbr) + 8;
         if (ws->xg_len < need) {
             if (ws->xg) NPG_HIP(hipFree(ws->xg));
             ws->xg = nullptr;
@@ -1296,7 +1301,8 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A_in, int precond_kind
             ws->xg_key[1] = A->nsurf;
             ws->xg_key[2] = (int)A->n;
         }
-        d.xg = GatherMap{ws->xg, 3 * A->nfull, A->nfull, (int)nbr, (int)(4 * A->nnode() - nbr)};
+        d.xg = GatherMap{ws->xg, 3 * A->nfull, A->nfull, (int)nbr, (int)(4 * nslots - nbr)};
+        d.gslot = A->wtile_ptr ? A->gslot : nullptr;
         // windowed tile set of the block rows (spmv_window.h; NPG_GMRES_WINDOW=0: the ordinary tiles)
         static const int win_env = getenv("NPG_GMRES_WINDOW") ? atoi(getenv("NPG_GMRES_WINDOW")) : 1;
         if (win_env && ws->gather32 != 2 && d.split && A->wtile_ptr && !A->pk9 && nbr > 0) {

@@ -36,6 +36,8 @@ namespace npg {
 struct WinDev {
     const uint16_t *widx, *gidx;   // 16-bit window indices of the node records / column records (indexed like pcol / gcol)
     int64_t ngrec;                 // column records in all (a tile WITHOUT any clamps its idle loads to the last one)
+    const double2 *gxy;            // the column records' values: the matrix's own (CsrDev::gxy / gz) or, when ghost nodes turned some
+    const double *gz;              // of them into node records, the windowed set's own arrays
     const int32_t *wlist, *vlist;  // per-tile lists of distinct column nodes / other columns (WTileDesc::woff, voff index them)
     const double2 *pkc2;           // {K, C} split by position in the record pair: [npairs] first records, [npairs] second records
     int64_t npairs;
@@ -43,6 +45,7 @@ struct WinDev {
     const uint16_t *dwidx;         // windowed tiles of the rows behind the block rows: window indices of the coupling records,
     const int32_t *dbk;            // per such row the tile-local end of its coupling record pairs (null: those rows keep
     const double2 *dxy2;           // ordinary tiles), (d_x, d_y) split like pkc2
+    const double *dz;              // d_z of those coupling records (the matrix's own array, or the windowed set's when ghost nodes added records)
     int64_t ndpairs;
 };
 
@@ -163,11 +166,11 @@ __device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const WinDev &W, 
             }
             // (a tile without column records - n = 0 - still issues these loads: keep them inside the arrays)
             const int64_t ge = min(base + e, W.ngrec - 1);
-            const double *__restrict__ gq = reinterpret_cast<const double *>(A.gxy + ge);
+            const double *__restrict__ gq = reinterpret_cast<const double *>(W.gxy + ge);
             gi[u] = __builtin_nontemporal_load(W.gidx + ge);
             ax[u] = __builtin_nontemporal_load(gq);
             ay[u] = __builtin_nontemporal_load(gq + 1);
-            az[u] = __builtin_nontemporal_load(A.gz + ge);
+            az[u] = __builtin_nontemporal_load(W.gz + ge);
         }
     }
     prof.stamp(9);
@@ -273,7 +276,7 @@ __device__ __forceinline__ void spmv_tile_winrows(const CsrDev &A, const WinDev 
         const uint32_t *__restrict__ wp = reinterpret_cast<const uint32_t *>(W.dwidx + pbase);
         const double *__restrict__ xa = reinterpret_cast<const double *>(W.dxy2 + (pbase >> 1));
         const double *__restrict__ xb = reinterpret_cast<const double *>(W.dxy2 + W.ndpairs + (pbase >> 1));
-        const double *__restrict__ zz = A.dz + pbase;
+        const double *__restrict__ zz = W.dz + pbase;
 #pragma unroll
         for (int u = 0; u < kWinPairs; ++u) {
             const int p = min(tid + u * NT, npair - 1);

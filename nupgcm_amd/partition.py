@@ -194,6 +194,29 @@ class RankLayout:
         order = np.lexsort((owned, node_bnd[inv], cls))                       # class, then interior before boundary, then global id
         return owned[order]
 
+    def ghost_nodes(self, fe_data):
+        """(first local column, components) of every velocity NODE among this rank's solver ghosts whose components are all ghosts
+        here: in the node-block numbering a full node's DoFs are 3c, 3c + 1, 3c + 2 and a surface node's 3 n_full + 2c, + 1, and the
+        ghosts are ordered by (owner, global id) - ownership is by node - so the components of a ghost node are adjacent columns.
+        What npg_csr_set_ghost_nodes takes (the windowed tiles then keep owned-ghost couplings as node records)."""
+        d = fe_data.dofs
+        g = np.asarray(self.inv.g_sol, dtype=np.int64)
+        nf3, nbr = 3 * int(getattr(d, "n_full", 0)), 3 * int(getattr(d, "n_full", 0)) + 2 * int(getattr(d, "n_surf", 0))
+        first, ncomp = [], []
+        if len(g) >= 3:
+            k = np.nonzero((g[:-2] < nf3) & (g[:-2] % 3 == 0) & (g[1:-1] == g[:-2] + 1) & (g[2:] == g[:-2] + 2))[0]
+            first.append(self.inv.n_own + k)
+            ncomp.append(np.full(len(k), 3))
+        if len(g) >= 2:
+            k = np.nonzero((g[:-1] >= nf3) & (g[:-1] < nbr) & ((g[:-1] - nf3) % 2 == 0) & (g[1:] == g[:-1] + 1))[0]
+            first.append(self.inv.n_own + k)
+            ncomp.append(np.full(len(k), 2))
+        if not first:
+            return np.zeros(0, np.int32), np.zeros(0, np.int32)
+        first, ncomp = np.concatenate(first), np.concatenate(ncomp)
+        o = np.argsort(first, kind="stable")
+        return first[o].astype(np.int32), ncomp[o].astype(np.int32)
+
     def local_tables(self, fe_data) -> DeviceTables:
         t = fe_data.tables
         cu, cp, cb = t.cell_u[self.cells], t.cell_p[self.cells], t.cell_b[self.cells]
@@ -381,7 +404,9 @@ def partitioned_model(arch, fe_data, params, forcings, ts, dist, atol=1e-6, rtol
     if block_nodes is None:
         block_nodes = d.nu + d.np >= 100000
     if block_nodes and not full_stress:
-        A.block_nodes(*part.local_nodes(rank))             # owned nodes lead the local numbering; ghost couplings stay CSR
+        if hasattr(lay, "ghost_nodes") and isinstance(part, NodePartition) and os.environ.get("NPG_GHOST_NODES", "1") != "0":
+            A.set_ghost_nodes(*lay.ghost_nodes(fe_data))   # (round 5) ghost nodes as record columns of the windowed tiles
+        A.block_nodes(*part.local_nodes(rank))             # owned nodes lead the local numbering
     elif block_nodes and sum(part.local_nodes(rank)) > 0 and os.environ.get("NPG_PACK_NODES", "1") != "0":
         A.pack_nodes(*part.local_nodes(rank))              # full-stress form: record-form companion (follows re-assembly)
     rp, ci, shp = lay.local_pattern(fe_data.pattern_B(), lay.inv, lay.b, solver_cols=False)

@@ -177,3 +177,27 @@ def test_second_multigrid_level_inherits_ownership_through_the_injection(world):
         known = np.concatenate([lay_c.inv.owned, lay_c.inv.g_sol, lay_c.inv.g_ext])
         assert np.isin(foreign, known).mean() > 0.9
     assert io_f.max() == world - 1
+
+
+def test_ghost_nodes_of_a_rank_are_whole_nodes_of_a_neighbour():
+    """RankLayout.ghost_nodes (what npg_csr_set_ghost_nodes takes): every listed node is 3 (full node) or 2 (surface node) ADJACENT
+    ghost columns holding consecutive global DoFs of one node, owned by another rank; most velocity ghosts belong to such a node"""
+    from nupgcm_amd import partition, workloads
+    fed = workloads.example_fe_data(workloads.bowl_mesh_model("bowl3D_h0.1"))
+    d = fed.dofs
+    part = partition.NodePartition(fed, 3)
+    nf3, nbr = 3 * d.n_full, 3 * d.n_full + 2 * d.n_surf
+    for r in range(3):
+        lay = partition.RankLayout(fed, part, r)
+        first, ncomp = lay.ghost_nodes(fed)
+        g = np.asarray(lay.inv.g_sol)
+        assert len(first) > 0 and set(ncomp.tolist()) <= {2, 3} and (np.diff(first) >= ncomp[:-1]).all()     # disjoint, ascending
+        k = first - lay.inv.n_own
+        for a in range(3):
+            sel = ncomp > a
+            assert (g[k[sel] + a] == g[k[sel]] + a).all()
+        assert (g[k[ncomp == 3]] % 3 == 0).all() and (g[k[ncomp == 3]] < nf3).all()
+        assert ((g[k[ncomp == 2]] - nf3) % 2 == 0).all() and (g[k[ncomp == 2]] >= nf3).all() and (g[k[ncomp == 2]] < nbr).all()
+        assert (lay.owner_inv[g[k]] != r).all()
+        nvel = int((g < nbr).sum())
+        assert ncomp.sum() >= 0.9 * nvel, (ncomp.sum(), nvel)

@@ -47,6 +47,8 @@ fe.set_coeff("f", prm.f)
 rp, ci, shp = lay.local_pattern(fed.pattern_A(structural=False), lay.inv, lay.inv)
 A = DeviceCSR.from_pattern(ctx, shp[0], shp[1], rp, ci)
 fe.assemble(L.NPG_MAT_A, A, scale=prm.alpha ** 2 * prm.eps ** 2, full_stress=False)
+if os.environ.get("NPG_GHOST_NODES", "1") != "0":
+    A.set_ghost_nodes(*lay.ghost_nodes(fed))
 A.block_nodes(*part.local_nodes(rank))
 n_own, n_gh = lay.inv.n_own, len(lay.inv.g_sol)
 # the rank's REAL plan (whom it would talk to, how much it would send) - then folded onto itself
