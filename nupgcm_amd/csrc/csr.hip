@@ -786,6 +786,13 @@ WinDev win_view(const npg_csr *A) {
 
 using namespace npg;
 
+// A block-diagonal inverse made by npg_csr_line_block_inverse also holds its blocks as DENSE packs (lb_val, lb_val32, lb_val16), which
+// products read instead of the CSR values; only that routine refreshes them.  Any other writer of the CSR values of such a handle
+// would leave the packs stale and products would silently use the old inverse: refused.
+#define NPG_REQUIRE_NO_PACKS(A, who)                                                                                           \
+    NPG_REQUIRE((A)->lb_nblocks == 0, who ": the matrix holds dense line-block packs (npg_csr_line_block_inverse); rewriting its CSR " \
+                "values would leave them stale - build the values through npg_csr_line_block_inverse")
+
 // Store the velocity block of A_inversion node by node (see spmv_device.h): one record {c, K, C} per coupled node pair.
 // The structure is verified entry by entry on the host (K_xx = K_yy = K_zz, C_xy = -C_yx within rtol * row scale, nothing
 // else in the block); if anything does not match the matrix is left untouched and *blocked = 0.
@@ -1574,6 +1581,7 @@ NPG_API int npg_csr_clone(const npg_csr *A, npg_csr **out) {
 NPG_API int npg_csr_zero_values(npg_csr *A) {
     NPG_REQUIRE(A, "npg_csr_zero_values: NULL matrix");
     NPG_REQUIRE_PLAIN(A, "npg_csr_zero_values");
+    NPG_REQUIRE_NO_PACKS(A, "npg_csr_zero_values");
     NPG_HIP(hipMemsetAsync(A->val, 0, (size_t)A->nnz * sizeof(double), A->ctx->stream));
     return csr_repack(A);
 }
@@ -1584,6 +1592,7 @@ NPG_API int npg_csr_combine(npg_csr *out, double a, const npg_csr *X, double b, 
                     Y->m == Z->m,
                 "npg_csr_combine: operands must share one sparsity pattern");
     NPG_REQUIRE_PLAIN(out, "npg_csr_combine");
+    NPG_REQUIRE_NO_PACKS(out, "npg_csr_combine");
     NPG_REQUIRE_PLAIN(X, "npg_csr_combine");
     NPG_REQUIRE_PLAIN(Y, "npg_csr_combine");
     NPG_REQUIRE_PLAIN(Z, "npg_csr_combine");
@@ -1818,6 +1827,7 @@ NPG_API int npg_index_destroy(npg_index *ix) {
 
 NPG_API int npg_csr_gather_values(npg_csr *dst, const npg_csr *src, const npg_index *map) {
     NPG_REQUIRE(dst && src && map, "npg_csr_gather_values: NULL argument");
+    NPG_REQUIRE_NO_PACKS(dst, "npg_csr_gather_values");
     NPG_REQUIRE(dst->nnode() == 0 && src->nnode() == 0, "npg_csr_gather_values: node-blocked matrices are not supported");
     NPG_REQUIRE(map->n == dst->nnz && map->bound == src->nnz,
                 "npg_csr_gather_values: the map has %lld entries into %lld values, the matrices have %lld and %lld",
@@ -1843,6 +1853,7 @@ NPG_API int npg_csr_values_to_vec(const npg_csr *A, npg_vec *v) {
 }
 NPG_API int npg_csr_values_from_vec(npg_csr *A, const npg_vec *v, const npg_index *map) {
     NPG_REQUIRE(A && v && map, "npg_csr_values_from_vec: NULL argument");
+    NPG_REQUIRE_NO_PACKS(A, "npg_csr_values_from_vec");
     NPG_REQUIRE(A->nnode() == 0 && !A->uperm, "npg_csr_values_from_vec: a plain-CSR matrix is required");
     NPG_REQUIRE(map->n == A->nnz && map->bound <= v->n, "npg_csr_values_from_vec: the map has %lld entries below %lld, the matrix %lld values, the vector %lld entries",
                 (long long)map->n, (long long)map->bound, (long long)A->nnz, (long long)v->n);
@@ -1854,6 +1865,7 @@ NPG_API int npg_csr_values_from_vec(npg_csr *A, const npg_vec *v, const npg_inde
 
 NPG_API int npg_csr_node_block_inverse(npg_csr *Dinv, const npg_csr *A, int64_t n_full, int64_t n_surf) {
     NPG_REQUIRE(Dinv && A && n_full >= 0 && n_surf >= 0, "npg_csr_node_block_inverse: bad argument");
+    NPG_REQUIRE_NO_PACKS(Dinv, "npg_csr_node_block_inverse");
     NPG_REQUIRE(A->nnode() == 0 && Dinv->nnode() == 0, "npg_csr_node_block_inverse: node-blocked matrices are not supported");
     const int64_t nu = Dinv->m;
     NPG_REQUIRE(Dinv->n == nu && A->m >= nu && A->n >= nu && 3 * n_full + 2 * n_surf <= nu,
@@ -2089,6 +2101,7 @@ NPG_API int npg_csr_line_schur(npg_csr *S, const npg_csr *D, const npg_csr *Dinv
 
 NPG_API int npg_csr_triple_product(npg_csr *S, const npg_csr *D, const npg_csr *Dinv, const npg_csr *G) {
     NPG_REQUIRE(S && D && Dinv && G, "npg_csr_triple_product: NULL argument");
+    NPG_REQUIRE_NO_PACKS(S, "npg_csr_triple_product");
     NPG_REQUIRE(S->nnode() == 0 && D->nnode() == 0 && Dinv->nnode() == 0 && G->nnode() == 0,
                 "npg_csr_triple_product: node-blocked matrices are not supported");
     NPG_REQUIRE(D->n == Dinv->m && Dinv->n == G->m && S->m == D->m && S->n == G->n, "npg_csr_triple_product: shapes do not chain");
@@ -2108,6 +2121,7 @@ NPG_API int npg_csr_triple_product(npg_csr *S, const npg_csr *D, const npg_csr *
 
 NPG_API int npg_csr_product(npg_csr *Cm, const npg_csr *A, const npg_csr *B) {
     NPG_REQUIRE(Cm && A && B, "npg_csr_product: NULL argument");
+    NPG_REQUIRE_NO_PACKS(Cm, "npg_csr_product");
     NPG_REQUIRE(Cm->nnode() == 0 && A->nnode() == 0 && B->nnode() == 0, "npg_csr_product: node-blocked matrices are not supported");
     NPG_REQUIRE(A->n == B->m && Cm->m == A->m && Cm->n == B->n, "npg_csr_product: shapes do not chain");
     npg_ctx *ctx = Cm->ctx;

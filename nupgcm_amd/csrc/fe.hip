@@ -790,6 +790,7 @@ NPG_API int npg_fe_assemble_rhs_diff(npg_fe *fe, double N2, npg_vec *out) {
 NPG_API int npg_fe_assemble_matrix(npg_fe *fe, int which, double scale, int full_stress, npg_csr *A, npg_vec *lift) {
     NPG_REQUIRE(fe && A, "npg_fe_assemble_matrix: NULL argument");
     NPG_REQUIRE(A->nnode() == 0, "npg_fe_assemble_matrix: the matrix is stored by node blocks and cannot be re-assembled");
+    NPG_REQUIRE(A->lb_nblocks == 0, "npg_fe_assemble_matrix: the matrix holds dense line-block packs (npg_csr_line_block_inverse)");
     hipStream_t st = fe->ctx->stream;
     const FeDev &d = fe->d;
     const bool f32 = fe->precision == NPG_FE_FP32;

@@ -30,7 +30,7 @@ constexpr int kTriLanes = 16;             // lanes per row in the triangular sol
 // rows[0, nrows) of one level: row i <- its ILU(0) row.  One wavefront (workgroup of 64) per row.
 __global__ void __launch_bounds__(64) k_ilu0_level(const int32_t *__restrict__ rows, int nrows, const int64_t *__restrict__ rp,
                                                    const int32_t *__restrict__ col, const int64_t *__restrict__ diag,
-                                                   double *__restrict__ lu) {
+                                                   double *__restrict__ lu, int *__restrict__ bad) {
     __shared__ double v[kIluMaxRow];
     __shared__ int32_t c[kIluMaxRow];
     __shared__ double lik_s;
@@ -71,6 +71,12 @@ __global__ void __launch_bounds__(64) k_ilu0_level(const int32_t *__restrict__ r
             __syncthreads();
         }
         for (int e = threadIdx.x; e < len; e += 64) lu[a + e] = v[e];
+        // the row's own pivot: rows of later levels divide by it.  A zero or non-finite pivot is counted (cuSPARSE's csrilu02 reports
+        // the position of a zero pivot; KrylovPreconditioners.kp_ilu0 of the reference goes through it) - the host fails the call
+        if (threadIdx.x == 0) {
+            const double ukk = v[nlow];
+            if (!(fabs(ukk) > 0.0) || !(fabs(ukk) < 1e300)) atomicAdd(bad, 1);
+        }
     }
 }
 
@@ -179,13 +185,23 @@ NPG_API int npg_ilu0_destroy(npg_ilu0 *m) {
 static int ilu_factor(npg_ilu0 *m, const npg_csr *A) {
     hipStream_t st = m->ctx->stream;
     NPG_HIP(hipMemcpyAsync(m->lu, A->val, (size_t)m->nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
+    int *bad = nullptr, nbad = 0;
+    NPG_HIP(hipMalloc((void **)&bad, sizeof(int)));
+    NPG_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
     for (size_t l = 0; l + 1 < m->lp.size(); ++l) {
         const int nr = m->lp[l + 1] - m->lp[l];
         hipLaunchKernelGGL(k_ilu0_level, dim3(std::min(nr, 65535)), dim3(64), 0, st, (const int32_t *)m->rows_l + m->lp[l], nr,
-                           (const int64_t *)m->rowptr, (const int32_t *)m->col, (const int64_t *)m->diag, m->lu);
+                           (const int64_t *)m->rowptr, (const int32_t *)m->col, (const int64_t *)m->diag, m->lu, bad);
     }
-    NPG_HIP(hipGetLastError());
-    NPG_HIP(hipStreamSynchronize(st));
+    const hipError_t e1 = hipGetLastError();
+    const hipError_t e2 = hipMemcpyAsync(&nbad, bad, sizeof(int), hipMemcpyDeviceToHost, st);
+    const hipError_t e3 = hipStreamSynchronize(st);
+    hipFree(bad);
+    NPG_HIP(e1);
+    NPG_HIP(e2);
+    NPG_HIP(e3);
+    NPG_REQUIRE(nbad == 0, "ILU(0): %d zero or non-finite pivot(s) - the matrix has no ILU(0) factorisation in its own pattern "
+                           "(csrilu02 would report a zero pivot)", nbad);
     return NPG_OK;
 }
 

@@ -516,6 +516,63 @@ static int dense_build(npg_precond *pc, const npg_csr *A, bool fp32, bool fp16 =
         hipLaunchKernelGGL(k_to_half_ld, dim3(4096), dim3(kBlock), 0, st, d.M, d.cs, d.Mh, n, d.ldf);
         NPG_HIP(hipGetLastError());
         NPG_HIP(hipStreamSynchronize(st));
+        // Column scaling keeps every column's largest entry exact, but rows of very different magnitude within one column (velocity
+        // against pressure rows of a Stokes inverse differ by alpha^2 eps^2) may fall below fp16's range and flush to zero: what the
+        // rounded inverse does to two probe vectors is compared, row by row, with the fp64 inverse while both are in memory; if the
+        // typical row is off by more than fp16's rounding explains, or any sizeable row is lost, the fp32 storage is taken instead
+        // (ADVICE round 4).  NPG_MG_COARSE_FP16_CHECK=0 skips the check.
+        static const bool check16 = !getenv("NPG_MG_COARSE_FP16_CHECK") || atoi(getenv("NPG_MG_COARSE_FP16_CHECK")) != 0;
+        bool keep16 = true;
+        if (check16) {
+            double *rv = nullptr, *y64 = nullptr, *y16 = nullptr;
+            NPG_HIP(hipMalloc((void **)&rv, 3 * (size_t)n * sizeof(double)));
+            y64 = rv + n;
+            y16 = y64 + n;
+            std::vector<double> h((size_t)n), a((size_t)n), b((size_t)n);
+            for (int probe = 0; probe < 2 && keep16; ++probe) {
+                for (int64_t i = 0; i < n; ++i)
+                    h[(size_t)i] = probe == 0 ? std::sin(0.37 * (double)i) + 0.5 : ((i * 2654435761u) & 64 ? 1.0 : -1.0) * (1.0 + (double)(i % 7));
+                NPG_HIP(hipMemcpy(rv, h.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+                _Float16 *keep = d.Mh;
+                d.Mh = nullptr;
+                int rcd = dense_apply(pc, rv, y64, 1.0, 0.0);          // fp64 inverse
+                d.Mh = keep;
+                if (!rcd) rcd = dense_apply(pc, rv, y16, 1.0, 0.0);    // column-scaled fp16 inverse
+                if (rcd) {
+                    hipFree(rv);
+                    return rcd;
+                }
+                NPG_HIP(hipMemcpyAsync(a.data(), y64, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+                NPG_HIP(hipMemcpyAsync(b.data(), y16, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+                NPG_HIP(hipStreamSynchronize(st));
+                double amax = 0.0;
+                for (double v : a) amax = std::max(amax, std::fabs(v));
+                std::vector<double> rel;
+                rel.reserve((size_t)n);
+                for (int64_t i = 0; i < n; ++i)
+                    if (std::fabs(a[(size_t)i]) > 1e-8 * amax) rel.push_back(std::fabs(b[(size_t)i] - a[(size_t)i]) / std::fabs(a[(size_t)i]));
+                if (rel.empty()) continue;
+                std::sort(rel.begin(), rel.end());
+                const double med = rel[rel.size() / 2], p99 = rel[(size_t)(0.99 * (double)(rel.size() - 1))];
+                if (!(med <= 5e-3 && p99 <= 0.2)) {
+                    keep16 = false;
+                    fprintf(stderr, "[npg mg] coarsest level: the column-scaled fp16 inverse differs from the fp64 one by %.1e (median row) / "
+                                    "%.1e (99th percentile) on a probe vector - fp32 storage instead\n", med, p99);
+                }
+            }
+            NPG_HIP(hipFree(rv));
+        }
+        if (!keep16) {
+            NPG_HIP(hipFree(d.Mh));
+            NPG_HIP(hipFree(d.cs));
+            d.Mh = nullptr;
+            d.cs = nullptr;
+            d.ldf = (n + 3) / 4 * 4;
+            NPG_HIP(hipMalloc((void **)&d.Mf, (size_t)d.ldf * n * sizeof(float)));
+            hipLaunchKernelGGL(k_to_float_ld, dim3(4096), dim3(kBlock), 0, st, d.M, d.Mf, n, d.ldf);
+            NPG_HIP(hipGetLastError());
+            NPG_HIP(hipStreamSynchronize(st));
+        }
         NPG_HIP(hipFree(d.M));
         d.M = nullptr;
     } else if (fp32) {

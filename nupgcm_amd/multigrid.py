@@ -219,11 +219,17 @@ def node_block_inverse(F, n_full, n_surf):
     return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nu, nu))
 
 
-def line_blocks(fed: FEData, decimals=7):
+MAX_LINE_UNKNOWNS = 136          # csrc/csr.hip kMaxLineBlock: one workgroup inverts a block in LDS (148 of the CU's 160 KB)
+
+
+def line_blocks(fed: FEData, decimals=7, max_unknowns=MAX_LINE_UNKNOWNS):
     """(block_ptr, block_dofs, line_of_dof): the velocity unknowns (positions in the device order) grouped by the (x, y) of their
     nodes - the unknowns of the nodes above one another form one block (a structured-to-tet mesh such as the channel basin's
     stacks its nodes in vertical lines; on an unstructured mesh the blocks fall back to the single nodes).  Blocks are numbered
-    by their first unknown; each block's unknowns ascend."""
+    by their first unknown; each block's unknowns ascend.  A line with more than `max_unknowns` unknowns (the device inverts a
+    block in the LDS of one CU: 136 = 45 three-component nodes, about 22 P2 layers) is cut into consecutive vertical segments of at
+    most that many - whole nodes, top down: finer vertical resolutions degrade to shorter blocks instead of failing the set-up
+    (ADVICE round 4)."""
     s, d = fed.spaces, fed.dofs
     nu = d.nu
     node_of = np.full(nu, -1, dtype=np.int64)
@@ -233,6 +239,19 @@ def line_blocks(fed: FEData, decimals=7):
     xy = np.round(fed.mesh.node_coords[node_of][:, :2], decimals)
     _, grp = np.unique(xy, axis=0, return_inverse=True)
     grp = np.asarray(grp).ravel()
+    if max_unknowns and np.bincount(grp).max() > max_unknowns:
+        # rank of every unknown's NODE within its line, top down; a segment holds max_unknowns // 3 nodes
+        z = fed.mesh.node_coords[node_of][:, 2]
+        o = np.lexsort((node_of, -z, grp))
+        new_node = np.r_[True, (node_of[o][1:] != node_of[o][:-1]) | (grp[o][1:] != grp[o][:-1])]
+        node_rank = np.cumsum(new_node) - 1
+        line_start = np.r_[True, grp[o][1:] != grp[o][:-1]]
+        first_rank = np.maximum.accumulate(np.where(line_start, node_rank, 0))
+        seg = np.empty(nu, dtype=np.int64)
+        seg[o] = (node_rank - first_rank) // max(1, max_unknowns // 3)
+        long_line = np.bincount(grp)[grp] > max_unknowns
+        _, grp = np.unique(np.stack([grp, np.where(long_line, seg, 0)], axis=1), axis=0, return_inverse=True)
+        grp = np.asarray(grp).ravel()
     first = np.full(grp.max() + 1, nu, dtype=np.int64)
     np.minimum.at(first, grp, np.arange(nu))
     line_of = np.argsort(np.argsort(first))[grp]                  # blocks renumbered by their first unknown
@@ -515,6 +534,8 @@ class MultigridPreconditioner(GeneralPreconditioner):
             self._inj = [injection(self.hierarchy[k].mesh, self.hierarchy[k + 1].mesh, p1) for k in range(top)]
         s_f = self._top.spaces
         nodal = np.where(s_f.b_dof >= 0, model.state.b[np.maximum(s_f.b_dof, 0)], s_f.b_diri_val)   # fine nodal values
+        if os.environ.get("NPG_MG_COARSE_NU", getattr(self, "coarse_nu", "inject")) == "average":
+            return self._refresh_coarse_levels_averaged(nodal, ep)
         for lev in range(top - 1, -1, -1):
             fed = self.hierarchy[lev]
             nodal = nodal[self._inj[lev]]
@@ -523,6 +544,42 @@ class MultigridPreconditioner(GeneralPreconditioner):
             bl = DeviceVector.from_host(self.ctx, nodal[s.b_dof >= 0], fed.dofs.p_b)
             fe.update_nu_eddy(ep.N2min, self.prm.alpha, self.prm.N2, bl)
             build_A_inversion(self.arch, fed, self.prm, None, A=self.A[lev])
+            self._update_level(lev, self.A[lev])
+        if self.coarse_dense:
+            L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, self._dense_mode))
+        return self
+
+    def _refresh_coarse_levels_averaged(self, nodal, ep):
+        """coarse levels re-discretised with the AVERAGE of the level above's eddy viscosity over each cell's eight children
+        (volume-weighted) instead of the viscosity of the buoyancy injected into the coarse mesh: nu_eddy = f^2 / sqrt(N2min^2 +
+        (alpha (N2 + d_z b))^2) is a strongly non-linear function of d_z b, and d_z of the injected buoyancy is not the average of
+        the fine d_z b - a Galerkin coarse operator R A P sees the fine viscosity, and the cell average is what the
+        re-discretisation can take of that without leaving the fixed patterns.  (Experiment of round 5: NPG_MG_COARSE_NU=average.)"""
+        from .assembly import eval_at_quad_points
+        top = len(self.levels) - 1
+        fed = self._top
+        m, sp_ = fed.mesh, fed.spaces
+        p1 = sp_.b_order == 1
+        dN = m.dN1 if p1 else m.dN2                                     # (nq, nloc, 4)
+        bn = nodal[sp_.cell_b_nodes]                                     # (nc, nloc)
+        gz = m.grad_lambda[:, :, 2]                                      # (nc, 4): d_z lambda_k
+        bz = np.einsum("ci,qik,ck->cq", bn, dN, gz)
+        abz = self.prm.alpha * (self.prm.N2 + bz)
+        f = eval_at_quad_points(m, self.prm.f)
+        nu_e = f * (f / np.sqrt(ep.N2min ** 2 + abz ** 2))
+        sm, nu_min = 10.0, 1.0                                           # nu_eddy's defaults, as run! calls it (src/inputs.jl:130-137)
+        nu = np.logaddexp(sm * nu_min, sm * nu_e) / sm
+        wq = m.q_w / m.q_w.sum()
+        for lev in range(top - 1, -1, -1):
+            fine, fedc = self.hierarchy[lev + 1], self.hierarchy[lev]
+            vol = fine.mesh.detJ
+            mean_f = nu @ wq                                             # quadrature mean per fine cell
+            num = (mean_f * vol).reshape(-1, 8).sum(axis=1)
+            den = vol.reshape(-1, 8).sum(axis=1)
+            nu = np.repeat((num / den)[:, None], len(wq), axis=1)
+            fe = device_fe(self.arch, fedc)
+            fe.set_coeff("nu", lambda xq, t=nu: t)
+            build_A_inversion(self.arch, fedc, self.prm, None, A=self.A[lev])
             self._update_level(lev, self.A[lev])
         if self.coarse_dense:
             L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, self._dense_mode))

@@ -131,3 +131,34 @@ def test_npz_roundtrip_keeps_the_pairing(model, tmp_path):
     m2 = gmsh_io.load_npz(str(tmp_path / "cb.npz"))
     assert np.array_equal(m2.periodic, model.periodic) and np.array_equal(m2.cells, model.cells)
     assert pfe.Mesh(m2).nv == pfe.Mesh(model).nv
+
+
+def test_over_long_vertical_lines_are_cut_into_segments():
+    """multigrid.line_blocks: the z-line smoother's blocks are inverted in the LDS of one CU (at most 136 unknowns); a line with
+    more than that - a mesh with more than ~22 P2 layers - is cut into consecutive vertical segments of whole nodes instead of
+    failing the set-up.  Every block stays inside one (x, y) column, its unknowns ascend, the segments of a column are contiguous in z
+    and together they still cover every velocity unknown once."""
+    from nupgcm_amd import channel_basin as cb
+    from nupgcm_amd import multigrid as mgm
+    from nupgcm_amd import workloads
+    fed = workloads.channel_basin_fe_data(cb.channel_basin_model(0.25, 1 / 8, dz=0.004), "flux")
+    bp0, _, _ = mgm.line_blocks(fed, max_unknowns=None)
+    assert np.diff(bp0).max() > mgm.MAX_LINE_UNKNOWNS                     # the mesh really has over-long lines
+    bp, bd, line_of = mgm.line_blocks(fed)
+    assert np.diff(bp).max() <= mgm.MAX_LINE_UNKNOWNS and len(bp) > len(bp0)
+    assert np.array_equal(np.sort(bd), np.arange(fed.dofs.nu))
+    s, d = fed.spaces, fed.dofs
+    node_of = np.full(d.nu, -1, dtype=np.int64)
+    for a in range(3):
+        nodes = np.nonzero(s.u_dof[:, a] >= 0)[0]
+        node_of[d.inv_p_u[s.u_dof[nodes, a]]] = nodes
+    xyz = fed.mesh.node_coords[node_of]
+    zr = {}
+    for b in range(len(bp) - 1):
+        idx = bd[bp[b]:bp[b + 1]]
+        assert (np.diff(idx) > 0).all() and (line_of[idx] == line_of[idx[0]]).all()
+        assert np.ptp(np.round(xyz[idx, 0], 7)) == 0 and np.ptp(np.round(xyz[idx, 1], 7)) == 0
+        zr.setdefault((round(xyz[idx[0], 0], 7), round(xyz[idx[0], 1], 7)), []).append((xyz[idx, 2].min(), xyz[idx, 2].max()))
+    for segs in zr.values():                                             # segments of one column do not interleave in z
+        segs.sort()
+        assert all(a[1] <= b[0] + 1e-12 for a, b in zip(segs, segs[1:]))

@@ -95,6 +95,22 @@ def test_argument_errors(arch):
     with pytest.raises(npg._lib.DeviceError, match="alias"):
         v = npg.DeviceVector(ctx, 200)
         npg._lib.check(npg._lib.lib().npg_ilu0_apply(M.h, v.h, v.h))
+    # a zero pivot is REPORTED (csrilu02 does; round 4 returned OK and the NaN factors surfaced later as a CG breakdown - ADVICE):
+    # u_11 = 0 after eliminating row 1 with row 0 of [[1, 1], [1, 1]]; and an explicitly stored zero on the diagonal
+    for Z in (np.array([[1.0, 1.0, 0.0], [1.0, 1.0, 1.0], [0.0, 1.0, 2.0]]), None):
+        if Z is None:
+            Zs = sp.csr_matrix((np.array([0.0, 1.0, 1.0, 3.0]), np.array([0, 1, 0, 1]), np.array([0, 2, 4])), shape=(2, 2))
+        else:
+            Zs = sp.csr_matrix(Z)
+        with pytest.raises(npg._lib.DeviceError, match="pivot"):
+            npg.DeviceILU0(npg.DeviceCSR.from_scipy(ctx, Zs))
+    Abad = sp.csr_matrix(A.copy())
+    Abad.sort_indices()
+    k = Abad.indptr[0] + int(np.searchsorted(Abad.indices[Abad.indptr[0]:Abad.indptr[1]], 0))
+    assert Abad.indices[k] == 0
+    Abad.data[k] = 0.0                                        # same pattern, first pivot zero
+    with pytest.raises(npg._lib.DeviceError, match="pivot"):
+        M.refactor(npg.DeviceCSR.from_scipy(ctx, Abad))
 
 
 def test_velocity_block_of_the_reference_with_ilu0(arch):

@@ -512,6 +512,12 @@ def test_line_block_entry_points_on_a_synthetic_matrix(arch):
         wrong = list(idx)
         wrong[5] = DeviceIndex(ctx, seg_ptr[:-1], len(seg_line) + 1)
         L.check(L.lib().npg_csr_line_schur(S1.h, Dd_sorted.h, Dinv.h, Gd.h, *[i.h for i in wrong]))
+    # the handle now carries dense packs of its blocks, which products read instead of the CSR values: any OTHER writer of those
+    # values would leave the packs stale and is refused
+    for call in (lambda: L.check(L.lib().npg_csr_zero_values(Dinv.h)), lambda: Dinv.combine(1.0, Dinv, 0.5, Dinv, Dinv),
+                 lambda: L.check(L.lib().npg_csr_node_block_inverse(Dinv.h, Ad.h, 0, 0))):
+        with pytest.raises(L.DeviceError, match="line-block packs"):
+            call()
     Fs = sp.csr_matrix(F.copy())
     Fs.data[Fs.indptr[bd[bp[3]]]:Fs.indptr[bd[bp[3]] + 1]] = 0.0                      # a zero row inside block 3: singular
     with pytest.raises(L.DeviceError, match="singular"):
