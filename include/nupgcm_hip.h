@@ -448,6 +448,11 @@ int npg_fe_update_kappa_convection(npg_fe *fe, const double *kappa_v0_host_or_nu
 /* nu <- LogSumExp(nu_min, f^2 / sqrt(N2min^2 + (alpha (N2 + d_z b))^2)) (nu_eddy, src/inputs.jl:130-137) */
 int npg_fe_update_nu_eddy(npg_fe *fe, double N2min, double alpha, double N2, double smoothing, double nu_min,
                           const npg_vec *b);
+/* Coefficient `name` of `coarse` <- the volume-weighted average, over each coarse cell's eight children (cells 8c .. 8c+7 of the
+ * uniformly refined mesh `fine` lives on), of the quadrature mean of `fine`'s table: the multigrid hierarchy's coarse levels follow
+ * a closure (nu_eddy, src/inputs.jl:130-137; refreshed at src/model.jl:160-170) through the FINE level's viscosity instead of
+ * re-evaluating the non-linear closure on an injected buoyancy.  No counterpart in the reference (it has no multigrid). */
+int npg_fe_restrict_coeff(npg_fe *coarse, const npg_fe *fine, const char *name);
 /* CFL:  min_K h_K / max(max_q |u|, u_min)   (update_dt!, src/timesteppers.jl:108-119) */
 int npg_fe_cfl_ratio(npg_fe *fe, const double *h_cells_host, double u_min, const npg_vec *x_inv, double *out);
 

@@ -125,6 +125,10 @@ class DeviceFE:
         L.check(L.lib().npg_fe_update_nu_eddy(self.h, float(N2min), float(alpha), float(N2), float(smoothing),
                                               float(nu_min), b.h))
 
+    def restrict_coeff(self, fine: "DeviceFE", name="nu"):
+        """this (coarse) engine's coefficient table <- the child-volume average of `fine`'s (npg_fe_restrict_coeff)"""
+        L.check(L.lib().npg_fe_restrict_coeff(self.h, fine.h, name.encode()))
+
     def cfl_ratio(self, x_inv, u_min=0.01, h_cells=None):
         out = C.c_double()
         hc = None if h_cells is None else L.as_f64(h_cells)

@@ -884,6 +884,41 @@ NPG_API int npg_fe_update_nu_eddy(npg_fe *fe, double N2min, double alpha, double
     return coeff_update(fe, 1, b, 0.0, N2min, alpha, N2, smoothing, nu_min, nullptr, fe->coef[0]);
 }
 
+// coarse[q][c] (every q) = sum_k |K_k| mean_q(fine[.][8c + k]) / sum_k |K_k|  over the eight children 8c .. 8c + 7 of coarse cell c
+__global__ void __launch_bounds__(kBlock) k_coeff_restrict(const double *__restrict__ fine, const double *__restrict__ wdet, const double *__restrict__ qw,
+                                                           int nq, int64_t ncf, int64_t ncc, int nqc, double *__restrict__ coarse) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= ncc) return;
+    double sw = 0.0;
+    for (int q = 0; q < nq; ++q) sw += qw[q];
+    double num = 0.0, den = 0.0;
+    for (int k = 0; k < 8; ++k) {
+        const int64_t cf = 8 * c + k;
+        double m = 0.0;
+        for (int q = 0; q < nq; ++q) m += qw[q] * fine[(size_t)q * ncf + cf];
+        num += wdet[cf] * (m / sw);
+        den += wdet[cf];
+    }
+    const double v = num / den;
+    for (int q = 0; q < nqc; ++q) coarse[(size_t)q * ncc + c] = v;
+}
+
+NPG_API int npg_fe_restrict_coeff(npg_fe *coarse, const npg_fe *fine, const char *name) {
+    NPG_REQUIRE(coarse && fine && name, "npg_fe_restrict_coeff: NULL argument");
+    const int k = coef_index(name);
+    NPG_REQUIRE(k >= 0, "npg_fe_restrict_coeff: unknown coefficient '%s'", name);
+    NPG_REQUIRE(coarse->ctx == fine->ctx, "npg_fe_restrict_coeff: the two element engines live on different contexts");
+    NPG_REQUIRE(fine->d.ncell == 8 * coarse->d.ncell, "npg_fe_restrict_coeff: the fine mesh (%lld cells) is not the uniform refinement of the coarse one (%lld)",
+                (long long)fine->d.ncell, (long long)coarse->d.ncell);
+    NPG_REQUIRE(fine->coef[k], "npg_fe_restrict_coeff: coefficient '%s' has not been set on the fine mesh", name);
+    int rc = ensure_coef(coarse, k);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_coeff_restrict, dim3(cell_grid(coarse->d.ncell)), dim3(kBlock), 0, coarse->ctx->stream, (const double *)fine->coef[k], fine->d.wdet,
+                       fine->d.qw, fine->d.nq, fine->d.ncell, coarse->d.ncell, coarse->d.nq, coarse->coef[k]);
+    NPG_HIP(hipGetLastError());
+    return NPG_OK;
+}
+
 NPG_API int npg_fe_cfl_ratio(npg_fe *fe, const double *h_cells_host, double u_min, const npg_vec *x_inv, double *out) {
     NPG_REQUIRE(fe && x_inv && out && x_inv->n == fe->n_inv, "npg_fe_cfl_ratio: bad argument");
     if (h_cells_host) {

@@ -438,12 +438,14 @@ class MultigridPreconditioner(GeneralPreconditioner):
 
     def __init__(self, arch, params, forcings, hierarchy, A_fine: DeviceCSR = None, omega=2.5, jacobi_weight=0.7,
                  schur_sweeps=3, nu1=2, nu2=2, coarse_sweeps=20, block_nodes=None, cycle="V", coarse_dense=None,
-                 mixed=False, scaled_gradient=None, smoother=None):
+                 mixed=False, scaled_gradient=None, smoother=None, coarse_nu="average"):
         """smoother: "node" (Braess-Sarazin on the node blocks of the velocity block) or "zline" (its blocks are the unknowns of
         the nodes above one another - the anisotropic, structured-in-z meshes: on the channel basin's three-level hierarchy a
         third of the outer iterations; None: NPG_MG_SMOOTHER, else "node").
         scaled_gradient: hand the smoother Dinv G, so that a step applies Dinv once instead of twice (None: on unless
         NPG_MG_SCALED_GRADIENT=0).
+        coarse_nu: how the coarser levels follow the eddy closure at a refresh: "average" (the level above's viscosity averaged
+        over a cell's children, on the device) or "inject" (rounds 3-4: the closure re-evaluated on the injected buoyancy).
         mixed: the cycle's SpMVs read fp32 copies of the level operators' values (npg_precond_mg_set_mixed); vectors,
         sums and the outer flexible GMRES stay fp64.
         coarse_dense: solve the coarsest level exactly with its dense inverse (DenseInversePreconditioner's machinery)
@@ -508,6 +510,7 @@ class MultigridPreconditioner(GeneralPreconditioner):
         if self._dense_mode:
             L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, self._dense_mode))
         self.coarse_dense = bool(coarse_dense)
+        self.coarse_nu = coarse_nu
         self.mixed = bool(mixed) or os.environ.get("NPG_MG_MIXED", "0") == "1"
         if self.mixed:
             L.check(L.lib().npg_precond_mg_set_mixed(self.h, 1))
@@ -529,13 +532,14 @@ class MultigridPreconditioner(GeneralPreconditioner):
         ep = self.frc.eddy_param
         if model is None or top == 0 or not ep.is_on:
             return self
+        if os.environ.get("NPG_MG_COARSE_NU", self.coarse_nu) == "average":
+            # (the fine engine's viscosity table is the one the caller has just re-assembled A from: model.run, src/model.jl:160-170)
+            return self._refresh_coarse_levels_averaged()
         if self._inj is None:
             p1 = self._top.spaces.b_order == 1
             self._inj = [injection(self.hierarchy[k].mesh, self.hierarchy[k + 1].mesh, p1) for k in range(top)]
         s_f = self._top.spaces
         nodal = np.where(s_f.b_dof >= 0, model.state.b[np.maximum(s_f.b_dof, 0)], s_f.b_diri_val)   # fine nodal values
-        if os.environ.get("NPG_MG_COARSE_NU", getattr(self, "coarse_nu", "inject")) == "average":
-            return self._refresh_coarse_levels_averaged(nodal, ep)
         for lev in range(top - 1, -1, -1):
             fed = self.hierarchy[lev]
             nodal = nodal[self._inj[lev]]
@@ -549,36 +553,18 @@ class MultigridPreconditioner(GeneralPreconditioner):
             L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, self._dense_mode))
         return self
 
-    def _refresh_coarse_levels_averaged(self, nodal, ep):
+    def _refresh_coarse_levels_averaged(self):
         """coarse levels re-discretised with the AVERAGE of the level above's eddy viscosity over each cell's eight children
-        (volume-weighted) instead of the viscosity of the buoyancy injected into the coarse mesh: nu_eddy = f^2 / sqrt(N2min^2 +
-        (alpha (N2 + d_z b))^2) is a strongly non-linear function of d_z b, and d_z of the injected buoyancy is not the average of
-        the fine d_z b - a Galerkin coarse operator R A P sees the fine viscosity, and the cell average is what the
-        re-discretisation can take of that without leaving the fixed patterns.  (Experiment of round 5: NPG_MG_COARSE_NU=average.)"""
-        from .assembly import eval_at_quad_points
+        (volume-weighted; npg_fe_restrict_coeff, level by level on the device) instead of the viscosity of the buoyancy injected
+        into the coarse mesh: nu_eddy = f^2 / sqrt(N2min^2 + (alpha (N2 + d_z b))^2) is a strongly non-linear function of d_z b, and
+        d_z of the injected buoyancy is not the average of the fine d_z b.  A Galerkin coarse operator R A P sees the fine
+        viscosity; the cell average is what a re-discretisation on the fixed patterns can take of that.  Channel basin h = 0.01:
+        16 -> 19-20 outer iterations after a re-assembly instead of 16 -> 31-35 (profiles/r05_coarse_viscosity.txt)."""
         top = len(self.levels) - 1
-        fed = self._top
-        m, sp_ = fed.mesh, fed.spaces
-        p1 = sp_.b_order == 1
-        dN = m.dN1 if p1 else m.dN2                                     # (nq, nloc, 4)
-        bn = nodal[sp_.cell_b_nodes]                                     # (nc, nloc)
-        gz = m.grad_lambda[:, :, 2]                                      # (nc, 4): d_z lambda_k
-        bz = np.einsum("ci,qik,ck->cq", bn, dN, gz)
-        abz = self.prm.alpha * (self.prm.N2 + bz)
-        f = eval_at_quad_points(m, self.prm.f)
-        nu_e = f * (f / np.sqrt(ep.N2min ** 2 + abz ** 2))
-        sm, nu_min = 10.0, 1.0                                           # nu_eddy's defaults, as run! calls it (src/inputs.jl:130-137)
-        nu = np.logaddexp(sm * nu_min, sm * nu_e) / sm
-        wq = m.q_w / m.q_w.sum()
         for lev in range(top - 1, -1, -1):
-            fine, fedc = self.hierarchy[lev + 1], self.hierarchy[lev]
-            vol = fine.mesh.detJ
-            mean_f = nu @ wq                                             # quadrature mean per fine cell
-            num = (mean_f * vol).reshape(-1, 8).sum(axis=1)
-            den = vol.reshape(-1, 8).sum(axis=1)
-            nu = np.repeat((num / den)[:, None], len(wq), axis=1)
+            fedc = self.hierarchy[lev]
             fe = device_fe(self.arch, fedc)
-            fe.set_coeff("nu", lambda xq, t=nu: t)
+            fe.restrict_coeff(device_fe(self.arch, self.hierarchy[lev + 1]), "nu")
             build_A_inversion(self.arch, fedc, self.prm, None, A=self.A[lev])
             self._update_level(lev, self.A[lev])
         if self.coarse_dense:

@@ -523,3 +523,43 @@ def test_line_block_entry_points_on_a_synthetic_matrix(arch):
     with pytest.raises(L.DeviceError, match="singular"):
         As = npg.DeviceCSR.from_scipy(ctx, sp.csr_matrix(sp.bmat([[Fs, G], [D, None]])))
         L.check(L.lib().npg_csr_line_block_inverse(Dinv.h, As.h, ip.h, idf.h))
+
+
+@pytest.mark.gpu
+def test_coarse_viscosity_is_the_child_volume_average_of_the_fine_one(arch):
+    """npg_fe_restrict_coeff (the multigrid refresh with the eddy closure, multigrid.MultigridPreconditioner.refresh): the coarse
+    engine's viscosity table = the volume-weighted average over a cell's eight children of the quadrature mean of the fine table -
+    checked through what it is for: the full-stress coarse matrix assembled from the restricted table equals the one assembled
+    from that average computed on the host, and differs from the one of the pointwise viscosity."""
+    from nupgcm_amd.assembly import eval_at_quad_points
+    from nupgcm_amd.inversion import device_fe
+    prm, frc = workloads.example_parameters()
+    hier = [workloads.example_fe_data(m) for m in workloads.bowl_hierarchy_models("bowl3D_h0.05")]
+    coarse, fine = hier
+
+    def nu(x):      # a strongly varying positive field
+        return 1.0 + 0.9 * np.sin(7.0 * x[..., 0]) * np.cos(5.0 * x[..., 1]) + 4.0 * x[..., 2] ** 2
+
+    fe_f, fe_c = device_fe(arch, fine), device_fe(arch, coarse)
+    fe_f.set_coeff("nu", nu)
+    fe_c.set_coeff("f", prm.f)
+    fe_c.restrict_coeff(fe_f, "nu")
+    A_dev = npg.build_A_inversion(arch, coarse, prm, None).to_scipy_csr()
+    # the same average on the host
+    m = fine.mesh
+    tab = eval_at_quad_points(m, nu)
+    wq = m.q_w / m.q_w.sum()
+    mean = tab @ wq
+    avg = (mean * m.detJ).reshape(-1, 8).sum(axis=1) / m.detJ.reshape(-1, 8).sum(axis=1)
+    table = np.repeat(avg[:, None], len(wq), axis=1)
+    A_host = npg.build_A_inversion(arch, coarse, prm, lambda x: table).to_scipy_csr()
+    scale = abs(A_host).max()
+    assert abs(A_dev - A_host).max() <= 1e-13 * scale
+    A_point = npg.build_A_inversion(arch, coarse, prm, nu).to_scipy_csr()
+    assert abs(A_dev - A_point).max() > 1e-3 * scale
+    # argument errors
+    L = npg._lib
+    with pytest.raises(L.DeviceError, match="uniform refinement"):
+        fe_f.restrict_coeff(fe_c, "nu")
+    with pytest.raises(L.DeviceError, match="unknown coefficient"):
+        fe_c.restrict_coeff(fe_f, "viscosity")
