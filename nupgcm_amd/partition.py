@@ -848,9 +848,9 @@ class DistributedMultigridPreconditioner:
             Q.sort_indices()
             return Q
         Gl, Sl = to_p_layout(G0g), to_p_layout(Sg)
-        if first and self.smoother == "node" and os.environ.get("NPG_MG_DIST_DEVICE", "1") != "0":
-            # ---- the device plan of later refreshes (npg_csr_gather_values / _node_block_inverse / _product and a halo plan on
-            # the VALUES of T = Dinv G): index work on the patterns, done once ---------------------------------------------------
+        if first and os.environ.get("NPG_MG_DIST_DEVICE", "1") != "0":
+            # ---- the device plan of later refreshes (npg_csr_gather_values / _node_block_inverse or _line_block_inverse / _product
+            # and a halo plan on the VALUES of T = Dinv G): index work on the patterns, done once ---------------------------------
             from .architectures import DeviceIndex
             one = lambda M: sp.csr_matrix((np.ones(M.nnz, dtype=np.float32), M.indices, M.indptr), shape=M.shape)
             G0t = sp.csr_matrix(Atag[:nu_o][:, p_cols_A])
@@ -858,7 +858,15 @@ class DistributedMultigridPreconditioner:
             Dt = sp.csr_matrix(Atag[nu_o:n_own][:, u_cols])
             assert np.array_equal(Gt.indices, Gl.indices) and np.array_equal(Dt.indices, Dh.indices)
             nfl, nsl = part.local_nodes(rank)
-            irp, icol = mgm._node_block_pattern(nu_o, nfl, nsl)
+            blocks = None
+            if self.smoother == "zline":                                      # the rank's pieces of the level's lines (round 5)
+                cut, order = lv.st["lines"]
+                piece_of = np.empty(nu_o, dtype=np.int64)
+                piece_of[order] = np.repeat(np.arange(len(cut) - 1, dtype=np.int64), np.diff(cut))
+                irp, icol = mgm._line_block_pattern(nu_o, cut, order, piece_of)
+                blocks = (DeviceIndex(ctx, cut, nu_o + 1), DeviceIndex(ctx, order, max(nu_o, 1)))
+            else:
+                irp, icol = mgm._node_block_pattern(nu_o, nfl, nsl)
             Ip = sp.csr_matrix((np.ones(len(icol), dtype=np.float32), icol, irp), shape=(nu_o, nu_o))
             Tp = sp.csr_matrix(Ip @ one(Gl))
             Tp.sort_indices()
@@ -909,7 +917,7 @@ class DistributedMultigridPreconditioner:
             indptr_e = np.concatenate([rptr[0], np.asarray(gptr[1:], dtype=np.int64)])
             cols_e, mapT = np.concatenate(cols_e), np.concatenate(mapT)
             dev = SimpleNamespace(
-                Ap=Ap, nfl=nfl, nsl=nsl,
+                Ap=Ap, nfl=nfl, nsl=nsl, blocks=blocks,
                 G=DeviceCSR.from_pattern(ctx, Gl.shape[0], Gl.shape[1], Gl.indptr, Gl.indices),
                 D=DeviceCSR.from_pattern(ctx, Dh.shape[0], Dh.shape[1], Dh.indptr, Dh.indices),
                 Dinv=DeviceCSR.from_pattern(ctx, nu_o, nu_o, irp, icol),
@@ -934,14 +942,17 @@ class DistributedMultigridPreconditioner:
 
     def _device_operators(self, lv, assemble=True):
         """refresh (G, D, Dinv, S) of a distributed level on the device from the rank's rows of the level's current matrix: values
-        gathered from the re-assembled rows, node-block inverse, T = Dinv G by the fixed-pattern product, its ghost rows' VALUES
-        through a halo plan, S = D T.  Collective (the halo exchange)."""
+        gathered from the re-assembled rows, node-block (or z-line piece) inverse, T = Dinv G by the fixed-pattern product, its ghost
+        rows' VALUES through a halo plan, S = D T.  Collective (the halo exchange)."""
         dev, prm = lv.st["dev"], self.prm
         if assemble:
             lv.fe.assemble(L.NPG_MAT_A, dev.Ap, scale=prm.alpha ** 2 * prm.eps ** 2, full_stress=self._full)
         dev.G.gather_values(dev.Ap, dev.mapG)
         dev.D.gather_values(dev.Ap, dev.mapD)
-        L.check(L.lib().npg_csr_node_block_inverse(dev.Dinv.h, dev.Ap.h, int(dev.nfl), int(dev.nsl)))
+        if dev.blocks is not None:
+            L.check(L.lib().npg_csr_line_block_inverse(dev.Dinv.h, dev.Ap.h, dev.blocks[0].h, dev.blocks[1].h))
+        else:
+            L.check(L.lib().npg_csr_node_block_inverse(dev.Dinv.h, dev.Ap.h, int(dev.nfl), int(dev.nsl)))
         L.check(L.lib().npg_csr_product(dev.T.h, dev.Dinv.h, dev.G.h))
         L.check(L.lib().npg_csr_values_to_vec(dev.T.h, dev.tv.h))
         dev.hT.exchange(dev.tv)

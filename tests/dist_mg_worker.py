@@ -45,7 +45,8 @@ def main():
              solved=[bool(s[1]["solved"]) and bool(s[0]["solved"]) for s in m.stats], rn=[s[1]["rnorm"] for s in m.stats],
              mg=np.array([m.inversion.solver.P.layout_mg[k] for k in ("ghost_u", "ghost_p", "S_nnz")]),
              mg2=np.array([getattr(m.inversion.solver.P, "layout_mg2", {}).get(k, 0) for k in ("rows", "ghost_x", "ghost_P", "ghost_R")]),
-             precond=repr(m.inversion.solver.P))
+             precond=repr(m.inversion.solver.P),
+             devplan=all(lv.st.get("dev") is not None for lv in m.inversion.solver.P._lv))      # refreshes stay on the device
     dist.barrier()
     dist.destroy_process_group()
 

@@ -246,7 +246,7 @@ def test_distributed_multigrid_with_the_zline_smoother(tmp_path):
     assert all(s[1]["solved"] == 1 for s in ref.stats)
     out = str(tmp_path / "dmgz")
     env = dict(os.environ, NPG_COMM_TRANSPORT="peer", NPG_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
-               NPG_PEER_TIMEOUT_S="90", NPG_TEST_SMOOTHER="zline")
+               NPG_PEER_TIMEOUT_S="90", NPG_TEST_SMOOTHER="zline", NPG_MG_DIST_CHECK="1")     # (device-side refresh of the line pieces against the host's)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_mg_worker.py"), out, str(nsteps), label]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -256,6 +256,7 @@ def test_distributed_multigrid_with_the_zline_smoother(tmp_path):
     for zz in ranks[1:]:
         assert np.array_equal(zz["its"], z["its"])
     assert z["solved"].all() and "z-line" in str(z["precond"])
+    assert bool(z["devplan"]), "the z-line level has no device plan: its refresh went through the host"
     print("distributed z-line", list(z["its"]), "one GPU z-line", ref_its, "node blocks", node_its)
     # (at this size - two levels, lines of five nodes - the node-block smoother is only a fifth behind; the gap opens with depth)
     assert int(np.sum(z["its"])) <= 1.35 * sum(ref_its) and int(np.sum(z["its"])) < sum(node_its), (list(z["its"]), ref_its, node_its)
