@@ -453,6 +453,10 @@ int npg_fe_update_nu_eddy(npg_fe *fe, double N2min, double alpha, double N2, dou
  * a closure (nu_eddy, src/inputs.jl:130-137; refreshed at src/model.jl:160-170) through the FINE level's viscosity instead of
  * re-evaluating the non-linear closure on an injected buoyancy.  No counterpart in the reference (it has no multigrid). */
 int npg_fe_restrict_coeff(npg_fe *coarse, const npg_fe *fine, const char *name);
+/* out[c] = quadrature mean of coefficient `name` over cell c (out: one entry per cell of the engine's mesh): what a rank of a
+ * partitioned multigrid level contributes to that average - its cells' children live on other ranks too, so the sums over children
+ * are formed on the host from the ranks' cell means (nupgcm_amd/partition.py). */
+int npg_fe_coeff_cell_mean(const npg_fe *fe, const char *name, npg_vec *out);
 /* CFL:  min_K h_K / max(max_q |u|, u_min)   (update_dt!, src/timesteppers.jl:108-119) */
 int npg_fe_cfl_ratio(npg_fe *fe, const double *h_cells_host, double u_min, const npg_vec *x_inv, double *out);
 

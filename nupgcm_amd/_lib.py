@@ -149,7 +149,7 @@ def _declare(L, partial=False):
         "npg_fe_advection_rhs": [P, C.c_int, D, D, P, P, P, P, P],
         "npg_fe_assemble_matrix": [P, C.c_int, D, C.c_int, P, P], "npg_fe_assemble_rhs_diff": [P, D, P],
         "npg_fe_update_kappa_convection": [P, VP, D, D, D, D, P],
-        "npg_fe_update_nu_eddy": [P, D, D, D, D, D, P], "npg_fe_restrict_coeff": [P, P, C.c_char_p], "npg_fe_cfl_ratio": [P, VP, D, P, C.POINTER(D)],
+        "npg_fe_update_nu_eddy": [P, D, D, D, D, D, P], "npg_fe_restrict_coeff": [P, P, C.c_char_p], "npg_fe_coeff_cell_mean": [P, C.c_char_p, P], "npg_fe_cfl_ratio": [P, VP, D, P, C.POINTER(D)],
         "npg_comm_unique_id": [VP], "npg_comm_init": [P, VP, C.c_int, C.c_int],
         "npg_comm_allreduce_sum": [P, C.POINTER(D), C.c_int], "npg_comm_info": [P, C.c_char_p, C.c_size_t], "npg_comm_disable_peer": [P], "npg_comm_allreduce_vec": [P, P],
         "npg_comm_allgather_segments": [P, P, C.c_int, VP, VP, VP, VP, P],

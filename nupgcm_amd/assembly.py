@@ -129,6 +129,11 @@ class DeviceFE:
         """this (coarse) engine's coefficient table <- the child-volume average of `fine`'s (npg_fe_restrict_coeff)"""
         L.check(L.lib().npg_fe_restrict_coeff(self.h, fine.h, name.encode()))
 
+    def coeff_cell_mean(self, name, out: DeviceVector):
+        """out[c] = quadrature mean of coefficient `name` over cell c (npg_fe_coeff_cell_mean)"""
+        L.check(L.lib().npg_fe_coeff_cell_mean(self.h, name.encode(), out.h))
+        return out
+
     def cfl_ratio(self, x_inv, u_min=0.01, h_cells=None):
         out = C.c_double()
         hc = None if h_cells is None else L.as_f64(h_cells)

@@ -903,6 +903,32 @@ __global__ void __launch_bounds__(kBlock) k_coeff_restrict(const double *__restr
     for (int q = 0; q < nqc; ++q) coarse[(size_t)q * ncc + c] = v;
 }
 
+// out[c] = quadrature mean of a coefficient table over cell c
+__global__ void __launch_bounds__(kBlock) k_coeff_cell_mean(const double *__restrict__ tab, const double *__restrict__ qw, int nq, int64_t nc,
+                                                            double *__restrict__ out) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= nc) return;
+    double sw = 0.0, m = 0.0;
+    for (int q = 0; q < nq; ++q) {
+        sw += qw[q];
+        m += qw[q] * tab[(size_t)q * nc + c];
+    }
+    out[c] = m / sw;
+}
+
+NPG_API int npg_fe_coeff_cell_mean(const npg_fe *fe, const char *name, npg_vec *out) {
+    NPG_REQUIRE(fe && name && out, "npg_fe_coeff_cell_mean: NULL argument");
+    const int k = coef_index(name);
+    NPG_REQUIRE(k >= 0, "npg_fe_coeff_cell_mean: unknown coefficient '%s'", name);
+    NPG_REQUIRE(fe->coef[k], "npg_fe_coeff_cell_mean: coefficient '%s' has not been set", name);
+    NPG_REQUIRE(out->n == fe->d.ncell && out->ctx == fe->ctx, "npg_fe_coeff_cell_mean: the output vector must hold one entry per cell (%lld)",
+                (long long)fe->d.ncell);
+    hipLaunchKernelGGL(k_coeff_cell_mean, dim3(cell_grid(fe->d.ncell)), dim3(kBlock), 0, fe->ctx->stream, (const double *)fe->coef[k], fe->d.qw, fe->d.nq,
+                       fe->d.ncell, out->d);
+    NPG_HIP(hipGetLastError());
+    return NPG_OK;
+}
+
 NPG_API int npg_fe_restrict_coeff(npg_fe *coarse, const npg_fe *fine, const char *name) {
     NPG_REQUIRE(coarse && fine && name, "npg_fe_restrict_coeff: NULL argument");
     const int k = coef_index(name);

@@ -1058,6 +1058,10 @@ static int precond_apply_raw(npg_precond *pc, const double *r, double *z) {
                        : npg_cg_solve(b.cg, b.A, NPG_PRECOND_DIAG, 0.0, b.jac, b.rk, b.xk, b.atol, b.rtol, b.itmax, &st);
         if (rc) return rc;
         pc->inner_iterations += st.niter;
+        // (a block solve that broke down - status 3: a non-finite or non-positive curvature, e.g. behind unusable ILU(0) factors - has
+        //  NaNs in its iterate: handing them to the outer flexible GMRES would poison its basis)
+        NPG_REQUIRE(st.status != 3, "npg_precond_apply: the inner CG of the block at offset %lld broke down after %d iterations; its output is not used",
+                    (long long)b.off, st.niter);
         NPG_HIP(hipMemcpyAsync(z + b.off, b.xk->d, (size_t)b.n * sizeof(double), hipMemcpyDeviceToDevice, pc->ctx->stream));
     }
     return NPG_OK;

@@ -587,11 +587,11 @@ class DistributedMultigridPreconditioner:
     for G and S) - three halo plans - and ONE operator that is not a row block of something local: S = D Dinv G, whose rows
     reach through ghost velocity nodes.  T = Dinv G is formed on the owned rows, the rows a neighbour needs travel once at
     set-up, and S_own = D_own T follows.  The set-up of the distributed level is host-side scipy on the rank's block; with the
-    eddy closure `refresh` repeats it on the re-assembled matrix (same layouts, new values; the replicated levels are
-    re-assembled on the device with the injected buoyancy's viscosity, as on one GPU)."""
+    eddy closure `refresh` repeats it on the re-assembled matrix (same layouts, new values; the coarser levels are re-assembled
+    with the child-volume average of the fine viscosity, as on one GPU - `_refresh_coarse_levels_averaged`)."""
 
     def __init__(self, arch, params, forcings, hierarchy, model, omega=2.5, jacobi_weight=0.7, schur_sweeps=3, nu1=2, nu2=2,
-                 coarse_sweeps=20, cycle="V", coarse_dense=None, distributed_levels=1, smoother=None):
+                 coarse_sweeps=20, cycle="V", coarse_dense=None, distributed_levels=1, smoother=None, coarse_nu="average"):
         """distributed_levels: 1 = the finest level row-partitioned, every coarser level replicated; 2 = the level below it
         partitioned as well (a coarse node belongs to the rank that owns the fine node it coincides with; its rows are assembled
         on that rank's cells of the coarse mesh; P / R between the two levels are row blocks with halo plans of their own) -
@@ -606,6 +606,8 @@ class DistributedMultigridPreconditioner:
         if distributed_levels == 2 and len(hierarchy) < 3:
             raise ValueError("two distributed levels need a hierarchy of >= 3 levels (the coarsest stays replicated)")
         self.distributed_levels = distributed_levels
+        self.coarse_nu = coarse_nu      # "average" | "inject": how the coarser levels follow the eddy closure (refresh)
+        self._avg = None
         # "zline": the velocity blocks of the smoother are the unknowns of the nodes above one another (multigrid.line_blocks) -
         # on a partitioned level the part of each line that this rank owns (a line cut by a rank boundary smooths in pieces)
         self.smoother = smoother or os.environ.get("NPG_MG_SMOOTHER", "node")
@@ -975,7 +977,9 @@ class DistributedMultigridPreconditioner:
         L.check(L.lib().npg_precond_mg_update_level(self.h, top, A.h, new[0].h, new[1].h, new[2].h, new[3].h))
         self._fine_ops[:4] = new
         ep = self.frc.eddy_param
-        if ep.is_on:
+        if ep.is_on and os.environ.get("NPG_MG_COARSE_NU", self.coarse_nu) == "average":
+            self._refresh_coarse_levels_averaged()
+        elif ep.is_on:
             fine = self.hierarchy[-1]
             if self._inj is None:
                 p1 = fine.spaces.b_order == 1
@@ -1013,6 +1017,70 @@ class DistributedMultigridPreconditioner:
             if self._dense_mode:
                 L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, self._dense_mode))
         return self
+
+    def _refresh_coarse_levels_averaged(self):
+        """The coarser levels follow the eddy closure through the FINE viscosity, as MultigridPreconditioner does on one GPU
+        (npg_fe_restrict_coeff there): a coarse cell's viscosity = the volume-weighted average of its eight children's cell means.
+        The children of a rank's coarse cell live on several ranks, so: every rank takes the cell means of its engine's table
+        (npg_fe_coeff_cell_mean), sums vol x mean and vol over the fine cells it OWNS (the lowest rank holding a cell owns it - fixed at
+        the first call) per coarse cell, the sparse partial sums travel once (all_gather_object, summed in rank order: identical
+        bits everywhere), and every level below is an average of that array on the host.  Collective."""
+        from .inversion import build_A_inversion, device_fe
+        lv0, top = self._lv[0], len(self.hierarchy) - 1
+        dist = lv0.dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        fine = self.hierarchy[-1]
+        if self._avg is None:
+            sets = [None] * world
+            dist.all_gather_object(sets, lv0.lay.cells)
+            owner = np.full(fine.mesh.ncell, world, dtype=np.int32)
+            for q in range(world - 1, -1, -1):
+                owner[sets[q]] = q
+            mine = owner[lv0.lay.cells] == rank
+            cells = lv0.lay.cells[mine]
+            idx, inv = np.unique(cells // 8, return_inverse=True)
+            self._avg = SimpleNamespace(mine=mine, idx=idx, inv=inv, vol=fine.mesh.detJ[cells], vec=DeviceVector(self.ctx, len(lv0.lay.cells)))
+        a = self._avg
+        mean = lv0.fe.coeff_cell_mean("nu", a.vec).to_host()[a.mine]
+        part = (a.idx, np.bincount(a.inv, weights=a.vol * mean, minlength=len(a.idx)), np.bincount(a.inv, weights=a.vol, minlength=len(a.idx)))
+        parts = [None] * world
+        dist.all_gather_object(parts, part)
+        ncc = self.hierarchy[top - 1].mesh.ncell
+        num, den = np.zeros(ncc), np.zeros(ncc)
+        for q in range(world):
+            num[parts[q][0]] += parts[q][1]
+            den[parts[q][0]] += parts[q][2]
+        if not (den > 0).all():
+            raise RuntimeError("distributed multigrid: a coarse cell has no child on any rank")
+        nu = num / den                                                     # the level below the finest, every cell, on every rank
+        lo = top - 1
+        if self.distributed_levels == 2:
+            lv1 = self._lv[1]
+            nq = len(lv1.fed.mesh.q_w)
+            tab = np.repeat(nu[lv1.lay.cells][:, None], nq, axis=1)
+            lv1.fe.set_coeff("nu", lambda xq, t=tab: t)
+            lv1.fe.assemble(L.NPG_MAT_A, lv1.A, scale=self.prm.alpha ** 2 * self.prm.eps ** 2, full_stress=self._full)
+            G1, D1, Dinv1, S1 = self._level_operators(lv1, first=False)
+            new1 = ([G1, D1, Dinv1, S1] if isinstance(G1, DeviceCSR) else
+                    [DeviceCSR.from_scipy(self.ctx, M) for M in (G1, D1, sp.csr_matrix(Dinv1), S1)])
+            L.check(L.lib().npg_precond_mg_update_level(self.h, top - 1, lv1.A.h, new1[0].h, new1[1].h, new1[2].h, new1[3].h))
+            lv1.ops[:4] = new1
+            vol = lv1.fed.mesh.detJ
+            nu = (nu * vol).reshape(-1, 8).sum(axis=1) / vol.reshape(-1, 8).sum(axis=1)
+            lo = top - 2
+        for lev in range(lo, -1, -1):
+            fed = self.hierarchy[lev]
+            fe = device_fe(self.arch, fed)
+            tab = np.repeat(nu[:, None], len(fed.mesh.q_w), axis=1)
+            fe.set_coeff("nu", lambda xq, t=tab: t)
+            build_A_inversion(self.arch, fed, self.prm, None, A=self.cA[lev])
+            ops = self.cops[lev].update(self.cA[lev])
+            L.check(L.lib().npg_precond_mg_update_level(self.h, lev, self.cA[lev].h, ops.G.h, ops.D.h, ops.Dinv.h, ops.S.h))
+            if lev > 0:
+                vol = fed.mesh.detJ
+                nu = (nu * vol).reshape(-1, 8).sum(axis=1) / vol.reshape(-1, 8).sum(axis=1)
+        if self._dense_mode:
+            L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, self._dense_mode))
 
     def counters(self):
         import ctypes as C

@@ -361,6 +361,16 @@ def test_preconditioner_abi_argument_errors(arch):
         L.check(lib.npg_csr_node_block_inverse(I.h, I.h, 2, 1))            # I holds 12 entries, the blocks would need 28
     with pytest.raises(L.DeviceError, match="outside S"):
         L.check(lib.npg_csr_triple_product(S.h, D.h, Di.h, G.h))           # D Dinv G is full, S's pattern is diagonal
+    # a block solve that breaks down (NaN in the block: CG status 3) is an error of the application, not a NaN in z
+    bad = sp.csr_matrix(sp.eye(12) * 2.0).tolil()
+    bad[3, 3] = np.nan
+    Ab = npg.on_architecture(arch, sp.csr_matrix(bad))
+    Pb = mgm.GeneralPreconditioner(ctx, L.NPG_PC_BLOCKDIAG, 1)
+    jac = npg.DeviceVector.from_host(ctx, np.full(12, 0.5))
+    L.check(lib.npg_precond_blockdiag_set(Pb.h, 0, 0, Ab.h, jac.h, 12, 1e-10, 1e-10))
+    r.fill(1.0)
+    with pytest.raises(L.DeviceError, match="broke down"):
+        Pb.apply(r, z)
     lib.npg_precond_destroy(pc) if pc else None
 
 
