@@ -2403,7 +2403,7 @@ __global__ void __launch_bounds__(kSpmvThreads, 6) k_spmv_g32(CsrDev A, WinDev W
                     if (!have) win_first<kSpmvThreads>(W, PaddedX{g}, td, pre);
                     have = tn < ntiles && nd.nw != 0;
                     if (td.r0 < block_rows(A))
-                        spmv_tile_win<kSpmvThreads, WL, PaddedX, kTileNnz, NoProf, (DIAG & 7)>(A, W, PaddedX{g}, td, nd, have, pre, tl, sw);
+                        spmv_tile_win<kSpmvThreads, WL, PaddedX, kTileNnz, NoProf, (DIAG & 39)>(A, W, PaddedX{g}, td, nd, have, pre, tl, sw);
                     else if (!(DIAG & 8))
                         spmv_tile_winrows<kSpmvThreads, L>(A, W, PaddedX{g}, td, nd, have, pre, tl, sw);
                 }
@@ -2546,6 +2546,9 @@ static void launch_spmv_g32(const npg_csr *A, const GatherMap &g, double *y, boo
             case 11: hipLaunchKernelGGL((k_spmv_g32<L, 4, 11>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
             case 12: hipLaunchKernelGGL((k_spmv_g32<L, 4, 12>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
             case 15: hipLaunchKernelGGL((k_spmv_g32<L, 4, 15>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
+            case 256: hipLaunchKernelGGL((k_spmv_g32<L, 4, 0>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;      // (the diagnostics' own baseline: 4 lanes per node)
+            case 32: hipLaunchKernelGGL((k_spmv_g32<L, 4, 32>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
+            case 40: hipLaunchKernelGGL((k_spmv_g32<L, 4, 40>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
             case 64: hipLaunchKernelGGL((k_spmv_g32<L, 4, 64>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
             case 72: hipLaunchKernelGGL((k_spmv_g32<L, 4, 72>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;
             default: hipLaunchKernelGGL((k_spmv_g32<L, 4, 7>), grid, blk, 0, A->ctx->stream, csr_view(A), W, tiles, nt, g, y); break;

@@ -98,7 +98,8 @@ __device__ __forceinline__ void win_first(const WinDev &W, const XF &x, const WT
 // record stream (hipcc's __syncthreads waits for LDS only: loads stay in flight across the barriers).
 // On return (after the trailing barrier) out[r - r0] holds (A x)[r] for the tile's rows.
 // DIAG (timing diagnostics of tools/window_ab.py only; results are then meaningless): bit 0 = the window is filled without
-// gathering, bit 1 = no segmented sums, bit 2 = no record loads (products of constants).
+// gathering, bit 1 = no segmented sums, bit 2 = no record loads (products of constants), bit 5 = the products never reach LDS: no
+// product slots, no segmented sums and one barrier less - an upper bound on what a register segmented scan could buy.
 template <int NT, int L, class XF, int TNNZ, class PROF = NoProf, int DIAG = 0>
 __device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const WinDev &W, const XF x, const WTileDesc &td, const WTileDesc &next, bool pre_next,
                                               WinPre &w, TileLdsT<TNNZ> &t, double *__restrict__ out, PROF prof = PROF()) {
@@ -185,12 +186,18 @@ __device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const WinDev &W, 
     // ---- (4) ONE gather per distinct column of the NEXT tile, ascending along the lanes: in flight until that tile starts
     if (pre_next) win_gather<NT, XF, DIAG>(x, next, wc, vc, w);
     // ---- (5) products: two adjacent records of one row node per lane, summed before they reach LDS
+    double dacc = 0.0;          // (DIAG bit 5: the products stay in the lane - no product slots, no segmented sums, one barrier less)
 #pragma unroll
     for (int u = 0; u < kWinPairs; ++u) {
         const int p = tid + u * NT;
         if (p < npair) {
             const float4 fa = win[ip[u] & 0xffffu], fb = win[ip[u] >> 16];
             const double xa = (double)fa.x, ya = (double)fa.y, xb = (double)fb.x, yb = (double)fb.y;
+            if constexpr ((DIAG & 32) != 0) {
+                dacc += ((k0[u] * xa + c0[u] * ya) + (k1[u] * xb + c1[u] * yb)) + ((k0[u] * ya - c0[u] * xa) + (k1[u] * yb - c1[u] * xb)) +
+                        (k0[u] * (double)fa.z + k1[u] * (double)fb.z);
+                continue;
+            }
             t.prod[p] = (k0[u] * xa + c0[u] * ya) + (k1[u] * xb + c1[u] * yb);
             t.prod[npair + p] = (k0[u] * ya - c0[u] * xa) + (k1[u] * yb - c1[u] * xb);
             if (full) t.prod[2 * npair + p] = k0[u] * (double)fa.z + k1[u] * (double)fb.z;
@@ -201,12 +208,21 @@ __device__ __forceinline__ void spmv_tile_win(const CsrDev &A, const WinDev &W, 
         const int e = tid + u * NT;
         if (e < n) {
             const double xv = (double)vwin[gi[u]];
+            if constexpr ((DIAG & 32) != 0) {
+                dacc += (ax[u] + ay[u] + az[u]) * xv;
+                continue;
+            }
             t.prod[slot0 + e] = ax[u] * xv;
             t.prod[slot0 + n + e] = ay[u] * xv;
             if (full) t.prod[slot0 + 2 * n + e] = az[u] * xv;
         }
     }
     prof.stamp(0);
+    if constexpr ((DIAG & 32) != 0) {
+        out[tid & (kTileRows - 1)] = dacc;
+        __syncthreads();
+        return;
+    }
     __syncthreads();
     prof.stamp(1);
     // ---- (6) segmented sums: a lane group sums the two or three rows of a NODE together (spmv_tile's node-wise loop)

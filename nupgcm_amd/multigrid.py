@@ -525,7 +525,8 @@ class MultigridPreconditioner(GeneralPreconditioner):
 
     def refresh(self, A: DeviceCSR, model=None):
         """the solver's matrix has been re-assembled (eddy closure): recompute the finest level's smoother from it and,
-        given the model, re-assemble the coarser levels with the eddy viscosity of the injected buoyancy"""
+        given the model, re-assemble the coarser levels with the child-volume average of the fine viscosity (coarse_nu="average",
+        the default) or with the eddy viscosity of the injected buoyancy ("inject")"""
         top = len(self.levels) - 1
         self.A[top] = A
         self._update_level(top, A)
