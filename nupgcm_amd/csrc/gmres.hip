@@ -1001,10 +1001,16 @@ static int launch_cycle_L(const GDev &d, hipStream_t st, hipEvent_t *pev, npg_gm
     // By DEFAULT the two-launch form is taken only when at least half of the tiles read no ghost column: splitting costs a second
     // launch with its prologue and a second partly filled round of workgroups, and with hardly any interior tiles there is nothing to
     // run beside the exchange (rank 4 of 8 of bowl3D h = 0.02 before the interior-first numbering of partition.py: 106 of 2 606 tiles
-    // interior, 81.8 us per iteration split against 73.5 us exchanged first - profiles/r05_dist_cycle.txt).  An explicit request
-    // (NPG_HALO_OVERLAP=1 / npg_gmres_set_dist_options) splits whenever both parts are non-empty.
+    // interior, 81.8 us per iteration split against 73.5 us exchanged first - profiles/r05_dist_cycle.txt) AND the exchange is large
+    // enough for its wire time to exceed what the split costs: the END ranks of the 8-rank partition of that system have 1 000 of
+    // 1 783 tiles interior and 19 k ghost entries (150 KB: ~1 us on an xGMI link) - split, they took 67 us per iteration where the
+    // inner ranks took 59, and the slowest rank sets the pace (section 5 there).  NPG_HALO_OVERLAP_MIN_GHOSTS: 200 000 entries
+    // = 1.6 MB ~ 10 us on one link.  An explicit request (NPG_HALO_OVERLAP=1 / npg_gmres_set_dist_options) splits whenever both
+    // parts are non-empty.
     const bool asked = dist && (ws->halo_overlap >= 0 || overlap_env >= 0);
-    const bool overlap = dist && d.split && want && a_int > 0 && a_int < a_nt && (asked || 2 * a_int >= a_nt);
+    static const int64_t min_ghosts = getenv("NPG_HALO_OVERLAP_MIN_GHOSTS") ? atoll(getenv("NPG_HALO_OVERLAP_MIN_GHOSTS")) : 200000;
+    const bool big = dist && ws->halo && ws->halo->n_ghost >= min_ghosts;
+    const bool overlap = dist && d.split && want && a_int > 0 && a_int < a_nt && (asked || (2 * a_int >= a_nt && big));
     const int maxg = ws ? std::min(kMaxG, 3 * ws->ctx->num_cu) : kMaxG;
     static const int reserve_env = getenv("NPG_HALO_RESERVE_CUS") ? atoi(getenv("NPG_HALO_RESERVE_CUS")) : 4;
     const int reserve = std::max(0, std::min(reserve_env, maxg / 6));
