@@ -11,7 +11,7 @@ from .inputs import (ConvectionParameterization, EddyParameterization, Forcings,
                      SurfaceFluxBC)
 from .inversion import InversionToolkit, build_A_inversion, build_B_inversion, build_b_inversion
 from .io import save_checkpoint, save_state, save_vtk, set_out_dir, set_state_from_file
-from .iterative_solvers import CgWorkspace, Diagonal, GmresWorkspace, IterativeSolverToolkit, iterative_solve
+from .iterative_solvers import CgWorkspace, Diagonal, GmresWorkspace, IterativeSolverToolkit, MgsGmresWorkspace, iterative_solve
 from .multigrid import BlockDiagonalPreconditioner, DenseInversePreconditioner, FgmresWorkspace, GeneralPreconditioner, MultigridPreconditioner
 from .model import BlowUp, Model, State, evolve, invert, run, set_b, sync_flow
 from .timesteppers import BDF1, BDF2, update_dt, update_t

@@ -115,6 +115,130 @@ class GmresWorkspace(_Workspace):
         return ms.value, n.value
 
 
+class MgsGmresWorkspace(_Workspace):
+    """Krylov.jl's gmres! in ITS OWN order of operations on device vectors: left-preconditioned restarted GMRES(memory) with
+    MODIFIED Gram-Schmidt - one dot product and one axpy per basis column, Givens rotations and the triangular solve on the host -
+    statement for statement what the reference runs through Krylov.gmres!(workspace, A, y, x; M = P, ldiv = false, restart = true,
+    atol, rtol, itmax, history) (src/iterative_solvers.jl:56-58; Krylov.jl v0.10's gmres.jl, restated in oracle/krylov_oracle.py).
+    Every dot is a host round trip: this is the solver for parity studies - on the bowl meshes it takes the oracle's iteration
+    counts to the digit and its residual history to rounding (tests/test_gpu_parity.py) -, not for production: GmresWorkspace
+    (classical Gram-Schmidt with a selective second pass, device-resident restart cycles) is 50-100 times faster per iteration
+    and within a few per cent of these counts."""
+
+    def __init__(self, ctx, n, memory=20):
+        super().__init__()
+        self.ctx, self.n, self.memory = ctx, n, memory
+        self.x = DeviceVector(ctx, n)
+        self.V = [DeviceVector(ctx, n) for _ in range(memory)]
+        self.w, self.q, self.dx = DeviceVector(ctx, n), DeviceVector(ctx, n), DeviceVector(ctx, n)
+        self._hist = np.zeros(0)
+
+    @staticmethod
+    def _sym_givens(a, b):
+        """Krylov.jl's sym_givens (krylov_utils.jl): (c, s, rho) with [c s; s -c] [a; b] = [rho; 0]"""
+        if b == 0.0:
+            return (1.0 if a >= 0.0 else -1.0) if a != 0.0 else 1.0, 0.0, abs(a)
+        if a == 0.0:
+            return 0.0, (1.0 if b >= 0.0 else -1.0), abs(b)
+        if abs(b) > abs(a):
+            t = a / b
+            s = (1.0 if b >= 0.0 else -1.0) / np.sqrt(1.0 + t * t)
+            return s * t, s, b / s
+        t = b / a
+        c = (1.0 if a >= 0.0 else -1.0) / np.sqrt(1.0 + t * t)
+        return c, c * t, a / c
+
+    def solve(self, A: DeviceCSR, y: DeviceVector, x: DeviceVector, P, atol=1e-6, rtol=1e-6, itmax=0, **_ignored):
+        n, mem = self.n, self.memory
+        if P is not None and not isinstance(P, Diagonal):
+            raise TypeError("MgsGmresWorkspace: P must be a Diagonal (or None)")
+
+        def apply_M(src, dst):
+            if P is None:
+                dst.copy_from(src)
+            elif P.scalar is not None:
+                dst.axpby(float(P.scalar), src, 0.0)
+            else:
+                dst.mul(P.diag, src)
+
+        w, q, dx, V = self.w, self.q, self.dx, self.V
+        # x = dx0 is the warm start (workspace.x, src/iterative_solvers.jl:56): w = b - A dx0
+        w.copy_from(y)
+        A.mul(x, w, alpha=-1.0, beta=1.0)
+        apply_M(w, q)                               # r0
+        beta = q.norm()
+        rnorm = rnorm0 = beta
+        hist = [beta]
+        eps_ = atol + rtol * rnorm
+        stats = dict(solved=1, niter=0, npass=0, status=1, nreorth=0, nflagged=0, rnorm0=rnorm0, rnorm=rnorm, seconds=0.0)
+        if beta == 0.0:
+            self._hist, self.stats = np.asarray(hist), stats
+            return stats
+        if itmax == 0:
+            itmax = 2 * n
+        inner_itmax = itmax
+        btol = np.finfo(float).eps ** 0.75
+        it = npass = 0
+        solved, tired, breakdown = rnorm <= eps_, it >= itmax, False
+        while not (solved or tired or breakdown):
+            c, s, z = np.zeros(mem), np.zeros(mem), np.zeros(mem)
+            R = np.zeros(mem * (mem + 1) // 2)
+            if npass >= 1:
+                w.copy_from(y)
+                A.mul(x, w, alpha=-1.0, beta=1.0)
+                apply_M(w, q)
+            beta = q.norm()
+            z[0] = beta
+            V[0].axpby(1.0 / beta, q, 0.0)
+            npass += 1
+            inner = nr = 0
+            inner_tired = False
+            while not (solved or inner_tired or breakdown):
+                inner += 1
+                A.mul(V[inner - 1], w)
+                apply_M(w, q)
+                for i in range(inner):
+                    R[nr + i] = V[i].dot(q)
+                    q.axpby(-R[nr + i], V[i], 1.0)
+                hbis = q.norm()
+                for i in range(inner - 1):
+                    tmp = c[i] * R[nr + i] + s[i] * R[nr + i + 1]
+                    R[nr + i + 1] = s[i] * R[nr + i] - c[i] * R[nr + i + 1]
+                    R[nr + i] = tmp
+                c[inner - 1], s[inner - 1], R[nr + inner - 1] = self._sym_givens(R[nr + inner - 1], hbis)
+                zeta = s[inner - 1] * z[inner - 1]
+                z[inner - 1] = c[inner - 1] * z[inner - 1]
+                rnorm = abs(zeta)
+                hist.append(rnorm)
+                nr += inner
+                solved = (rnorm <= eps_) or (rnorm + 1.0 <= 1.0)
+                breakdown = hbis <= btol
+                inner_tired = inner >= min(mem, inner_itmax)
+                if not (solved or inner_tired or breakdown):
+                    V[inner].axpby(1.0 / hbis, q, 0.0)
+                    z[inner] = zeta
+            yv = z.copy()
+            for i in range(inner - 1, -1, -1):
+                pos = nr + i - inner
+                for j in range(inner - 1, i, -1):
+                    yv[i] -= R[pos] * yv[j]
+                    pos -= j
+                yv[i] = 0.0 if abs(R[pos]) <= btol else yv[i] / R[pos]
+            dx.fill(0.0)
+            for i in range(inner):
+                dx.axpby(yv[i], V[i], 1.0)
+            x.axpby(1.0, dx, 1.0)
+            inner_itmax -= inner
+            it += inner
+            tired = it >= itmax
+        stats.update(solved=int(bool(solved)), niter=it, npass=npass, status=1 if solved else (2 if tired else 3), rnorm=rnorm)
+        self._hist, self.stats = np.asarray(hist), stats
+        return stats
+
+    def history(self):
+        return self._hist
+
+
 class CgWorkspace(_Workspace):
     """Krylov.CgWorkspace(n, n, VT) at src/evolution.jl:120"""
 
