@@ -276,7 +276,7 @@ int64_t npg_cg_history(npg_cg *ws, double *buf, int64_t cap);
 #define NPG_PC_BLOCKDIAG 1   /* BlockDiagonalPreconditioner([Block(CgPreconditioner(A_k, Diagonal), indices_k)...])
                                 (src/preconditioners.jl:53-125): nparts blocks                                        */
 #define NPG_PC_MG 2          /* geometric multigrid V-cycle on the saddle-point system (new work): nparts levels      */
-#define NPG_PC_DENSE 3       /* explicit dense inverse in HBM (new work; small systems, <= 65 536 unknowns): nparts = 1 */
+#define NPG_PC_DENSE 3       /* explicit dense inverse in HBM (new work; small systems, <= 46 340 unknowns: rocSOLVER indexes n x n with 32 bits): nparts = 1 */
 int npg_precond_create(npg_ctx *ctx, int kind, int nparts, npg_precond **out);
 int npg_precond_destroy(npg_precond *pc);
 /* Block k acts on x[offset, offset + n_k): CG on A_k with M = Diagonal(jacobi) (ldiv = false), itmax / atol / rtol as given

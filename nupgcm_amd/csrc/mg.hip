@@ -468,7 +468,9 @@ static int dense_apply(npg_precond *pc, const double *r, double *z, double a, do
 static int dense_build(npg_precond *pc, const npg_csr *A, bool fp32, bool fp16 = false) {
     NPG_REQUIRE(A && A->m == A->n && A->nnode() == 0, "dense inverse: a square plain-CSR matrix is required");
     const int64_t n = A->m;
-    NPG_REQUIRE(n > 0 && n <= 65536, "dense inverse: %lld unknowns (limit 65 536: n^2 doubles must fit in HBM with room to spare)",
+    // (46 340 = floor(sqrt(2^31)): rocSOLVER's getrf / getri address the n x n array with 32-bit element offsets - at 58 295 unknowns,
+    //  the channel basin's coarsest level, they fault; round 5, profiles/r05_coarse_viscosity.txt)
+    NPG_REQUIRE(n > 0 && n <= 46340, "dense inverse: %lld unknowns (limit 46 340: rocSOLVER's getrf / getri index the n x n array with 32-bit offsets)",
                 (long long)n);
     hipStream_t st = pc->ctx->stream;
     DenseInv &d = pc->dense;

@@ -498,7 +498,8 @@ class MultigridPreconditioner(GeneralPreconditioner):
             coarse_sweeps, cycle = int(kv.get("coarse_sweeps", coarse_sweeps)), kv.get("cycle", cycle)
         self.set_params(omega, jacobi_weight, schur_sweeps, nu1, nu2, coarse_sweeps, cycle)
         if coarse_dense is None:
-            coarse_dense = "fp16" if len(hierarchy) > 1 and self.levels[0]["n"] <= 40000 else False
+            limit = min(46340, int(os.environ.get("NPG_MG_COARSE_DENSE_MAX", 40000)))     # (46 340: the library's limit, rocSOLVER's 32-bit offsets)
+            coarse_dense = "fp16" if len(hierarchy) > 1 and self.levels[0]["n"] <= limit else False
         # True / "fp32": inverse stored in fp32 (half the bytes per V-cycle; a coarse-grid correction inside a preconditioner
         # needs no more: same 19 iterations, 4.0 instead of 4.7 ms each at 2.15 M unknowns); "fp64": full precision;
         # "fp16" (what None picks): every column scaled by its largest magnitude and stored in fp16 - a quarter of the bytes,
@@ -550,9 +551,21 @@ class MultigridPreconditioner(GeneralPreconditioner):
             fe.update_nu_eddy(ep.N2min, self.prm.alpha, self.prm.N2, bl)
             build_A_inversion(self.arch, fed, self.prm, None, A=self.A[lev])
             self._update_level(lev, self.A[lev])
-        if self.coarse_dense:
-            L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, self._dense_mode))
+        self._refresh_coarse_dense()
         return self
+
+    def _refresh_coarse_dense(self):
+        """the coarsest level's dense inverse after a re-assembly: rebuilt (getrf + getri of the level's matrix) - or, with
+        dense_refresh_every = k > 1 (NPG_MG_DENSE_REFRESH_EVERY), only at every k-th refresh: in between the cycle keeps the inverse
+        of the previous operator as its coarse solve (an approximate one: the smoother's operators and the level matrices above
+        are current), which a coarsest level of several 1e4 unknowns needs - its inversion takes seconds"""
+        if not self.coarse_dense:
+            return
+        self._dense_refreshes = getattr(self, "_dense_refreshes", 0) + 1
+        every = int(os.environ.get("NPG_MG_DENSE_REFRESH_EVERY", getattr(self, "dense_refresh_every", 1)))
+        if every <= 0 or (every > 1 and self._dense_refreshes % every != 0):
+            return
+        L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, self._dense_mode))
 
     def _refresh_coarse_levels_averaged(self):
         """coarse levels re-discretised with the AVERAGE of the level above's eddy viscosity over each cell's eight children
@@ -568,8 +581,7 @@ class MultigridPreconditioner(GeneralPreconditioner):
             fe.restrict_coeff(device_fe(self.arch, self.hierarchy[lev + 1]), "nu")
             build_A_inversion(self.arch, fedc, self.prm, None, A=self.A[lev])
             self._update_level(lev, self.A[lev])
-        if self.coarse_dense:
-            L.check(L.lib().npg_precond_mg_set_coarse_dense(self.h, self._dense_mode))
+        self._refresh_coarse_dense()
         return self
 
     def set_params(self, omega=2.5, jacobi_weight=0.7, schur_sweeps=3, nu1=2, nu2=2, coarse_sweeps=20, cycle="V"):
