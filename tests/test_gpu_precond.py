@@ -352,6 +352,8 @@ def test_preconditioner_abi_argument_errors(arch):
     assert lib.npg_precond_dense_set(Pd.h, G.h, 0) != 0                                           # not square
     sing = npg.on_architecture(arch, sp.csr_matrix(np.array([[1.0, 2.0], [2.0, 4.0]])))
     assert lib.npg_precond_dense_set(Pd.h, sing.h, 0) != 0 and b"singular" in lib.npg_last_error()
+    big = npg.on_architecture(arch, sp.identity(50000, format="csr"))          # n^2 > 2^31: refused before anything is allocated
+    assert lib.npg_precond_dense_set(Pd.h, big.h, 0) != 0 and b"46 340" in lib.npg_last_error()
     # fixed-pattern helpers
     with pytest.raises(L.DeviceError, match="outside"):
         DeviceIndex(ctx, np.array([0, 5, 99]), 12)
