@@ -192,3 +192,61 @@ def test_hooked_methods_are_typed_as_the_dispatch_argument_says():
     assert "invoke(nuPGCM.build_A_inversion!, Tuple{Any, Any, Any, Any, nuPGCM.FEData, nuPGCM.Parameters, Any}" in t
     # uploads keep Gridap's explicit zeros (the reference re-assembles into the pattern it downloads)
     assert "return upload_csc(A, 0)" in t
+
+
+def _julia_code_tokens(src):
+    """(token, line) of the extension's code with comments, string literals (also multi-line and triple-quoted) and character
+    literals removed - enough of a lexer for the block-structure check below"""
+    out, i, n, line = [], 0, len(src), 1
+    while i < n:
+        c = src[i]
+        if c == "\n":
+            line += 1
+            i += 1
+        elif c == "#":
+            while i < n and src[i] != "\n":
+                i += 1
+        elif src.startswith('"""', i):
+            j = src.index('"""', i + 3)
+            line += src.count("\n", i, j)
+            i = j + 3
+        elif c == '"':
+            j = i + 1
+            while src[j] != '"':
+                j += 2 if src[j] == "\\" else 1
+            line += src.count("\n", i, j)
+            i = j + 1
+        elif c == "'" and i + 2 < n and src[i + 2] == "'":
+            i += 3
+        elif c in "[](){}":
+            out.append((c, line))
+            i += 1
+        else:
+            m = re.match(r"[A-Za-z_][A-Za-z_0-9!]*", src[i:])
+            if m and (i == 0 or not (src[i - 1].isalnum() or src[i - 1] in "_.:")):
+                out.append((m.group(0), line))
+                i += m.end()
+            else:
+                i += 1
+    return out
+
+
+def test_block_structure_of_the_extension_is_balanced():
+    """No Julia here to parse ext/nuPGCMHIPExt.jl: the least a parser would check is checked by hand - every block opener at
+    bracket depth 0 (function, if, for, while, let, begin, struct, module, try, do, macro, quote; `for` / `if` inside brackets are
+    comprehensions) has its `end`, `end` inside brackets is an index, brackets balance, and the file closes its module last."""
+    openers = {"function", "if", "for", "while", "let", "begin", "struct", "module", "try", "do", "macro", "quote"}
+    depth, stack = 0, []
+    for tok, line in _julia_code_tokens(open(EXT).read()):
+        if tok in "[({":
+            depth += 1
+        elif tok in "])}":
+            depth -= 1
+            assert depth >= 0, f"line {line}: closing bracket without an opening one"
+        elif depth == 0 and tok in openers:
+            stack.append((tok, line))
+        elif depth == 0 and tok == "end":
+            assert stack, f"line {line}: `end` without a block"
+            last = stack.pop()
+    assert depth == 0 and not stack, (depth, stack[-3:])
+    assert last[0] == "module"
