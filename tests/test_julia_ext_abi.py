@@ -250,3 +250,35 @@ def test_block_structure_of_the_extension_is_balanced():
             last = stack.pop()
     assert depth == 0 and not stack, (depth, stack[-3:])
     assert last[0] == "module"
+
+
+def test_names_and_fields_of_the_reference_that_the_extension_uses_exist():
+    """Every `nuPGCM.<name>` the extension extends, constructs or dispatches on is defined at top level of the reference's src/*.jl,
+    and every field it reads off the reference's objects (model.forcings.eddy_param.N²min, ev.rhsᵥ, dofs.p_inversion ...) is a field of
+    one of its structs - against tests/golden/reference_api_names.json (names only; tests/golden/make_api_names.py, re-derived here
+    when the reference is present)."""
+    import json
+    api = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_api_names.json")))
+    src = open(EXT).read()
+    used = set(re.findall(r"nuPGCM\.([^\W\d][\w!]*)", src))
+    assert len(used) >= 20 and not used - set(api["defined"]), sorted(used - set(api["defined"]))
+    code = re.sub(r'"(?:\\.|[^"\\])*"', '""', src, flags=re.S)
+    code = "\n".join(line.split("#")[0] for line in code.splitlines())
+    receivers = ["model", "ev", "evolution", "solver", "dofs", "ts", "timestepper", "params", "forcings", "inversion", "tk", "toolkit", "block",
+                 "state", "cp", "ep", "mesh", "fe_data", "spaces", "inv", "P"]
+    chains = set(re.findall(r"\b((?:%s)(?:\.[^\W\d][\w!]*)+)" % "|".join(receivers), code))
+    # fields of the extension's own structs / named tuples, of LinearAlgebra.Diagonal (diag) and of Gridap's FE functions (free_values)
+    own = {"h", "n", "m", "parent", "M", "ok", "Kv", "Kh", "A", "P", "x", "y", "jac", "F", "itmax", "label", "fe", "dm", "ws", "diag", "free_values"}
+    known = set(api["struct_fields"]) | own
+    bad = sorted((ch, f) for ch in chains for f in ch.split(".")[1:] if f not in known)
+    assert len(chains) >= 50 and not bad, bad
+    if os.path.isdir("/root/reference/src"):          # the fixture is current
+        import subprocess
+        import sys
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            script = os.path.join(ROOT, "tests", "golden", "make_api_names.py")
+            copy = os.path.join(tmp, "make_api_names.py")
+            open(copy, "w").write(open(script).read())
+            subprocess.run([sys.executable, copy], check=True, capture_output=True)
+            assert json.load(open(os.path.join(tmp, "reference_api_names.json"))) == api
