@@ -22,5 +22,40 @@ for f in sorted(glob.glob(os.path.join(REF, "src", "*.jl"))):
             m = re.match(rf"\s*({ident})\s*(::|$)", line)
             if m and m.group(1) not in ("function", "end"):
                 fields.add(m.group(1))
-json.dump({"defined": sorted(defs), "struct_fields": sorted(fields)}, open(os.path.join(HERE, "reference_api_names.json"), "w"), indent=0, ensure_ascii=False)
+
+
+def arities(src, prefix):
+    """name -> set of positional-argument counts of its method definitions (long and short form)"""
+    out = {}
+    for m in re.finditer(r"(?:^|\n)\s*(?:function\s+)?%s(%s)\s*(?:\{[^}]*\})?\(" % (prefix, ident), src):
+        i, depth, args = m.end(), 1, ""
+        while depth and i < len(src):
+            c = src[i]
+            depth += (c in "([{") - (c in ")]}")
+            if depth:
+                args += c
+            i += 1
+        d, pos = 0, ""
+        for c in args:
+            d += (c in "([{") - (c in ")]}")
+            if c == ";" and d == 0:
+                break
+            pos += c
+        d, n, cur = 0, 0, ""
+        for c in pos:
+            d += (c in "([{") - (c in ")]}")
+            if c == "," and d == 0:
+                n, cur = n + 1, ""
+            else:
+                cur += c
+        out.setdefault(m.group(1), set()).add(n + (1 if cur.strip() else 0))
+    return out
+
+
+ar = {}
+for f in sorted(glob.glob(os.path.join(REF, "src", "*.jl"))) + [os.path.join(REF, "ext", "nuPGCMCUDAExt.jl")]:
+    for k, v in arities(open(f).read(), r"(?:nuPGCM\.)?").items():
+        if k in defs or k in ("on_architecture", "architecture", "vector_type", "print_memory_status"):
+            ar.setdefault(k, set()).update(v)
+json.dump({"defined": sorted(defs), "struct_fields": sorted(fields), "arities": {k: sorted(v) for k, v in sorted(ar.items())}}, open(os.path.join(HERE, "reference_api_names.json"), "w"), indent=0, ensure_ascii=False)
 print(len(defs), "definitions,", len(fields), "struct fields")

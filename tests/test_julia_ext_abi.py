@@ -272,6 +272,17 @@ def test_names_and_fields_of_the_reference_that_the_extension_uses_exist():
     known = set(api["struct_fields"]) | own
     bad = sorted((ch, f) for ch in chains for f in ch.split(".")[1:] if f not in known)
     assert len(chains) >= 50 and not bad, bad
+    # a method added to one of the reference's functions takes as many positional arguments as one of the reference's own methods
+    # of that function - with another count no call site of the reference would ever reach it
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_api_names_arities", os.path.join(ROOT, "tests", "golden", "make_api_names.py"))
+    src_m = open(spec.origin).read()
+    ns = {}
+    exec(src_m[src_m.index("def arities"):src_m.index("ar = {}")], {"re": re, "ident": r"[^\W\d][\w!]*"}, ns)
+    mine = ns["arities"](src, r"nuPGCM\.")
+    assert len(mine) >= 10
+    for name, counts in mine.items():
+        assert name in api["arities"] and counts <= set(api["arities"][name]), (name, sorted(counts), api["arities"].get(name))
     if os.path.isdir("/root/reference/src"):          # the fixture is current
         import subprocess
         import sys
