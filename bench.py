@@ -316,6 +316,23 @@ def main():
         A.mul(x, y)
     spmv_ms = ctx.timer_stop() / reps
 
+    # the inversion SpMV AS THE SOLVER RUNS IT, stand-alone: the gather-layout product on the windowed tiles (npg_spmv_gather32 - the
+    # tile code of the Arnoldi kernel without its Givens prologue and its epilogue's wt / w / basis-column traffic), priced in the
+    # bytes of the windowed set as stored.  Wall clock over back-to-back launches (the entry point synchronises once at the end).
+    spmv_g32 = None
+    if rank == 0 and world == 1 and getattr(A, "paired", False) and hasattr(A, "window_info"):
+        wi = A.window_info()
+        if wi.get("tiles"):
+            A.mul_gather32(x, y, windowed=True, reps=3)
+            t0g = time.perf_counter()
+            A.mul_gather32(x, y, windowed=True, reps=200)
+            g_ms = 1e3 * (time.perf_counter() - t0g) / 200
+            spmv_g32 = {"avg_launch_us": g_ms * 1e3, "stored_bytes_per_launch": int(wi["bytes"]), "GBps": wi["bytes"] / (g_ms * 1e-3) / 1e9,
+                        "frac_of_8TBps": wi["bytes"] / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches": 200,
+                        "kernel": "k_spmv_g32 (npg_spmv_gather32): fp32 gather-layout input, fp64 products and sums, windowed tiles",
+                        "note": "the SpMV of the Arnoldi kernel's instance alone; wall clock / 200 back-to-back launches including one "
+                                "allocation and one fill of the gather-layout copy (~0.1 us per launch)"}
+
     # the same product on a plain-CSR copy of the matrix (what the reference's cuSPARSE path streams): real bytes = algorithmic
     # bytes there, so this is the kernel's bandwidth figure without the node-block storage's byte savings
     spmv_plain = None
@@ -373,6 +390,7 @@ def main():
                             "csr_equivalent_GBps": alg_bytes / (spmv_ms * 1e-3) / 1e9,
                             "note": "GBps = bytes of the stored layout (records) per launch time; csr_equivalent_GBps = what a plain-CSR "
                                     "SpMV of the same matrix would have had to stream in that time (not a physical rate)"},
+        "spmv_gather32_standalone": spmv_g32,
         "spmv_plain_csr": spmv_plain,
     }
     # ---- the same loop with the multigrid-preconditioned inversion (new work; the headline above stays the reference's
