@@ -1271,7 +1271,9 @@ NPG_API int npg_gmres_solve(npg_gmres *ws, const npg_csr *A_in, int precond_kind
     const bool basis32 = d.split && (basis_req == 32 || (basis_req == 0 && rtol >= 1e-7));
     d.Vf = basis32 ? reinterpret_cast<float *>(ws->Vi) : nullptr;
     if (basis32) {          // the row kernels take two rows per thread there
-        d.GR = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + 2 * kRB - 1) / (2 * kRB), std::min(dist ? 256 : kMaxG, 3 * ctx->num_cu)));
+        // (NPG_GMRES_ROWS_WG: tuning - fewer workgroups = fewer partial rows for the next kernel's prologue to fold)
+        static const int rows_wg = getenv("NPG_GMRES_ROWS_WG") ? std::max(64, atoi(getenv("NPG_GMRES_ROWS_WG"))) : kMaxG;
+        d.GR = (int)std::max<int64_t>(1, std::min<int64_t>((ws->n + 2 * kRB - 1) / (2 * kRB), std::min(dist ? 256 : std::min(kMaxG, rows_wg), 3 * ctx->num_cu)));
         d.GP1 = d.GR;
         d.GP2 = d.GR;
     }
