@@ -495,8 +495,14 @@ static int build_window_tiles_scaled(npg_csr *A, const std::vector<int32_t> &pco
         }
         if (pass == 0) nint = (int32_t)ord.size();
     }
+    // NPG_WIN_UNCACHED=1 (experiment): the once-read record streams in uncached device memory, so that they do not displace the
+    // Krylov basis and the gather-layout copy from L2 / the Infinity Cache
+    static const bool uncached = getenv("NPG_WIN_UNCACHED") && atoi(getenv("NPG_WIN_UNCACHED")) != 0;
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
-        NPG_HIP(hipMalloc(dst, std::max<size_t>(bytes, 16)));
+        if (uncached && bytes >= (1u << 20))
+            NPG_HIP(hipExtMallocWithFlags(dst, bytes, hipDeviceMallocUncached));
+        else
+            NPG_HIP(hipMalloc(dst, std::max<size_t>(bytes, 16)));
         if (bytes) NPG_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
         return NPG_OK;
     };
